@@ -1,0 +1,190 @@
+/* mrfa_hip.h -- C ABI of libmrfa_hip.so: the MI355X (gfx950) kernels behind the MRFA hot path.
+ *
+ * The reference (JialeTao/MRFA) has no FFI: its "kernels" are the ATen ops reached from
+ * modules/{util,kp_detector,dense_motion,raft,generator}.py.  Each entry point below replaces one ATen op class
+ * on that path and cites the reference call sites it stands in for.
+ *
+ * Conventions
+ *   - all activations are fp32 NHWC "views": base pointer + leading dimension `ld` (floats between consecutive
+ *     pixels) so producers can write straight into a slice of a concatenated buffer (removes the torch.cat copies
+ *     at util.py:262, raft.py:66,68,83,86, generator.py:51,60);
+ *   - every function takes the hipStream_t to launch on (as void*), returns 0 on success, non-zero on error;
+ *     mrfa_last_error() returns a thread-local message.  Nothing synchronises the device, nothing allocates.
+ *   - plain pointers and sizes only; no torch types.
+ */
+#ifndef MRFA_HIP_H
+#define MRFA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mrfa_last_error(void);
+int mrfa_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K1/K2/K3/K12: implicit-GEMM convolution / batched NT GEMM on v_mfma_f32_32x32x2_f32.
+ * Replaces F.conv2d at util.py:118,142,144,168,187,206; raft.py:54-58,73-78,123-124,138; generator.py:13,32;
+ * dense_motion.py:22,25; kp_detector.py:29,36 and the einsum/bmm at raft.py:185 (taps=1, nbatch=B).
+ * Also used as the data-gradient conv (weights packed flipped/transposed).                                      */
+typedef struct {
+    const float* x;        /* input NHWC view                                                                   */
+    int ldx;               /* floats between consecutive input pixels                                           */
+    int Hin, Win;          /* stored input spatial size                                                         */
+    int ups;               /* 1: fused nearest x2 upsample of the input (UpBlock2d, util.py:173)                */
+    int N, Cin;
+    const float* w;        /* packed weights, see mrfa_pack_conv_weight                                         */
+    int w_ld;              /* floats between consecutive output-channel rows of the packed weight               */
+    long long w_tap;       /* floats between consecutive taps (chunked mode)                                    */
+    int w_rows;            /* rows present in the packed weight (>= Cout; rows beyond are read as zero)         */
+    float* y;              /* output NHWC view                                                                  */
+    int ldy;
+    int Cout;
+    int Hout, Wout;
+    int R, S, pad;
+    const float* in_scale; /* optional per-Cin affine + ReLU applied to in-bounds inputs (pre-activation BN:    */
+    const float* in_shift; /*   ResBlock2d / ChannelBlock2d, util.py:126-128,150-155)                           */
+    int in_relu;
+    const float* bias;     /* optional per-Cout bias                                                            */
+    const float* out_scale;/* optional per-Cout affine on the output (eval-mode BN folded into the epilogue)    */
+    const float* out_shift;
+    int relu;              /* ReLU on the output                                                                */
+    const float* res;      /* optional residual NHWC view added to the output (ResBlock2d skip, util.py:156)    */
+    int ldr;
+    double* stats;         /* optional [2*Cout] per-channel sum / sum-of-squares of the stored output (BN train) */
+    float alpha;           /* scale on the accumulator before bias (corr volume 1/sqrt(dim), raft.py:185)       */
+    int accumulate;        /* 1: y += result (gradient accumulation)                                            */
+    int nbatch;            /* >1: batched GEMM; x/w/y advance by the strides below per batch                    */
+    long long x_bs, w_bs, y_bs;
+    int splitk;            /* >1: K split over gridDim.z, partial sums atomically added into y (y pre-initialised,
+                              epilogue options other than alpha are ignored)                                    */
+    const int* ktab;       /* flat-K mode (Cin % 32 != 0): table of (dy,dx,ci) per k, see mrfa_build_ktab       */
+    int kflat;             /* R*S*Cin in flat mode, 0 in chunked mode                                           */
+    int tile;              /* 0 = auto; else force a tile config (tests / tuning)                               */
+} mrfa_conv_params;
+
+int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
+
+/* weight-gradient (and TN GEMM): dW[tap][co][ci] += sum_p dY[p][co] * X'[p + tap][ci]   (X' = prologue(ups(x)))
+ * Replaces the weight-gradient half of conv2d backward for every call site above, and d(k_s) of raft.py:185.    */
+typedef struct {
+    const float* x; int ldx; int Hin, Win; int ups; int N, Cin;
+    const float* in_scale; const float* in_shift; int in_relu;
+    const float* dy; int ldy; int Cout; int Hout, Wout;
+    int R, S, pad;
+    float* dw;             /* [taps][Cout][Cin] fp32, accumulated with atomics (caller zero-initialises)         */
+    float* dbias;          /* optional [Cout], accumulated with atomics                                          */
+    float alpha;
+    int nbatch; long long x_bs, dy_bs, dw_bs;
+    int ksplit;            /* 0 = auto: number of pixel-range splits                                            */
+    const int* ktab;       /* flat mode (small / odd Cin): GEMM N axis = taps*Cin gathered through the table      */
+    int kflat;             /* R*S*Cin in flat mode, else 0                                                      */
+} mrfa_wgrad_params;
+
+int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
+
+/* weight (un)packing between the reference's OIHW parameter layout and the kernel layouts.
+ * mode 0: OIHW -> fwd  chunked [tap][CoutPad][CinPad]            (CoutPad % 128 == 0, CinPad % 32 == 0)
+ * mode 1: OIHW -> fwd  flat    [CoutPad][KPad], k = tap*Cin+ci   (KPad % 32 == 0)
+ * mode 2: OIHW -> dgrad chunked [tap'][CinPad128][CoutPad32], tap' = flipped tap (data gradient = conv with
+ *         180-degree rotated, in/out-transposed weights)
+ * mode 3: OIHW -> dgrad flat   [CinPad128][KPad], k = tap'*Cout+co
+ * mode 4: grad [tap][Cout][Cin] -> OIHW, accumulating (dst += src)                                              */
+int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
+/* host-side helper: fills tab[KPad] for flat mode; entry = (dy+128) | (dx+128)<<8 | c<<16, invalid k -> -1      */
+int mrfa_build_ktab(int* tab_host, int C, int R, int S, int pad, int flip);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K5/K6/K7: BatchNorm (train + eval) with fused ReLU / 2x2 avg-pool / occlusion blend.
+ * Replaces batch_norm at util.py:122,146-147,170,189,208, relu, avg_pool2d (util.py:190) and the blend at
+ * generator.py:57.                                                                                              */
+int mrfa_bn_stats(void* stream, const float* x, int ldx, long long rows, int C, double* stats /*[2C] zeroed*/);
+int mrfa_bn_finalize(void* stream, const double* stats, long long count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int C, int train,
+                     float* scale, float* shift, float* mean_out, float* invstd_out);
+typedef struct {
+    const float* x; int ldx; int N, H, W, C;
+    const float* scale; const float* shift; int relu;
+    int pool;                        /* 1: 2x2 average pool after the activation (DownBlock2d)                   */
+    const float* blend_a; int lda;   /* optional: y = a*occ + act(x)*(1-occ)  (generator.py:57)                  */
+    const float* occ; int ldo;       /* occ: one channel per pixel                                               */
+    float* y; int ldy;
+} mrfa_bnact_params;
+int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* p);
+
+typedef struct {
+    const float* x; int ldx; int N, H, W, C;     /* pre-BN activation (saved)                                    */
+    const float* scale; const float* shift; int relu; int pool;
+    const float* mean; const float* invstd; const float* gamma;
+    const float* dy; int lddy;                   /* gradient wrt the op output (pooled size if pool)             */
+    const float* blend_a; int lda; const float* occ; int ldo;
+    float* dblend_a; int ldda;                   /* += dy*occ                                                    */
+    float* docc; int lddo;                       /* += sum_c dy*(a - act)                                        */
+    double* red;                                 /* [2C] zeroed: sum(dz), sum(dz*xhat)                           */
+    float* dx; int lddx;                         /* += BN input gradient                                         */
+    float* dgamma; float* dbeta;                 /* += (phase 2)                                                 */
+    int train;                                   /* 0: eval-mode BN (no batch-statistics terms)                  */
+    int phase;                                   /* 1: reductions, 2: apply                                      */
+} mrfa_bnbwd_params;
+int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K10: bilinear grid_sample, zeros padding, NHWC, channel-vectorised.
+ * mode 0: grid = normalised (x,y) in [-1,1], align_corners=False  (dense_motion.py:83; raft.py:166,168,271)
+ * mode 1: grid = flow (dx,dy) in pixels; sample at (x+dx, y+dy), align_corners=True semantics
+ *         (bilinear_sampler(img, flow+coords_grid), util.py:26-38; raft.py:247,260,302)
+ * grid is (N,Ho,Wo,2) fp32 with leading dimension ldg.  Output image n samples input image n / in_rep (in_rep = 11
+ * for DenseMotion's repeated source, dense_motion.py:80-81, else 1); in_bstride = floats between input images.     */
+int mrfa_grid_sample_fwd(void* stream, const float* in, int ldi, long long in_bstride, int in_rep, int Hi, int Wi, int C,
+                         const float* grid, int ldg, int N, int Ho, int Wo, float* out, int ldo, int mode);
+int mrfa_grid_sample_bwd(void* stream, const float* in, int ldi, long long in_bstride, int in_rep, int Hi, int Wi, int C,
+                         const float* grid, int ldg, int N, int Ho, int Wo, const float* dout, int lddo, int mode,
+                         float* din /*+= atomics, may be null*/, int lddi, long long din_bstride,
+                         float* dgrid /*+= , may be null*/, int lddg);
+
+/* K9: bilinear resize, align_corners=True (F.interpolate, raft.py:161-162,205-206,228,243,266-267,279-295,308)  */
+int mrfa_resize_bilinear_fwd(void* stream, const float* in, int ldi, int N, int Hi, int Wi, int C,
+                             float* out, int ldo, int Ho, int Wo, float scale_mul, int accumulate);
+int mrfa_resize_bilinear_bwd(void* stream, const float* dout, int lddo, int N, int Hi, int Wi, int C,
+                             float* din /*+=*/, int lddi, int Ho, int Wo, float scale_mul);
+
+/* K11/K13: correlation-pyramid window lookup (CorrBlock, raft.py:12-48).  vol0: (N*Q, Hs*Ws) rows, one source map
+ * per query pixel; vol1: the 2x2 source-pooled level (N*Q, Hs/2*Ws/2).  coords (N,h1,w1,2) pixel (x,y) already
+ * multiplied by the level scale.  out (N,h1,w1,2*(2r+1)^2) NHWC; channel = lvl*49 + a*7 + b at (x+a-r, y+b-r).    */
+int mrfa_corr_lookup_fwd(void* stream, const float* vol0, const float* vol1, int Hs, int Ws, const float* coords,
+                         int ldc, long long Q, int radius, float* out, int ldo);
+int mrfa_corr_lookup_bwd(void* stream, const float* vol0, const float* vol1, int Hs, int Ws, const float* coords,
+                         int ldc, long long Q, int radius, const float* dout, int lddo,
+                         float* dvol0 /*+= atomics*/, float* dvol1, float* dcoords /*+=*/, int lddc);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * small layout / elementwise helpers                                                                            */
+int mrfa_nchw_to_nhwc(void* stream, const float* src, float* dst, int ldd, int N, int C, int H, int W, int accumulate);
+int mrfa_nhwc_to_nchw(void* stream, const float* src, int lds, float* dst, int N, int C, int H, int W, int accumulate);
+int mrfa_avgpool2_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, float* y, int ldy);
+int mrfa_sumpool2_acc(void* stream, const float* x, int ldx, int N, int Ho, int Wo, int C, float* y, int ldy, float mul);
+int mrfa_unpool2_acc(void* stream, const float* dy, int lddy, int N, int Ho, int Wo, int C, float* dx, int lddx, float mul);
+/* y = act(x (+ bias)) elementwise on a view; act 0 none, 1 relu, 2 sigmoid; stats optional (BN after split-K)    */
+int mrfa_bias_act(void* stream, const float* x, int ldx, long long rows, int C, const float* bias, int act,
+                  float* y, int ldy, double* stats);
+/* dx += dy * act'(y) ; act 1: (y>0), 2: y*(1-y)                                                                  */
+int mrfa_act_bwd(void* stream, const float* y, int ldy, const float* dy, int lddy, long long rows, int C, int act,
+                 float* dx, int lddx, int accumulate);
+int mrfa_copy_view(void* stream, const float* x, int ldx, long long rows, int C, float* y, int ldy, float mul, int accumulate);
+/* y = a*occ + b*(1-occ) on NHWC views with a 1-channel occ  (generator.py:47,57,63)                              */
+int mrfa_blend_fwd(void* stream, const float* a, int lda, const float* b, int ldb, const float* occ, int ldo,
+                   long long rows, int C, float* y, int ldy);
+int mrfa_blend_bwd(void* stream, const float* a, int lda, const float* b, int ldb, const float* occ, int ldo,
+                   const float* dy, int lddy, long long rows, int C, float* da, int ldda, float* db, int lddb,
+                   float* docc, int lddo);
+/* K18: AntiAliasInterpolation2d (util.py:318-326) computing only the kept outputs: NCHW in -> NHWC out           */
+int mrfa_antialias_down(void* stream, const float* x_nchw, int N, int C, int H, int W, const float* kern, int k,
+                        int stride, float* y, int ldy);
+int mrfa_colsum(void* stream, const float* x, int ldx, long long rows, int C, float* out /*+=*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+// Shared helpers for the gfx950 kernels of libmrfa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "mrfa_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void mrfa_set_error(const char* fmt, ...);
+
+#define MRFA_CHECK_ARG(cond, ...)                      \
+    do {                                               \
+        if (!(cond)) {                                 \
+            mrfa_set_error(__VA_ARGS__);               \
+            return 1;                                  \
+        }                                              \
+    } while (0)
+
+#define MRFA_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            mrfa_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// grid size for streaming (HBM-bound) kernels: enough workgroups to fill 256 CUs x 8, grid-stride the rest
+static inline int stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

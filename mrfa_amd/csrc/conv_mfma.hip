@@ -1,0 +1,380 @@
+// Implicit-GEMM convolution / batched NT GEMM on the CDNA4 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+//   out[p, co] = alpha * sum_{r,s,ci} in'[pix(p)+(r,s)-pad, ci] * W[co, r, s, ci]   (+bias, affine, ReLU, residual)
+//
+// GEMM view: M = N*Hout*Wout output pixels, N = Cout, K = R*S*Cin.  NHWC activations make K (channels) the
+// contiguous axis of both operands, so both tiles are staged in LDS as [row][k] (k contiguous, row stride 36
+// floats = conflict-free for ds_read_b128) and every lane fetches FOUR consecutive k of its MFMA row with one
+// ds_read_b128: lane l (row i = l&31, half h = l>>5) reads k = 8q+4h..8q+4h+3 and feeds them to four successive
+// 32x32x2 MFMAs; A and B use the same k permutation, so the sum over k is complete and exact fp32 FMA chains.
+//
+// 256 threads = 4 wave64 per workgroup; block tile BM x BN (128x128 default: each wave owns a 64x64 sub-tile =
+// 2x2 MFMA tiles = 64 accumulator VGPRs), BK = 32, register-staged double-buffered LDS, one barrier per k-tile.
+// fp32 MFMA issues once per 64 cycles per SIMD and needs only 2 operand floats per lane per issue, so this kernel
+// is bounded by the matrix pipe (157.3 TF/s peak), not by LDS or L2: per k-tile a workgroup moves 32 KiB from L2
+// and spends 64 MFMAs x 64 cycles = 4096 cycles per wave on it (8 B/cycle/CU).
+//
+// Reference call sites replaced: every F.conv2d on the hot path (see include/mrfa_hip.h) and the all-pairs
+// correlation einsum (modules/raft.py:185).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;   // 36 floats = 144 B row stride: 16-B slots (9*i + h) mod 16 are distinct per lane group
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split,
+                                                       const long long M, const int tiles_n) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    constexpr int RA = BM / 32;   // float4 global loads per thread per k-tile (A)
+    constexpr int RB = BN / 32;   // (B)
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(TM >= 1 && TN >= 1, "tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+
+    const float* __restrict__ x = p.x + (size_t)bz * p.x_bs;
+    const float* __restrict__ w = p.w + (size_t)bz * p.w_bs;
+    float* __restrict__ y = p.y + (size_t)bz * p.y_bs;
+
+    const int lrow = tid >> 3;   // 0..31
+    const int kq = tid & 7;      // which float4 of the 32-wide k-tile
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    const int HWo = p.Hout * p.Wout;
+    const int KC = FLAT ? 1 : (p.Cin >> 5);
+
+    int a_oy[RA], a_ox[RA], a_base[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const long long m = m0 + lrow + 32 * j;
+        a_ok[j] = m < M;
+        const long long mm = a_ok[j] ? m : 0;
+        const int n_img = (int)(mm / HWo);
+        const int rem = (int)(mm - (long long)n_img * HWo);
+        a_oy[j] = rem / p.Wout;
+        a_ox[j] = rem - a_oy[j] * p.Wout;
+        a_base[j] = n_img * p.Hin * p.Win;
+    }
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) b_ok[j] = (n0 + lrow + 32 * j) < p.w_rows;
+
+    f32x4 ra[RA], rb[RB];
+
+    auto load_tiles = [&](int kt) {
+        if constexpr (!FLAT) {
+            const int tap = kt / KC;
+            const int c0 = (kt - tap * KC) * 32 + kq * 4;
+            const int r = tap / p.S;
+            const int s = tap - r * p.S;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.in_scale) {
+                sc = *reinterpret_cast<const f32x4*>(p.in_scale + c0);
+                sh = *reinterpret_cast<const f32x4*>(p.in_shift + c0);
+            }
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const int iy = a_oy[j] + r - p.pad;
+                const int ix = a_ox[j] + s - p.pad;
+                const bool inb = a_ok[j] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (inb) {
+                    const size_t pix = (size_t)(a_base[j] + (iy >> p.ups) * p.Win + (ix >> p.ups));
+                    v = *reinterpret_cast<const f32x4*>(x + pix * p.ldx + c0);
+                    if (p.in_scale) {
+                        v = v * sc + sh;
+                        if (p.in_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                }
+                ra[j] = v;
+            }
+            const float* wt = w + (size_t)tap * p.w_tap + c0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(wt + (size_t)(n0 + lrow + 32 * j) * p.w_ld);
+                rb[j] = v;
+            }
+        } else {
+            const int k0 = kt * 32 + kq * 4;
+            const int4 ent = *reinterpret_cast<const int4*>(p.ktab + k0);
+            const int e[4] = {ent.x, ent.y, ent.z, ent.w};
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                float vv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = 0.f;
+                    if (e[q] >= 0 && a_ok[j]) {
+                        const int dy = (e[q] & 255) - 128, dx = ((e[q] >> 8) & 255) - 128, ci = e[q] >> 16;
+                        const int iy = a_oy[j] + dy, ix = a_ox[j] + dx;
+                        if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv) {
+                            const size_t pix = (size_t)(a_base[j] + (iy >> p.ups) * p.Win + (ix >> p.ups));
+                            v = x[pix * p.ldx + ci];
+                            if (p.in_scale) {
+                                v = v * p.in_scale[ci] + p.in_shift[ci];
+                                if (p.in_relu) v = fmaxf(v, 0.f);
+                            }
+                        }
+                    }
+                    vv[q] = v;
+                }
+                ra[j] = f32x4{vv[0], vv[1], vv[2], vv[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(w + (size_t)(n0 + lrow + 32 * j) * p.w_ld + k0);
+                rb[j] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * LDK;
+        float* Bs = As + BM * LDK;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDK + kq * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDK + kq * 4) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kt_begin = blockIdx.z * kt_per_split;
+    const int kt_end = min(KT, kt_begin + kt_per_split);
+
+    if (kt_begin < kt_end) {
+        load_tiles(kt_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tiles(kt + 1);
+        const float* As = smem + cur * (BM + BN) * LDK + (wm * TM * 32 + frag_row) * LDK + frag_k;
+        const float* Bs = smem + cur * (BM + BN) * LDK + BM * LDK + (wn * TN * 32 + frag_row) * LDK + frag_k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + q * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int half = lane >> 5;
+    const bool splitk = p.splitk > 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool c_ok = c < p.Cout;
+        float bias = 0.f, osc = 1.f, osh = 0.f;
+        if (c_ok && !splitk) {
+            if (p.bias) bias = p.bias[c];
+            if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c_ok && m < M) {
+                    float v = acc[i][j][r] * p.alpha;
+                    float* dst = y + (size_t)m * p.ldy + c;
+                    if (splitk) {
+                        atomicAdd(dst, v);
+                    } else {
+                        v += bias;
+                        v = v * osc + osh;
+                        if (p.res) v += p.res[(size_t)m * p.ldr + c];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+            }
+        }
+        if (p.stats && !splitk) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (half == 0 && c_ok) {
+                atomicAdd(p.stats + c, (double)s1);
+                atomicAdd(p.stats + p.Cout + c, (double)s2);
+            }
+        }
+    }
+}
+
+// y = bias (or 0) broadcast: initialises the output of a split-K launch
+__global__ void splitk_init_kernel(float* y, int ldy, long long rows, int C, const float* bias) {
+    const long long total = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        y[(size_t)r * ldy + c] = bias ? bias[c] : 0.f;
+    }
+}
+
+// second pass of a split-K launch: affine / residual / ReLU / BN statistics on the summed output
+__global__ void splitk_epilogue_kernel(float* y, int ldy, long long rows, int C, const float* osc, const float* osh,
+                                       const float* res, int ldr, int relu, double* stats) {
+    // one thread per channel-column chunk; rows strided over blockIdx.y so statistics reduce per thread first
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = osc ? osc[c] : 1.f, sh = osh ? osh[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+        float v = y[(size_t)r * ldy + c] * sc + sh;
+        if (res) v += res[(size_t)r * ldr + c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)r * ldy + c] = v;
+        s1 += v;
+        s2 += v * v;
+    }
+    if (stats) {
+        atomicAdd(stats + c, (double)s1);
+        atomicAdd(stats + C + c, (double)s2);
+    }
+}
+
+template <int BM, int BN, int WM_, int WN_>
+int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk) {
+    const int tiles_n = cdiv(p.Cout, BN);
+    const long long tiles_m = (M + BM - 1) / BM;
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)(p.nbatch > 1 ? p.nbatch : 1), (unsigned)splitk);
+    const int kps = cdiv(KT, splitk);
+    mrfa_conv_params q = p;
+    q.splitk = splitk;
+    if (p.kflat > 0)
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, true>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, false>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n);
+    MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
+    const mrfa_conv_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    MRFA_CHECK_ARG(p.x && p.w && p.y, "conv2d: null pointer");
+    MRFA_CHECK_ARG(p.N > 0 && p.Cin > 0 && p.Cout > 0 && p.Hout > 0 && p.Wout > 0, "conv2d: bad sizes");
+    MRFA_CHECK_ARG(p.R >= 1 && p.S >= 1 && p.R <= 15 && p.S <= 15, "conv2d: kernel size %dx%d unsupported", p.R, p.S);
+    MRFA_CHECK_ARG((p.w_ld % 4) == 0 && aligned16(p.w), "conv2d: packed weight must be 16-B aligned, w_ld %% 4 == 0");
+    const bool flat = p.kflat > 0;
+    if (!flat) {
+        MRFA_CHECK_ARG((p.Cin % 32) == 0, "conv2d: chunked mode needs Cin %% 32 == 0 (got %d); use flat mode", p.Cin);
+        MRFA_CHECK_ARG((p.ldx % 4) == 0 && aligned16(p.x), "conv2d: chunked mode needs 16-B aligned x and ldx %% 4 == 0");
+        if (p.in_scale) MRFA_CHECK_ARG(aligned16(p.in_scale) && aligned16(p.in_shift), "conv2d: in_scale/in_shift alignment");
+    } else {
+        MRFA_CHECK_ARG(p.ktab != nullptr && aligned16(p.ktab), "conv2d: flat mode needs a 16-B aligned ktab");
+    }
+    const long long M = (long long)p.N * p.Hout * p.Wout;
+    const int Ktot = flat ? p.kflat : p.R * p.S * p.Cin;
+    const int KT = (Ktot + BK - 1) / BK;
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+
+    // ---- tile selection: largest BN whose padding waste is small, then BM by how many workgroups result
+    int BN = 128;
+    {
+        const int cands[3] = {128, 64, 32};
+        double best = 1e9;
+        for (int i = 0; i < 3; ++i) {
+            const double waste = (double)cdiv(p.Cout, cands[i]) * cands[i] / p.Cout;
+            if (waste < best - 0.07) { best = waste; BN = cands[i]; }
+        }
+    }
+    auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * cdiv(p.Cout, bn) * nb; };
+    int BM = 128;
+    if (BN == 128) {
+        if (ntiles(128, 128) < 384) BM = 64;
+        if (ntiles(64, 128) < 384) BM = 32;
+    } else if (BN == 64) {
+        if (ntiles(128, 64) < 384) BM = 64;
+    }
+    if (p.tile) { BM = p.tile >> 16; BN = p.tile & 0xffff; }
+
+    int splitk = 1;
+    if (p.splitk > 1) {
+        splitk = p.splitk;
+    } else if (p.splitk == 0) {
+        const long long t = ntiles(BM, BN);
+        if (t < 192 && KT >= 8) {
+            splitk = (int)((512 + t - 1) / t);
+            if (splitk > KT / 4) splitk = KT / 4;
+            if (splitk < 1) splitk = 1;
+        }
+    }
+    if (splitk > 1) {
+        if (!p.accumulate) {
+            const long long rows = M * nb;
+            MRFA_CHECK_ARG(nb == 1 || p.y_bs == (long long)M * p.ldy, "conv2d: split-K batched output must be dense");
+            hipLaunchKernelGGL(splitk_init_kernel, dim3(stream_grid(rows * p.Cout, 256)), dim3(256), 0, st, p.y, p.ldy, rows,
+                               p.Cout, p.bias);
+            MRFA_CHECK_LAUNCH("splitk_init");
+        }
+    }
+    int rc = 1;
+#define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
+    CFG(128, 128, 2, 2);
+    else CFG(128, 64, 2, 2);
+    else CFG(128, 32, 4, 1);
+    else CFG(64, 128, 2, 2);
+    else CFG(64, 64, 2, 2);
+    else CFG(32, 128, 1, 4);
+    else { mrfa_set_error("conv2d: no tile config %dx%d", BM, BN); return 1; }
+#undef CFG
+    if (rc) return rc;
+    if (splitk > 1 && (p.relu || p.stats || p.out_scale || p.res)) {
+        MRFA_CHECK_ARG(!p.accumulate, "conv2d: split-K with accumulate cannot apply an epilogue");
+        const long long rows = M * nb;
+        dim3 grid(cdiv(p.Cout, 64), (unsigned)(rows < 256 ? rows : 256));
+        hipLaunchKernelGGL(splitk_epilogue_kernel, grid, dim3(64), 0, st, p.y, p.ldy, rows, p.Cout, p.out_scale, p.out_shift,
+                           p.res, p.ldr, p.relu, p.stats);
+        MRFA_CHECK_LAUNCH("splitk_epilogue");
+    }
+    return 0;
+}

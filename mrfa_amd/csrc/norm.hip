@@ -1,0 +1,258 @@
+// BatchNorm2d (train + eval) on NHWC views, fused with ReLU, the DownBlock 2x2 average pool and the generator's
+// occlusion blend.  HBM-bound: every kernel streams the activation once with 64 consecutive channels per wave
+// (256-B coalesced rows) and reduces per-channel statistics with per-thread partial sums -> LDS -> one fp64 atomic per
+// channel per workgroup.  Replaces aten::batch_norm / relu / avg_pool2d at modules/util.py:122,146-147,170,189-190,208
+// and the blend at modules/generator.py:57, forward and backward.
+#include "common.h"
+
+namespace {
+
+constexpr int CH = 64;        // channels per workgroup (one per lane)
+constexpr int NW = 4;         // waves per workgroup, each walks its own rows
+
+// ---------------------------------------------------------------------------------------------- statistics
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int ldx, long long rows, int C,
+                                                      double* __restrict__ stats, int rows_per_block) {
+    __shared__ float red[2][NW][CH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * CH + lane;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        for (long long r = r0 + wave; r < r1; r += NW) {
+            const float v = x[(size_t)r * ldx + c];
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    red[0][wave][lane] = s1;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < NW; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
+        atomicAdd(stats + c, a);
+        atomicAdd(stats + C + c, b);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float momentum, float eps, int C, int train, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, invstd;
+    if (train) {
+        const double m = stats[c] / (double)count;
+        double var = stats[C + c] / (double)count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    } else {
+        mean = rmean[c];
+        invstd = 1.0f / sqrtf(rvar[c] + eps);
+    }
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (mean_out) mean_out[c] = mean;
+    if (invstd_out) invstd_out[c] = invstd;
+}
+
+// ---------------------------------------------------------------------------------------------- forward apply
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params p, long long total) {
+    const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long opix = i / p.C;
+        const int c = (int)(i - opix * p.C);
+        const float sc = p.scale[c], sh = p.shift[c];
+        float v;
+        if (!p.pool) {
+            v = p.x[(size_t)opix * p.ldx + c] * sc + sh;
+            if (p.relu) v = fmaxf(v, 0.f);
+        } else {
+            const int ox = (int)(opix % Wo);
+            const long long t = opix / Wo;
+            const int oy = (int)(t % Ho);
+            const long long n = t / Ho;
+            const size_t base = ((size_t)n * p.H + 2 * oy) * p.W + 2 * ox;
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u = p.x[(base + (q >> 1) * p.W + (q & 1)) * p.ldx + c] * sc + sh;
+                if (p.relu) u = fmaxf(u, 0.f);
+                a += u;
+            }
+            v = 0.25f * a;
+        }
+        if (p.blend_a) {
+            const float o = p.occ[(size_t)opix * p.ldo];
+            v = p.blend_a[(size_t)opix * p.lda + c] * o + v * (1.f - o);
+        }
+        p.y[(size_t)opix * p.ldy + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// u = x*scale+shift ; a = relu(u) ; out = pool(a) or blend(A, a, occ).  PHASE 1: per-channel sum(du), sum(du*xhat),
+// plus dA / docc of the blend.  PHASE 2: dx += gamma*invstd*(du - mean(du) - xhat*mean(du*xhat)) (train) or du*scale.
+template <int PHASE>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+    __shared__ float red[2][NW][CH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * CH + lane;
+    const bool c_ok = c < p.C;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    const int Wo = p.W / 2, Ho = p.H / 2;
+    float sc = 0.f, sh = 0.f, mean = 0.f, invstd = 0.f, k1 = 0.f, k2 = 0.f, gi = 0.f;
+    if (c_ok) {
+        sc = p.scale[c]; sh = p.shift[c];
+        if (p.mean) { mean = p.mean[c]; invstd = p.invstd[c]; }
+        if (PHASE == 2 && p.train) {
+            const double cnt = (double)rows;
+            k1 = (float)(p.red[c] / cnt);
+            k2 = (float)(p.red[p.C + c] / cnt);
+            gi = p.gamma[c] * invstd;
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (long long r = r0 + wave; r < r1; r += NW) {
+        // r indexes INPUT pixels (full resolution)
+        long long opix = r;
+        float gmul = 1.f;
+        if (p.pool) {
+            const int xx = (int)(r % p.W);
+            const long long t = r / p.W;
+            const int yy = (int)(t % p.H);
+            const long long n = t / p.H;
+            opix = ((long long)n * Ho + (yy >> 1)) * Wo + (xx >> 1);
+            gmul = 0.25f;
+        }
+        float du = 0.f, xv = 0.f, docc_part = 0.f;
+        if (c_ok) {
+            xv = p.x[(size_t)r * p.ldx + c];
+            const float u = xv * sc + sh;
+            const float a = p.relu ? fmaxf(u, 0.f) : u;
+            float da = p.dy[(size_t)opix * p.lddy + c] * gmul;
+            if (p.blend_a) {
+                const float o = p.occ[(size_t)opix * p.ldo];
+                if (PHASE == 1) {
+                    const float A = p.blend_a[(size_t)opix * p.lda + c];
+                    if (p.dblend_a) p.dblend_a[(size_t)opix * p.ldda + c] += da * o;
+                    docc_part = da * (A - a);
+                }
+                da *= (1.f - o);
+            }
+            du = (p.relu && u <= 0.f) ? 0.f : da;
+        }
+        if (PHASE == 1) {
+            if (p.blend_a && p.docc) {
+                const float t = wave_sum(docc_part);
+                if (lane == 0) atomicAdd(p.docc + (size_t)opix * p.lddo, t);
+            }
+            if (c_ok) {
+                s1 += du;
+                s2 += du * (xv - mean) * invstd;
+            }
+        } else if (c_ok) {
+            float dx;
+            if (p.train) dx = gi * (du - k1 - (xv - mean) * invstd * k2);
+            else dx = du * sc;
+            p.dx[(size_t)r * p.lddx + c] += dx;
+        }
+    }
+    if (PHASE == 1) {
+        red[0][wave][lane] = s1;
+        red[1][wave][lane] = s2;
+        __syncthreads();
+        if (wave == 0 && c_ok) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < NW; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
+            atomicAdd(p.red + c, a);
+            atomicAdd(p.red + p.C + c, b);
+        }
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                     int train, const float* __restrict__ rmean, const float* __restrict__ rvar, float eps) {
+    // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] += (float)red[c];
+    if (dgamma) dgamma[c] += (float)red[C + c];
+}
+
+static int pick_rows_per_block(long long rows, int chunks) {
+    // aim for ~2048 workgroups, at least 64 rows each
+    long long want = (2048 + chunks - 1) / chunks;
+    long long rpb = (rows + want - 1) / want;
+    if (rpb < 64) rpb = 64;
+    if (rpb > 4096) rpb = 4096;
+    return (int)rpb;
+}
+
+}  // namespace
+
+extern "C" int mrfa_bn_stats(void* stream, const float* x, int ldx, long long rows, int C, double* stats) {
+    MRFA_CHECK_ARG(x && stats && rows > 0 && C > 0, "bn_stats: bad args");
+    const int chunks = cdiv(C, CH);
+    const int rpb = pick_rows_per_block(rows, chunks);
+    dim3 grid(chunks, cdiv(rows, rpb));
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C, stats, rpb);
+    MRFA_CHECK_LAUNCH("bn_stats");
+    return 0;
+}
+
+extern "C" int mrfa_bn_finalize(void* stream, const double* stats, long long count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int C, int train,
+                                float* scale, float* shift, float* mean_out, float* invstd_out) {
+    MRFA_CHECK_ARG(gamma && beta && scale && shift && C > 0, "bn_finalize: bad args");
+    MRFA_CHECK_ARG(train ? stats != nullptr : (running_mean && running_var), "bn_finalize: missing statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, C, train, scale, shift, mean_out, invstd_out);
+    MRFA_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* pp) {
+    const mrfa_bnact_params& p = *pp;
+    MRFA_CHECK_ARG(p.x && p.y && p.scale && p.shift, "bn_act_fwd: null pointer");
+    MRFA_CHECK_ARG(!p.pool || ((p.H % 2) == 0 && (p.W % 2) == 0), "bn_act_fwd: pool needs even H,W");
+    MRFA_CHECK_ARG(!(p.pool && p.blend_a), "bn_act_fwd: pool and blend are exclusive");
+    const long long opix = (long long)p.N * (p.pool ? p.H / 2 : p.H) * (p.pool ? p.W / 2 : p.W);
+    const long long total = opix * p.C;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p, total);
+    MRFA_CHECK_LAUNCH("bn_act_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
+    const mrfa_bnbwd_params& p = *pp;
+    MRFA_CHECK_ARG(p.x && p.dy && p.scale && p.shift && p.red, "bn_act_bwd: null pointer");
+    MRFA_CHECK_ARG(!p.train || (p.mean && p.invstd && p.gamma), "bn_act_bwd: train mode needs mean/invstd/gamma");
+    const long long rows = (long long)p.N * p.H * p.W;
+    const int chunks = cdiv(p.C, CH);
+    const int rpb = pick_rows_per_block(rows, chunks);
+    dim3 grid(chunks, cdiv(rows, rpb));
+    if (p.phase == 1) {
+        hipLaunchKernelGGL((bn_act_bwd_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
+    } else {
+        MRFA_CHECK_ARG(p.dx != nullptr, "bn_act_bwd: phase 2 needs dx");
+        hipLaunchKernelGGL((bn_act_bwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
+        if (p.dgamma || p.dbeta) {
+            hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(p.C, 256)), dim3(256), 0, (hipStream_t)stream, p.red, p.dgamma, p.dbeta,
+                               p.C, p.train, nullptr, nullptr, 0.f);
+        }
+    }
+    MRFA_CHECK_LAUNCH("bn_act_bwd");
+    return 0;
+}

@@ -1,0 +1,312 @@
+// Gather kernels of the MRFA hot path on NHWC views: bilinear grid_sample (both coordinate conventions the reference
+// uses), align_corners=True bilinear resize, and the correlation-pyramid window lookup.  All HBM/L2-bound gathers:
+// one thread per (output pixel, channel) with channels fastest so every bilinear tap is a contiguous 4*C-byte read
+// (the NCHW reference gathers one 4-byte element per tap per channel plane).
+// Replaces aten::grid_sampler_2d (+backward) at modules/util.py:34, dense_motion.py:83, raft.py:166,168,247,260,271,302,
+// aten::upsample_bilinear2d (+backward) at raft.py:161-162,205-206,228,243,266-267,279-295,308 and CorrBlock.__call__
+// (raft.py:23-48) including its avg_pool2d pyramid (raft.py:20) and the two 64 MiB/sample transposes (raft.py:208,235).
+#include "common.h"
+
+namespace {
+
+struct Taps {
+    int x0, y0;
+    float fx, fy;   // fractional parts; tap weights (1-fx)(1-fy) etc.
+};
+
+__device__ __forceinline__ Taps make_taps(float ix, float iy) {
+    Taps t;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    t.x0 = (int)fx0;
+    t.y0 = (int)fy0;
+    t.fx = ix - fx0;
+    t.fy = iy - fy0;
+    return t;
+}
+
+__device__ __forceinline__ void sample_coords(const float* __restrict__ grid, int ldg, long long opix, int ox, int oy, int Wi, int Hi,
+                                              int mode, float& ix, float& iy) {
+    const float gx = grid[(size_t)opix * ldg], gy = grid[(size_t)opix * ldg + 1];
+    if (mode == 0) {   // normalised, align_corners=False
+        ix = ((gx + 1.f) * (float)Wi - 1.f) * 0.5f;
+        iy = ((gy + 1.f) * (float)Hi - 1.f) * 0.5f;
+    } else {           // flow in pixels added to the identity grid, align_corners=True
+        ix = (float)ox + gx;
+        iy = (float)oy + gy;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __restrict__ in, int ldi, long long in_bstride, int in_rep,
+                                                             int Hi, int Wi, int C, const float* __restrict__ grid, int ldg, int N,
+                                                             int Ho, int Wo, float* __restrict__ out, int ldo, int mode, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long opix = i / C;
+        const int c = (int)(i - opix * C);
+        const int ox = (int)(opix % Wo);
+        const long long t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float ix, iy;
+        sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
+        float v = 0.f;
+        // NaN / huge coordinates fall through the bounds tests as "outside"
+        if (ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi) {
+            const Taps tp = make_taps(ix, iy);
+            const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
+            const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
+            const float w00 = (1.f - tp.fx) * (1.f - tp.fy), w01 = tp.fx * (1.f - tp.fy), w10 = (1.f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+            if (y0ok && x0ok) v += w00 * base[((size_t)tp.y0 * Wi + tp.x0) * ldi];
+            if (y0ok && x1ok) v += w01 * base[((size_t)tp.y0 * Wi + tp.x0 + 1) * ldi];
+            if (y1ok && x0ok) v += w10 * base[((size_t)(tp.y0 + 1) * Wi + tp.x0) * ldi];
+            if (y1ok && x1ok) v += w11 * base[((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * ldi];
+        }
+        out[(size_t)opix * ldo + c] = v;
+    }
+}
+
+// one wave per output pixel chunk of 64 channels: lanes = channels, so d(grid) reduces with wave shuffles
+__global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __restrict__ in, int ldi, long long in_bstride, int in_rep,
+                                                             int Hi, int Wi, int C, const float* __restrict__ grid, int ldg,
+                                                             long long npix, int Ho, int Wo, const float* __restrict__ dout, int lddo,
+                                                             int mode, float* __restrict__ din, int lddi, long long din_bstride,
+                                                             float* __restrict__ dgrid, int lddg) {
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int chunks = (C + 63) / 64;
+    for (long long wi = wave_id; wi < npix * chunks; wi += nwaves) {
+        const long long opix = wi / chunks;
+        const int c = (int)(wi - opix * chunks) * 64 + lane;
+        const bool c_ok = c < C;
+        const int ox = (int)(opix % Wo);
+        const long long t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float ix, iy;
+        sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
+        float gxs = 0.f, gys = 0.f;
+        if (ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi) {     // wave-uniform
+            const Taps tp = make_taps(ix, iy);
+            const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
+            const float g = c_ok ? dout[(size_t)opix * lddo + c] : 0.f;
+            const size_t ib = (size_t)(n / in_rep) * in_bstride + c;
+            float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+            if (c_ok) {
+                if (y0ok && x0ok) v00 = in[ib + ((size_t)tp.y0 * Wi + tp.x0) * ldi];
+                if (y0ok && x1ok) v01 = in[ib + ((size_t)tp.y0 * Wi + tp.x0 + 1) * ldi];
+                if (y1ok && x0ok) v10 = in[ib + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * ldi];
+                if (y1ok && x1ok) v11 = in[ib + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * ldi];
+            }
+            if (din && c_ok) {
+                float* db = din + (size_t)(n / in_rep) * din_bstride + c;
+                if (y0ok && x0ok) atomicAdd(db + ((size_t)tp.y0 * Wi + tp.x0) * lddi, g * (1.f - tp.fx) * (1.f - tp.fy));
+                if (y0ok && x1ok) atomicAdd(db + ((size_t)tp.y0 * Wi + tp.x0 + 1) * lddi, g * tp.fx * (1.f - tp.fy));
+                if (y1ok && x0ok) atomicAdd(db + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * lddi, g * (1.f - tp.fx) * tp.fy);
+                if (y1ok && x1ok) atomicAdd(db + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * lddi, g * tp.fx * tp.fy);
+            }
+            // d val / d ix = (v01 - v00)(1-fy) + (v11 - v10) fy ; d val / d iy = (v10 - v00)(1-fx) + (v11 - v01) fx
+            gxs = g * ((v01 - v00) * (1.f - tp.fy) + (v11 - v10) * tp.fy);
+            gys = g * ((v10 - v00) * (1.f - tp.fx) + (v11 - v01) * tp.fx);
+        }
+        if (dgrid) {
+            gxs = wave_sum(gxs);
+            gys = wave_sum(gys);
+            if (lane == 0) {
+                const float mx = mode == 0 ? 0.5f * (float)Wi : 1.f, my = mode == 0 ? 0.5f * (float)Hi : 1.f;
+                if (chunks == 1) {
+                    dgrid[(size_t)opix * lddg] += gxs * mx;
+                    dgrid[(size_t)opix * lddg + 1] += gys * my;
+                } else {
+                    atomicAdd(dgrid + (size_t)opix * lddg, gxs * mx);
+                    atomicAdd(dgrid + (size_t)opix * lddg + 1, gys * my);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- bilinear resize (ac=True)
+__device__ __forceinline__ void resize_src(int o, int Ni, int No, int& i0, int& i1, float& f) {
+    const float s = No > 1 ? (float)(Ni - 1) / (float)(No - 1) : 0.f;
+    const float src = s * (float)o;
+    i0 = (int)src;                      // src >= 0
+    if (i0 > Ni - 1) i0 = Ni - 1;
+    i1 = i0 + (i0 < Ni - 1 ? 1 : 0);
+    f = src - (float)i0;
+}
+
+__global__ void resize_fwd_kernel(const float* __restrict__ in, int ldi, int N, int Hi, int Wi, int C, float* __restrict__ out, int ldo,
+                                  int Ho, int Wo, float mul, int acc, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long opix = i / C;
+        const int c = (int)(i - opix * C);
+        const int ox = (int)(opix % Wo);
+        const long long t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const long long n = t / Ho;
+        int x0, x1, y0, y1;
+        float fx, fy;
+        resize_src(ox, Wi, Wo, x0, x1, fx);
+        resize_src(oy, Hi, Ho, y0, y1, fy);
+        const float* b = in + (size_t)n * Hi * Wi * ldi + c;
+        const float top = b[((size_t)y0 * Wi + x0) * ldi] * (1.f - fx) + b[((size_t)y0 * Wi + x1) * ldi] * fx;
+        const float bot = b[((size_t)y1 * Wi + x0) * ldi] * (1.f - fx) + b[((size_t)y1 * Wi + x1) * ldi] * fx;
+        const float v = (top * (1.f - fy) + bot * fy) * mul;
+        float* d = out + (size_t)opix * ldo + c;
+        *d = acc ? (*d + v) : v;
+    }
+}
+
+__global__ void resize_bwd_kernel(const float* __restrict__ dout, int lddo, int N, int Hi, int Wi, int C, float* __restrict__ din,
+                                  int lddi, int Ho, int Wo, float mul, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long opix = i / C;
+        const int c = (int)(i - opix * C);
+        const int ox = (int)(opix % Wo);
+        const long long t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const long long n = t / Ho;
+        int x0, x1, y0, y1;
+        float fx, fy;
+        resize_src(ox, Wi, Wo, x0, x1, fx);
+        resize_src(oy, Hi, Ho, y0, y1, fy);
+        const float g = dout[(size_t)opix * lddo + c] * mul;
+        float* b = din + (size_t)n * Hi * Wi * lddi + c;
+        atomicAdd(b + ((size_t)y0 * Wi + x0) * lddi, g * (1.f - fx) * (1.f - fy));
+        atomicAdd(b + ((size_t)y0 * Wi + x1) * lddi, g * fx * (1.f - fy));
+        atomicAdd(b + ((size_t)y1 * Wi + x0) * lddi, g * (1.f - fx) * fy);
+        atomicAdd(b + ((size_t)y1 * Wi + x1) * lddi, g * fx * fy);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- correlation window lookup
+// One wave per query pixel.  Lane e < (2r+1)^2 owns window element (a,b) = (e / (2r+1), e % (2r+1)) sampled at
+// (x + a - r, y + b - r) on its level's source map; all 49 lanes share the fractional offsets, so the wave touches an
+// 8x8 block of the 16 KiB map row (L2/L1 resident).  Channel order of the reference: lvl*49 + a*7 + b (raft.py:31-37).
+template <bool BWD>
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ vol0, const float* __restrict__ vol1, int Hs, int Ws,
+                                                         const float* __restrict__ coords, int ldc, long long Q, int radius,
+                                                         float* __restrict__ out, int ldo, const float* __restrict__ dout, int lddo,
+                                                         float* __restrict__ dvol0, float* __restrict__ dvol1,
+                                                         float* __restrict__ dcoords, int lddc) {
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int win = 2 * radius + 1, nwin = win * win;
+    const int a = lane / win, b = lane - a * win;
+    for (long long q = wave_id; q < Q; q += nwaves) {
+        const float cx = coords[(size_t)q * ldc], cy = coords[(size_t)q * ldc + 1];
+        float gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            const int H = Hs >> lvl, W = Ws >> lvl;
+            const float* vol = (lvl == 0 ? vol0 : vol1) + (size_t)q * H * W;
+            float* dvol = BWD ? ((lvl == 0 ? dvol0 : dvol1) + (size_t)q * H * W) : nullptr;
+            const float inv = lvl == 0 ? 1.f : 0.5f;
+            const float ix = cx * inv + (float)(a - radius), iy = cy * inv + (float)(b - radius);
+            float v = 0.f, dx = 0.f, dy = 0.f;
+            const bool active = lane < nwin;
+            if (active && ix > -1.f && iy > -1.f && ix < (float)W && iy < (float)H) {
+                const Taps tp = make_taps(ix, iy);
+                const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < W, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < H;
+                const float v00 = (y0ok && x0ok) ? vol[tp.y0 * W + tp.x0] : 0.f;
+                const float v01 = (y0ok && x1ok) ? vol[tp.y0 * W + tp.x0 + 1] : 0.f;
+                const float v10 = (y1ok && x0ok) ? vol[(tp.y0 + 1) * W + tp.x0] : 0.f;
+                const float v11 = (y1ok && x1ok) ? vol[(tp.y0 + 1) * W + tp.x0 + 1] : 0.f;
+                if (!BWD) {
+                    v = v00 * (1.f - tp.fx) * (1.f - tp.fy) + v01 * tp.fx * (1.f - tp.fy) + v10 * (1.f - tp.fx) * tp.fy + v11 * tp.fx * tp.fy;
+                } else {
+                    const float g = dout[(size_t)q * lddo + lvl * nwin + lane];
+                    if (dvol) {
+                        if (y0ok && x0ok) atomicAdd(dvol + tp.y0 * W + tp.x0, g * (1.f - tp.fx) * (1.f - tp.fy));
+                        if (y0ok && x1ok) atomicAdd(dvol + tp.y0 * W + tp.x0 + 1, g * tp.fx * (1.f - tp.fy));
+                        if (y1ok && x0ok) atomicAdd(dvol + (tp.y0 + 1) * W + tp.x0, g * (1.f - tp.fx) * tp.fy);
+                        if (y1ok && x1ok) atomicAdd(dvol + (tp.y0 + 1) * W + tp.x0 + 1, g * tp.fx * tp.fy);
+                    }
+                    dx = g * ((v01 - v00) * (1.f - tp.fy) + (v11 - v10) * tp.fy) * inv;
+                    dy = g * ((v10 - v00) * (1.f - tp.fx) + (v11 - v01) * tp.fx) * inv;
+                }
+            }
+            if (!BWD) {
+                if (active) out[(size_t)q * ldo + lvl * nwin + lane] = v;
+            } else {
+                gx += dx;
+                gy += dy;
+            }
+        }
+        if (BWD && dcoords) {
+            gx = wave_sum(gx);
+            gy = wave_sum(gy);
+            if (lane == 0) {
+                dcoords[(size_t)q * lddc] += gx;
+                dcoords[(size_t)q * lddc + 1] += gy;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mrfa_grid_sample_fwd(void* stream, const float* in, int ldi, long long in_bstride, int in_rep, int Hi, int Wi, int C,
+                                    const float* grid, int ldg, int N, int Ho, int Wo, float* out, int ldo, int mode) {
+    MRFA_CHECK_ARG(in && grid && out && C > 0 && N > 0 && in_rep >= 1, "grid_sample_fwd: bad args");
+    const long long total = (long long)N * Ho * Wo * C;
+    hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, ldi, in_bstride,
+                       in_rep, Hi, Wi, C, grid, ldg, N, Ho, Wo, out, ldo, mode, total);
+    MRFA_CHECK_LAUNCH("grid_sample_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_grid_sample_bwd(void* stream, const float* in, int ldi, long long in_bstride, int in_rep, int Hi, int Wi, int C,
+                                    const float* grid, int ldg, int N, int Ho, int Wo, const float* dout, int lddo, int mode,
+                                    float* din, int lddi, long long din_bstride, float* dgrid, int lddg) {
+    MRFA_CHECK_ARG(in && grid && dout && C > 0 && N > 0 && in_rep >= 1, "grid_sample_bwd: bad args");
+    const long long npix = (long long)N * Ho * Wo;
+    const long long waves = npix * cdiv(C, 64);
+    hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(stream_grid(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, in, ldi, in_bstride,
+                       in_rep, Hi, Wi, C, grid, ldg, npix, Ho, Wo, dout, lddo, mode, din, lddi, din_bstride, dgrid, lddg);
+    MRFA_CHECK_LAUNCH("grid_sample_bwd");
+    return 0;
+}
+
+extern "C" int mrfa_resize_bilinear_fwd(void* stream, const float* in, int ldi, int N, int Hi, int Wi, int C, float* out, int ldo,
+                                        int Ho, int Wo, float scale_mul, int accumulate) {
+    MRFA_CHECK_ARG(in && out && C > 0 && N > 0, "resize_fwd: bad args");
+    const long long total = (long long)N * Ho * Wo * C;
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, ldi, N, Hi, Wi, C, out, ldo,
+                       Ho, Wo, scale_mul, accumulate, total);
+    MRFA_CHECK_LAUNCH("resize_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_resize_bilinear_bwd(void* stream, const float* dout, int lddo, int N, int Hi, int Wi, int C, float* din, int lddi,
+                                        int Ho, int Wo, float scale_mul) {
+    MRFA_CHECK_ARG(dout && din && C > 0 && N > 0, "resize_bwd: bad args");
+    const long long total = (long long)N * Ho * Wo * C;
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, lddo, N, Hi, Wi, C, din,
+                       lddi, Ho, Wo, scale_mul, total);
+    MRFA_CHECK_LAUNCH("resize_bwd");
+    return 0;
+}
+
+extern "C" int mrfa_corr_lookup_fwd(void* stream, const float* vol0, const float* vol1, int Hs, int Ws, const float* coords, int ldc,
+                                    long long Q, int radius, float* out, int ldo) {
+    MRFA_CHECK_ARG(vol0 && vol1 && coords && out && Q > 0, "corr_lookup_fwd: bad args");
+    MRFA_CHECK_ARG((2 * radius + 1) * (2 * radius + 1) <= 64, "corr_lookup: window must fit one wave (radius <= 3)");
+    hipLaunchKernelGGL((corr_lookup_kernel<false>), dim3(stream_grid(Q * 64, 256)), dim3(256), 0, (hipStream_t)stream, vol0, vol1, Hs, Ws,
+                       coords, ldc, Q, radius, out, ldo, nullptr, 0, nullptr, nullptr, nullptr, 0);
+    MRFA_CHECK_LAUNCH("corr_lookup_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_corr_lookup_bwd(void* stream, const float* vol0, const float* vol1, int Hs, int Ws, const float* coords, int ldc,
+                                    long long Q, int radius, const float* dout, int lddo, float* dvol0, float* dvol1, float* dcoords,
+                                    int lddc) {
+    MRFA_CHECK_ARG(vol0 && vol1 && coords && dout && Q > 0, "corr_lookup_bwd: bad args");
+    MRFA_CHECK_ARG((dvol0 == nullptr) == (dvol1 == nullptr), "corr_lookup_bwd: dvol0/dvol1 must both be given or both null");
+    MRFA_CHECK_ARG((2 * radius + 1) * (2 * radius + 1) <= 64, "corr_lookup: window must fit one wave (radius <= 3)");
+    hipLaunchKernelGGL((corr_lookup_kernel<true>), dim3(stream_grid(Q * 64, 256)), dim3(256), 0, (hipStream_t)stream, vol0, vol1, Hs, Ws,
+                       coords, ldc, Q, radius, nullptr, 0, dout, lddo, dvol0, dvol1, dcoords, lddc);
+    MRFA_CHECK_LAUNCH("corr_lookup_bwd");
+    return 0;
+}

@@ -1,0 +1,660 @@
+"""Host-side execution engine for the HIP hot path.
+
+MI355X-first design: instead of a torch autograd graph of ~1000 small ATen nodes per step, each module of the path
+(KPDetector, DenseMotionNetwork, RaftFlow) runs as ONE program of explicit kernel launches on the current HIP stream.
+Activations are fp32 NHWC `View`s (pointer + leading dimension) so producers write straight into slices of
+concatenated buffers; the forward pass records a tape of backward closures (hand-written HIP backward kernels),
+replayed in reverse by a single torch.autograd.Function per module, which is what makes `loss.backward()`, DDP
+gradient hooks and optimizers work unchanged on top.
+
+No CPU path exists here: every op goes through libmrfa_hip.so (mrfa_amd.hip.lib()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import hip
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _r4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+# ------------------------------------------------------------------------------------------------- storage / views
+class Storage:
+    """[rows, ld] fp32 buffer + lazily allocated gradient buffer of the same geometry."""
+    __slots__ = ("data", "grad", "rows", "ld")
+
+    def __init__(self, data: torch.Tensor):
+        assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
+        self.data = data
+        self.rows, self.ld = data.shape
+        self.grad: Optional[torch.Tensor] = None
+
+    def grad_buf(self) -> torch.Tensor:
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.data)
+        return self.grad
+
+
+class View:
+    """NHWC activation view: C channels starting at channel offset `coff` of a Storage with leading dimension ld."""
+    __slots__ = ("st", "N", "H", "W", "C", "coff")
+
+    def __init__(self, st: Storage, N: int, H: int, W: int, C_: int, coff: int = 0):
+        assert N * H * W == st.rows and coff + C_ <= st.ld, (N, H, W, C_, coff, st.rows, st.ld)
+        self.st, self.N, self.H, self.W, self.C, self.coff = st, N, H, W, C_, coff
+
+    @property
+    def rows(self) -> int:
+        return self.st.rows
+
+    @property
+    def ld(self) -> int:
+        return self.st.ld
+
+    @property
+    def ptr(self) -> int:
+        return self.st.data.data_ptr() + 4 * self.coff
+
+    @property
+    def gptr(self) -> int:
+        return self.st.grad_buf().data_ptr() + 4 * self.coff
+
+    @property
+    def has_grad(self) -> bool:
+        return self.st.grad is not None
+
+    def slice(self, c0: int, c1: int) -> "View":
+        assert 0 <= c0 < c1 <= self.C
+        return View(self.st, self.N, self.H, self.W, c1 - c0, self.coff + c0)
+
+    def tensor(self) -> torch.Tensor:
+        """(N,H,W,C) torch view of the data (strided when the storage is wider)."""
+        return self.st.data.view(self.N, self.H, self.W, self.ld)[..., self.coff:self.coff + self.C]
+
+    def grad_tensor(self) -> torch.Tensor:
+        return self.st.grad_buf().view(self.N, self.H, self.W, self.ld)[..., self.coff:self.coff + self.C]
+
+
+# ------------------------------------------------------------------------------------------------- parameters
+class ConvW:
+    """Packed-weight cache + packed-gradient accumulator for one nn.Conv2d parameter pair (OIHW weight, bias)."""
+
+    def __init__(self, conv: torch.nn.Conv2d):
+        self.conv = conv
+        w = conv.weight
+        self.Cout, self.Cin, self.R, self.S = w.shape
+        self.pad = conv.padding[0] if isinstance(conv.padding, tuple) else int(conv.padding)
+        self.T = self.R * self.S
+        self.fwd_flat = (self.Cin % 32) != 0
+        self.dgrad_flat = (self.Cout % 32) != 0
+        self.wgrad_flat = self.Cin < 32
+        self._fwd = None
+        self._dg = None
+        self._ver_f = self._ver_d = None
+        self._ktab_f = None
+        self._ktab_d = None
+        self.dw_acc: Optional[torch.Tensor] = None
+        self.db_acc: Optional[torch.Tensor] = None
+
+    # -- tables
+    @staticmethod
+    def _ktab(Cc: int, R: int, S: int, pad: int, device) -> torch.Tensor:
+        kp = (R * S * Cc + 31) // 32 * 32
+        buf = (C.c_int * kp)()
+        hip.check(hip.lib().mrfa_build_ktab(buf, Cc, R, S, pad, 0), "mrfa_build_ktab")
+        return torch.tensor(list(buf), dtype=torch.int32, device=device)
+
+    def ktab_fwd(self):
+        if self._ktab_f is None or self._ktab_f.device != self.conv.weight.device:
+            self._ktab_f = self._ktab(self.Cin, self.R, self.S, self.pad, self.conv.weight.device)
+        return self._ktab_f
+
+    def ktab_dgrad(self):
+        if self._ktab_d is None or self._ktab_d.device != self.conv.weight.device:
+            self._ktab_d = self._ktab(self.Cout, self.R, self.S, self.R - 1 - self.pad, self.conv.weight.device)
+        return self._ktab_d
+
+    # -- packs (re-done whenever the parameter was modified in place, e.g. by the optimizer)
+    def _key(self):
+        w = self.conv.weight
+        return (w._version, w.data_ptr())
+
+    def fwd_pack(self) -> torch.Tensor:
+        if self._fwd is None or self._ver_f != self._key():
+            w = self.conv.weight.detach()
+            cop = (self.Cout + 127) // 128 * 128
+            if self.fwd_flat:
+                kp = (self.T * self.Cin + 31) // 32 * 32
+                n, mode = cop * kp, 1
+            else:
+                n, mode = self.T * cop * self.Cin, 0
+            if self._fwd is None or self._fwd.numel() != n or self._fwd.device != w.device:
+                self._fwd = torch.empty(n, dtype=torch.float32, device=w.device)
+            hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), w.contiguous().data_ptr(), self._fwd.data_ptr(),
+                                                      self.Cout, self.Cin, self.R, self.S, mode), "pack(fwd)")
+            self._ver_f = self._key()
+        return self._fwd
+
+    def dgrad_pack(self) -> torch.Tensor:
+        if self._dg is None or self._ver_d != self._key():
+            w = self.conv.weight.detach()
+            cip = (self.Cin + 127) // 128 * 128
+            if self.dgrad_flat:
+                kp = (self.T * self.Cout + 31) // 32 * 32
+                n, mode = cip * kp, 3
+            else:
+                n, mode = self.T * cip * self.Cout, 2
+            if self._dg is None or self._dg.numel() != n or self._dg.device != w.device:
+                self._dg = torch.empty(n, dtype=torch.float32, device=w.device)
+            hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), w.contiguous().data_ptr(), self._dg.data_ptr(),
+                                                      self.Cout, self.Cin, self.R, self.S, mode), "pack(dgrad)")
+            self._ver_d = self._key()
+        return self._dg
+
+    def grad_acc(self):
+        if self.dw_acc is None:
+            dev = self.conv.weight.device
+            self.dw_acc = torch.zeros(self.T * self.Cout * self.Cin, dtype=torch.float32, device=dev)
+            self.db_acc = torch.zeros(self.Cout, dtype=torch.float32, device=dev) if self.conv.bias is not None else None
+        return self.dw_acc, self.db_acc
+
+    def take_grads(self):
+        """-> (dW OIHW or None, dbias or None); clears the accumulators."""
+        if self.dw_acc is None:
+            return None, None
+        dw = torch.zeros_like(self.conv.weight)
+        hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), self.dw_acc.data_ptr(), dw.data_ptr(), self.Cout, self.Cin,
+                                                  self.R, self.S, 4), "unpack(wgrad)")
+        db = self.db_acc
+        self.dw_acc = self.db_acc = None
+        return dw, db
+
+
+def convw(conv: torch.nn.Conv2d) -> ConvW:
+    cw = getattr(conv, "_mrfa_convw", None)
+    if cw is None:
+        cw = ConvW(conv)
+        object.__setattr__(conv, "_mrfa_convw", cw)
+    return cw
+
+
+class BNGrad:
+    """gradient accumulators for one BatchNorm2d (gamma, beta)."""
+
+    def __init__(self, bn: torch.nn.BatchNorm2d):
+        self.bn = bn
+        self.dg: Optional[torch.Tensor] = None
+        self.db: Optional[torch.Tensor] = None
+
+    def acc(self):
+        if self.dg is None:
+            self.dg = torch.zeros_like(self.bn.weight)
+            self.db = torch.zeros_like(self.bn.bias)
+        return self.dg, self.db
+
+    def take(self):
+        dg, db = self.dg, self.db
+        self.dg = self.db = None
+        return dg, db
+
+
+def bngrad(bn) -> BNGrad:
+    g = getattr(bn, "_mrfa_bngrad", None)
+    if g is None:
+        g = BNGrad(bn)
+        object.__setattr__(bn, "_mrfa_bngrad", g)
+    return g
+
+
+# ------------------------------------------------------------------------------------------------- the op context
+class Ctx:
+    def __init__(self, device: torch.device, train: bool, record: bool):
+        self.dev = device
+        self.train = train
+        self.record = record
+        self.tape: List[Callable[[], None]] = []
+        self.L = hip.lib()
+        self.touched_convs: List[ConvW] = []
+        self.touched_bns: List[BNGrad] = []
+        self.param_grads = {}            # id(param) -> grad tensor for non-conv/bn parameters
+
+    # -- plumbing
+    @property
+    def s(self):
+        return hip.stream_ptr()
+
+    def _chk(self, rc, what):
+        if rc:
+            hip.check(rc, what)
+
+    def rec(self, fn):
+        if self.record:
+            self.tape.append(fn)
+
+    def new(self, N, H, W, C_, ld=None, zero=False) -> View:
+        ld = _r4(C_) if ld is None else ld
+        alloc = torch.zeros if zero else torch.empty
+        return View(Storage(alloc((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_)
+
+    def wrap_nhwc(self, t: torch.Tensor) -> View:
+        """Zero-copy view of a contiguous (N,H,W,C) fp32 tensor."""
+        assert t.dim() == 4 and t.is_contiguous() and t.dtype == torch.float32
+        N, H, W, C_ = t.shape
+        return View(Storage(t.view(N * H * W, C_)), N, H, W, C_)
+
+    def from_nchw(self, t: torch.Tensor, out: Optional[View] = None) -> View:
+        N, C_, H, W = t.shape
+        t = t.contiguous().float()
+        out = out or self.new(N, H, W, C_)
+        self._chk(self.L.mrfa_nchw_to_nhwc(self.s, t.data_ptr(), out.ptr, out.ld, N, C_, H, W, 0), "nchw_to_nhwc")
+        return out
+
+    def to_nchw(self, v: View) -> torch.Tensor:
+        t = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=self.dev)
+        self._chk(self.L.mrfa_nhwc_to_nchw(self.s, v.ptr, v.ld, t.data_ptr(), v.N, v.C, v.H, v.W, 0), "nhwc_to_nchw")
+        return t
+
+    def grad_to_nchw(self, v: View) -> torch.Tensor:
+        t = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=self.dev)
+        self._chk(self.L.mrfa_nhwc_to_nchw(self.s, v.gptr, v.ld, t.data_ptr(), v.N, v.C, v.H, v.W, 0), "nhwc_to_nchw(grad)")
+        return t
+
+    def seed_grad_nchw(self, v: View, g: torch.Tensor):
+        g = g.contiguous().float()
+        self._chk(self.L.mrfa_nchw_to_nhwc(self.s, g.data_ptr(), v.gptr, v.ld, v.N, v.C, v.H, v.W, 1), "seed grad")
+
+    def f32(self, n, zero=False):
+        return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.dev)
+
+    def f64z(self, n):
+        return torch.zeros(n, dtype=torch.float64, device=self.dev)
+
+    # -- convolution ------------------------------------------------------------------------------------------
+    def conv(self, x: View, conv: torch.nn.Conv2d, out: Optional[View] = None, *, relu=False, ups=False, pre=None,
+             stats: Optional[torch.Tensor] = None, res: Optional[View] = None, need_dx=True, use_bias=True) -> View:
+        """y = conv(pre(ups(x))) (+bias)(+res)(ReLU).  pre = (scale, shift) tensors of a pre-activation BN+ReLU."""
+        cw = convw(conv)
+        assert x.C == cw.Cin, (x.C, cw.Cin)
+        Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
+        Ho, Wo = Hv + 2 * cw.pad - cw.R + 1, Wv + 2 * cw.pad - cw.S + 1
+        out = out or self.new(x.N, Ho, Wo, cw.Cout)
+        assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cw.Cout)
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
+        wp = cw.fwd_pack()
+        cop = (cw.Cout + 127) // 128 * 128
+        p.w = wp.data_ptr()
+        if cw.fwd_flat:
+            kp = (cw.T * cw.Cin + 31) // 32 * 32
+            p.w_ld, p.w_tap, p.kflat = kp, 0, cw.T * cw.Cin
+            p.ktab = cw.ktab_fwd().data_ptr()
+        else:
+            p.w_ld, p.w_tap, p.kflat = cw.Cin, cop * cw.Cin, 0
+        p.w_rows = cop
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout = out.ptr, out.ld, cw.Cout, Ho, Wo
+        p.R, p.S, p.pad = cw.R, cw.S, cw.pad
+        if pre is not None:
+            p.in_scale, p.in_shift, p.in_relu = pre[0].data_ptr(), pre[1].data_ptr(), 1
+        bias = conv.bias if use_bias else None
+        p.bias = bias.data_ptr() if bias is not None else None
+        p.relu = int(relu)
+        if res is not None:
+            p.res, p.ldr = res.ptr, res.ld
+        if stats is not None:
+            p.stats = stats.data_ptr()
+        p.alpha, p.nbatch = 1.0, 1
+        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), "conv2d")
+
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                if relu:
+                    self._chk(self.L.mrfa_act_bwd(self.s, out.ptr, out.ld, out.gptr, out.ld, out.rows, out.C, 1, out.gptr, out.ld, 0),
+                              "relu_bwd")
+                if res is not None:
+                    self._chk(self.L.mrfa_copy_view(self.s, out.gptr, out.ld, out.rows, out.C, res.gptr, res.ld, 1.0, 1), "res_bwd")
+                self._conv_wgrad(x, cw, out, ups, pre, bias is not None)
+                if need_dx:
+                    self._conv_dgrad(x, cw, out, ups, pre)
+            self.tape.append(bwd)
+            if cw not in self.touched_convs:
+                self.touched_convs.append(cw)
+        return out
+
+    def _conv_wgrad(self, x: View, cw: ConvW, out: View, ups, pre, has_bias):
+        dw, db = cw.grad_acc()
+        q = hip.WgradParams()
+        q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
+        if pre is not None:
+            q.in_scale, q.in_shift, q.in_relu = pre[0].data_ptr(), pre[1].data_ptr(), 1
+        q.dy, q.ldy, q.Cout, q.Hout, q.Wout = out.gptr, out.ld, cw.Cout, out.H, out.W
+        q.R, q.S, q.pad = cw.R, cw.S, cw.pad
+        q.dw = dw.data_ptr()
+        q.dbias = db.data_ptr() if (has_bias and db is not None) else None
+        q.alpha, q.nbatch, q.ksplit = 1.0, 1, 0
+        if cw.wgrad_flat:
+            q.ktab, q.kflat = cw.ktab_fwd().data_ptr(), cw.T * cw.Cin
+        self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "wgrad")
+
+    def _conv_dgrad(self, x: View, cw: ConvW, out: View, ups, pre):
+        """x.grad += conv_transpose(out.grad); with ups the hi-res gradient is sum-pooled; with pre it is pushed
+        through the pre-activation BN+ReLU by the caller-registered closure (see prebn)."""
+        Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
+        direct = (not ups) and pre is None
+        tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.gptr, out.ld, out.H, out.W, 0, out.N, cw.Cout
+        wp = cw.dgrad_pack()
+        cip = (cw.Cin + 127) // 128 * 128
+        p.w = wp.data_ptr()
+        if cw.dgrad_flat:
+            kp = (cw.T * cw.Cout + 31) // 32 * 32
+            p.w_ld, p.w_tap, p.kflat = kp, 0, cw.T * cw.Cout
+            p.ktab = cw.ktab_dgrad().data_ptr()
+        else:
+            p.w_ld, p.w_tap, p.kflat = cw.Cout, cip * cw.Cout, 0
+        p.w_rows = cip
+        p.y, p.ldy = (tgt.gptr if direct else tgt.ptr), tgt.ld
+        p.Cout, p.Hout, p.Wout = cw.Cin, Hv, Wv
+        p.R, p.S, p.pad = cw.R, cw.S, cw.R - 1 - cw.pad
+        p.alpha, p.nbatch = 1.0, 1
+        p.accumulate = 1 if direct else 0
+        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), "dgrad")
+        if direct:
+            return
+        cur = tgt            # holds d(pre(ups(x))) as DATA
+        if pre is not None:
+            # gradient through relu(scale*x+shift) is handled by the BN closure: it reads pre[2] (stash)
+            pre[2]["dz"] = cur
+            pre[2]["ups"] = ups
+            return
+        # ups only
+        self._chk(self.L.mrfa_sumpool2_acc(self.s, cur.ptr, cur.ld, x.N, x.H, x.W, x.C, x.gptr, x.ld, 1.0), "sumpool2")
+
+    # -- batch norm -------------------------------------------------------------------------------------------
+    def _bn_finalize(self, bn, stats, count):
+        Cn = bn.num_features
+        scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
+        train = self.train
+        self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
+                                          bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                          BN_MOMENTUM, BN_EPS, Cn, int(train), scale.data_ptr(), shift.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr()), "bn_finalize")
+        if train:
+            bn.num_batches_tracked.add_(1)
+        return scale, shift, mean, invstd
+
+    def bn_stats_buf(self, bn):
+        return self.f64z(2 * bn.num_features) if self.train else None
+
+    def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None) -> View:
+        """out = [blend_a*occ +] act(bn(x)) [*(1-occ)], optional 2x2 avg-pool.  x = raw conv output, stats = its
+        epilogue-accumulated sums (train) or None (eval)."""
+        scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
+        Ho, Wo = (x.H // 2, x.W // 2) if pool else (x.H, x.W)
+        out = out or self.new(x.N, Ho, Wo, x.C)
+        p = hip.BnActParams()
+        p.x, p.ldx, p.N, p.H, p.W, p.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
+        p.scale, p.shift, p.relu, p.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
+        if blend is not None:
+            a, occ = blend
+            p.blend_a, p.lda, p.occ, p.ldo = a.ptr, a.ld, occ.ptr, occ.ld
+        p.y, p.ldy = out.ptr, out.ld
+        self._chk(self.L.mrfa_bn_act_fwd(self.s, C.byref(p)), "bn_act_fwd")
+        if self.record:
+            train = self.train
+
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x)
+            self.tape.append(bwd)
+        return out
+
+    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view):
+        bg = bngrad(bn)
+        if bg not in self.touched_bns:
+            self.touched_bns.append(bg)
+        dg, db = bg.acc()
+        red = self.f64z(2 * x.C)
+        q = hip.BnBwdParams()
+        q.x, q.ldx, q.N, q.H, q.W, q.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
+        q.scale, q.shift, q.relu, q.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
+        q.mean, q.invstd, q.gamma = mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr()
+        q.dy, q.lddy = dy_ptr, dy_ld
+        if blend is not None:
+            a, occ = blend
+            q.blend_a, q.lda, q.occ, q.ldo = a.ptr, a.ld, occ.ptr, occ.ld
+            q.dblend_a, q.ldda, q.docc, q.lddo = a.gptr, a.ld, occ.gptr, occ.ld
+        q.red = red.data_ptr()
+        q.dx, q.lddx = dx_view.gptr, dx_view.ld
+        q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
+        q.train = int(train)
+        q.phase = 1
+        self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
+        q.phase = 2
+        self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(2)")
+
+    def prebn(self, x: View, bn, stats=None):
+        """Pre-activation BN+ReLU folded into the next conv's prologue (ResBlock2d / ChannelBlock2d).  Returns the `pre`
+        triple for conv(); must be called BEFORE that conv so the tape order is right (its closure runs AFTER the conv's)."""
+        if self.train and stats is None:
+            stats = self.f64z(2 * x.C)
+            self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
+        scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
+        stash = {}
+        if self.record:
+            train = self.train
+
+            def bwd():
+                dz = stash.get("dz")
+                if dz is None:
+                    return
+                assert not stash.get("ups", False)
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, True, False, dz.ptr, dz.ld, None, train, x)
+            self.tape.append(bwd)
+        return (scale, shift, stash)
+
+    # -- samplers ---------------------------------------------------------------------------------------------
+    def grid_sample(self, inp: View, grid: View, mode: int, out: Optional[View] = None, in_rep: int = 1, need_din=True,
+                    need_dgrid=True) -> View:
+        n_out = grid.N
+        assert grid.C == 2 and n_out == inp.N * in_rep
+        out = out or self.new(n_out, grid.H, grid.W, inp.C)
+        bs = inp.H * inp.W * inp.ld
+        self._chk(self.L.mrfa_grid_sample_fwd(self.s, inp.ptr, inp.ld, bs, in_rep, inp.H, inp.W, inp.C, grid.ptr, grid.ld, n_out,
+                                              grid.H, grid.W, out.ptr, out.ld, mode), "grid_sample_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_grid_sample_bwd(self.s, inp.ptr, inp.ld, bs, in_rep, inp.H, inp.W, inp.C, grid.ptr, grid.ld, n_out,
+                                                      grid.H, grid.W, out.gptr, out.ld, mode,
+                                                      inp.gptr if need_din else None, inp.ld, bs,
+                                                      grid.gptr if need_dgrid else None, grid.ld), "grid_sample_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def resize(self, x: View, Ho: int, Wo: int, mul: float = 1.0, out: Optional[View] = None, acc: bool = False) -> View:
+        out = out or self.new(x.N, Ho, Wo, x.C)
+        self._chk(self.L.mrfa_resize_bilinear_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld, Ho, Wo, mul, int(acc)),
+                  "resize_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_resize_bilinear_bwd(self.s, out.gptr, out.ld, x.N, x.H, x.W, x.C, x.gptr, x.ld, Ho, Wo, mul),
+                          "resize_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def corr_lookup(self, vol0: torch.Tensor, vol1: torch.Tensor, dvols, Hs: int, Ws: int, coords: View, radius: int = 3,
+                    out: Optional[View] = None) -> View:
+        """vol0 (Q,Hs*Ws), vol1 (Q,Hs/2*Ws/2) torch tensors; dvols: callable returning (dvol0, dvol1) grad tensors or None."""
+        Q = coords.rows
+        nwin = (2 * radius + 1) ** 2
+        out = out or self.new(coords.N, coords.H, coords.W, 2 * nwin)
+        self._chk(self.L.mrfa_corr_lookup_fwd(self.s, vol0.data_ptr(), vol1.data_ptr(), Hs, Ws, coords.ptr, coords.ld, Q, radius,
+                                              out.ptr, out.ld), "corr_lookup_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                d0, d1 = dvols() if dvols is not None else (None, None)
+                self._chk(self.L.mrfa_corr_lookup_bwd(self.s, vol0.data_ptr(), vol1.data_ptr(), Hs, Ws, coords.ptr, coords.ld, Q, radius,
+                                                      out.gptr, out.ld, d0.data_ptr() if d0 is not None else None,
+                                                      d1.data_ptr() if d1 is not None else None, coords.gptr, coords.ld),
+                          "corr_lookup_bwd")
+            self.tape.append(bwd)
+        return out
+
+    # -- elementwise ------------------------------------------------------------------------------------------
+    def copy(self, x: View, out: Optional[View] = None, mul: float = 1.0, acc: bool = False) -> View:
+        """out (=|+=) mul * x"""
+        out = out or self.new(x.N, x.H, x.W, x.C)
+        self._chk(self.L.mrfa_copy_view(self.s, x.ptr, x.ld, x.rows, x.C, out.ptr, out.ld, mul, int(acc)), "copy_view")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_copy_view(self.s, out.gptr, out.ld, out.rows, out.C, x.gptr, x.ld, mul, 1), "copy_view_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def act(self, x: View, kind: int, out: Optional[View] = None) -> View:
+        """kind 1 relu, 2 sigmoid"""
+        out = out or self.new(x.N, x.H, x.W, x.C)
+        self._chk(self.L.mrfa_bias_act(self.s, x.ptr, x.ld, x.rows, x.C, None, kind, out.ptr, out.ld, None), "act")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_act_bwd(self.s, out.ptr, out.ld, out.gptr, out.ld, out.rows, out.C, kind, x.gptr, x.ld, 1), "act_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def blend(self, a: View, b: Optional[View], occ: View, out: Optional[View] = None) -> View:
+        """out = a*occ + b*(1-occ)   (b None -> a*occ)"""
+        out = out or self.new(a.N, a.H, a.W, a.C)
+        self._chk(self.L.mrfa_blend_fwd(self.s, a.ptr, a.ld, b.ptr if b else None, b.ld if b else 0, occ.ptr, occ.ld, a.rows, a.C,
+                                        out.ptr, out.ld), "blend_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_blend_bwd(self.s, a.ptr, a.ld, b.ptr if b else None, b.ld if b else 0, occ.ptr, occ.ld,
+                                                out.gptr, out.ld, a.rows, a.C, a.gptr, a.ld, b.gptr if b else None, b.ld if b else 0,
+                                                occ.gptr, occ.ld), "blend_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def avgpool2(self, x: View, out: Optional[View] = None) -> View:
+        out = out or self.new(x.N, x.H // 2, x.W // 2, x.C)
+        self._chk(self.L.mrfa_avgpool2_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld), "avgpool2")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_unpool2_acc(self.s, out.gptr, out.ld, x.N, out.H, out.W, x.C, x.gptr, x.ld, 0.25), "avgpool2_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def antialias_down(self, img_nchw: torch.Tensor, kern: torch.Tensor, stride: int, out: Optional[View] = None) -> View:
+        """AntiAliasInterpolation2d on an NCHW image -> NHWC view (no gradient: inputs are images)."""
+        N, C_, H, W = img_nchw.shape
+        img_nchw = img_nchw.contiguous().float()
+        k = kern.shape[-1]
+        kern2d = kern[0, 0].contiguous().float()
+        out = out or self.new(N, H // stride, W // stride, C_)
+        self._chk(self.L.mrfa_antialias_down(self.s, img_nchw.data_ptr(), N, C_, H, W, kern2d.data_ptr(), k, stride, out.ptr, out.ld),
+                  "antialias_down")
+        return out
+
+    # -- GEMMs for the correlation volume -----------------------------------------------------------------------
+    def gemm_nt(self, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, M, Nn, K, alpha, nbatch, a_bs, b_bs, c_bs, accumulate=False):
+        """C[b] (=|+=) alpha * A[b] (M x K, k contiguous) @ B[b]^T (Nn x K, k contiguous)"""
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = a_ptr, lda, 1, M, 0, 1, K
+        p.w, p.w_ld, p.w_tap, p.w_rows = b_ptr, ldb, 0, Nn
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout = c_ptr, ldc, Nn, 1, M
+        p.R, p.S, p.pad = 1, 1, 0
+        p.alpha, p.accumulate = alpha, int(accumulate)
+        p.nbatch, p.x_bs, p.w_bs, p.y_bs = nbatch, a_bs, b_bs, c_bs
+        p.splitk = 1
+        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), "gemm_nt")
+
+    def gemm_tn_acc(self, a_ptr, lda, b_ptr, ldb, c_ptr, M, Nn, K, alpha, nbatch, a_bs, b_bs, c_bs):
+        """C[b][m][n] += alpha * sum_k A[b][k][m] * B[b][k][n]   (C dense M x Nn, atomics)"""
+        q = hip.WgradParams()
+        q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = b_ptr, ldb, 1, K, 0, 1, Nn
+        q.dy, q.ldy, q.Cout, q.Hout, q.Wout = a_ptr, lda, M, 1, K
+        q.R, q.S, q.pad = 1, 1, 0
+        q.dw, q.alpha = c_ptr, alpha
+        q.nbatch, q.x_bs, q.dy_bs, q.dw_bs = nbatch, b_bs, a_bs, c_bs
+        q.ksplit = 0
+        self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "gemm_tn")
+
+    # -- backward driver --------------------------------------------------------------------------------------
+    def run_backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+# ------------------------------------------------------------------------------------------------- autograd bridge
+class _ProgramFn(torch.autograd.Function):
+    """Runs `program(ctx, *inputs) -> (outputs, seeders, input_grad_fns)` as one autograd node.
+
+    outputs: tuple of torch tensors returned to the caller; seeders[i](grad) pushes d(outputs[i]) into the engine;
+    input_grad_fns[j]() returns the gradient of inputs[j] (or None) after the tape ran."""
+
+    @staticmethod
+    def forward(actx, program, module, n_in, *args):
+        inputs, params = args[:n_in], args[n_in:]
+        dev = inputs[0].device
+        need = any(actx.needs_input_grad[3:])
+        ectx = Ctx(dev, train=module.training, record=need)
+        outs, seeders, in_grad_fns = program(ectx, *inputs)
+        actx.ectx, actx.seeders, actx.in_grad_fns = ectx, seeders, in_grad_fns
+        actx.params, actx.n_in = params, n_in
+        return tuple(outs)
+
+    @staticmethod
+    def backward(actx, *gouts):
+        ectx = actx.ectx
+        for seed, g in zip(actx.seeders, gouts):
+            if g is not None and seed is not None:
+                seed(g)
+        ectx.run_backward()
+        pgrads = {}
+        for cw in ectx.touched_convs:
+            dw, db = cw.take_grads()
+            if dw is not None:
+                pgrads[id(cw.conv.weight)] = dw
+                if cw.conv.bias is not None and db is not None:
+                    pgrads[id(cw.conv.bias)] = db
+        for bg in ectx.touched_bns:
+            dg, db = bg.take()
+            if dg is not None:
+                pgrads[id(bg.bn.weight)] = dg
+                pgrads[id(bg.bn.bias)] = db
+        pgrads.update(ectx.param_grads)
+        in_grads = [fn() if (fn is not None and need) else None
+                    for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[3:3 + actx.n_in])]
+        out = [None, None, None] + in_grads + [pgrads.get(id(p)) for p in actx.params]
+        actx.ectx = None
+        return tuple(out)
+
+
+def run_program(module: torch.nn.Module, program, inputs: Sequence[torch.Tensor]):
+    params = [p for p in module.parameters()]
+    return _ProgramFn.apply(program, module, len(inputs), *inputs, *params)

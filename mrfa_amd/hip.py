@@ -1,0 +1,147 @@
+"""ctypes binding of libmrfa_hip.so (C ABI: include/mrfa_hip.h).
+
+The library is the product: if it cannot be loaded the import of any op raises -- there is no CPU or eager fallback.
+Kernels are launched on torch's current HIP stream with raw device pointers taken from torch tensors; torch is only
+the allocator / stream owner here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libmrfa_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("ups", C.c_int),
+        ("N", C.c_int), ("Cin", C.c_int),
+        ("w", C.c_void_p), ("w_ld", C.c_int), ("w_tap", C.c_longlong), ("w_rows", C.c_int),
+        ("y", C.c_void_p), ("ldy", C.c_int), ("Cout", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("R", C.c_int), ("S", C.c_int), ("pad", C.c_int),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_relu", C.c_int),
+        ("bias", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("relu", C.c_int),
+        ("res", C.c_void_p), ("ldr", C.c_int),
+        ("stats", C.c_void_p),
+        ("alpha", C.c_float), ("accumulate", C.c_int),
+        ("nbatch", C.c_int), ("x_bs", C.c_longlong), ("w_bs", C.c_longlong), ("y_bs", C.c_longlong),
+        ("splitk", C.c_int),
+        ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile", C.c_int),
+    ]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("ups", C.c_int),
+        ("N", C.c_int), ("Cin", C.c_int),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_relu", C.c_int),
+        ("dy", C.c_void_p), ("ldy", C.c_int), ("Cout", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("R", C.c_int), ("S", C.c_int), ("pad", C.c_int),
+        ("dw", C.c_void_p), ("dbias", C.c_void_p), ("alpha", C.c_float),
+        ("nbatch", C.c_int), ("x_bs", C.c_longlong), ("dy_bs", C.c_longlong), ("dw_bs", C.c_longlong),
+        ("ksplit", C.c_int), ("ktab", C.c_void_p), ("kflat", C.c_int),
+    ]
+
+
+class BnActParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int), ("pool", C.c_int),
+        ("blend_a", C.c_void_p), ("lda", C.c_int), ("occ", C.c_void_p), ("ldo", C.c_int),
+        ("y", C.c_void_p), ("ldy", C.c_int),
+    ]
+
+
+class BnBwdParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int), ("pool", C.c_int),
+        ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
+        ("dy", C.c_void_p), ("lddy", C.c_int),
+        ("blend_a", C.c_void_p), ("lda", C.c_int), ("occ", C.c_void_p), ("ldo", C.c_int),
+        ("dblend_a", C.c_void_p), ("ldda", C.c_int), ("docc", C.c_void_p), ("lddo", C.c_int),
+        ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
+        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int),
+    ]
+
+
+_V, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+_SIGNATURES = {
+    "mrfa_version": ([], C.c_int),
+    "mrfa_last_error": ([], C.c_char_p),
+    "mrfa_conv2d_nhwc": ([_V, C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_wgrad_nhwc": ([_V, C.POINTER(WgradParams)], C.c_int),
+    "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_build_ktab": ([c_int_p, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_bn_stats": ([_V, _V, _I, _L, _I, _V], C.c_int),
+    "mrfa_bn_finalize": ([_V, _V, _L, _V, _V, _V, _V, _F, _F, _I, _I, _V, _V, _V, _V], C.c_int),
+    "mrfa_bn_act_fwd": ([_V, C.POINTER(BnActParams)], C.c_int),
+    "mrfa_bn_act_bwd": ([_V, C.POINTER(BnBwdParams)], C.c_int),
+    "mrfa_grid_sample_fwd": ([_V, _V, _I, _L, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _I, _I], C.c_int),
+    "mrfa_grid_sample_bwd": ([_V, _V, _I, _L, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _I, _I, _V, _I, _L, _V, _I], C.c_int),
+    "mrfa_resize_bilinear_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _F, _I], C.c_int),
+    "mrfa_resize_bilinear_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _F], C.c_int),
+    "mrfa_corr_lookup_fwd": ([_V, _V, _V, _I, _I, _V, _I, _L, _I, _V, _I], C.c_int),
+    "mrfa_corr_lookup_bwd": ([_V, _V, _V, _I, _I, _V, _I, _L, _I, _V, _I, _V, _V, _V, _I], C.c_int),
+    "mrfa_nchw_to_nhwc": ([_V, _V, _V, _I, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_nhwc_to_nchw": ([_V, _V, _I, _V, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_avgpool2_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
+    "mrfa_sumpool2_acc": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _F], C.c_int),
+    "mrfa_unpool2_acc": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _F], C.c_int),
+    "mrfa_bias_act": ([_V, _V, _I, _L, _I, _V, _I, _V, _I, _V], C.c_int),
+    "mrfa_act_bwd": ([_V, _V, _I, _V, _I, _L, _I, _I, _V, _I, _I], C.c_int),
+    "mrfa_copy_view": ([_V, _V, _I, _L, _I, _V, _I, _F, _I], C.c_int),
+    "mrfa_blend_fwd": ([_V, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
+    "mrfa_blend_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I, _V, _I, _V, _I], C.c_int),
+    "mrfa_antialias_down": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V, _I], C.c_int),
+    "mrfa_colsum": ([_V, _V, _I, _L, _I, _V], C.c_int),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libmrfa_hip.so once; raises loudly if it is absent (the HIP path is the only path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m mrfa_amd.build` (hipcc --offload-arch=gfx950). "
+                "mrfa_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the ABI and the header drift apart
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().mrfa_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, offset_elems: int = 0):
+    """Raw device pointer of a tensor (+ element offset); None -> NULL."""
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * offset_elems if offset_elems else t.data_ptr()

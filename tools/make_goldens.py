@@ -1,0 +1,283 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference does not exist on the GPU box).  Inputs/weights are the
+deterministic cases of tests/cases.py; only the reference outputs are stored.  Re-run:
+    python tools/make_goldens.py            # writes tests/golden/, prints oracle-vs-reference deltas
+Reference pins torch 1.10.1; this container runs torch 2.10 (CPU).  The ops used have unchanged semantics.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_import  # noqa: E402
+from tests import cases  # noqa: E402
+from mrfa_amd.utils.prng import det_uniform, det_normal  # noqa: E402
+from oracle import mrfa_oracle as O  # noqa: E402
+
+ref_import.import_reference()
+from modules import util as RU  # noqa: E402
+from modules.kp_detector import KPDetector  # noqa: E402
+from modules.dense_motion import DenseMotionNetwork  # noqa: E402
+from modules.raft import RaftFlow, CorrBlock  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.manual_seed(0)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def delta(name, a, b):
+    d = (a.detach() - b.detach()).abs()
+    print(f"   oracle-vs-ref {name:28s} max {d.max().item():.3e}  mean {d.mean().item():.3e}  |ref| {b.abs().mean().item():.3e}")
+    return d.max().item()
+
+
+def load(mod, tag, **kw):
+    sd = cases.weights_for(mod.state_dict(), tag, **kw)
+    mod.load_state_dict(sd, strict=True)
+    return sd
+
+
+def manifest(mod):
+    return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in mod.state_dict().items()]
+
+
+# ----------------------------------------------------------------------------------------------- G1 manifests
+def g1():
+    kp = KPDetector(**cases.KP_DETECTOR_CFG)
+    dm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+    rf = RaftFlow(**cases.raft_cfg(256))
+    rfp = RaftFlow(**cases.raft_cfg(256, prior_only=True))
+    man = {"KPDetector": manifest(kp), "DenseMotionNetwork": manifest(dm), "RaftFlow": manifest(rf),
+           "RaftFlow_prior_only": manifest(rfp)}
+    with open(os.path.join(GOLD, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0)
+    print("G1 manifests:", {k: len(v) for k, v in man.items()})
+
+
+# ----------------------------------------------------------------------------------------------- G2 units
+def g2():
+    out = {}
+    like = torch.zeros(1)
+    out["grid_5x7"] = npy(RU.make_coordinate_grid((5, 7), like.type()))
+    out["coords_2x3x4"] = npy(RU.coords_grid(2, 3, 4, "cpu"))
+    kp = det_uniform("u/kp", (2, 3, 2), -0.9, 0.9)
+    out["gauss_001"] = npy(RU.kp2gaussian(kp, (8, 8), 0.01))
+    out["gauss_01"] = npy(RU.kp2gaussian(kp, (6, 9), 0.1))
+    img = cases.images("u/aa", 1, 32)
+    for s in (0.25, 0.5, 0.125):
+        out[f"aa_{s}"] = npy(RU.AntiAliasInterpolation2d(3, s)(img))
+        delta(f"antialias {s}", O.antialias_down(img, s), torch.from_numpy(out[f"aa_{s}"]))
+    small = det_uniform("u/bs_img", (2, 4, 6, 7), -1, 1)
+    coords = det_uniform("u/bs_xy", (2, 5, 6, 2), -1.5, 7.5)
+    out["bilinear_sampler"] = npy(RU.bilinear_sampler(small, coords))
+    delta("bilinear_sampler", O.sample_px(small, coords), torch.from_numpy(out["bilinear_sampler"]))
+    gridn = det_uniform("u/gs_xy", (2, 5, 6, 2), -1.3, 1.3)
+    out["grid_sample_default"] = npy(F.grid_sample(small, gridn))
+    delta("grid_sample default", O.sample_norm(small, gridn), torch.from_numpy(out["grid_sample_default"]))
+    xr = det_uniform("u/rs", (2, 3, 8, 8), -1, 1)
+    out["resize_ac_8to3"] = npy(F.interpolate(xr, scale_factor=1.0 / 8.0 * 3, mode="bilinear", align_corners=True))
+    out["resize_ac_8to16"] = npy(F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True))
+    out["resize_ac_8to13"] = npy(F.interpolate(xr, size=13, mode="bilinear", align_corners=True))
+    # CorrBlock: 2*3*3 query pixels, 8x8 source maps
+    maps = det_uniform("u/corr_maps", (18, 1, 8, 8), -1, 1)
+    cxy = det_uniform("u/corr_xy", (2, 2, 3, 3), -2.0, 9.0)
+    out["corrblock"] = npy(CorrBlock(maps)(cxy))
+    delta("corrblock", O.corr_lookup(maps, cxy), torch.from_numpy(out["corrblock"]))
+    # blocks
+    blocks = {
+        "down": (RU.DownBlock2d(8, 16), (2, 8, 8, 8), lambda x, P, t: O.down_block(x, P, "b", t)),
+        "up": (RU.UpBlock2d(16, 8), (2, 16, 4, 4), lambda x, P, t: O.up_block(x, P, "b", t)),
+        "same7": (RU.SameBlock2d(3, 8, kernel_size=(7, 7), padding=(3, 3)), (2, 3, 8, 8), lambda x, P, t: O.same_block(x, P, "b", t, 3)),
+        "res": (RU.ResBlock2d(8, kernel_size=(3, 3), padding=(1, 1)), (2, 8, 8, 8), lambda x, P, t: O.res_block(x, P, "b", t)),
+        "chan": (RU.ChannelBlock2d(16, kernel_size=(3, 3), padding=(1, 1)), (2, 16, 8, 8), lambda x, P, t: O.channel_block(x, P, "b", t)),
+    }
+    for name, (mod, shp, ofn) in blocks.items():
+        sd = load(mod, f"u/{name}")
+        x = det_uniform(f"u/{name}/x", shp, -1, 1)
+        for train in (False, True):
+            mod.train(train)
+            y = mod(x.clone())
+            key = f"block_{name}_{'train' if train else 'eval'}"
+            out[key] = npy(y)
+            P = {("b." + k): v.clone() for k, v in sd.items()}
+            delta(key, ofn(x.clone(), P, train), y)
+        mod.load_state_dict(sd)
+    hg = RU.Hourglass(block_expansion=8, in_features=5, num_blocks=3, max_features=32)
+    sd = load(hg, "u/hg")
+    x = det_uniform("u/hg/x", (2, 5, 16, 16), -1, 1)
+    for train in (False, True):
+        hg.load_state_dict(sd)
+        hg.train(train)
+        y = hg(x)
+        out[f"hourglass_{'train' if train else 'eval'}"] = npy(y)
+        P = {("hg." + k): v.clone() for k, v in sd.items()}
+        delta(f"hourglass train={train}", O.hourglass(x, P, "hg", train), y)
+    # sparse motions (dense_motion.py:48-76) through a tiny DenseMotionNetwork instance
+    dmn = DenseMotionNetwork(block_expansion=8, num_blocks=2, max_features=16, num_kp=10, num_channels=3)
+    kd, ks = cases.keypoints("u/kd", 2), cases.keypoints("u/ks", 2)
+    sm = dmn.create_sparse_motions(torch.zeros(2, 3, 8, 8), kd, ks)
+    out["sparse_motions"] = npy(sm)
+    delta("sparse_motions", O.sparse_motions(kd, ks, 8, 8), sm)
+    np.savez_compressed(os.path.join(GOLD, "unit.npz"), **out)
+    print("G2 unit goldens:", len(out))
+
+
+# ----------------------------------------------------------------------------------------------- G3 modules
+def g3_prior():
+    out = {}
+    kpm = KPDetector(**cases.KP_DETECTOR_CFG)
+    sd = load(kpm, "kp")
+    x = cases.images("g3/src", 2, 256)
+    for train in (False, True):
+        kpm.load_state_dict(sd)
+        kpm.train(train)
+        with torch.no_grad():
+            r = kpm(x)
+        sfx = "train" if train else "eval"
+        out[f"kp_{sfx}"] = npy(r["kp"])
+        out[f"jac_{sfx}"] = npy(r["jacobian"])
+        P = {k: v.clone() for k, v in sd.items()}
+        with torch.no_grad():
+            o = O.kp_detector(x, P, "", train)
+        delta(f"KPDetector kp {sfx}", o["kp"], r["kp"])
+        delta(f"KPDetector jac {sfx}", o["jacobian"], r["jacobian"])
+    dmm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+    sd = load(dmm, "dm")
+    kd, ks = cases.keypoints("g3/kd", 2), cases.keypoints("g3/ks", 2)
+    for train in (False, True):
+        dmm.load_state_dict(sd)
+        dmm.train(train)
+        with torch.no_grad():
+            r = dmm(x, kd, ks)
+        sfx = "train" if train else "eval"
+        out[f"dm_deformation_{sfx}"] = npy(r["deformation"])
+        out[f"dm_occlusion_{sfx}"] = npy(r["occlusion"])
+        out[f"dm_mask_{sfx}_s4"] = npy(r["mask"][:, :, ::4, ::4])
+        out[f"dm_logit_mask_{sfx}_s4"] = npy(r["logit_mask"][:, :, ::4, ::4])
+        out[f"dm_sparse_deformed_{sfx}_s4"] = npy(r["sparse_deformed"][:, :, :, ::4, ::4])
+        P = {k: v.clone() for k, v in sd.items()}
+        with torch.no_grad():
+            o = O.dense_motion(x, kd, ks, P, "", train)
+        for key in ("deformation", "occlusion", "mask", "sparse_deformed"):
+            delta(f"DenseMotion {key} {sfx}", o[key], r[key])
+        disp = (r["deformation"] - O.coordinate_grid(64, 64, x)[None]) * 31.5
+        print(f"   prior displacement px: mean {disp.abs().mean():.2f} max {disp.abs().max():.2f}; mask max-prob {r['mask'].max(1).values.mean():.2f}")
+    np.savez_compressed(os.path.join(GOLD, "prior.npz"), **out)
+    print("G3 prior goldens:", len(out))
+
+
+def run_raft(rf, sd, size, b, train, tagp, prior_only=False):
+    rf.load_state_dict(sd)
+    rf.train(train)
+    h = size // 4
+    img_full = cases.images(f"{tagp}/src", b, size)
+    img = O.antialias_down(img_full, 0.25)
+    kp_s = cases.keypoints(f"{tagp}/ks", b)["kp"]
+    kp_d = cases.keypoints(f"{tagp}/kd", b)["kp"]
+    dmo = cases.synthetic_dense_motion(f"{tagp}/dm", b, h)
+    return (kp_s, kp_d, dmo, img, img_full)
+
+
+def g3_raft():
+    for size, b, stride in ((64, 2, 1), (128, 2, 2), (256, 1, 4)):
+        out = {}
+        for prior_only in (False, True):
+            rf = RaftFlow(**cases.raft_cfg(size, prior_only))
+            sd = load(rf, "rf")
+            for train in ((False, True) if size <= 128 else (False,)):
+                args = run_raft(rf, sd, size, b, train, f"g3/raft{size}", prior_only)
+                with torch.no_grad():
+                    o_ref, w_ref, s_ref = rf(*args)
+                sfx = ("prior_" if prior_only else "") + ("train" if train else "eval")
+                out[f"out_{sfx}"] = npy(o_ref[:, :, ::stride, ::stride])
+                out[f"warp_{sfx}"] = npy(w_ref[:, :, ::stride, ::stride])
+                out[f"strip_{sfx}"] = npy(s_ref[:, :, ::stride * 2, ::stride * 2])
+                out[f"out_mean_{sfx}"] = npy(o_ref.mean(dim=(2, 3)))
+                out[f"out_std_{sfx}"] = npy(o_ref.std(dim=(2, 3)))
+                P = {k: v.clone() for k, v in sd.items()}
+                trace = {}
+                with torch.no_grad():
+                    o, w, s = O.raft_flow(*args, P, "", size=size, prior_only=prior_only, train=train, trace=trace)
+                delta(f"RaftFlow{size} out {sfx}", o, o_ref)
+                delta(f"RaftFlow{size} warp {sfx}", w, w_ref)
+                delta(f"RaftFlow{size} strip {sfx}", s, s_ref)
+                if not prior_only and not train:
+                    for i in range(6):
+                        df = trace[f"d_flow_{i}"]
+                        print(f"      level {i}: |flow_in| mean {trace[f'flow_in_{i}'].abs().mean():.3f} max {trace[f'flow_in_{i}'].abs().max():.2f}"
+                              f"  |d_flow| mean {df[:, :2].abs().mean():.3f} max {df[:, :2].abs().max():.2f}")
+                        if size <= 128:
+                            out[f"trace_flow_in_{i}"] = npy(trace[f"flow_in_{i}"][:, :, ::stride, ::stride])
+                            out[f"trace_d_flow_{i}"] = npy(df[:, :, ::stride, ::stride])
+        np.savez_compressed(os.path.join(GOLD, f"raft_{size}.npz"), **out)
+        print(f"G3 raft size={size}: {len(out)} arrays")
+
+
+# ----------------------------------------------------------------------------------------------- G4 gradients
+def g4():
+    size, b = 64, 2
+    out = {}
+    rf = RaftFlow(**cases.raft_cfg(size))
+    sd = load(rf, "rf")
+    rf.train(True)
+    kp_s, kp_d, dmo, img, img_full = run_raft(rf, sd, size, b, True, "g4/raft")
+    driving = cases.images("g4/drv", b, size)
+    leaves = [kp_s, kp_d, dmo["deformation"], dmo["occlusion"]]
+    for t in leaves:
+        t.requires_grad_(True)
+    o_ref, _, _ = rf(kp_s, kp_d, dmo, img, img_full)
+    loss = (o_ref - driving).abs().mean()
+    loss.backward()
+    out["loss"] = np.array([loss.item()], np.float32)
+    for n, t in zip(("kp_s", "kp_d", "deformation", "occlusion"), leaves):
+        out[f"grad_{n}"] = npy(t.grad)
+    names, norms = [], []
+    for n, p in rf.named_parameters():
+        names.append(n)
+        norms.append(0.0 if p.grad is None else p.grad.norm().item())
+    out["param_grad_norms"] = np.array(norms, np.float32)
+    for n in ("refine.conv2.weight", "refine.convo2.bias", "to_context.5.weight", "generator.final.weight",
+              "corr_enc.convf1.weight", "kp_head.weight", "generator.first.conv.weight", "pos_embedding"):
+        out["pgrad_" + n] = npy(dict(rf.named_parameters())[n].grad)
+    with open(os.path.join(GOLD, "grads_64_param_names.json"), "w") as f:
+        json.dump(names, f)
+    # oracle gradients
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    l2 = [t.detach().clone().requires_grad_(True) for t in leaves]
+    o, _, _ = O.raft_flow(l2[0], l2[1], {"deformation": l2[2], "occlusion": l2[3]}, img, img_full, P, "", size=size, train=True)
+    lo = (o - driving).abs().mean()
+    lo.backward()
+    print(f"   loss ref {loss.item():.6f} oracle {lo.item():.6f}")
+    for n, t, t2 in zip(("kp_s", "kp_d", "deformation", "occlusion"), leaves, l2):
+        delta(f"grad {n}", t2.grad, t.grad)
+    worst = 0.0
+    for n, p in rf.named_parameters():
+        g = P[n].grad
+        if p.grad is None:
+            continue
+        rel = (g - p.grad).norm().item() / (p.grad.norm().item() + 1e-12)
+        worst = max(worst, rel)
+    print(f"   worst relative param-grad error oracle-vs-ref: {worst:.3e}")
+    np.savez_compressed(os.path.join(GOLD, "grads_64.npz"), **out)
+    print("G4 gradient goldens:", len(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4"]
+    for w in which:
+        print("==", w)
+        globals()[w]()
