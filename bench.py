@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: 256x256 (source, driving) pairs/s, forward+backward(+clip+Adam), fp32,
+vox1.yaml shapes with the FOMM prior and RAFT refinement, B=8 per GPU, synthetic inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant kernel
+(the 128x128-tile fp32 MFMA implicit-GEMM convolution, forward + data-gradient launches) inside the timed region;
+`cpu_baseline` times the CPU oracle (the reference restated, oracle/mrfa_oracle.py) on a bounded sample on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(batch: int, max_seconds: float = 25.0):
+    """Oracle fwd+bwd (train-mode BN, same loss) on the host cores: B=1 pairs until ~max_seconds are spent."""
+    from mrfa_amd.train import VOX1
+    from mrfa_amd.utils.prng import det_uniform
+    from oracle import mrfa_oracle as O
+    from tests import cases
+    from mrfa_amd.modules.manifest import manifest_of
+    from mrfa_amd.train import HotPath
+    # oneDNN fp32 convs stop scaling (and collapse with 256 threads on the GPU box's 2-socket host): cap at 32 threads
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    model = HotPath(VOX1)
+    P = {}
+    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+        sd = cases.weights_for(mod.state_dict(), pfx)
+        P.update({pfx + k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()})
+    del model
+    n, t0 = 0, time.time()
+    while True:
+        src = det_uniform(f"cpu/src{n}", (1, 3, 256, 256), 0, 1)
+        drv = det_uniform(f"cpu/drv{n}", (1, 3, 256, 256), 0, 1)
+        gen, _, _, _, _ = O.mrfa_forward(src, drv, P, size=256, train=True)
+        loss = (gen - drv).abs().mean()
+        loss.backward()
+        n += 1
+        if time.time() - t0 > max_seconds * 0.6 or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x (B=1 fwd+bwd, train-mode BN, L1 loss) of the CPU oracle in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE config: bs=8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", init_method="env://")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from mrfa_amd import hip
+    from mrfa_amd.engine import Ctx
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    hip.lib()                                       # fail loudly if the HIP library is missing
+
+    model = HotPath(VOX1)
+    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+        sd = fill_state_dict(mod.state_dict(), tag=pfx)
+        for k in list(sd):
+            if k.endswith("jacobian.weight"):
+                sd[k] = sd[k] * 0.05
+            if k.endswith("jacobian.bias"):
+                sd[k] = torch.tensor([1.0, 0.0, 0.0, 1.0]) + sd[k] * 0.5
+            if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
+                sd[k] = sd[k] * 0.3
+        mod.load_state_dict(sd)
+    model.to(dev).train(True)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                          broadcast_buffers=False, gradient_as_bucket_view=True)
+    opt = make_optimizer(model, lr=VOX1["train_params"]["lr"])
+    B = a.batch
+    # synthetic pairs, different per rank (weak scaling: per-GPU work fixed), resident in HBM before timing
+    src = det_uniform(f"bench/src/r{rank}", (B, 3, 256, 256), 0, 1).to(dev)
+    drv = det_uniform(f"bench/drv/r{rank}", (B, 3, 256, 256), 0, 1).to(dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = train_step(model, opt, src, drv, clip=VOX1["train_params"]["clip"])
+    barrier()
+    if not a.no_roofline:
+        Ctx.profile = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = train_step(model, opt, src, drv, clip=VOX1["train_params"]["clip"])
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, Ctx.profile = Ctx.profile, None
+    loss_val = float(loss.item())
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / a.steps
+        value = world * B * a.steps / dt
+        roof = None
+        if prof:
+            dom = (128 << 16) | (128 << 4)           # BM=128, BN=128, chunked, no split-K
+            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof if cfg == dom]
+            allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof]
+            if sel:
+                fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
+                achieved = fl / (ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "kernel": "conv_mfma_kernel<128,128,2,2,false> (fwd + dgrad launches)",
+                        "launches_per_step": len(sel) / a.steps, "avg_launch_ms": round(ms / len(sel), 4),
+                        "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
+                        "kernel_ms_per_step": round(ms / a.steps, 2),
+                        "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / a.steps, 2),
+                        "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
+        cpu = None
+        if not a.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(B)
+            except Exception as ex:               # the baseline must never take the GPU number down with it
+                cpu = {"error": repr(ex)}
+        line = {
+            "metric": "frames/sec (256x256 source+driving pair) fwd+bwd", "value": round(value, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "vox1.yaml shapes, FOMM KPDetector prior + DenseMotion + RaftFlow refinement, 256x256, "
+                                   f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "loss": float(f"{loss_val:.6f}")},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,8 @@ typedef struct {
 } mrfa_conv_params;
 
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
+/* (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) chosen by the most recent call on this thread (for roofline accounting) */
+int mrfa_conv2d_last_config(void);
 
 /* weight-gradient (and TN GEMM): dW[tap][co][ci] += sum_p dY[p][co] * X'[p + tap][ci]   (X' = prologue(ups(x)))
  * Replaces the weight-gradient half of conv2d backward for every call site above, and d(k_s) of raft.py:185.    */

@@ -297,6 +297,10 @@ int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, i
 
 }  // namespace
 
+static thread_local int g_last_tile = 0;
+// (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) of the most recent mrfa_conv2d_nhwc launch on this thread
+extern "C" int mrfa_conv2d_last_config(void) { return g_last_tile; }
+
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     const mrfa_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
@@ -357,6 +361,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
             MRFA_CHECK_LAUNCH("splitk_init");
         }
     }
+    g_last_tile = (BM << 16) | (BN << 4) | ((flat ? 1 : 0) << 1) | (splitk > 1 ? 1 : 0);
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
     CFG(128, 128, 2, 2);

@@ -19,7 +19,7 @@ constexpr int WBK = 32;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
-                                                        const int tiles_n, const int nsplit) {
+                                                        const int tiles_n, const int nsplit, const int dy_scalar) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;   // per-wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
@@ -87,9 +87,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
             const long long pp = k0 + a_row0 + j * A_RSTEP;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pp < ke && a_any) {
-                v = *reinterpret_cast<const f32x4*>(dy + (size_t)pp * p.ldy + co0 + a_col);
+                if (!dy_scalar) {
+                    v = *reinterpret_cast<const f32x4*>(dy + (size_t)pp * p.ldy + co0 + a_col);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (!amask[q]) v[q] = 0.f;
+                    for (int q = 0; q < 4; ++q) if (!amask[q]) v[q] = 0.f;
+                } else {       // unaligned dY view (e.g. a 1-channel slice at an odd channel offset): element loads
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (amask[q]) v[q] = dy[(size_t)pp * p.ldy + co0 + a_col + q];
+                }
             }
             ra[j] = v;
         }
@@ -207,7 +212,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     const mrfa_wgrad_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     MRFA_CHECK_ARG(p.x && p.dy && p.dw, "wgrad: null pointer");
-    MRFA_CHECK_ARG((p.ldy % 4) == 0 && aligned16(p.dy), "wgrad: dy must be a 16-B aligned view with ld %% 4 == 0");
+    const int dy_scalar = ((p.ldy % 4) == 0 && aligned16(p.dy) && (p.dy_bs % 4) == 0) ? 0 : 1;
     const bool flat = p.kflat > 0;
     if (!flat) MRFA_CHECK_ARG((p.ldx % 4) == 0 && aligned16(p.x), "wgrad: x must be a 16-B aligned view with ld %% 4 == 0");
     else MRFA_CHECK_ARG(p.ktab != nullptr, "wgrad: flat mode needs ktab");
@@ -236,8 +241,8 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)taps, (unsigned)(nsplit * nb));
 #define WCFG(bm, bn, wm, wn)                                                                                                       \
     if (BM == bm && BN == bn) {                                                                                                    \
-        if (flat) hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, true>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit); \
-        else hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, false>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit);     \
+        if (flat) hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, true>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar); \
+        else hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, false>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar); \
     }
     WCFG(128, 128, 2, 2)
     else WCFG(128, 64, 2, 2)

@@ -214,8 +214,41 @@ def bngrad(bn) -> BNGrad:
     return g
 
 
+# ------------------------------------------------------------------------------------------------- torch "glue islands"
+class IslandOut:
+    """Output of a torch glue island: a detached contiguous tensor that can be re-entered into the engine as an NHWC
+    View (zero copy), fed to another island, or returned to the caller; gradients from all three routes are summed."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+        self._view: Optional[View] = None
+        self.ext_grad: Optional[torch.Tensor] = None
+
+    def view(self) -> "View":
+        if self._view is None:
+            t = self.t
+            assert t.dim() == 4
+            N, H, W, C_ = t.shape
+            self._view = View(Storage(t.view(N * H * W, C_)), N, H, W, C_)
+        return self._view
+
+    def add_grad(self, g: torch.Tensor):
+        g = g.reshape(self.t.shape)
+        self.ext_grad = g.clone() if self.ext_grad is None else self.ext_grad + g
+
+    def total_grad(self) -> Optional[torch.Tensor]:
+        g = self.ext_grad
+        if self._view is not None and self._view.has_grad:
+            vg = self._view.st.grad.view(self.t.shape)
+            g = vg if g is None else g + vg
+        return g
+
+
 # ------------------------------------------------------------------------------------------------- the op context
 class Ctx:
+    # bench.py sets this to a list to collect (config, flops, start_event, end_event) per MFMA conv/GEMM launch
+    profile: Optional[list] = None
+
     def __init__(self, device: torch.device, train: bool, record: bool):
         self.dev = device
         self.train = train
@@ -224,7 +257,7 @@ class Ctx:
         self.L = hip.lib()
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
-        self.param_grads = {}            # id(param) -> grad tensor for non-conv/bn parameters
+        self.ext_grads = {}              # id(tensor) -> grad for module inputs / parameters touched by islands
 
     # -- plumbing
     @property
@@ -238,6 +271,19 @@ class Ctx:
     def rec(self, fn):
         if self.record:
             self.tape.append(fn)
+
+    def _launch_conv(self, p, what: str):
+        prof = Ctx.profile
+        if prof is None:
+            self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), what)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), what)
+        e1.record()
+        nb = max(p.nbatch, 1)
+        flops = 2.0 * nb * p.N * p.Hout * p.Wout * p.Cout * p.Cin * p.R * p.S
+        prof.append((self.L.mrfa_conv2d_last_config(), flops, e0, e1))
 
     def new(self, N, H, W, C_, ld=None, zero=False) -> View:
         ld = _r4(C_) if ld is None else ld
@@ -311,7 +357,7 @@ class Ctx:
         if stats is not None:
             p.stats = stats.data_ptr()
         p.alpha, p.nbatch = 1.0, 1
-        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), "conv2d")
+        self._launch_conv(p, "conv2d")
 
         if self.record:
             def bwd():
@@ -368,7 +414,7 @@ class Ctx:
         p.R, p.S, p.pad = cw.R, cw.S, cw.R - 1 - cw.pad
         p.alpha, p.nbatch = 1.0, 1
         p.accumulate = 1 if direct else 0
-        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), "dgrad")
+        self._launch_conv(p, "dgrad")
         if direct:
             return
         cur = tgt            # holds d(pre(ups(x))) as DATA
@@ -590,7 +636,7 @@ class Ctx:
         p.alpha, p.accumulate = alpha, int(accumulate)
         p.nbatch, p.x_bs, p.w_bs, p.y_bs = nbatch, a_bs, b_bs, c_bs
         p.splitk = 1
-        self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), "gemm_nt")
+        self._launch_conv(p, "gemm_nt")
 
     def gemm_tn_acc(self, a_ptr, lda, b_ptr, ldb, c_ptr, M, Nn, K, alpha, nbatch, a_bs, b_bs, c_bs):
         """C[b][m][n] += alpha * sum_k A[b][k][m] * B[b][k][n]   (C dense M x Nn, atomics)"""
@@ -602,6 +648,49 @@ class Ctx:
         q.nbatch, q.x_bs, q.dy_bs, q.dw_bs = nbatch, b_bs, a_bs, c_bs
         q.ksplit = 0
         self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "gemm_tn")
+
+    # -- torch glue islands (tiny tensors only: keypoint maths, soft-argmax, flow bookkeeping) ------------------
+    def island(self, fn, ins) -> List[IslandOut]:
+        """outs = fn(*ins) with torch device ops; ins may be Views (seen as strided (N,H,W,C) tensors), IslandOuts or
+        plain tensors (module inputs / parameters).  Backward = torch.autograd.grad over the recorded sub-graph."""
+        leafs = []
+        for x in ins:
+            if isinstance(x, View):
+                t = x.tensor().detach()
+            elif isinstance(x, IslandOut):
+                t = x.t.detach()
+            else:
+                t = x.detach()
+            if self.record and t.is_floating_point():
+                t.requires_grad_(True)
+            leafs.append(t)
+        if self.record:
+            with torch.enable_grad():
+                graph_outs = [o.contiguous() for o in fn(*leafs)]
+        else:
+            with torch.no_grad():
+                graph_outs = [o.contiguous() for o in fn(*leafs)]
+        outs = [IslandOut(o.detach()) for o in graph_outs]
+        if self.record:
+            def bwd():
+                sel = [(o, io.total_grad()) for o, io in zip(graph_outs, outs)]
+                sel = [(o, g) for o, g in sel if g is not None and o.requires_grad]
+                if not sel:
+                    return
+                req = [(x, l) for x, l in zip(ins, leafs) if l.requires_grad]
+                grads = torch.autograd.grad([o for o, _ in sel], [l for _, l in req], [g for _, g in sel], allow_unused=True)
+                for (x, _), g in zip(req, grads):
+                    if g is None:
+                        continue
+                    if isinstance(x, View):
+                        x.grad_tensor().add_(g)
+                    elif isinstance(x, IslandOut):
+                        x.add_grad(g)
+                    else:
+                        k = id(x)
+                        self.ext_grads[k] = g if k not in self.ext_grads else self.ext_grads[k] + g
+            self.tape.append(bwd)
+        return outs
 
     # -- backward driver --------------------------------------------------------------------------------------
     def run_backward(self):
@@ -647,7 +736,7 @@ class _ProgramFn(torch.autograd.Function):
             if dg is not None:
                 pgrads[id(bg.bn.weight)] = dg
                 pgrads[id(bg.bn.bias)] = db
-        pgrads.update(ectx.param_grads)
+        pgrads.update(ectx.ext_grads)
         in_grads = [fn() if (fn is not None and need) else None
                     for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[3:3 + actx.n_in])]
         out = [None, None, None] + in_grads + [pgrads.get(id(p)) for p in actx.params]

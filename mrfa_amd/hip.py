@@ -78,6 +78,7 @@ _SIGNATURES = {
     "mrfa_version": ([], C.c_int),
     "mrfa_last_error": ([], C.c_char_p),
     "mrfa_conv2d_nhwc": ([_V, C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_last_config": ([], C.c_int),
     "mrfa_conv2d_wgrad_nhwc": ([_V, C.POINTER(WgradParams)], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_build_ktab": ([c_int_p, _I, _I, _I, _I, _I], C.c_int),

@@ -1,0 +1,13 @@
+"""nn.Module surface of the MRFA hot path (same class names / kwargs / state_dict keys as the reference's
+modules/ package), executing on the HIP engine."""
+from .util import (AntiAliasInterpolation2d, AttributeDict, ChannelBlock2d, DownBlock2d, Hourglass, ResBlock2d,
+                   SameBlock2d, UpBlock2d, convert_dict_to_attrit_dict)
+from .kp_detector import KPDetector
+from .dense_motion import DenseMotionNetwork
+from .generator import OcclusionAwareGenerator
+from .raft import RaftFlow
+from .model import MRFA
+
+__all__ = ["AntiAliasInterpolation2d", "AttributeDict", "ChannelBlock2d", "DownBlock2d", "Hourglass", "ResBlock2d",
+           "SameBlock2d", "UpBlock2d", "convert_dict_to_attrit_dict", "KPDetector", "DenseMotionNetwork",
+           "OcclusionAwareGenerator", "RaftFlow", "MRFA"]

@@ -1,0 +1,64 @@
+"""KPDetector (FOMM prior).  reference: modules/kp_detector.py:17-133."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..engine import Ctx, run_program
+from .util import AntiAliasInterpolation2d, Hourglass, make_coordinate_grid
+
+
+class KPDetector(nn.Module):
+    """Keypoints (B,K,2) in [-1,1] + heat-map-weighted 2x2 Jacobians.  Same kwargs / state_dict as the reference
+    (kp_detector.py:22-53): predictor.{encoder,decoder}.*, kp, jacobian, down.weight."""
+
+    def __init__(self, block_expansion=32, num_kp=15, num_channels=3, max_features=1024, num_blocks=5, temperature=0.1,
+                 scale_factor=0.25, estimate_jacobian=False, estimate_occlusion=False):
+        super().__init__()
+        if estimate_occlusion:
+            raise NotImplementedError("estimate_occlusion is disabled in every reference config (vox1/celebvhq)")
+        self.predictor = Hourglass(block_expansion, in_features=num_channels, max_features=max_features, num_blocks=num_blocks)
+        self.kp = nn.Conv2d(self.predictor.out_filters, num_kp, kernel_size=(7, 7), padding=0)
+        self.num_kp = num_kp
+        self.estimate_jacobian = estimate_jacobian
+        if estimate_jacobian:
+            self.num_jacobian_maps = 1
+            self.jacobian = nn.Conv2d(self.predictor.out_filters, 4 * self.num_jacobian_maps, kernel_size=(7, 7), padding=0)
+            self.jacobian.weight.data.zero_()
+            self.jacobian.bias.data.copy_(torch.tensor([1, 0, 0, 1] * self.num_jacobian_maps, dtype=torch.float))
+        self.estimate_occlusion = False
+        self.temperature = temperature
+        self.scale_factor = scale_factor
+        if self.scale_factor != 1:
+            self.down = AntiAliasInterpolation2d(num_channels, self.scale_factor)
+
+    def _program(self, e: Ctx, x: torch.Tensor):
+        xs = self.down.run(e, x) if self.scale_factor != 1 else e.from_nchw(x)
+        fmap = self.predictor.run(e, xs, need_dx=False)
+        logits = e.conv(fmap, self.kp)                                     # (B,58,58,K) NHWC
+        views = [logits]
+        if self.estimate_jacobian:
+            views.append(e.conv(fmap, self.jacobian))                      # (B,58,58,4)
+        temp = self.temperature
+
+        def glue(lg, jm=None):
+            # spatial softmax + soft-argmax (+ Jacobian pooling): kp_detector.py:90-120
+            b, hh, ww, k = lg.shape
+            heat = F.softmax(lg.reshape(b, hh * ww, k) / temp, dim=1)                    # (B,HW,K)
+            grid = make_coordinate_grid((hh, ww), lg).reshape(1, hh * ww, 2)
+            kp = torch.einsum("bpk,bpc->bkc", heat, grid.expand(b, -1, -1))
+            outs = [kp]
+            if jm is not None:
+                jac = torch.einsum("bpk,bpj->bkj", heat, jm.reshape(b, hh * ww, 4)).reshape(b, k, 2, 2)
+                outs.append(jac)
+            return outs
+        outs = e.island(glue, views)
+        return tuple(o.t for o in outs), tuple(o.add_grad for o in outs), (None,)
+
+    def forward(self, x):
+        outs = run_program(self, self._program, [x])
+        out = {'kp': outs[0]}
+        if self.estimate_jacobian:
+            out['jacobian'] = outs[1]
+        return out

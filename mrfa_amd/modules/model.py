@@ -1,0 +1,55 @@
+"""MRFA model assembly (inference wiring).  reference: modules/model.py:145-216.
+
+Only the hot-path wiring is reproduced: encoder (FOMM KPDetector) -> dense_motion -> decoder (RaftFlow).  The training
+losses of the reference (VGG19 perceptual pyramid, equivariance, background) need torchvision + downloaded weights and
+are out of scope; bench.py trains with the surrogate L1 loss defined there."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .dense_motion import DenseMotionNetwork
+from .kp_detector import KPDetector
+from .raft import RaftFlow
+from .util import AntiAliasInterpolation2d
+
+
+def _get(cfg, key):
+    return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+
+class MRFA(nn.Module):
+    """attributes used by the reference's callers: .encoder .dense_motion .decoder .down (train.py:21-24, demo.py:40-42)"""
+
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        train_params = _get(cfg, 'train_params')
+        self.train_params = train_params
+        prior = train_params['prior_model']
+        if prior == 'fomm':
+            self.encoder = KPDetector(**_get(cfg, 'fomm_kp_detector'))
+            self.dense_motion = DenseMotionNetwork(**_get(cfg, 'dense_motion'))
+        else:
+            raise NotImplementedError(
+                f"prior_model={prior!r}: only the FOMM KPDetector prior is built natively so far (the MTIA TokenPose_B "
+                "encoder is SURVEY.md section 8(f) rank 1; TPSM is out of scope)")
+        self.bg_start = train_params['bg_start']
+        if self.bg_start < train_params['num_epochs']:
+            raise NotImplementedError("BGMotionPredictor (resnet18) is out of scope: SURVEY.md section 8(f) rank 2")
+        self.decoder = RaftFlow(**_get(cfg, 'raft_flow'))
+        self.down = AntiAliasInterpolation2d(3, 0.25)
+
+    def forward(self, x, epoch=100, is_train=True):
+        kp_s = self.encoder(x['source'])
+        kp_d = self.encoder(x['driving'])
+        img_down = self.down(x['source'])
+        dense_motion = self.dense_motion(x['source'], kp_d, kp_s, bg_param=None, dropout_flag=False, dropout_p=0)
+        gen, warp_img, occlusion = self.decoder(kp_s['kp'], kp_d['kp'], dense_motion, img=img_down, img_full=x['source'])
+        warp_img = torch.cat([warp_img, occlusion.repeat(1, 3, 1, 1)], dim=3)
+        loss_values = {}
+        if not is_train:
+            return gen, warp_img, loss_values, kp_s['kp'], kp_d['kp']
+        raise NotImplementedError(
+            "MRFA.forward(is_train=True): the reference's perceptual/equivariance losses need torchvision VGG19 weights "
+            "(out of scope); use mrfa_amd.train.surrogate_step or compute a loss on `gen` yourself")

@@ -1,0 +1,263 @@
+"""RaftFlow: structure correlation volume + 6-level coarse-to-fine motion refinement + feature warps + decode.
+reference: modules/raft.py:12-311 (CorrBlock, BasicMotionEncoder, RefineFlow, RaftFlow)."""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..engine import Ctx, View, run_program
+from .generator import OcclusionAwareGenerator
+from .util import Hourglass, coords_grid_nhwc, kp2gaussian
+
+
+class BasicMotionEncoder(nn.Module):
+    """reference: modules/raft.py:50-68 (98 corr channels + 2 flow channels -> 128)"""
+
+    def __init__(self, num_levels=2, radius=3):
+        super().__init__()
+        cor_planes = num_levels * (2 * radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 128, 1, padding=0)
+        self.convc2 = nn.Conv2d(128, 96, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 96, 128 - 2, 3, padding=1)
+
+    def run(self, e: Ctx, flow: View, corr: View, out: View):
+        """writes [conv(126) | flow(2)] into `out` (128 channels of the RefineFlow input buffer)"""
+        cor1 = e.conv(corr, self.convc1, relu=True)
+        corflo = e.new(flow.N, flow.H, flow.W, 160)
+        e.conv(cor1, self.convc2, out=corflo.slice(0, 96), relu=True)
+        flo1 = e.conv(flow, self.convf1, relu=True)
+        e.conv(flo1, self.convf2, out=corflo.slice(96, 160), relu=True)
+        e.conv(corflo, self.conv, out=out.slice(0, 126), relu=True)
+        e.copy(flow, out=out.slice(126, 128))
+
+
+class RefineFlow(nn.Module):
+    """The stateless update operator (NOT a GRU).  reference: modules/raft.py:70-88"""
+
+    def __init__(self):
+        super().__init__()
+        self.convc1 = nn.Conv2d(192, 128, 3, padding=1)
+        self.conv1 = nn.Conv2d(256, 128, 3, padding=1)
+        self.conv2 = nn.Conv2d(128, 2, 3, padding=1)
+        self.convo1 = nn.Conv2d(256, 128, 3, padding=1)
+        self.convo2 = nn.Conv2d(128, 1, 3, padding=1)
+
+    def run(self, e: Ctx, inp: View, ctx: View) -> View:
+        """inp: 256-channel buffer whose first 128 channels hold the motion features; returns d_flow (.,.,.,3)"""
+        e.conv(ctx, self.convc1, out=inp.slice(128, 256), relu=True)
+        h1 = e.conv(inp, self.conv1, relu=True)
+        d = e.new(inp.N, inp.H, inp.W, 3)
+        e.conv(h1, self.conv2, out=d.slice(0, 2))
+        h2 = e.conv(inp, self.convo1, relu=True)
+        e.conv(h2, self.convo2, out=d.slice(2, 3))
+        return d
+
+
+class _CorrVolume:
+    """All-pairs structure correlation (raft.py:183-185) as two batched MFMA GEMMs: level 0 against k_s and level 1
+    against the 2x2-pooled k_s (avg-pooling the volume over its source dims == correlating with pooled keys).
+    Gradients: lookup backward scatters into dense dvol buffers; dq = dvol.k, dk = dvol^T.q are GEMMs again."""
+
+    def __init__(self, e: Ctx, q: View, k: View, kpool: View, scale: float):
+        self.e, self.q, self.k, self.kp, self.scale = e, q, k, kpool, scale
+        B, Q, S0, S1, D = q.N, q.H * q.W, k.H * k.W, kpool.H * kpool.W, q.C
+        self.B, self.Q, self.S0, self.S1, self.D = B, Q, S0, S1, D
+        self.vol0 = torch.empty((B * Q, S0), dtype=torch.float32, device=e.dev)
+        self.vol1 = torch.empty((B * Q, S1), dtype=torch.float32, device=e.dev)
+        e.gemm_nt(q.ptr, q.ld, k.ptr, k.ld, self.vol0.data_ptr(), S0, Q, S0, D, scale, B, Q * q.ld, S0 * k.ld, Q * S0)
+        e.gemm_nt(q.ptr, q.ld, kpool.ptr, kpool.ld, self.vol1.data_ptr(), S1, Q, S1, D, scale, B, Q * q.ld, S1 * kpool.ld, Q * S1)
+        self.dvol0 = self.dvol1 = None
+        if e.record:
+            e.tape.append(self._bwd)
+
+    def dvols(self):
+        if self.dvol0 is None:
+            self.dvol0 = torch.zeros_like(self.vol0)
+            self.dvol1 = torch.zeros_like(self.vol1)
+        return self.dvol0, self.dvol1
+
+    def _bwd(self):
+        if self.dvol0 is None:
+            return
+        e, q, k, kp = self.e, self.q, self.k, self.kp
+        B, Q, S0, S1, D = self.B, self.Q, self.S0, self.S1, self.D
+        for dvol, kk, S in ((self.dvol0, k, S0), (self.dvol1, kp, S1)):
+            # dq[b,i,:] += scale * sum_j dvol[b,i,j] k[b,j,:]   -> NT GEMM against k^T (D x S per batch)
+            kt = torch.empty((B, D, S), dtype=torch.float32, device=e.dev)
+            e._chk(e.L.mrfa_nhwc_to_nchw(e.s, kk.ptr, kk.ld, kt.data_ptr(), B, D, 1, S, 0), "transpose(k)")
+            e.gemm_nt(dvol.data_ptr(), S, kt.data_ptr(), S, q.gptr, q.ld, Q, D, S, self.scale, B, Q * S, D * S, Q * q.ld, accumulate=True)
+            # dk[b,j,:] += scale * sum_i dvol[b,i,j] q[b,i,:]   -> TN GEMM (atomics into a dense temp, then added)
+            tmp = torch.zeros((B, S, D), dtype=torch.float32, device=e.dev)
+            e.gemm_tn_acc(dvol.data_ptr(), S, q.ptr, q.ld, tmp.data_ptr(), S, D, Q, self.scale, B, Q * S, Q * q.ld, S * D)
+            e._chk(e.L.mrfa_copy_view(e.s, tmp.data_ptr(), D, B * S, D, kk.gptr, kk.ld, 1.0, 1), "dk")
+        self.dvol0 = self.dvol1 = None
+
+
+class RaftFlow(nn.Module):
+    """Same kwargs / state_dict / forward signature as the reference (raft.py:92-141):
+    forward(kp_s, kp_d, dense_motion, img, img_full) -> (out, warp_img, occlusion_strip)."""
+
+    def __init__(self, prior_only=False, num_kp=10, dim=256, size=256, generator=None, driving_encoder=None, source_encoder=None):
+        super().__init__()
+        self.scale = dim ** -0.5
+        self.size = size
+        self.h = size // 4
+        self.w = size // 4
+        self.prior_only = prior_only
+        self.generator = OcclusionAwareGenerator(**generator)
+        channels = {size // 32: 512, size // 16: 512, size // 8: 512, size // 4: 256, size // 2: 128, size: 64}
+        self.total_iter = int(math.log(2 ** 5, 2)) + 1
+        self.num_iter = int(math.log(2 ** 5, 2)) + 1
+        self.basic_res_index = int(math.log(self.h // (size // 32), 2))
+        if not self.prior_only:
+            self.kp = Hourglass(**driving_encoder)
+            self.kp_img = Hourglass(**source_encoder)
+            self.kp_head = nn.Conv2d(self.kp.out_filters, dim, kernel_size=1, padding=0)
+            self.kp_img_head = nn.Conv2d(self.kp_img.out_filters, dim, kernel_size=1, padding=0)
+            self.pos_embedding = nn.Parameter(torch.zeros(1, num_kp, self.h, self.w))
+            nn.init.trunc_normal_(self.pos_embedding, std=.02)
+            self.corr_enc = BasicMotionEncoder()
+            self.refine = RefineFlow()
+            self.to_context = nn.ModuleList()
+            for i in range(self.num_iter):
+                self.to_context.append(nn.Conv2d(channels[(size // 32) * (2 ** i)], 192, 1, padding=0))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _strip(self, e: Ctx, occs: List[View]) -> torch.Tensor:
+        """visualisation strip (B,1,size,len*size) (raft.py:170-172,305-309); detached (no caller differentiates it)"""
+        with torch.no_grad():
+            maps = [F.interpolate(o.tensor().permute(0, 3, 1, 2), size=self.size, mode='bilinear', align_corners=True) for o in occs]
+            return torch.cat(maps, dim=3)
+
+    def _program(self, e: Ctx, kp_s, kp_d, deformation, occlusion, img, img_full):
+        gen = self.generator
+        imgf = e.from_nchw(img_full)
+        feature = gen.run_encode(e, imgf)
+        b, h, w = img.shape[0], img.shape[2], img.shape[3]
+        size = self.size
+        deform = e.wrap_nhwc(deformation.contiguous())                          # (B,h,w,2) normalised sampling grid
+        prior_occ = e.wrap_nhwc(occlusion.contiguous().view(b, h, w, 1))        # logits
+        in_grads = (None, None, (lambda: deform.st.grad.view(b, h, w, 2) if deform.has_grad else None),
+                    (lambda: prior_occ.st.grad.view(b, 1, h, w) if prior_occ.has_grad else None), None, None)
+
+        if self.prior_only:                                                     # raft.py:156-173
+            warp_f, occs = [], []
+            grid_res = None
+            for i in range(self.total_iter):
+                f = feature[i]
+                if deform.H != f.H:
+                    grid_res = e.resize(deform, f.H, f.W)
+                    occ_res = e.resize(prior_occ, f.H, f.W)
+                else:
+                    grid_res, occ_res = deform, prior_occ
+                warp_f.append(e.grid_sample(f, grid_res, 0))
+                occs.append(e.act(occ_res, 2))
+            warp_img = e.grid_sample(imgf, grid_res, 0, need_din=False)
+            out = gen.run_decode(e, warp_f, warp_img, occs, None)
+            outs = (e.to_nchw(out), e.to_nchw(warp_img), self._strip(e, occs))
+            seed = ((lambda g: e.seed_grad_nchw(out, g)), (lambda g: e.seed_grad_nchw(warp_img, g)), None)
+            return outs, seed, in_grads
+
+        # ---- structure encoders + correlation volumes (raft.py:177-185)
+        pos = self.pos_embedding
+
+        def heatmaps(ks_, kd_, pos_, img_):
+            hs = (kp2gaussian(ks_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)
+            hd = (kp2gaussian(kd_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)
+            return [torch.cat([hs, img_.permute(0, 2, 3, 1)], dim=-1), hd]
+        in_s, in_d = e.island(heatmaps, [kp_s, kp_d, pos, img])
+        in_grads = ((lambda: e.ext_grads.get(id(kp_s))), (lambda: e.ext_grads.get(id(kp_d)))) + in_grads[2:]
+        fe_s = self.kp_img.run(e, in_s.view())
+        fe_d = self.kp.run(e, in_d.view())
+        k_s = e.conv(fe_s, self.kp_img_head)                                   # (B,h,w,dim)
+        q_d = e.conv(fe_d, self.kp_head)
+        k_pool = e.avgpool2(k_s)
+        base = self.basic_res_index
+        q_levels = {base: q_d}
+        for i in range(base - 1, -1, -1):                                       # pooled queries == volume pooled over driving dims
+            q_levels[i] = e.avgpool2(q_levels[i + 1])
+        vols = {i: _CorrVolume(e, q_levels[i], k_s, k_pool, self.scale) for i in range(base + 1)}
+
+        # ---- prior initialisation (raft.py:189-206)
+        ident_h = coords_grid_nhwc(h, w, img_full)
+        init_flow = e.copy(deform, mul=(h - 1) / 2.0)
+        init_flow.tensor().add_((h - 1) / 2.0 - ident_h)
+        r0 = size // 32
+        flow = e.resize(init_flow, r0, r0, mul=1.0 / 8.0)
+        occ = e.resize(prior_occ, r0, r0)
+
+        # decode concat buffers [blend | coarse warp]
+        lv_c = gen.level_channels()
+        cats = [e.new(b, r0 * (2 ** i), r0 * (2 ** i), 2 * lv_c[i]) for i in range(gen.num_up_blocks)]
+
+        out_warp_f, out_occ = [], []
+        d_f_pre = d_occ_pre = None
+        for i in range(self.total_iter):
+            r = r0 * (2 ** i)
+            f = feature[i]
+            if i < base:
+                cscale, vol, rq = float(2 ** (base - i)), vols[i], r
+                flow_q = flow
+            else:
+                cscale, vol, rq = 1.0, vols[base], h
+                flow_q = e.resize(flow, h, w, mul=0.5 ** (i - base)) if i > base else flow
+            coords = e.copy(flow_q, mul=cscale)
+            coords.tensor().add_(coords_grid_nhwc(rq, rq, img_full) * cscale)
+            cfeat = e.corr_lookup(vol.vol0, vol.vol1, vol.dvols, h, w, coords)
+            if i > base:
+                cfeat = e.resize(cfeat, r, r)
+            inp = e.new(b, r, r, 256)
+            self.corr_enc.run(e, flow, cfeat, inp)
+            ctx = e.grid_sample(f, flow, 1)
+            ctx = e.conv(ctx, self.to_context[i], relu=True)
+            d_flow = self.refine.run(e, inp, ctx)
+            flow_w = e.copy(flow)
+            e.copy(d_flow.slice(0, 2), out=flow_w, acc=True)
+            occ_new = e.copy(occ)
+            e.copy(d_flow.slice(2, 3), out=occ_new, acc=True)
+            out_warp_f.append(e.grid_sample(f, flow_w, 1))
+            out_occ.append(e.act(occ_new, 2))
+            # coarse (prior-motion) warp straight into its decode concat slot (raft.py:265-272); level 5's is never read
+            if i < gen.num_up_blocks:
+                grid_c = e.resize(deform, r, r) if i != base else deform
+                e.grid_sample(f, grid_c, 0, out=cats[i].slice(lv_c[i], 2 * lv_c[i]))
+            if i < self.num_iter - 1:                                           # raft.py:276-295
+                r2 = r * 2
+                sc = 2 ** (base - i) / 2.0
+                nflow = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
+                e.resize(init_flow, r2, r2, mul=1.0 / sc, out=nflow, acc=True)
+                nocc = e.resize(d_flow.slice(2, 3), r2, r2)
+                e.resize(prior_occ, r2, r2, out=nocc, acc=True)
+                if i == 0:
+                    d_f_pre = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
+                    d_occ_pre = e.resize(d_flow.slice(2, 3), r2, r2)
+                else:
+                    e.resize(d_f_pre, r2, r2, mul=2.0, out=nflow, acc=True)
+                    e.resize(d_occ_pre, r2, r2, out=nocc, acc=True)
+                    nd = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
+                    e.resize(d_f_pre, r2, r2, mul=2.0, out=nd, acc=True)
+                    no = e.resize(d_flow.slice(2, 3), r2, r2)
+                    e.resize(d_occ_pre, r2, r2, out=no, acc=True)
+                    d_f_pre, d_occ_pre = nd, no
+                flow, occ = nflow, nocc
+        # NB: the image is warped with the last level's INPUT flow, not flow_w (raft.py:302)
+        warp_img = e.grid_sample(imgf, flow, 1, need_din=False)
+        out = gen.run_decode(e, out_warp_f, warp_img, out_occ, cats)
+        strip = self._strip(e, out_occ + [e.act(prior_occ, 2)])
+        outs = (e.to_nchw(out), e.to_nchw(warp_img), strip)
+        seed = ((lambda g: e.seed_grad_nchw(out, g)), (lambda g: e.seed_grad_nchw(warp_img, g)), None)
+        return outs, seed, in_grads
+
+    def forward(self, kp_s, kp_d, dense_motion, img, img_full):
+        if img is None:
+            raise ValueError("RaftFlow.forward needs `img` (the 1/4-resolution source); the reference crashes on None too "
+                             "(raft.py:144-145 uses a commented-out self.down)")
+        ins = [kp_s, kp_d, dense_motion['deformation'], dense_motion['occlusion'], img, img_full]
+        out, warp_img, strip = run_program(self, self._program, ins)
+        return out, warp_img, strip

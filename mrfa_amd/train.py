@@ -1,0 +1,68 @@
+"""Minimal data-parallel training harness for the hot path (the reference's train.py:21-25,39-48,58-70 restated):
+Adam(lr 2e-4, betas (0.5, 0.999)) over encoder/decoder/dense_motion, inf-norm gradient clipping on encoder and
+dense_motion, DistributedDataParallel over RCCL for gradient sync only (no model sharding).
+
+The reference's real losses (VGG19 perceptual pyramid, equivariance) need torchvision weights and are out of scope
+(SURVEY.md 8f-2); the step here uses the surrogate L1 loss mean|gen - driving| that SURVEY.md 8(d) defines for the
+fwd+bwd metric."""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .modules import DenseMotionNetwork, KPDetector, RaftFlow
+from .modules.util import AntiAliasInterpolation2d
+
+VOX1 = dict(
+    fomm_kp_detector=dict(block_expansion=32, num_kp=10, num_channels=3, max_features=1024, num_blocks=5, temperature=0.1,
+                          scale_factor=0.25, estimate_jacobian=True, estimate_occlusion=False),
+    dense_motion=dict(block_expansion=64, max_features=1024, num_blocks=5, scale_factor=0.25, num_kp=10, num_channels=3,
+                      estimate_occlusion_map=True),
+    raft_flow=dict(prior_only=False, num_kp=10, dim=256, size=256,
+                   generator=dict(num_channels=3, block_expansion=64, max_features=512, num_up_blocks=5),
+                   driving_encoder=dict(in_features=10, block_expansion=32, max_features=512, num_blocks=5),
+                   source_encoder=dict(in_features=13, block_expansion=32, max_features=512, num_blocks=5)),
+    train_params=dict(lr=2.0e-4, clip=10.0),
+)
+
+
+class HotPath(nn.Module):
+    """encoder -> dense_motion -> decoder wiring of MRFA.forward (modules/model.py:185-210), attribute names as in the
+    reference so checkpoints and train.py's parameter groups line up."""
+
+    def __init__(self, cfg=VOX1):
+        super().__init__()
+        self.encoder = KPDetector(**cfg["fomm_kp_detector"])
+        self.dense_motion = DenseMotionNetwork(**cfg["dense_motion"])
+        self.decoder = RaftFlow(**cfg["raft_flow"])
+        self.down = AntiAliasInterpolation2d(3, 0.25)
+
+    def forward(self, source, driving):
+        kp_s = self.encoder(source)
+        kp_d = self.encoder(driving)
+        img_down = self.down(source)
+        dm = self.dense_motion(source, kp_d, kp_s)
+        gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
+        return gen
+
+
+def make_optimizer(model: HotPath, lr=2.0e-4):
+    m = model.module if hasattr(model, "module") else model
+    return torch.optim.Adam([{"params": m.encoder.parameters()}, {"params": m.decoder.parameters()},
+                             {"params": m.dense_motion.parameters()}], lr=lr, betas=(0.5, 0.999))
+
+
+def train_step(model, optimizer, source, driving, clip=10.0):
+    """one fwd + bwd + clip + Adam step; returns the (device) loss tensor"""
+    optimizer.zero_grad(set_to_none=True)
+    gen = model(source, driving)
+    loss = (gen - driving).abs().mean()
+    loss.backward()
+    m = model.module if hasattr(model, "module") else model
+    if clip:
+        nn.utils.clip_grad_norm_(m.encoder.parameters(), max_norm=clip, norm_type=math.inf)
+        nn.utils.clip_grad_norm_(m.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
+    optimizer.step()
+    return loss

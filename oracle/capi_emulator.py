@@ -1,0 +1,443 @@
+"""Executable specification of the C ABI in include/mrfa_hip.h  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Every entry point of libmrfa_hip.so restated with plain torch CPU ops on host memory addressed through the same raw
+pointers / parameter structs.  Two uses, both in tests/ only:
+  * `-m gpu` kernel tests run the HIP library and this emulator on the same seeded inputs and compare;
+  * `-m "not gpu"` wiring tests inject it in place of the library (monkeypatching mrfa_amd.hip) so that the host-side
+    engine and nn.Module programs can be checked against the reference goldens on a machine without a GPU.
+mrfa_amd never imports this file; without libmrfa_hip.so the product raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+
+def _flat(ptr: int, n: int, dtype=torch.float32) -> torch.Tensor:
+    ct = {torch.float32: C.c_float, torch.float64: C.c_double, torch.int32: C.c_int}[dtype]
+    return torch.frombuffer((ct * n).from_address(ptr), dtype=dtype)
+
+
+def mat(ptr: int, rows: int, ld: int, cols: int) -> torch.Tensor:
+    """[rows, cols] strided view (row stride ld) of host memory at ptr."""
+    return torch.as_strided(_flat(ptr, (rows - 1) * ld + cols), (rows, cols), (ld, 1))
+
+
+def nhwc(ptr, N, H, W, ld, Cc) -> torch.Tensor:
+    return mat(ptr, N * H * W, ld, Cc).view(N, H, W, Cc) if ld == Cc else \
+        torch.as_strided(_flat(ptr, (N * H * W - 1) * ld + Cc), (N, H, W, Cc), (H * W * ld, W * ld, ld, 1))
+
+
+def vec(ptr, n, dtype=torch.float32):
+    return _flat(ptr, n, dtype) if ptr else None
+
+
+def _obj(ref):
+    return ref._obj if hasattr(ref, "_obj") else ref
+
+
+class Emulator:
+    def __init__(self):
+        self._err = b""
+
+    # ---------------------------------------------------------------- misc
+    def mrfa_version(self):
+        return 1
+
+    def mrfa_last_error(self):
+        return self._err
+
+    def mrfa_conv2d_last_config(self):
+        return 0
+
+    def mrfa_build_ktab(self, tab, Cc, R, S, pad, flip):
+        K = R * S * Cc
+        KP = (K + 31) // 32 * 32
+        for k in range(KP):
+            if k >= K:
+                tab[k] = -1
+                continue
+            tap, c = divmod(k, Cc)
+            r, s = divmod(tap, S)
+            tab[k] = ((r - pad) + 128) | (((s - pad) + 128) << 8) | (c << 16)
+        return 0
+
+    def mrfa_pack_conv_weight(self, stream, src, dst, Cout, Cin, R, S, mode):
+        T = R * S
+        if mode == 4:
+            g = _flat(src, T * Cout * Cin).view(T, Cout, Cin)
+            d = _flat(dst, Cout * Cin * T).view(Cout, Cin, T)
+            d += g.permute(1, 2, 0)
+            return 0
+        w = _flat(src, Cout * Cin * T).view(Cout, Cin, T)
+        if mode == 0:
+            cop, cip = (Cout + 127) // 128 * 128, (Cin + 31) // 32 * 32
+            d = _flat(dst, T * cop * cip).view(T, cop, cip)
+            d.zero_()
+            d[:, :Cout, :Cin] = w.permute(2, 0, 1)
+        elif mode == 1:
+            cop, kp = (Cout + 127) // 128 * 128, (T * Cin + 31) // 32 * 32
+            d = _flat(dst, cop * kp).view(cop, kp)
+            d.zero_()
+            d[:Cout, :T * Cin] = w.permute(0, 2, 1).reshape(Cout, T * Cin)
+        elif mode == 2:
+            cip, cop = (Cin + 127) // 128 * 128, (Cout + 31) // 32 * 32
+            d = _flat(dst, T * cip * cop).view(T, cip, cop)
+            d.zero_()
+            d[:, :Cin, :Cout] = w.flip(2).permute(2, 1, 0)
+        elif mode == 3:
+            cip, kp = (Cin + 127) // 128 * 128, (T * Cout + 31) // 32 * 32
+            d = _flat(dst, cip * kp).view(cip, kp)
+            d.zero_()
+            d[:Cin, :T * Cout] = w.flip(2).permute(1, 2, 0).reshape(Cin, T * Cout)
+        else:
+            return 1
+        return 0
+
+    # ---------------------------------------------------------------- conv / gemm
+    @staticmethod
+    def _prep_input(p, x_ptr):
+        x = nhwc(x_ptr, p.N, p.Hin, p.Win, p.ldx, p.Cin).permute(0, 3, 1, 2).clone()
+        if p.in_scale:
+            x = x * vec(p.in_scale, p.Cin).view(1, -1, 1, 1) + vec(p.in_shift, p.Cin).view(1, -1, 1, 1)
+            if p.in_relu:
+                x = F.relu(x)
+        if p.ups:
+            x = F.interpolate(x, scale_factor=2)
+        return x
+
+    def mrfa_conv2d_nhwc(self, stream, pref):
+        p = _obj(pref)
+        T = p.R * p.S
+        nb = max(p.nbatch, 1)
+        for b in range(nb):
+            xp = p.x + 4 * b * p.x_bs
+            wp = p.w + 4 * b * p.w_bs
+            yp = p.y + 4 * b * p.y_bs
+            x = self._prep_input(p, xp)
+            if p.kflat > 0:
+                wm = mat(wp, p.Cout, p.w_ld, p.kflat)
+                w = wm.reshape(p.Cout, T, p.Cin).permute(0, 2, 1).reshape(p.Cout, p.Cin, p.R, p.S)
+            else:
+                wt = torch.as_strided(_flat(wp, (T - 1) * p.w_tap + (p.Cout - 1) * p.w_ld + p.Cin), (T, p.Cout, p.Cin),
+                                      (p.w_tap, p.w_ld, 1))
+                w = wt.permute(1, 2, 0).reshape(p.Cout, p.Cin, p.R, p.S)
+            acc = F.conv2d(x, w.contiguous(), None, padding=p.pad) * p.alpha
+            assert acc.shape[2] == p.Hout and acc.shape[3] == p.Wout, (acc.shape, p.Hout, p.Wout)
+            v = acc.permute(0, 2, 3, 1)
+            y = nhwc(yp, p.N, p.Hout, p.Wout, p.ldy, p.Cout)
+            if p.splitk > 1 and False:
+                pass
+            if p.bias:
+                v = v + vec(p.bias, p.Cout)
+            if p.out_scale:
+                v = v * vec(p.out_scale, p.Cout) + vec(p.out_shift, p.Cout)
+            if p.res:
+                v = v + nhwc(p.res, p.N, p.Hout, p.Wout, p.ldr, p.Cout)
+            if p.relu:
+                v = F.relu(v)
+            if p.accumulate:
+                v = v + y
+            y.copy_(v)
+            if p.stats:
+                st = vec(p.stats, 2 * p.Cout, torch.float64)
+                flat = v.reshape(-1, p.Cout).double()
+                st[:p.Cout] += flat.sum(0)
+                st[p.Cout:] += (flat * flat).sum(0)
+        return 0
+
+    def mrfa_conv2d_wgrad_nhwc(self, stream, pref):
+        p = _obj(pref)
+        T = p.R * p.S
+        nb = max(p.nbatch, 1)
+        for b in range(nb):
+            x = self._prep_input(p, p.x + 4 * b * p.x_bs)
+            dy = nhwc(p.dy + 4 * b * p.dy_bs, p.N, p.Hout, p.Wout, p.ldy, p.Cout).permute(0, 3, 1, 2)
+            with torch.enable_grad():
+                w = torch.zeros(p.Cout, p.Cin, p.R, p.S, requires_grad=True)
+                y = F.conv2d(x, w, None, padding=p.pad)
+                (gw,) = torch.autograd.grad(y, w, dy.contiguous())
+            dw = _flat(p.dw + 4 * b * p.dw_bs, T * p.Cout * p.Cin).view(T, p.Cout, p.Cin)
+            dw += p.alpha * gw.reshape(p.Cout, p.Cin, T).permute(2, 0, 1)
+            if p.dbias:
+                vec(p.dbias, p.Cout).add_(dy.sum(dim=(0, 2, 3)))
+        return 0
+
+    # ---------------------------------------------------------------- batch norm
+    def mrfa_bn_stats(self, stream, x, ldx, rows, Cc, stats):
+        v = mat(x, rows, ldx, Cc).double()
+        st = vec(stats, 2 * Cc, torch.float64)
+        st[:Cc] += v.sum(0)
+        st[Cc:] += (v * v).sum(0)
+        return 0
+
+    def mrfa_bn_finalize(self, stream, stats, count, gamma, beta, rmean, rvar, momentum, eps, Cc, train, scale, shift, mean_out,
+                         invstd_out):
+        g, b = vec(gamma, Cc), vec(beta, Cc)
+        if train:
+            st = vec(stats, 2 * Cc, torch.float64)
+            m = st[:Cc] / count
+            var = (st[Cc:] / count - m * m).clamp_min(0)
+            mean = m.float()
+            invstd = (1.0 / torch.sqrt(var + eps)).float()
+            if rmean:
+                unb = var * count / (count - 1) if count > 1 else var
+                rm, rv = vec(rmean, Cc), vec(rvar, Cc)
+                rm.mul_(1 - momentum).add_(momentum * mean)
+                rv.mul_(1 - momentum).add_(momentum * unb.float())
+        else:
+            mean = vec(rmean, Cc).clone()
+            invstd = 1.0 / torch.sqrt(vec(rvar, Cc) + eps)
+        sc = g * invstd
+        vec(scale, Cc).copy_(sc)
+        vec(shift, Cc).copy_(b - mean * sc)
+        if mean_out:
+            vec(mean_out, Cc).copy_(mean)
+        if invstd_out:
+            vec(invstd_out, Cc).copy_(invstd)
+        return 0
+
+    def mrfa_bn_act_fwd(self, stream, pref):
+        p = _obj(pref)
+        x = nhwc(p.x, p.N, p.H, p.W, p.ldx, p.C)
+        u = x * vec(p.scale, p.C) + vec(p.shift, p.C)
+        if p.relu:
+            u = F.relu(u)
+        Ho, Wo = p.H, p.W
+        if p.pool:
+            u = F.avg_pool2d(u.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            Ho, Wo = p.H // 2, p.W // 2
+        if p.blend_a:
+            o = nhwc(p.occ, p.N, Ho, Wo, p.ldo, 1)
+            u = nhwc(p.blend_a, p.N, Ho, Wo, p.lda, p.C) * o + u * (1 - o)
+        nhwc(p.y, p.N, Ho, Wo, p.ldy, p.C).copy_(u)
+        return 0
+
+    def mrfa_bn_act_bwd(self, stream, pref):
+        p = _obj(pref)
+        Cc = p.C
+        x = nhwc(p.x, p.N, p.H, p.W, p.ldx, Cc)
+        sc, sh = vec(p.scale, Cc), vec(p.shift, Cc)
+        u = x * sc + sh
+        a = F.relu(u) if p.relu else u
+        Ho, Wo = (p.H // 2, p.W // 2) if p.pool else (p.H, p.W)
+        dy = nhwc(p.dy, p.N, Ho, Wo, p.lddy, Cc)
+        if p.pool:
+            da = 0.25 * dy.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        else:
+            da = dy.clone()
+        if p.blend_a:
+            o = nhwc(p.occ, p.N, Ho, Wo, p.ldo, 1)
+            A = nhwc(p.blend_a, p.N, Ho, Wo, p.lda, Cc)
+            if p.phase == 1:
+                if p.dblend_a:
+                    nhwc(p.dblend_a, p.N, Ho, Wo, p.ldda, Cc).add_(da * o)
+                if p.docc:
+                    nhwc(p.docc, p.N, Ho, Wo, p.lddo, 1).add_((da * (A - a)).sum(-1, keepdim=True))
+            da = da * (1 - o)
+        du = torch.where(u > 0, da, torch.zeros_like(da)) if p.relu else da
+        mean = vec(p.mean, Cc) if p.mean else torch.zeros(Cc)
+        invstd = vec(p.invstd, Cc) if p.invstd else torch.zeros(Cc)
+        xhat = (x - mean) * invstd
+        red = vec(p.red, 2 * Cc, torch.float64)
+        if p.phase == 1:
+            red[:Cc] += du.reshape(-1, Cc).double().sum(0)
+            red[Cc:] += (du * xhat).reshape(-1, Cc).double().sum(0)
+            return 0
+        rows = p.N * p.H * p.W
+        if p.train:
+            k1 = (red[:Cc] / rows).float()
+            k2 = (red[Cc:] / rows).float()
+            dx = vec(p.gamma, Cc) * invstd * (du - k1 - xhat * k2)
+        else:
+            dx = du * sc
+        nhwc(p.dx, p.N, p.H, p.W, p.lddx, Cc).add_(dx)
+        if p.dbeta:
+            vec(p.dbeta, Cc).add_(red[:Cc].float())
+        if p.dgamma:
+            vec(p.dgamma, Cc).add_(red[Cc:].float())
+        return 0
+
+    # ---------------------------------------------------------------- samplers
+    @staticmethod
+    def _norm_grid(grid, mode, Hi, Wi):
+        """-> (normalised grid, align_corners) exactly as the reference builds it."""
+        if mode == 0:
+            return grid, False
+        n, ho, wo, _ = grid.shape
+        ys, xs = torch.meshgrid(torch.arange(ho, dtype=grid.dtype), torch.arange(wo, dtype=grid.dtype), indexing="ij")
+        px = grid[..., 0] + xs
+        py = grid[..., 1] + ys
+        return torch.stack([2 * px / (Wi - 1) - 1, 2 * py / (Hi - 1) - 1], dim=-1), True
+
+    def _gs_inputs(self, inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, N):
+        n_in = (N + in_rep - 1) // in_rep
+        assert in_bstride == Hi * Wi * ldi
+        x = nhwc(inp, n_in, Hi, Wi, ldi, Cc).permute(0, 3, 1, 2)
+        return x, n_in
+
+    def mrfa_grid_sample_fwd(self, stream, inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, grid, ldg, N, Ho, Wo, out, ldo, mode):
+        x, n_in = self._gs_inputs(inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, N)
+        xr = x.repeat_interleave(in_rep, dim=0)[:N]
+        g, ac = self._norm_grid(nhwc(grid, N, Ho, Wo, ldg, 2), mode, Hi, Wi)
+        y = F.grid_sample(xr, g, mode="bilinear", padding_mode="zeros", align_corners=ac)
+        nhwc(out, N, Ho, Wo, ldo, Cc).copy_(y.permute(0, 2, 3, 1))
+        return 0
+
+    def mrfa_grid_sample_bwd(self, stream, inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, grid, ldg, N, Ho, Wo, dout, lddo, mode, din, lddi,
+                             din_bstride, dgrid, lddg):
+        x, n_in = self._gs_inputs(inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, N)
+        gy = nhwc(dout, N, Ho, Wo, lddo, Cc).permute(0, 3, 1, 2)
+        with torch.enable_grad():
+            xl = x.clone().requires_grad_(True)
+            gl = nhwc(grid, N, Ho, Wo, ldg, 2).clone().requires_grad_(True)
+            g, ac = self._norm_grid(gl, mode, Hi, Wi)
+            y = F.grid_sample(xl.repeat_interleave(in_rep, dim=0)[:N], g, mode="bilinear", padding_mode="zeros", align_corners=ac)
+            gx, gg = torch.autograd.grad(y, [xl, gl], gy.contiguous())
+        if din:
+            nhwc(din, n_in, Hi, Wi, lddi, Cc).add_(gx.permute(0, 2, 3, 1))
+        if dgrid:
+            nhwc(dgrid, N, Ho, Wo, lddg, 2).add_(gg)
+        return 0
+
+    def mrfa_resize_bilinear_fwd(self, stream, inp, ldi, N, Hi, Wi, Cc, out, ldo, Ho, Wo, mul, acc):
+        x = nhwc(inp, N, Hi, Wi, ldi, Cc).permute(0, 3, 1, 2)
+        y = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) * mul
+        o = nhwc(out, N, Ho, Wo, ldo, Cc)
+        o.copy_(o + y if acc else y)
+        return 0
+
+    def mrfa_resize_bilinear_bwd(self, stream, dout, lddo, N, Hi, Wi, Cc, din, lddi, Ho, Wo, mul):
+        with torch.enable_grad():
+            xl = torch.zeros(N, Cc, Hi, Wi, requires_grad=True)
+            y = F.interpolate(xl, size=(Ho, Wo), mode="bilinear", align_corners=True) * mul
+            (gx,) = torch.autograd.grad(y, xl, nhwc(dout, N, Ho, Wo, lddo, Cc).permute(0, 3, 1, 2).contiguous())
+        nhwc(din, N, Hi, Wi, lddi, Cc).add_(gx.permute(0, 2, 3, 1))
+        return 0
+
+    @staticmethod
+    def _lookup(v0, v1, coords, radius):
+        Q = coords.shape[0]
+        d = torch.linspace(-radius, radius, 2 * radius + 1)
+        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1).view(1, 2 * radius + 1, 2 * radius + 1, 2)
+        outs = []
+        for lvl, vol in enumerate((v0, v1)):
+            hh, ww = vol.shape[-2:]
+            c = coords.view(Q, 1, 1, 2) / (2 ** lvl) + delta
+            g = torch.stack([2 * c[..., 0] / (ww - 1) - 1, 2 * c[..., 1] / (hh - 1) - 1], dim=-1)
+            outs.append(F.grid_sample(vol, g, align_corners=True).view(Q, -1))
+        return torch.cat(outs, dim=1)
+
+    def mrfa_corr_lookup_fwd(self, stream, vol0, vol1, Hs, Ws, coords, ldc, Q, radius, out, ldo):
+        v0 = _flat(vol0, Q * Hs * Ws).view(Q, 1, Hs, Ws)
+        v1 = _flat(vol1, Q * (Hs // 2) * (Ws // 2)).view(Q, 1, Hs // 2, Ws // 2)
+        r = self._lookup(v0, v1, mat(coords, Q, ldc, 2), radius)
+        mat(out, Q, ldo, r.shape[1]).copy_(r)
+        return 0
+
+    def mrfa_corr_lookup_bwd(self, stream, vol0, vol1, Hs, Ws, coords, ldc, Q, radius, dout, lddo, dvol0, dvol1, dcoords, lddc):
+        with torch.enable_grad():
+            v0 = _flat(vol0, Q * Hs * Ws).view(Q, 1, Hs, Ws).clone().requires_grad_(True)
+            v1 = _flat(vol1, Q * (Hs // 2) * (Ws // 2)).view(Q, 1, Hs // 2, Ws // 2).clone().requires_grad_(True)
+            cl = mat(coords, Q, ldc, 2).clone().requires_grad_(True)
+            r = self._lookup(v0, v1, cl, radius)
+            g0, g1, gc = torch.autograd.grad(r, [v0, v1, cl], mat(dout, Q, lddo, r.shape[1]).contiguous())
+        if dvol0:
+            _flat(dvol0, Q * Hs * Ws).add_(g0.reshape(-1))
+            _flat(dvol1, Q * (Hs // 2) * (Ws // 2)).add_(g1.reshape(-1))
+        if dcoords:
+            mat(dcoords, Q, lddc, 2).add_(gc)
+        return 0
+
+    # ---------------------------------------------------------------- layout / elementwise
+    def mrfa_nchw_to_nhwc(self, stream, src, dst, ldd, N, Cc, H, W, acc):
+        s = _flat(src, N * Cc * H * W).view(N, Cc, H, W).permute(0, 2, 3, 1)
+        d = nhwc(dst, N, H, W, ldd, Cc)
+        d.copy_(d + s if acc else s)
+        return 0
+
+    def mrfa_nhwc_to_nchw(self, stream, src, lds, dst, N, Cc, H, W, acc):
+        s = nhwc(src, N, H, W, lds, Cc).permute(0, 3, 1, 2)
+        d = _flat(dst, N * Cc * H * W).view(N, Cc, H, W)
+        d.copy_(d + s if acc else s)
+        return 0
+
+    def mrfa_copy_view(self, stream, x, ldx, rows, Cc, y, ldy, mul, acc):
+        s = mat(x, rows, ldx, Cc) * mul
+        d = mat(y, rows, ldy, Cc)
+        d.copy_(d + s if acc else s)
+        return 0
+
+    def mrfa_avgpool2_fwd(self, stream, x, ldx, N, H, W, Cc, y, ldy):
+        v = F.avg_pool2d(nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        nhwc(y, N, H // 2, W // 2, ldy, Cc).copy_(v)
+        return 0
+
+    def mrfa_sumpool2_acc(self, stream, x, ldx, N, Ho, Wo, Cc, y, ldy, mul):
+        v = 4 * F.avg_pool2d(nhwc(x, N, 2 * Ho, 2 * Wo, ldx, Cc).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        nhwc(y, N, Ho, Wo, ldy, Cc).add_(mul * v)
+        return 0
+
+    def mrfa_unpool2_acc(self, stream, dy, lddy, N, Ho, Wo, Cc, dx, lddx, mul):
+        g = nhwc(dy, N, Ho, Wo, lddy, Cc).repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        nhwc(dx, N, 2 * Ho, 2 * Wo, lddx, Cc).add_(mul * g)
+        return 0
+
+    def mrfa_bias_act(self, stream, x, ldx, rows, Cc, bias, act, y, ldy, stats):
+        v = mat(x, rows, ldx, Cc).clone()
+        if bias:
+            v = v + vec(bias, Cc)
+        if act == 1:
+            v = F.relu(v)
+        elif act == 2:
+            v = torch.sigmoid(v)
+        mat(y, rows, ldy, Cc).copy_(v)
+        if stats:
+            self.mrfa_bn_stats(stream, y, ldy, rows, Cc, stats)
+        return 0
+
+    def mrfa_act_bwd(self, stream, y, ldy, dy, lddy, rows, Cc, act, dx, lddx, acc):
+        yy = mat(y, rows, ldy, Cc)
+        g = mat(dy, rows, lddy, Cc).clone()
+        if act == 1:
+            g = torch.where(yy > 0, g, torch.zeros_like(g))
+        elif act == 2:
+            g = g * yy * (1 - yy)
+        d = mat(dx, rows, lddx, Cc)
+        d.copy_(d + g if acc else g)
+        return 0
+
+    def mrfa_blend_fwd(self, stream, a, lda, b, ldb, occ, ldo, rows, Cc, y, ldy):
+        o = mat(occ, rows, ldo, 1)
+        v = mat(a, rows, lda, Cc) * o
+        if b:
+            v = v + mat(b, rows, ldb, Cc) * (1 - o)
+        mat(y, rows, ldy, Cc).copy_(v)
+        return 0
+
+    def mrfa_blend_bwd(self, stream, a, lda, b, ldb, occ, ldo, dy, lddy, rows, Cc, da, ldda, db, lddb, docc, lddo):
+        o = mat(occ, rows, ldo, 1)
+        g = mat(dy, rows, lddy, Cc)
+        av = mat(a, rows, lda, Cc)
+        bv = mat(b, rows, ldb, Cc) if b else torch.zeros_like(av)
+        if da:
+            mat(da, rows, ldda, Cc).add_(g * o)
+        if db:
+            mat(db, rows, lddb, Cc).add_(g * (1 - o))
+        if docc:
+            mat(docc, rows, lddo, 1).add_((g * (av - bv)).sum(1, keepdim=True))
+        return 0
+
+    def mrfa_colsum(self, stream, x, ldx, rows, Cc, out):
+        vec(out, Cc).add_(mat(x, rows, ldx, Cc).sum(0))
+        return 0
+
+    def mrfa_antialias_down(self, stream, x, N, Cc, H, W, kern, k, stride, y, ldy):
+        img = _flat(x, N * Cc * H * W).view(N, Cc, H, W)
+        ker = _flat(kern, k * k).view(1, 1, k, k).expand(Cc, 1, k, k)
+        ka = k // 2
+        v = F.conv2d(F.pad(img, (ka, ka, ka, ka)), ker, groups=Cc)[:, :, ::stride, ::stride]
+        nhwc(y, N, H // stride, W // stride, ldy, Cc).copy_(v.permute(0, 2, 3, 1))
+        return 0

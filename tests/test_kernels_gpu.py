@@ -1,0 +1,464 @@
+"""Kernel-level parity (-m gpu): every C-ABI entry point of libmrfa_hip.so on the MI355X against the executable
+specification of the ABI (oracle/capi_emulator.py, plain torch CPU ops) on identical seeded inputs.  fp32 tolerance
+2e-4 relative to the output scale (MFMA fp32 = exact fmaf chains; differences are summation order only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mrfa_amd import hip
+from mrfa_amd.utils.prng import det_uniform
+from oracle.capi_emulator import Emulator
+
+pytestmark = pytest.mark.gpu
+
+
+class Side:
+    """one execution side: (library object, device, stream)"""
+
+    def __init__(self, gpu: bool):
+        self.gpu = gpu
+        self.L = hip.lib() if gpu else Emulator()
+        self.dev = torch.device("cuda:0") if gpu else torch.device("cpu")
+
+    @property
+    def s(self):
+        return hip.stream_ptr() if self.gpu else 0
+
+    def t(self, name, shape, lo=-1.0, hi=1.0):
+        return det_uniform(name, shape, lo, hi).to(self.dev)
+
+    def z(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype, device=self.dev)
+
+    def garbage(self, shape):
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=self.dev)
+
+    def call(self, name, *args):
+        rc = getattr(self.L, name)(self.s, *args)
+        if rc:
+            raise RuntimeError(f"{name} rc={rc}: {self.L.mrfa_last_error()}")
+
+    def done(self, *ts):
+        if self.gpu:
+            torch.cuda.synchronize()
+        return [x.detach().cpu().double() for x in ts]
+
+
+def both(fn):
+    a = fn(Side(False))
+    b = fn(Side(True))
+    return a, b
+
+
+def assert_close(ref, got, tol=2e-4, what=""):
+    for i, (r, g) in enumerate(zip(ref, got)):
+        assert r.shape == g.shape
+        assert torch.isfinite(g).all(), f"{what}[{i}] non-finite"
+        scale = max(r.abs().max().item(), 1e-6)
+        err = (r - g).abs().max().item()
+        assert err <= tol * scale + 1e-6, f"{what}[{i}]: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def pack(side, w, mode):
+    Co, Ci, R, S = w.shape
+    T = R * S
+    n = {0: T * ((Co + 127) // 128 * 128) * ((Ci + 31) // 32 * 32),
+         1: ((Co + 127) // 128 * 128) * ((T * Ci + 31) // 32 * 32),
+         2: T * ((Ci + 127) // 128 * 128) * ((Co + 31) // 32 * 32),
+         3: ((Ci + 127) // 128 * 128) * ((T * Co + 31) // 32 * 32)}[mode]
+    out = side.garbage((n,))
+    side.call("mrfa_pack_conv_weight", w.contiguous().data_ptr(), out.data_ptr(), Co, Ci, R, S, mode)
+    return out
+
+
+def ktab(side, Cc, R, S, pad):
+    kp = (R * S * Cc + 31) // 32 * 32
+    buf = (C.c_int * kp)()
+    assert side.L.mrfa_build_ktab(buf, Cc, R, S, pad, 0) == 0
+    return torch.tensor(list(buf), dtype=torch.int32, device=side.dev)
+
+
+def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
+              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, tag="c"):
+    S = R
+    x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
+    w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
+    flat = (Cin % 32) != 0
+    Hv, Wv = H << ups, W << ups
+    Ho, Wo = Hv + 2 * pad - R + 1, Wv + 2 * pad - S + 1
+    ldy = (Cout + 3) // 4 * 4 + ldy_extra
+    y = side.t(f"{tag}/y0", (N * Ho * Wo, ldy)) if acc else side.garbage((N * Ho * Wo, ldy))
+    p = hip.ConvParams()
+    p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.data_ptr(), x.shape[1], H, W, ups, N, Cin
+    cop = (Cout + 127) // 128 * 128
+    keep = []
+    if flat:
+        wp = pack(side, w, 1)
+        kp = (R * S * Cin + 31) // 32 * 32
+        kt = ktab(side, Cin, R, S, pad)
+        keep.append(kt)
+        p.w, p.w_ld, p.w_tap, p.kflat, p.ktab = wp.data_ptr(), kp, 0, R * S * Cin, kt.data_ptr()
+    else:
+        wp = pack(side, w, 0)
+        p.w, p.w_ld, p.w_tap, p.kflat = wp.data_ptr(), Cin, cop * Cin, 0
+    p.w_rows = cop
+    p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), ldy, Cout, Ho, Wo
+    p.R, p.S, p.pad = R, S, pad
+    if pro:
+        sc, sh = side.t(f"{tag}/sc", (Cin,), 0.5, 1.5), side.t(f"{tag}/sh", (Cin,), -0.3, 0.3)
+        keep += [sc, sh]
+        p.in_scale, p.in_shift, p.in_relu = sc.data_ptr(), sh.data_ptr(), 1
+    if bias:
+        bt = side.t(f"{tag}/b", (Cout,))
+        keep.append(bt)
+        p.bias = bt.data_ptr()
+    if oaff:
+        osc, osh = side.t(f"{tag}/osc", (Cout,), 0.5, 1.5), side.t(f"{tag}/osh", (Cout,), -0.3, 0.3)
+        keep += [osc, osh]
+        p.out_scale, p.out_shift = osc.data_ptr(), osh.data_ptr()
+    p.relu = int(relu)
+    if res:
+        rt = side.t(f"{tag}/res", (N * Ho * Wo, Cout + 4))
+        keep.append(rt)
+        p.res, p.ldr = rt.data_ptr(), Cout + 4
+    st = side.z((2 * Cout,), torch.float64)
+    if stats:
+        p.stats = st.data_ptr()
+    p.alpha, p.accumulate, p.nbatch, p.splitk, p.tile = alpha, int(acc), 1, splitk, tile
+    side.call("mrfa_conv2d_nhwc", C.byref(p))
+    return side.done(y[:, :Cout], st)
+
+
+CONV_CASES = {
+    "basic": dict(),
+    "t128x128_oddM": dict(N=1, H=9, W=11, Cin=64, Cout=130, tile=(128 << 16) | 128),
+    "t128x64": dict(Cout=96, tile=(128 << 16) | 64),
+    "t128x32": dict(Cout=24, tile=(128 << 16) | 32),
+    "t64x128": dict(Cout=126, tile=(64 << 16) | 128),
+    "t64x64": dict(Cout=64, tile=(64 << 16) | 64),
+    "t32x128": dict(N=1, H=4, W=4, Cin=128, Cout=256, tile=(32 << 16) | 128),
+    "ups": dict(ups=1, H=6, W=5),
+    "prologue": dict(pro=True, relu=False),
+    "residual_stats": dict(res=True, stats=True, relu=False, Cout=64),
+    "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False),
+    "out_affine": dict(oaff=True),
+    "conv1x1": dict(R=1, pad=0, Cin=128, Cout=192),
+    "conv7x7_c64_to3": dict(R=7, pad=3, Cin=64, Cout=3, relu=False),
+    "flat_7x7_c3": dict(R=7, pad=3, Cin=3, Cout=64, ldx_extra=1),
+    "flat_7x7_c2": dict(R=7, pad=3, Cin=2, Cout=128, ldx_extra=2),
+    "flat_1x1_c98": dict(R=1, pad=0, Cin=98, Cout=128, ldx_extra=2),
+    "flat_7x7_c35_pad0": dict(R=7, pad=0, Cin=35, Cout=10, relu=False, ldx_extra=1),
+    "flat_3x3_c13_pro": dict(Cin=13, Cout=64, pro=True),
+    "flat_ups_c44": dict(Cin=44, Cout=128, ups=1, H=5, W=7),
+    "splitk4_relu_stats": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True),
+    "splitk_auto_small": dict(N=1, H=2, W=2, Cin=512, Cout=512, splitk=0, stats=True, relu=False),
+    "splitk3_accumulate": dict(N=1, H=4, W=4, Cin=128, Cout=64, splitk=3, acc=True, relu=False, bias=False),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv2d(name):
+    ref, got = both(lambda s: conv_case(s, tag=f"conv/{name}", **CONV_CASES[name]))
+    assert_close(ref, got, what=name)
+
+
+def test_gemm_nt_batched():
+    def run(side):
+        B, M, Nn, K = 3, 100, 72, 64
+        a = side.t("g/a", (B * M, K))
+        bm = side.t("g/b", (B * Nn, K))
+        c = side.garbage((B * M, Nn))
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = a.data_ptr(), K, 1, M, 1, K
+        p.w, p.w_ld, p.w_rows = bm.data_ptr(), K, Nn
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout = c.data_ptr(), Nn, Nn, 1, M
+        p.R, p.S, p.pad, p.alpha = 1, 1, 0, 0.0625
+        p.nbatch, p.x_bs, p.w_bs, p.y_bs, p.splitk = B, M * K, Nn * K, M * Nn, 1
+        side.call("mrfa_conv2d_nhwc", C.byref(p))
+        return side.done(c)
+    ref, got = both(run)
+    assert_close(ref, got, what="gemm_nt")
+    a = det_uniform("g/a", (3, 100, 64)).double()
+    b = det_uniform("g/b", (3, 72, 64)).double()
+    assert_close([torch.einsum("bik,bjk->bij", a, b).reshape(300, 72) * 0.0625], got, what="gemm_nt vs einsum")
+
+
+def dgrad_case(side, *, N=2, H=8, W=9, Cin=64, Cout=96, R=3, pad=1, tag="d"):
+    """data gradient = conv of dY with the flipped/transposed pack; checked against autograd in the test body"""
+    w = side.t(f"{tag}/w", (Cout, Cin, R, R), -0.2, 0.2)
+    Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    dy = side.t(f"{tag}/dy", (N * Ho * Wo, (Cout + 3) // 4 * 4))
+    dx = side.garbage((N * H * W, (Cin + 3) // 4 * 4))
+    flat = (Cout % 32) != 0
+    p = hip.ConvParams()
+    p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = dy.data_ptr(), dy.shape[1], Ho, Wo, N, Cout
+    cip = (Cin + 127) // 128 * 128
+    keep = []
+    if flat:
+        wp = pack(side, w, 3)
+        kt = ktab(side, Cout, R, R, R - 1 - pad)
+        keep.append(kt)
+        p.w, p.w_ld, p.kflat, p.ktab = wp.data_ptr(), (R * R * Cout + 31) // 32 * 32, R * R * Cout, kt.data_ptr()
+    else:
+        wp = pack(side, w, 2)
+        p.w, p.w_ld, p.w_tap = wp.data_ptr(), Cout, cip * Cout
+    p.w_rows = cip
+    p.y, p.ldy, p.Cout, p.Hout, p.Wout = dx.data_ptr(), dx.shape[1], Cin, H, W
+    p.R, p.S, p.pad, p.alpha, p.nbatch, p.splitk = R, R, R - 1 - pad, 1.0, 1, 1
+    side.call("mrfa_conv2d_nhwc", C.byref(p))
+    return side.done(dx[:, :Cin])
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(Cout=126), dict(Cout=3, Cin=64, R=7, pad=3), dict(Cout=10, Cin=35, R=7, pad=0),
+                                 dict(Cin=3, Cout=64, R=7, pad=3), dict(R=1, pad=0, Cin=98, Cout=128)])
+def test_dgrad_matches_autograd(cfg):
+    tag = "dgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+    (got,) = dgrad_case(Side(True), tag=tag, **cfg)
+    c = dict(N=2, H=8, W=9, Cin=64, Cout=96, R=3, pad=1)
+    c.update(cfg)
+    w = det_uniform(f"{tag}/w", (c["Cout"], c["Cin"], c["R"], c["R"]), -0.2, 0.2).double()
+    Ho, Wo = c["H"] + 2 * c["pad"] - c["R"] + 1, c["W"] + 2 * c["pad"] - c["R"] + 1
+    dy = det_uniform(f"{tag}/dy", (c["N"] * Ho * Wo, (c["Cout"] + 3) // 4 * 4)).double()[:, :c["Cout"]]
+    dy = dy.reshape(c["N"], Ho, Wo, c["Cout"]).permute(0, 3, 1, 2)
+    x = torch.zeros(c["N"], c["Cin"], c["H"], c["W"], dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w, padding=c["pad"])
+    (gx,) = torch.autograd.grad(y, x, dy)
+    assert_close([gx.permute(0, 2, 3, 1).reshape(-1, c["Cin"])], [got], what=tag)
+
+
+def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, tag="w"):
+    x = side.t(f"{tag}/x", (N * H * W, (Cin + 3) // 4 * 4))
+    Hv, Wv = H << ups, W << ups
+    Ho, Wo = Hv + 2 * pad - R + 1, Wv + 2 * pad - R + 1
+    dy = side.t(f"{tag}/dy", (N * Ho * Wo, (Cout + dy_off + 3) // 4 * 4))
+    dw = side.z((R * R * Cout * Cin,))
+    db = side.z((Cout,))
+    q = hip.WgradParams()
+    q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = x.data_ptr(), x.shape[1], H, W, ups, N, Cin
+    keep = []
+    if pro:
+        sc, sh = side.t(f"{tag}/sc", (Cin,), 0.5, 1.5), side.t(f"{tag}/sh", (Cin,), -0.3, 0.3)
+        keep += [sc, sh]
+        q.in_scale, q.in_shift, q.in_relu = sc.data_ptr(), sh.data_ptr(), 1
+    q.dy, q.ldy, q.Cout, q.Hout, q.Wout = dy.data_ptr() + 4 * dy_off, dy.shape[1], Cout, Ho, Wo
+    q.R, q.S, q.pad = R, R, pad
+    q.dw = dw.data_ptr()
+    q.dbias = db.data_ptr() if dbias else None
+    q.alpha, q.nbatch, q.ksplit = 1.0, 1, ksplit
+    if Cin < 32:
+        kt = ktab(side, Cin, R, R, pad)
+        keep.append(kt)
+        q.ktab, q.kflat = kt.data_ptr(), R * R * Cin
+    side.call("mrfa_conv2d_wgrad_nhwc", C.byref(q))
+    return side.done(dw, db)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(Cout=126, Cin=160), dict(ups=1, H=5, W=6), dict(pro=True, Cin=128, Cout=64),
+                                 dict(Cin=3, Cout=64, R=7, pad=3), dict(Cin=2, Cout=128, R=7, pad=3), dict(Cin=128, Cout=2),
+                                 dict(Cin=64, Cout=3, R=7, pad=3), dict(Cin=35, Cout=10, R=7, pad=0), dict(Cin=13, Cout=64, pro=True),
+                                 dict(R=1, pad=0, Cin=98, Cout=128), dict(N=4, H=32, W=32, Cin=64, Cout=64, ksplit=7),
+                                 dict(Cin=128, Cout=1, dy_off=2), dict(Cin=128, Cout=64, dy_off=3)])
+def test_wgrad(cfg):
+    tag = "wgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+    ref, got = both(lambda s: wgrad_case(s, tag=tag, **cfg))
+    assert_close(ref, got, tol=5e-4, what=tag)
+
+
+def test_gemm_tn_batched():
+    def run(side):
+        B, K, M, Nn = 2, 300, 96, 64
+        a = side.t("tn/a", (B * K, M))
+        bm = side.t("tn/b", (B * K, Nn))
+        c = side.z((B * M * Nn,))
+        q = hip.WgradParams()
+        q.x, q.ldx, q.Hin, q.Win, q.N, q.Cin = bm.data_ptr(), Nn, 1, K, 1, Nn
+        q.dy, q.ldy, q.Cout, q.Hout, q.Wout = a.data_ptr(), M, M, 1, K
+        q.R, q.S, q.pad, q.dw, q.alpha = 1, 1, 0, c.data_ptr(), 0.5
+        q.nbatch, q.x_bs, q.dy_bs, q.dw_bs = B, K * Nn, K * M, M * Nn
+        side.call("mrfa_conv2d_wgrad_nhwc", C.byref(q))
+        return side.done(c)
+    ref, got = both(run)
+    assert_close(ref, got, what="gemm_tn")
+    a = det_uniform("tn/a", (2, 300, 96)).double()
+    b = det_uniform("tn/b", (2, 300, 64)).double()
+    assert_close([0.5 * torch.einsum("bkm,bkn->bmn", a, b).reshape(-1)], got, what="gemm_tn vs einsum")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_pack_modes(mode):
+    def run(side):
+        Co, Ci, R = 70, 45, 3
+        if mode == 4:
+            g = side.t("pk/g", (R * R * Co * Ci,))
+            d = side.t("pk/d", (Co, Ci, R, R))
+            side.call("mrfa_pack_conv_weight", g.data_ptr(), d.data_ptr(), Co, Ci, R, R, 4)
+            return side.done(d)
+        return side.done(pack(side, side.t("pk/w", (Co, Ci, R, R)), mode))
+    ref, got = both(run)
+    assert_close(ref, got, tol=0, what=f"pack{mode}")
+
+
+def test_bn_forward_backward():
+    def run(side):
+        N, H, W, Cc, ld = 2, 8, 6, 96, 100
+        x = side.t("bn/x", (N * H * W, ld), -2, 2)
+        gamma, beta = side.t("bn/g", (Cc,), 0.5, 1.5), side.t("bn/b", (Cc,))
+        rm, rv = side.t("bn/rm", (Cc,)), side.t("bn/rv", (Cc,), 0.5, 1.5)
+        outs = []
+        for train in (1, 0):
+            st = side.z((2 * Cc,), torch.float64)
+            side.call("mrfa_bn_stats", x.data_ptr(), ld, N * H * W, Cc, st.data_ptr())
+            sc, sh, mean, inv = (side.z((Cc,)) for _ in range(4))
+            side.call("mrfa_bn_finalize", st.data_ptr(), N * H * W, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                      0.1, 1e-5, Cc, train, sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr())
+            for pool, blend in ((0, 0), (1, 0), (0, 1)):
+                Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+                y = side.garbage((N * Ho * Wo, Cc + 4))
+                a = side.t("bn/a", (N * Ho * Wo, Cc))
+                occ = side.t("bn/occ", (N * Ho * Wo, 1), 0, 1)
+                p = hip.BnActParams()
+                p.x, p.ldx, p.N, p.H, p.W, p.C = x.data_ptr(), ld, N, H, W, Cc
+                p.scale, p.shift, p.relu, p.pool = sc.data_ptr(), sh.data_ptr(), 1, pool
+                if blend:
+                    p.blend_a, p.lda, p.occ, p.ldo = a.data_ptr(), Cc, occ.data_ptr(), 1
+                p.y, p.ldy = y.data_ptr(), Cc + 4
+                side.call("mrfa_bn_act_fwd", C.byref(p))
+                dy = side.t("bn/dy", (N * Ho * Wo, Cc))
+                dx = side.t("bn/dx0", (N * H * W, Cc))
+                da, docc = side.z((N * Ho * Wo, Cc)), side.z((N * Ho * Wo, 1))
+                dg, dbt = side.z((Cc,)), side.z((Cc,))
+                red = side.z((2 * Cc,), torch.float64)
+                q = hip.BnBwdParams()
+                q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), ld, N, H, W, Cc
+                q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), 1, pool
+                q.mean, q.invstd, q.gamma = mean.data_ptr(), inv.data_ptr(), gamma.data_ptr()
+                q.dy, q.lddy = dy.data_ptr(), Cc
+                if blend:
+                    q.blend_a, q.lda, q.occ, q.ldo = a.data_ptr(), Cc, occ.data_ptr(), 1
+                    q.dblend_a, q.ldda, q.docc, q.lddo = da.data_ptr(), Cc, docc.data_ptr(), 1
+                q.red, q.dx, q.lddx, q.dgamma, q.dbeta, q.train = red.data_ptr(), dx.data_ptr(), Cc, dg.data_ptr(), dbt.data_ptr(), train
+                for ph in (1, 2):
+                    q.phase = ph
+                    side.call("mrfa_bn_act_bwd", C.byref(q))
+                outs += [y[:, :Cc], dx, da, docc, dg, dbt]
+            outs += [rm.clone(), rv.clone(), sc, sh]
+        return side.done(*outs)
+    ref, got = both(run)
+    assert_close(ref, got, tol=5e-4, what="bn")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("Cc,in_rep", [(64, 1), (3, 1), (96, 1), (3, 11), (130, 1)])
+def test_grid_sample(mode, Cc, in_rep):
+    def run(side):
+        Nin, Hi, Wi, Ho, Wo = 2, 9, 7, 6, 8
+        N = Nin * in_rep
+        ldi = (Cc + 3) // 4 * 4
+        inp = side.t("gs/in", (Nin * Hi * Wi, ldi))
+        if mode == 0:
+            grid = side.t("gs/g0", (N * Ho * Wo, 2), -1.3, 1.3)
+        else:
+            grid = side.t("gs/g1", (N * Ho * Wo, 2), -5.0, 5.0)
+        out = side.garbage((N * Ho * Wo, ldi))
+        side.call("mrfa_grid_sample_fwd", inp.data_ptr(), ldi, Hi * Wi * ldi, in_rep, Hi, Wi, Cc, grid.data_ptr(), 2, N, Ho, Wo,
+                  out.data_ptr(), ldi, mode)
+        dout = side.t("gs/dout", (N * Ho * Wo, Cc))
+        din = side.t("gs/din0", (Nin * Hi * Wi, ldi))
+        dgrid = side.t("gs/dg0", (N * Ho * Wo, 2))
+        side.call("mrfa_grid_sample_bwd", inp.data_ptr(), ldi, Hi * Wi * ldi, in_rep, Hi, Wi, Cc, grid.data_ptr(), 2, N, Ho, Wo,
+                  dout.data_ptr(), Cc, mode, din.data_ptr(), ldi, Hi * Wi * ldi, dgrid.data_ptr(), 2)
+        return side.done(out[:, :Cc], din[:, :Cc], dgrid)
+    ref, got = both(run)
+    assert_close(ref, got, tol=5e-4, what="grid_sample")
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 16, 16, 2), (64, 64, 8, 8, 1), (8, 8, 13, 5, 98), (16, 16, 64, 64, 3)])
+def test_resize(shape):
+    Hi, Wi, Ho, Wo, Cc = shape
+
+    def run(side):
+        N = 2
+        ld = (Cc + 3) // 4 * 4
+        x = side.t("rs/x", (N * Hi * Wi, ld))
+        y = side.t("rs/y0", (N * Ho * Wo, ld))
+        side.call("mrfa_resize_bilinear_fwd", x.data_ptr(), ld, N, Hi, Wi, Cc, y.data_ptr(), ld, Ho, Wo, 2.0, 1)
+        y2 = side.garbage((N * Ho * Wo, ld))
+        side.call("mrfa_resize_bilinear_fwd", x.data_ptr(), ld, N, Hi, Wi, Cc, y2.data_ptr(), ld, Ho, Wo, 1.0, 0)
+        dout = side.t("rs/do", (N * Ho * Wo, Cc))
+        din = side.t("rs/di0", (N * Hi * Wi, ld))
+        side.call("mrfa_resize_bilinear_bwd", dout.data_ptr(), Cc, N, Hi, Wi, Cc, din.data_ptr(), ld, Ho, Wo, 0.5)
+        return side.done(y[:, :Cc], y2[:, :Cc], din[:, :Cc])
+    ref, got = both(run)
+    assert_close(ref, got, what="resize")
+
+
+def test_corr_lookup():
+    def run(side):
+        Q, Hs, Ws = 50, 16, 16
+        v0 = side.t("cl/v0", (Q, Hs * Ws))
+        v1 = side.t("cl/v1", (Q, Hs * Ws // 4))
+        coords = side.t("cl/xy", (Q, 2), -4.0, 20.0)
+        out = side.garbage((Q, 100))
+        side.call("mrfa_corr_lookup_fwd", v0.data_ptr(), v1.data_ptr(), Hs, Ws, coords.data_ptr(), 2, Q, 3, out.data_ptr(), 100)
+        dout = side.t("cl/do", (Q, 98))
+        d0, d1, dc = side.z((Q, Hs * Ws)), side.z((Q, Hs * Ws // 4)), side.t("cl/dc0", (Q, 2))
+        side.call("mrfa_corr_lookup_bwd", v0.data_ptr(), v1.data_ptr(), Hs, Ws, coords.data_ptr(), 2, Q, 3, dout.data_ptr(), 98,
+                  d0.data_ptr(), d1.data_ptr(), dc.data_ptr(), 2)
+        return side.done(out[:, :98], d0, d1, dc)
+    ref, got = both(run)
+    assert_close(ref, got, tol=5e-4, what="corr_lookup")
+
+
+def test_layout_and_elementwise():
+    def run(side):
+        N, Cc, H, W = 2, 45, 6, 10
+        outs = []
+        src = side.t("el/nchw", (N, Cc, H, W))
+        d = side.t("el/nhwc0", (N * H * W, 48))
+        side.call("mrfa_nchw_to_nhwc", src.data_ptr(), d.data_ptr(), 48, N, Cc, H, W, 1)
+        back = side.t("el/back0", (N, Cc, H, W))
+        side.call("mrfa_nhwc_to_nchw", d.data_ptr(), 48, back.data_ptr(), N, Cc, H, W, 1)
+        outs += [d[:, :Cc], back]
+        y = side.garbage((N * (H // 2) * (W // 2), 48))
+        side.call("mrfa_avgpool2_fwd", d.data_ptr(), 48, N, H, W, Cc, y.data_ptr(), 48)
+        acc = side.t("el/acc", (N * (H // 2) * (W // 2), Cc))
+        side.call("mrfa_sumpool2_acc", d.data_ptr(), 48, N, H // 2, W // 2, Cc, acc.data_ptr(), Cc, 0.5)
+        up = side.t("el/up", (N * H * W, Cc))
+        side.call("mrfa_unpool2_acc", y.data_ptr(), 48, N, H // 2, W // 2, Cc, up.data_ptr(), Cc, 0.25)
+        outs += [y[:, :Cc], acc, up]
+        rows = N * H * W
+        bias = side.t("el/bias", (Cc,))
+        for act in (0, 1, 2):
+            o = side.garbage((rows, Cc))
+            st = side.z((2 * Cc,), torch.float64)
+            side.call("mrfa_bias_act", d.data_ptr(), 48, rows, Cc, bias.data_ptr(), act, o.data_ptr(), Cc, st.data_ptr())
+            g = side.t("el/g", (rows, Cc))
+            dx = side.t("el/dx0", (rows, Cc))
+            side.call("mrfa_act_bwd", o.data_ptr(), Cc, g.data_ptr(), Cc, rows, Cc, act, dx.data_ptr(), Cc, 1)
+            outs += [o, st, dx]
+        a, b2, occ = side.t("el/a", (rows, Cc)), side.t("el/b2", (rows, Cc)), side.t("el/occ", (rows, 1), 0, 1)
+        yb = side.garbage((rows, Cc))
+        side.call("mrfa_blend_fwd", a.data_ptr(), Cc, b2.data_ptr(), Cc, occ.data_ptr(), 1, rows, Cc, yb.data_ptr(), Cc)
+        yb2 = side.garbage((rows, Cc))
+        side.call("mrfa_blend_fwd", a.data_ptr(), Cc, None, 0, occ.data_ptr(), 1, rows, Cc, yb2.data_ptr(), Cc)
+        da, db, do = side.z((rows, Cc)), side.z((rows, Cc)), side.z((rows, 1))
+        g = side.t("el/gb", (rows, Cc))
+        side.call("mrfa_blend_bwd", a.data_ptr(), Cc, b2.data_ptr(), Cc, occ.data_ptr(), 1, g.data_ptr(), Cc, rows, Cc, da.data_ptr(), Cc,
+                  db.data_ptr(), Cc, do.data_ptr(), 1)
+        cs = side.z((Cc,))
+        side.call("mrfa_colsum", a.data_ptr(), Cc, rows, Cc, cs.data_ptr())
+        cp = side.t("el/cp0", (rows, Cc))
+        side.call("mrfa_copy_view", a.data_ptr(), Cc, rows, Cc, cp.data_ptr(), Cc, 0.3, 1)
+        outs += [yb, yb2, da, db, do, cs, cp]
+        img = side.t("el/img", (2, 3, 32, 32), 0, 1)
+        t = torch.arange(13, dtype=torch.float32)
+        g1 = torch.exp(-((t - 6) ** 2) / (2 * 1.5 ** 2))
+        ker = (g1[:, None] * g1[None, :] / (g1.sum() ** 2)).contiguous().to(side.dev)
+        ya = side.garbage((2 * 8 * 8, 4))
+        side.call("mrfa_antialias_down", img.data_ptr(), 2, 3, 32, 32, ker.data_ptr(), 13, 4, ya.data_ptr(), 4)
+        outs.append(ya[:, :3])
+        return side.done(*outs)
+    ref, got = both(run)
+    assert_close(ref, got, what="elementwise")

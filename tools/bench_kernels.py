@@ -1,0 +1,96 @@
+"""Micro-benchmarks of the dominant kernels at the bench configuration's shapes (vox1, 256^2, B=8), hipEvent-timed.
+    python tools/bench_kernels.py [--b 8]
+Prints TFLOP/s against the 157.3 TF fp32 MFMA peak and GB/s against 8 TB/s HBM."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mrfa_amd import hip  # noqa: E402
+from mrfa_amd.engine import Ctx, convw  # noqa: E402
+
+PEAK_TF = 157.3
+
+
+def time_it(fn, iters=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=8)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    e = Ctx(dev, train=True, record=True)
+    B = a.b
+    shapes = [  # (name, Cin, Cout, k, res, ups)
+        ("refine.conv1 256->128 3x3 @256", 256, 128, 3, 256, 0),
+        ("refine.convc1 192->128 3x3 @256", 192, 128, 3, 256, 0),
+        ("corr_enc.conv 160->126 3x3 @256", 160, 126, 3, 256, 0),
+        ("corr_enc.convc2 128->96 3x3 @256", 128, 96, 3, 256, 0),
+        ("gen.down0 64->128 3x3 @256", 64, 128, 3, 256, 0),
+        ("gen.up4 128->64 3x3 ups @128->256", 128, 64, 3, 128, 1),
+        ("gen.res 128->128 3x3 @128", 128, 128, 3, 128, 0),
+        ("gen.chan 512->256 3x3 @64", 512, 256, 3, 64, 0),
+        ("gen 512->512 3x3 @32", 512, 512, 3, 32, 0),
+        ("gen 512->512 3x3 @8", 512, 512, 3, 8, 0),
+        ("hg 1024->1024 3x3 @4", 1024, 1024, 3, 4, 0),
+        ("to_context 64->192 1x1 @256", 64, 192, 1, 256, 0),
+        ("convc1 98->128 1x1 @256 (flat)", 98, 128, 1, 256, 0),
+        ("first 3->64 7x7 @256 (flat)", 3, 64, 7, 256, 0),
+        ("convf1 2->128 7x7 @256 (flat)", 2, 128, 7, 256, 0),
+        ("final 64->3 7x7 @256", 64, 3, 7, 256, 0),
+        ("conv2 128->2 3x3 @256", 128, 2, 3, 256, 0),
+    ]
+    print(f"{'layer':42s} {'fwd ms':>8s} {'TF/s':>7s} {'%pk':>5s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
+    for name, ci, co, k, res, ups in shapes:
+        conv = torch.nn.Conv2d(ci, co, k, padding=k // 2).to(dev)
+        x = e.new(B, res, res, ci)
+        x.st.data.normal_()
+        ro = res << ups
+        out = e.new(B, ro, ro, co)
+        cw = convw(conv)
+        flops = 2.0 * B * ro * ro * co * ci * k * k
+        e.record = False
+        t_f = time_it(lambda: e.conv(x, conv, out=out, relu=True, ups=bool(ups)))
+        out.st.grad_buf().normal_()
+        x.st.grad_buf()
+        t_d = time_it(lambda: e._conv_dgrad(x, cw, out, bool(ups), None))
+        t_w = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True))
+        cw.dw_acc = None
+        tf = lambda t: flops / t / 1e9
+        print(f"{name:42s} {t_f:8.3f} {tf(t_f):7.1f} {100*tf(t_f)/PEAK_TF:5.1f} | {t_d:8.3f} {tf(t_d):7.1f} | {t_w:8.3f} {tf(t_w):7.1f}", flush=True)
+    # HBM-bound kernels
+    print("\nHBM-bound kernels (GB/s of algorithmic bytes)")
+    for cch, res in ((64, 256), (128, 128), (256, 64)):
+        f = e.new(B, res, res, cch)
+        f.st.data.normal_()
+        flow = e.new(B, res, res, 2)
+        flow.st.data.uniform_(-3, 3)
+        o = e.new(B, res, res, cch)
+        t = time_it(lambda: e.grid_sample(f, flow, 1, out=o))
+        byt = 4.0 * (2 * B * res * res * cch + 2 * B * res * res)
+        print(f"grid_sample C={cch} @{res}: {t:.3f} ms  {byt/t/1e6:.0f} GB/s")
+        bn = torch.nn.BatchNorm2d(cch).to(dev)
+        st = e.f64z(2 * cch)
+        t = time_it(lambda: e.L.mrfa_bn_stats(e.s, f.ptr, f.ld, f.rows, cch, st.data_ptr()))
+        print(f"bn_stats    C={cch} @{res}: {t:.3f} ms  {4.0*B*res*res*cch/t/1e6:.0f} GB/s")
+        t = time_it(lambda: e.bn_act(f, bn, st, relu=True, out=o))
+        print(f"bn_act      C={cch} @{res}: {t:.3f} ms  {8.0*B*res*res*cch/t/1e6:.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
