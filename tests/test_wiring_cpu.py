@@ -1,0 +1,193 @@
+"""CPU-only checks of the host side (`-m "not gpu"`): state_dict layout, C-ABI surface, no-fallback guarantees, and the
+engine programs of the product modules executed through the C-ABI emulator against the REFERENCE goldens -- i.e. the
+host logic (buffer layout, zero-copy concatenation, tape order, algebraic shortcuts of the correlation pyramid) is
+verified here; the kernels themselves are verified against the same emulator on the GPU (tests/test_kernels_gpu.py)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mrfa_amd import hip
+from mrfa_amd.modules import DenseMotionNetwork, KPDetector, RaftFlow
+from mrfa_amd.modules.manifest import manifest_of
+from tests import cases
+from tests.emu import emulated_hip
+from tests.test_oracle_golden import raft_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _g(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    man = json.load(open(os.path.join(golden_dir, "state_dict_manifest.json")))
+    assert manifest_of(KPDetector(**cases.KP_DETECTOR_CFG)) == man["KPDetector"]
+    assert manifest_of(DenseMotionNetwork(**cases.DENSE_MOTION_CFG)) == man["DenseMotionNetwork"]
+    assert manifest_of(RaftFlow(**cases.raft_cfg(256))) == man["RaftFlow"]
+    assert manifest_of(RaftFlow(**cases.raft_cfg(256, True))) == man["RaftFlow_prior_only"]
+
+
+def test_reference_style_checkpoint_loads():
+    """checkpoint layout of the reference: {'model': {'module.<name>': tensor}} (logger.py:50-58, train.py:94)"""
+    from mrfa_amd.train import HotPath
+    m = HotPath()
+    ck = {"module." + k: v.clone() for k, v in m.state_dict().items()}
+    m2 = HotPath()
+    missing = torch.nn.DataParallel(m2).load_state_dict(ck, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from mrfa_amd.build import build
+    lib_path = build(verbose=False)
+    header = open(os.path.join(ROOT, "include", "mrfa_hip.h")).read()
+    declared = set(re.findall(r"\b(mrfa_[a-z0-9_]+)\s*\(", header))
+    declared = {d for d in declared if not d.endswith("_params")}
+    lib = ctypes.CDLL(lib_path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mrfa_hip.h but not exported"
+    assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
+    assert lib.mrfa_version() >= 1
+
+
+def test_product_fails_loudly_without_the_hip_library(monkeypatch):
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/libmrfa_hip.so")
+    with pytest.raises(hip.HipLibraryMissing):
+        hip.lib()
+    kp = KPDetector(**cases.KP_DETECTOR_CFG)
+    with pytest.raises(hip.HipLibraryMissing):
+        kp(torch.zeros(1, 3, 256, 256))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mrfa_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", ""), f"{f} mentions oracle"
+                assert "capi_emulator" not in src
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_prior_modules_through_emulator(golden_dir, train):
+    g = _g(golden_dir, "prior.npz")
+    sfx = "train" if train else "eval"
+    x = cases.images("g3/src", 2, 256)
+    with emulated_hip():
+        kp = KPDetector(**cases.KP_DETECTOR_CFG)
+        kp.load_state_dict(cases.weights_for(kp.state_dict(), "kp"))
+        kp.train(train)
+        with torch.no_grad():
+            o = kp(x)
+        assert np.abs(o["kp"].numpy() - g[f"kp_{sfx}"]).max() < 5e-5
+        assert np.abs(o["jacobian"].numpy() - g[f"jac_{sfx}"]).max() < 5e-5
+        dm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+        dm.load_state_dict(cases.weights_for(dm.state_dict(), "dm"))
+        dm.train(train)
+        with torch.no_grad():
+            o = dm(x, cases.keypoints("g3/kd", 2), cases.keypoints("g3/ks", 2))
+        assert np.abs(o["deformation"].numpy() - g[f"dm_deformation_{sfx}"]).max() < 5e-5
+        assert np.abs(o["occlusion"].numpy() - g[f"dm_occlusion_{sfx}"]).max() < 5e-5
+        assert np.abs(o["mask"][:, :, ::4, ::4].numpy() - g[f"dm_mask_{sfx}_s4"]).max() < 5e-5
+        assert o["sparse_deformed"].shape == (2, 11, 3, 64, 64) and o["logit_mask"].shape == (2, 11, 64, 64)
+
+
+@pytest.mark.parametrize("prior_only", [False, True])
+def test_raft_flow_through_emulator(golden_dir, prior_only):
+    size, b = 64, 2
+    g = _g(golden_dir, "raft_64.npz")
+    with emulated_hip():
+        rf = RaftFlow(**cases.raft_cfg(size, prior_only))
+        rf.load_state_dict(cases.weights_for(rf.state_dict(), "rf"))
+        rf.eval()
+        kp_s, kp_d, dmo, img, img_full = raft_inputs(size, b, "g3/raft64")
+        with torch.no_grad():
+            o, w, s = rf(kp_s, kp_d, dmo, img, img_full)
+    sfx = ("prior_" if prior_only else "") + "eval"
+    assert np.abs(o.numpy() - g[f"out_{sfx}"]).max() < 1e-4
+    assert np.abs(w.numpy() - g[f"warp_{sfx}"]).max() < 1e-4
+    assert np.abs(s[:, :, ::2, ::2].numpy() - g[f"strip_{sfx}"]).max() < 1e-4
+    assert s.shape == (b, 1, size, (6 if prior_only else 7) * size)
+
+
+def test_raft_flow_backward_through_emulator(golden_dir):
+    """the hand-written backward tape (every op's gradient wiring) against the reference's autograd gradients"""
+    g = _g(golden_dir, "grads_64.npz")
+    names = json.load(open(os.path.join(golden_dir, "grads_64_param_names.json")))
+    size, b = 64, 2
+    with emulated_hip():
+        rf = RaftFlow(**cases.raft_cfg(size))
+        rf.load_state_dict(cases.weights_for(rf.state_dict(), "rf"))
+        rf.train(True)
+        kp_s, kp_d, dmo, img, img_full = raft_inputs(size, b, "g4/raft")
+        leaves = [t.clone().requires_grad_(True) for t in (kp_s, kp_d, dmo["deformation"], dmo["occlusion"])]
+        driving = cases.images("g4/drv", b, size)
+        o, _, _ = rf(leaves[0], leaves[1], {"deformation": leaves[2], "occlusion": leaves[3]}, img, img_full)
+        loss = (o - driving).abs().mean()
+        loss.backward()
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-6
+    for n, t in zip(("kp_s", "kp_d", "deformation", "occlusion"), leaves):
+        assert np.abs(t.grad.numpy() - g[f"grad_{n}"]).max() < 1e-4, n
+    P = dict(rf.named_parameters())
+    norms = np.array([0.0 if P[n].grad is None else P[n].grad.norm().item() for n in names], np.float32)
+    ref = g["param_grad_norms"]
+    assert np.abs(norms - ref).max() <= 1e-4 + 1e-3 * np.abs(ref).max()
+    for key in g:
+        if key.startswith("pgrad_"):
+            assert np.abs(P[key[6:]].grad.numpy() - g[key]).max() <= 1e-5 + 1e-3 * np.abs(g[key]).max(), key
+
+
+DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from tests.emu import emulated_hip
+from mrfa_amd.modules.util import Hourglass
+from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+with emulated_hip():
+    m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+    m.load_state_dict(fill_state_dict(m.state_dict(), "ddp"))
+    m.eval()                                  # eval-mode BN: samples are independent, so DP == big batch exactly
+    ddp = torch.nn.parallel.DistributedDataParallel(m)
+    x = det_uniform("ddp/x", (4, 5, 8, 8))[rank * 2:(rank + 1) * 2]
+    y = ddp(x)
+    (y * det_uniform("ddp/w", (4, 13, 8, 8))[rank * 2:(rank + 1) * 2]).sum().div(4.0).mul(world).backward()
+    if rank == 0:
+        torch.save({n: p.grad for n, p in m.named_parameters()}, out)
+dist.destroy_process_group()
+"""
+
+
+def test_ddp_gloo_world2_matches_single_process(tmp_path):
+    """Data-parallel gradient sync through the engine's single-autograd-node bridge: 2 ranks x 2 samples (gloo, CPU,
+    emulated kernels) must reproduce the 1-process gradients on the 4-sample batch."""
+    from mrfa_amd.modules.util import Hourglass
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    script = tmp_path / "worker.py"
+    script.write_text(DDP_WORKER)
+    out = tmp_path / "grads.pt"
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = torch.load(out)
+    with emulated_hip():
+        m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+        m.load_state_dict(fill_state_dict(m.state_dict(), "ddp"))
+        m.eval()
+        y = m(det_uniform("ddp/x", (4, 5, 8, 8)))
+        (y * det_uniform("ddp/w", (4, 13, 8, 8))).sum().div(4.0).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(got[n], p.grad, atol=1e-5, rtol=1e-4), n
