@@ -25,7 +25,7 @@ constexpr int LDK = BK + 4;   // 36 floats = 144 B row stride: 16-B slots (9*i +
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split,
-                                                       const long long M, const int tiles_n) {
+                                                       const long long M, const int tiles_n, const int total_tiles) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int RA = BM / 32;   // float4 global loads per thread per k-tile (A)
@@ -40,8 +40,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
-    const int tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has a private 4 MiB L2).  Give every XCD one
+    // contiguous band of output tiles so the 3x3 halo rows and the tile's Cout-siblings are re-read from ITS L2
+    // instead of being fetched by all eight.
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (lin >= total_tiles) return;
+    const int tile_m = lin / tiles_n;
+    const int tile_n = lin - tile_m * tiles_n;
     const long long m0 = (long long)tile_m * BM;
     const int n0 = tile_n * BN;
     const int bz = blockIdx.y;
@@ -283,14 +289,15 @@ template <int BM, int BN, int WM_, int WN_>
 int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk) {
     const int tiles_n = cdiv(p.Cout, BN);
     const long long tiles_m = (M + BM - 1) / BM;
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)(p.nbatch > 1 ? p.nbatch : 1), (unsigned)splitk);
+    const int total_tiles = (int)(tiles_m * tiles_n);
+    dim3 grid((unsigned)(cdiv(total_tiles, 8) * 8), (unsigned)(p.nbatch > 1 ? p.nbatch : 1), (unsigned)splitk);
     const int kps = cdiv(KT, splitk);
     mrfa_conv_params q = p;
     q.splitk = splitk;
     if (p.kflat > 0)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, true>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, true>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n, total_tiles);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, false>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, false>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n, total_tiles);
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc");
     return 0;
 }

@@ -2,38 +2,60 @@
 //
 //   dW[tap][co][ci] += alpha * sum_p dY[p][co] * X'[pix(p) + tap - pad][ci]        X' = relu(scale*ups(x)+shift)
 //
-// GEMM view: M = Cout, N = Cin, K = N*Hout*Wout pixels.  Both operands are pixel-major NHWC, i.e. K is the strided
-// axis of both ("TN"): tiles are staged in LDS exactly as they sit in memory, [k][m] and [k][n] (ds_write_b128 of
-// coalesced float4 loads), and MFMA fragments are fetched with conflict-free ds_read_b32 (lane i reads column i of
-// row k = 2j + lane/32).  One MFMA = 64 cycles on its SIMD against two 4-byte LDS reads, so the matrix pipe is the
-// bound.  The reduction over pixels is split across workgroups (gridDim.z) and combined with fp32 atomics into a
-// zero-initialised [tap][Cout][Cin] buffer; the same launch optionally produces the bias gradient sum_p dY[p][co].
+// GEMM view: M = Cout, N = Cin (or taps*Cin in flat mode), K = N*Hout*Wout pixels.  Both operands are pixel-major
+// NHWC, i.e. K is the STRIDED axis of both ("TN").  Each thread loads a 4(k) x 4(m) block with four coalesced float4
+// row loads, transposes it in registers and stores four float4 {k..k+3} vectors, so the LDS image is
+// [k/4][m%4][m/4 (+4 pad)][k%4]: stores are lane-contiguous, and an MFMA lane fetches FOUR consecutive k of its row
+// with one conflict-free ds_read_b128 (16-B slot = (9*(m%4) + m/4) mod 16 distinct per lane group) -- the same
+// operand cadence as the forward kernel: 16 ds_read_b128 feed 64 MFMAs per k-tile per wave, so the matrix pipe
+// (64 cycles per MFMA per SIMD) is the bound.  The pixel reduction is split across workgroups (gridDim.z) and combined
+// with fp32 atomics into a zero-initialised [tap][Cout][Cin] buffer; the bias gradient sum_p dY[p][co] falls out of
+// the A-operand loads.
 //
 // Replaces the weight/bias-gradient half of aten::convolution_backward for every F.conv2d on the hot path
 // (call sites listed in include/mrfa_hip.h) and d(k_s) of the correlation einsum (modules/raft.py:185).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
-constexpr int WBK = 32;
+constexpr int WBK = 32;      // pixels per k-tile
+constexpr int KG = WBK / 4;  // k-groups (planes) per tile
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT, bool ROWAL>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
-                                                        const int tiles_n, const int nsplit, const int dy_scalar) {
+                                                        const int tiles_n, const int nsplit, const int dy_scalar,
+                                                        const int inner, const int total_splits, const int taps) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;   // per-wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
-    constexpr int RA = BM / 32, RB = BN / 32;      // float4 loads per thread: 32 rows x (BM/4) float4 / 256 threads
-    constexpr int CA = BM / 4, CB = BN / 4;        // float4 columns per row
-    __shared__ __attribute__((aligned(16))) float smem[2 * WBK * (BM + BN)];
+    constexpr int SA = BM / 4 + 4, SB = BN / 4 + 4;         // float4 stride between the four (m%4) groups of a plane
+    constexpr int PLA = 4 * SA, PLB = 4 * SB;               // float4 per plane
+    constexpr int IA = (BM / 4) * KG, IB = (BN / 4) * KG;   // (column-group, k-group) work items per tile
+    __shared__ f32x4 smem[2 * KG * (PLA + PLB)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    // XCD-aware order: workgroup b runs on XCD b % 8.  All `inner` = tiles*taps workgroups that stream the SAME pixel
+    // range (one split) are placed on one XCD, back to back, so dY and the tap-shifted X rows are fetched into that
+    // XCD's L2 once and re-read by the other taps / channel tiles instead of 9-18x from HBM.
+    int gsplit, t_in;
+    if (total_splits >= 8) {
+        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+        gsplit = (jj / inner) * 8 + xcd;                    // global split index = batch * nsplit + split
+        if (gsplit >= total_splits) return;
+        t_in = jj - (jj / inner) * inner;
+    } else {                                                // too few splits to give every XCD its own: plain order
+        gsplit = blockIdx.x / inner;
+        if (gsplit >= total_splits) return;
+        t_in = blockIdx.x - gsplit * inner;
+    }
+    const int tile = t_in / taps;
+    const int tap = FLAT ? 0 : (t_in - tile * taps);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int co0 = tile_m * BM, ci0 = tile_n * BN;
-    const int tap = FLAT ? 0 : blockIdx.y;
     const int NTOT = FLAT ? p.kflat : p.Cin;                // extent of the GEMM N axis
-    const int bz = blockIdx.z / nsplit, split = blockIdx.z - bz * nsplit;
+    const int bz = gsplit / nsplit, split = gsplit - bz * nsplit;
     const int r = tap / p.S, s = tap - r * p.S;
 
     const float* __restrict__ x = p.x + (size_t)bz * p.x_bs;
@@ -42,20 +64,20 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
 
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
     const int HWo = p.Hout * p.Wout;
-    const long long kb = (long long)split * k_per_split;
-    const long long ke = min(M, kb + k_per_split);
+    const int kb = (int)((long long)split * k_per_split);
+    const int ke = (int)min(M, (long long)kb + k_per_split);
 
-    // loader geometry: A: CA float4 per row -> rows per pass = 256/CA
-    const int a_col = (tid % CA) * 4, a_row0 = tid / CA;
-    constexpr int A_RSTEP = 256 / CA;
-    const int b_col = (tid % CB) * 4, b_row0 = tid / CB;
-    constexpr int B_RSTEP = 256 / CB;
+    // loader work item of this thread: column group (4 columns) x k-group (4 pixels)
+    const bool a_item = tid < IA, b_item = tid < IB;
+    const int a_cg = tid % (BM / 4), a_kg = tid / (BM / 4);
+    const int b_cg = tid % (BN / 4), b_kg = tid / (BN / 4);
+    const int a_col = a_cg * 4, b_col = b_cg * 4;
     const bool do_bias = (p.dbias != nullptr) && tap == 0 && tile_n == 0;
 
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     bool cmask[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cmask[q] = (ci0 + b_col + q) < NTOT;
+    for (int q = 0; q < 4; ++q) cmask[q] = b_item && (ci0 + b_col + q) < NTOT;
     int fdy[4] = {0, 0, 0, 0}, fdx[4] = {0, 0, 0, 0}, fci[4] = {0, 0, 0, 0};
     if constexpr (FLAT) {
 #pragma unroll
@@ -75,16 +97,99 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
     }
     bool amask[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) amask[q] = (co0 + a_col + q) < p.Cout;
-    const bool a_any = (co0 + a_col) < p.Cout, b_any = (ci0 + b_col) < NTOT;
+    for (int q = 0; q < 4; ++q) amask[q] = a_item && (co0 + a_col + q) < p.Cout;
+    const bool a_any = amask[0], b_any = cmask[0];
 
-    f32x4 ra[RA], rb[RB];
+    f32x4 ra[4], rb[4];                 // [row r of the k-group] x 4 columns
     f32x4 bias_acc = {0.f, 0.f, 0.f, 0.f};
 
-    auto load_tiles = [&](long long k0) {
+    // pixel coordinates of this thread's first B row, advanced incrementally (no divisions in the loop)
+    int b_n, b_oy, b_ox;
+    {
+        const int pp = kb + 4 * b_kg;
+        b_n = pp / HWo;
+        const int rem = pp - b_n * HWo;
+        b_oy = rem / p.Wout;
+        b_ox = rem - b_oy * p.Wout;
+    }
+
+    // ROWAL fast path (Wout % 32 == 0, every level >= 32^2): a k-tile is 32 consecutive pixels of ONE image row, so the
+    // image / row part of every address and the vertical bounds test are wave-uniform scalars; only the horizontal
+    // bound is per lane.  (n, oy, ox0) of the current tile are advanced with scalar adds.
+    int t_n = 0, t_oy = 0, t_ox0 = 0;
+    if constexpr (ROWAL) {
+        t_n = kb / HWo;
+        const int rem = kb - t_n * HWo;
+        t_oy = rem / p.Wout;
+        t_ox0 = rem - t_oy * p.Wout;
+    }
+
+    auto load_tiles = [&](int k0) {
+        if constexpr (ROWAL) {
+            if (a_any) {
+                const float* ap = dy + (size_t)(k0 + 4 * a_kg) * p.ldy + co0 + a_col;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const long long pp = k0 + a_row0 + j * A_RSTEP;
+                for (int rr = 0; rr < 4; ++rr) {
+                    f32x4 v;
+                    if (!dy_scalar) {
+                        v = *reinterpret_cast<const f32x4*>(ap + (size_t)rr * p.ldy);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (!amask[q]) v[q] = 0.f;
+                    } else {
+                        v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (amask[q]) v[q] = ap[(size_t)rr * p.ldy + q];
+                    }
+                    ra[rr] = v;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ra[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int ox = t_ox0 + 4 * b_kg;
+            if constexpr (!FLAT) {
+                const int iy = t_oy + r - p.pad;
+                const bool rowok = b_any && (unsigned)iy < (unsigned)Hv;
+                const float* bp = x + ((size_t)t_n * p.Hin + (iy >> p.ups)) * p.Win * p.ldx + ci0 + b_col;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ix = ox + rr + s - p.pad;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (rowok && (unsigned)ix < (unsigned)Wv) {
+                        v = *reinterpret_cast<const f32x4*>(bp + (size_t)(ix >> p.ups) * p.ldx);
+                        if (p.in_scale) {
+                            v = v * sc + sh;
+                            if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (!cmask[q]) v[q] = 0.f;
+                    }
+                    rb[rr] = v;
+                }
+            } else {
+                const float* bp = x + (size_t)t_n * p.Hin * p.Win * p.ldx;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int iy = t_oy + fdy[q], ix = ox + rr + fdx[q];
+                        if (cmask[q] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv) {
+                            float t = bp[((size_t)(iy >> p.ups) * p.Win + (ix >> p.ups)) * p.ldx + fci[q]];
+                            if (p.in_scale) { t = t * sc[q] + sh[q]; if (p.in_relu) t = fmaxf(t, 0.f); }
+                            v[q] = t;
+                        }
+                    }
+                    rb[rr] = v;
+                }
+            }
+            t_ox0 += WBK;
+            if (t_ox0 == p.Wout) { t_ox0 = 0; if (++t_oy == p.Hout) { t_oy = 0; ++t_n; } }
+            return;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int pp = k0 + 4 * a_kg + rr;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pp < ke && a_any) {
                 if (!dy_scalar) {
@@ -96,16 +201,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
                     for (int q = 0; q < 4; ++q) if (amask[q]) v[q] = dy[(size_t)pp * p.ldy + co0 + a_col + q];
                 }
             }
-            ra[j] = v;
+            ra[rr] = v;
         }
+        int n_img = b_n, oy = b_oy, ox = b_ox;
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const long long pp = k0 + b_row0 + j * B_RSTEP;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int pp = k0 + 4 * b_kg + rr;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pp < ke && b_any) {
-                const int n_img = (int)(pp / HWo);
-                const int rem = (int)(pp - (long long)n_img * HWo);
-                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
                 if constexpr (!FLAT) {
                     const int iy = oy + r - p.pad, ix = ox + s - p.pad;
                     if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv) {
@@ -131,19 +234,27 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
                     }
                 }
             }
-            rb[j] = v;
+            rb[rr] = v;
+            if (++ox == p.Wout) { ox = 0; if (++oy == p.Hout) { oy = 0; ++n_img; } }      // next pixel of the k-group
+        }
+        // advance the first row by one k-tile (WBK pixels)
+        b_ox += WBK;
+        while (b_ox >= p.Wout) {
+            b_ox -= p.Wout;
+            if (++b_oy == p.Hout) { b_oy = 0; ++b_n; }
         }
     };
     auto store_tiles = [&](int buf) {
-        float* As = smem + buf * WBK * (BM + BN);
-        float* Bs = As + WBK * BM;
+        f32x4* As = smem + buf * KG * (PLA + PLB);
+        f32x4* Bs = As + KG * PLA;
+        if (a_item) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<f32x4*>(As + (a_row0 + j * A_RSTEP) * BM + a_col) = ra[j];
+            for (int e = 0; e < 4; ++e) As[a_kg * PLA + e * SA + a_cg] = f32x4{ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+            if (do_bias) bias_acc += ra[0] + ra[1] + ra[2] + ra[3];
+        }
+        if (b_item) {
 #pragma unroll
-        for (int j = 0; j < RB; ++j) *reinterpret_cast<f32x4*>(Bs + (b_row0 + j * B_RSTEP) * BN + b_col) = rb[j];
-        if (do_bias) {
-#pragma unroll
-            for (int j = 0; j < RA; ++j) bias_acc += ra[j];
+            for (int e = 0; e < 4; ++e) Bs[b_kg * PLB + e * SB + b_cg] = f32x4{rb[0][e], rb[1][e], rb[2][e], rb[3][e]};
         }
     };
 
@@ -161,23 +272,28 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
     }
     __syncthreads();
     const int fi = lane & 31, fh = lane >> 5;
+    const int a_lane = (fi & 3) * SA + (fi >> 2) + ((wm * WTM) >> 2);
+    const int b_lane = (fi & 3) * SB + (fi >> 2) + ((wn * WTN) >> 2);
     int cur = 0;
-    for (long long k0 = kb; k0 < ke; k0 += WBK) {
+    for (int k0 = kb; k0 < ke; k0 += WBK) {
         const bool more = (k0 + WBK) < ke;
         if (more) load_tiles(k0 + WBK);
-        const float* As = smem + cur * WBK * (BM + BN) + wm * WTM + fi;
-        const float* Bs = smem + cur * WBK * (BM + BN) + WBK * BM + wn * WTN + fi;
+        const f32x4* As = smem + cur * KG * (PLA + PLB) + a_lane;
+        const f32x4* Bs = smem + cur * KG * (PLA + PLB) + KG * PLA + b_lane;
 #pragma unroll
-        for (int kk = 0; kk < WBK / 2; ++kk) {
-            float a[TM], b[TN];
+        for (int q = 0; q < KG / 2; ++q) {
+            f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + fh) * BM + i * 32];
+            for (int i = 0; i < TM; ++i) a[i] = As[(2 * q + fh) * PLA + i * 8];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + fh) * BN + j * 32];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * q + fh) * PLB + j * 8];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         if (more) store_tiles(cur ^ 1);
         __syncthreads();
@@ -202,7 +318,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
     if (do_bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (amask[q] && a_any) atomicAdd(p.dbias + co0 + a_col + q, bias_acc[q]);
+            if (amask[q]) atomicAdd(p.dbias + co0 + a_col + q, bias_acc[q]);
     }
 }
 
@@ -217,40 +333,75 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     if (!flat) MRFA_CHECK_ARG((p.ldx % 4) == 0 && aligned16(p.x), "wgrad: x must be a 16-B aligned view with ld %% 4 == 0");
     else MRFA_CHECK_ARG(p.ktab != nullptr, "wgrad: flat mode needs ktab");
     const long long M = (long long)p.N * p.Hout * p.Wout;
+    MRFA_CHECK_ARG(M < (1ll << 31) - 64, "wgrad: too many pixels");
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
     const int taps = flat ? 1 : p.R * p.S;
     const int NTOT = flat ? p.kflat : p.Cin;
     // tile selection: (BM over Cout) x (BN over Cin or taps*Cin)
-    int BM = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
-    int BN = NTOT > 64 ? 128 : 64;
-    if (BM == 32) BN = 128;
+    auto pick = [](int n) {                 // padded size x small-tile penalty (loads ~ BM+BN, MFMAs ~ BM*BN)
+        const int cands[3] = {128, 64, 32};
+        const double pen[3] = {1.0, 1.35, 1.8};
+        int best_t = 128;
+        double best = 1e18;
+        for (int i = 0; i < 3; ++i) {
+            const double cost = (double)cdiv(n, cands[i]) * cands[i] * pen[i];
+            if (cost < best) { best = cost; best_t = cands[i]; }
+        }
+        return best_t;
+    };
+    int BM = pick(p.Cout), BN = pick(NTOT);
+    if (BM < 128 && BN < 128) {             // supported: one edge 128, or 64x64
+        if (BM == 64 && BN == 64) {}
+        else if (BM <= BN) BN = 128;
+        else BM = 128;
+    }
     const int tiles_m = cdiv(p.Cout, BM), tiles_n = cdiv(NTOT, BN);
     const long long base = (long long)tiles_m * tiles_n * taps * nb;
     int nsplit = p.ksplit;
     if (nsplit <= 0) {
-        nsplit = (int)((1536 + base - 1) / base);
-        const long long max_split = (M + 255) / 256;      // at least 8 k-tiles per split
-        if (nsplit > max_split) nsplit = (int)max_split;
-        if (nsplit < 1) nsplit = 1;
-        if (nsplit > 1024) nsplit = 1024;
+        // Choose the number of pixel-range splits by a small cost model: 2 workgroups fit a CU (LDS) => 64 run
+        // concurrently per XCD, 512 per chip; with the XCD-aware order every XCD executes ceil(S/8) splits x `inner`
+        // workgroups.  cost = rounds x k-tiles per workgroup (+ a term for the atomic epilogue of each workgroup).
+        const long long max_split = std::max<long long>(1, M / (8 * WBK));     // >= 8 k-tiles per split
+        double best = 1e30;
+        nsplit = 1;
+        const long long inner_ = (long long)tiles_m * tiles_n * taps;
+        for (long long ns = 1; ns <= std::min<long long>(max_split, 1024); ++ns) {
+            const long long S = ns * nb;
+            const long long ktiles = ((M + ns - 1) / ns + WBK - 1) / WBK;
+            double rounds;
+            if (S >= 8) rounds = (double)(((S + 7) / 8 * inner_ + 63) / 64);
+            else rounds = (double)((S * inner_ + 511) / 512);
+            const double cost = rounds * (double)(ktiles + 6);
+            if (cost < best * 0.999) { best = cost; nsplit = (int)ns; }
+        }
     }
     long long kps = (M + nsplit - 1) / nsplit;
     kps = (kps + WBK - 1) / WBK * WBK;
     nsplit = (int)((M + kps - 1) / kps);
-    MRFA_CHECK_ARG((long long)nsplit * nb <= 65535, "wgrad: grid.z too large");
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)taps, (unsigned)(nsplit * nb));
-#define WCFG(bm, bn, wm, wn)                                                                                                       \
-    if (BM == bm && BN == bn) {                                                                                                    \
-        if (flat) hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, true>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar); \
-        else hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, false>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar); \
+    const int inner = tiles_m * tiles_n * taps;
+    const int total_splits = nsplit * nb;
+    dim3 grid((unsigned)(cdiv(total_splits, 8) * 8 * inner));
+    const bool rowal = (p.Wout % WBK) == 0;
+#define WLAUNCH(bm, bn, wm, wn, fl, ra)                                                                                     \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, fl, ra>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar, \
+                       inner, total_splits, taps)
+#define WCFG(bm, bn, wm, wn)                                              \
+    if (BM == bm && BN == bn) {                                           \
+        if (flat && rowal) WLAUNCH(bm, bn, wm, wn, true, true);           \
+        else if (flat) WLAUNCH(bm, bn, wm, wn, true, false);              \
+        else if (rowal) WLAUNCH(bm, bn, wm, wn, false, true);             \
+        else WLAUNCH(bm, bn, wm, wn, false, false);                       \
     }
     WCFG(128, 128, 2, 2)
     else WCFG(128, 64, 2, 2)
     else WCFG(64, 128, 2, 2)
     else WCFG(64, 64, 2, 2)
     else WCFG(32, 128, 1, 4)
+    else WCFG(128, 32, 4, 1)
     else { mrfa_set_error("wgrad: no tile config"); return 1; }
 #undef WCFG
+#undef WLAUNCH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc");
     return 0;
 }
