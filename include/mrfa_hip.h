@@ -93,10 +93,23 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * mode 2: OIHW -> dgrad chunked [tap'][CinPad128][CoutPad32], tap' = flipped tap (data gradient = conv with
  *         180-degree rotated, in/out-transposed weights)
  * mode 3: OIHW -> dgrad flat   [CinPad128][KPad], k = tap'*Cout+co
- * mode 4: grad [tap][Cout][Cin] -> OIHW, accumulating (dst += src)                                              */
+ * mode 4: grad [tap][Cout][Cin] -> OIHW, accumulating (dst += src)
+ * mode 5: OIHW -> [Cout][tap][Cin]            (few-output direct kernels)
+ * mode 6: grad [Cout][tap][Cin] -> OIHW, accumulating
+ * mode 7: OIHW -> [Cin][tap'][Cout] flipped   (data gradient of a few-INPUT conv run as a few-output conv over dY)    */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 /* host-side helper: fills tab[KPad] for flat mode; entry = (dy+128) | (dx+128)<<8 | c<<16, invalid k -> -1      */
 int mrfa_build_ktab(int* tab_host, int C, int R, int S, int pad, int flip);
+
+/* K4: direct (VALU/LDS) convolution for layers with <= 4 output channels (generator.final 64->3 7x7, refine.conv2
+ * 128->2, refine.convo2 128->1, dense_motion.occlusion 108->1; modules/generator.py:32, raft.py:76,78, dense_motion.py:25)
+ * and, with mode-7 weights, the data gradient of corr_enc.convf1 (2 input channels, raft.py:56).
+ * w: [Cout][R*R][Cin] (pack mode 5 / 7); Cin %% 4 == 0; stride 1; square kernel.                                 */
+int mrfa_conv_fewout_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int Cin, const float* w,
+                         const float* bias, float* y, int ldy, int Cout, int R, int pad, int accumulate);
+/* dw [Cout][R*R][Cin] += sum_p dY[p][co] * X[p+tap-pad][ci] (atomics; caller zero-initialises); dbias optional    */
+int mrfa_conv_fewout_wgrad(void* stream, const float* x, int ldx, int N, int H, int W, int Cin, const float* dy, int lddy,
+                           int Cout, int R, int pad, float* dw, float* dbias);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K5/K6/K7: BatchNorm (train + eval) with fused ReLU / 2x2 avg-pool / occlusion blend.

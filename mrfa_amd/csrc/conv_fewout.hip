@@ -1,0 +1,208 @@
+// Direct (VALU) convolution kernels for layers with <= 4 output channels, where a 32-wide MFMA tile would waste >= 8x:
+//   generator.final 64->3 7x7, refine.conv2 128->2, refine.convo2 128->1, dense_motion.occlusion 108->1 7x7
+//   (modules/generator.py:32, raft.py:76,78, dense_motion.py:25) and the data gradient of corr_enc.convf1 (2 input
+//   channels, raft.py:56), which is a 128->2 7x7 convolution over dY.
+//
+// forward  (K4 of SURVEY 2.2): one workgroup = a 16x16 output tile of one image; the input halo tile is staged in LDS
+//   in 16-channel chunks (pixel stride 20 floats => the 16 lanes of a ds_read_b128 group hit distinct 16-B slots),
+//   every thread owns one output pixel and all Cout accumulators; weights are wave-uniform (scalar loads).
+// wgrad: persistent workgroups walk their share of 16x16 tiles; a thread owns one (tap, 4-channel group) of the
+//   current channel chunk and accumulates dW[co][tap][c..c+3] over the tile's pixels from LDS (x halo tile + dY tile),
+//   so only one atomic per weight per workgroup per chunk is issued.
+// Both are bound by LDS / VALU issue, not HBM: every input element is fetched from HBM once.
+#include "common.h"
+
+namespace {
+
+constexpr int FT = 16;          // output tile edge
+constexpr int FCC = 16;         // channels per LDS chunk
+constexpr int FPS = FCC + 4;    // padded pixel stride in floats (20): conflict-free b128 reads of consecutive pixels
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_fewout_fwd_kernel(const float* __restrict__ x, int ldx, int H, int W, int Cin,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int ldy, int Ho, int Wo, int R, int pad,
+                                                             int accumulate, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HT = FT + R - 1;                       // halo tile edge
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int bt = blockIdx.x;
+    const int n = bt / (tiles_x * tiles_y);
+    const int trem = bt - n * tiles_x * tiles_y;
+    const int ty0 = (trem / tiles_x) * FT, tx0 = (trem % tiles_x) * FT;
+    const int T = R * R;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    const float* xin = x + (size_t)n * H * W * ldx;
+
+    for (int c0 = 0; c0 < Cin; c0 += FCC) {
+        __syncthreads();
+        // stage the halo tile: HT*HT pixels x 4 float4
+        for (int i = tid; i < HT * HT * 4; i += 256) {
+            const int c4 = i & 3, pix = i >> 2;
+            const int hy = pix / HT, hx = pix - hy * HT;
+            const int iy = ty0 + hy - pad, ix = tx0 + hx - pad;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + c4 * 4 < Cin)
+                v = *reinterpret_cast<const f32x4*>(xin + ((size_t)iy * W + ix) * ldx + c0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(smem + pix * FPS + c4 * 4) = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < T; ++tap) {
+            const int r = tap / R, s = tap - r * R;
+            const float* px = smem + ((ty + r) * HT + tx + s) * FPS;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(px + c4 * 4);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    // wave-uniform address -> scalar loads
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ((size_t)co * T + tap) * Cin + c0 + c4 * 4);
+                    acc[co] = fmaf(xv.x, wv.x, acc[co]);
+                    acc[co] = fmaf(xv.y, wv.y, acc[co]);
+                    acc[co] = fmaf(xv.z, wv.z, acc[co]);
+                    acc[co] = fmaf(xv.w, wv.w, acc[co]);
+                }
+            }
+        }
+    }
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    if (oy < Ho && ox < Wo) {
+        float* d = y + ((size_t)(n * Ho + oy) * Wo + ox) * ldy;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = acc[co] + (bias ? bias[co] : 0.f);
+            d[co] = accumulate ? d[co] + v : v;
+        }
+    }
+}
+
+// dW[co][tap][ci] += sum_p dY[p][co] * X[p + tap - pad][ci]
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_fewout_wgrad_kernel(const float* __restrict__ x, int ldx, int H, int W, int Cin,
+                                                               const float* __restrict__ dy, int lddy, int Ho, int Wo, int R, int pad,
+                                                               float* __restrict__ dw, float* __restrict__ dbias, int tiles_x,
+                                                               int tiles_y, int ntiles, int cc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HT = FT + R - 1;
+    const int T = R * R;
+    const int ps = cc + 4;                                  // pixel stride of the x tile (floats)
+    float* xs = smem;                                        // HT*HT*ps
+    float* dys = smem + HT * HT * ps;                        // 256 * 4
+    const int tid = threadIdx.x;
+    const int groups = cc / 4;                               // float4 groups per chunk
+    const int items = T * groups;                            // (tap, group) work items (<= 256)
+    const bool active = tid < items;
+    const int tap = active ? tid / groups : 0, g4 = active ? tid - (tid / groups) * groups : 0;
+    const int r = tap / R, s = tap - r * R;
+
+    for (int c0 = 0; c0 < Cin; c0 += cc) {
+        f32x4 acc[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const int n = t / (tiles_x * tiles_y);
+            const int trem = t - n * tiles_x * tiles_y;
+            const int ty0 = (trem / tiles_x) * FT, tx0 = (trem % tiles_x) * FT;
+            const float* xin = x + (size_t)n * H * W * ldx;
+            __syncthreads();
+            for (int i = tid; i < HT * HT * groups; i += 256) {
+                const int gg = i % groups, pix = i / groups;
+                const int hy = pix / HT, hx = pix - hy * HT;
+                const int iy = ty0 + hy - pad, ix = tx0 + hx - pad;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + gg * 4 < Cin)
+                    v = *reinterpret_cast<const f32x4*>(xin + ((size_t)iy * W + ix) * ldx + c0 + gg * 4);
+                *reinterpret_cast<f32x4*>(xs + pix * ps + gg * 4) = v;
+            }
+            {
+                const int py = tid >> 4, pxx = tid & 15;
+                const int oy = ty0 + py, ox = tx0 + pxx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (oy < Ho && ox < Wo) {
+                    const float* d = dy + ((size_t)(n * Ho + oy) * Wo + ox) * lddy;
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) v[c] = d[c];
+                }
+                *reinterpret_cast<f32x4*>(dys + tid * 4) = v;
+            }
+            __syncthreads();
+            if (active) {
+                for (int py = 0; py < FT; ++py) {
+                    const float* xrow = xs + ((py + r) * HT + s) * ps + g4 * 4;
+                    const float* drow = dys + py * FT * 4;
+#pragma unroll 4
+                    for (int pxx = 0; pxx < FT; ++pxx) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + pxx * ps);
+                        const f32x4 dv = *reinterpret_cast<const f32x4*>(drow + pxx * 4);      // broadcast
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) acc[c] += xv * dv[c];
+                    }
+                }
+            }
+            if (dbias && c0 == 0 && tid < COUT) {
+                float sacc = 0.f;
+                for (int q = 0; q < 256; ++q) sacc += dys[q * 4 + tid];
+                bsum += sacc;
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                float* d = dw + ((size_t)c * T + tap) * Cin + c0 + g4 * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + g4 * 4 + q < Cin) atomicAdd(d + q, acc[c][q]);
+            }
+        }
+        if (dbias && c0 == 0 && tid < COUT) atomicAdd(dbias + tid, bsum);
+    }
+}
+
+}  // namespace
+
+extern "C" int mrfa_conv_fewout_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int Cin, const float* w,
+                                    const float* bias, float* y, int ldy, int Cout, int R, int pad, int accumulate) {
+    MRFA_CHECK_ARG(x && w && y && Cout >= 1 && Cout <= 4 && (Cin % 4) == 0 && (ldx % 4) == 0 && aligned16(x) && aligned16(w),
+                   "conv_fewout_fwd: needs Cout <= 4, Cin %% 4 == 0, 16-B aligned x / w");
+    const int Ho = H + 2 * pad - R + 1, Wo = W + 2 * pad - R + 1;
+    const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
+    const int HT = FT + R - 1;
+    const size_t lds = (size_t)HT * HT * FPS * sizeof(float);
+    dim3 grid((unsigned)(N * tiles_x * tiles_y));
+    hipStream_t st = (hipStream_t)stream;
+#define FWD(co) hipLaunchKernelGGL((conv_fewout_fwd_kernel<co>), grid, dim3(256), lds, st, x, ldx, H, W, Cin, w, bias, y, ldy, Ho, Wo, R, pad, \
+                                   accumulate, tiles_x, tiles_y)
+    switch (Cout) { case 1: FWD(1); break; case 2: FWD(2); break; case 3: FWD(3); break; default: FWD(4); break; }
+#undef FWD
+    MRFA_CHECK_LAUNCH("conv_fewout_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_conv_fewout_wgrad(void* stream, const float* x, int ldx, int N, int H, int W, int Cin, const float* dy, int lddy,
+                                      int Cout, int R, int pad, float* dw, float* dbias) {
+    MRFA_CHECK_ARG(x && dy && dw && Cout >= 1 && Cout <= 4 && (Cin % 4) == 0 && (ldx % 4) == 0 && aligned16(x),
+                   "conv_fewout_wgrad: needs Cout <= 4, Cin %% 4 == 0, 16-B aligned x");
+    const int Ho = H + 2 * pad - R + 1, Wo = W + 2 * pad - R + 1;
+    const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
+    const int ntiles = N * tiles_x * tiles_y;
+    const int T = R * R;
+    MRFA_CHECK_ARG(T * 1 <= 256, "conv_fewout_wgrad: kernel too large");
+    int cc = 4;                                   // largest chunk with T * cc/4 <= 256 work items, <= 64 channels
+    const int HT = FT + R - 1;
+    auto lds_of = [&](int c) { return ((size_t)HT * HT * (c + 4) + 256 * 4) * sizeof(float); };
+    while (cc * 2 <= 64 && T * (cc * 2 / 4) <= 256 && cc * 2 <= ((Cin + 3) / 4 * 4) && lds_of(cc * 2) <= 64 * 1024) cc *= 2;
+    const size_t lds = lds_of(cc);
+    MRFA_CHECK_ARG(lds <= 64 * 1024, "conv_fewout_wgrad: LDS tile too large");
+    int grid = ntiles < 512 ? ntiles : 512;
+    hipStream_t st = (hipStream_t)stream;
+#define WG(co) hipLaunchKernelGGL((conv_fewout_wgrad_kernel<co>), dim3(grid), dim3(256), lds, st, x, ldx, H, W, Cin, dy, lddy, Ho, Wo, R, pad, dw, \
+                                  dbias, tiles_x, tiles_y, ntiles, cc)
+    switch (Cout) { case 1: WG(1); break; case 2: WG(2); break; case 3: WG(3); break; default: WG(4); break; }
+#undef WG
+    MRFA_CHECK_LAUNCH("conv_fewout_wgrad");
+    return 0;
+}

@@ -331,15 +331,18 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     // ---- tile selection: largest BN whose padding waste is small, then BM by how many workgroups result
     int BN = 128;
     {
-        const int cands[3] = {128, 64, 32};
-        double best = 1e9;
-        for (int i = 0; i < 3; ++i) {
-            const double waste = (double)cdiv(p.Cout, cands[i]) * cands[i] / p.Cout;
-            if (waste < best - 0.07) { best = waste; BN = cands[i]; }
+        const int cands[4] = {128, 96, 64, 32};
+        const double pen[4] = {1.0, 1.08, 1.16, 1.3};       // measured per-tile efficiency relative to 128x128
+        double best = 1e18;
+        for (int i = 0; i < 4; ++i) {
+            if (cands[i] == 96 && flat) continue;
+            const double cost = (double)cdiv(p.Cout, cands[i]) * cands[i] * pen[i];
+            if (cost < best) { best = cost; BN = cands[i]; }
         }
     }
     auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * cdiv(p.Cout, bn) * nb; };
     int BM = 128;
+    if (BN == 96 && ntiles(128, 96) < 384) BN = 128;     // few tiles: the 128-wide family has the 64/32-row variants
     if (BN == 128) {
         if (ntiles(128, 128) < 384) BM = 64;
         if (ntiles(64, 128) < 384) BM = 32;
@@ -372,6 +375,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
     CFG(128, 128, 2, 2);
+    else CFG(128, 96, 4, 1);
     else CFG(128, 64, 2, 2);
     else CFG(128, 32, 4, 1);
     else CFG(64, 128, 2, 2);

@@ -38,8 +38,31 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
                 const int tap = T - 1 - tapf;
                 v = src[((size_t)co * Cin + ci) * T + tap];
             }
+        } else if (mode == 5) {     // few-output direct kernels: [Cout][tap][Cin]
+            const int ci = (int)(i % Cin);
+            const long long t1 = i / Cin;
+            const int tap = (int)(t1 % T);
+            const int co = (int)(t1 / T);
+            v = src[((size_t)co * Cin + ci) * T + tap];
+        } else if (mode == 7) {     // few-INPUT data gradient as a few-output conv over dY: [Cin][tap'][Cout], tap' flipped
+            const int co = (int)(i % Cout);
+            const long long t1 = i / Cout;
+            const int tapf = (int)(t1 % T);
+            const int ci = (int)(t1 / T);
+            v = src[((size_t)co * Cin + ci) * T + (T - 1 - tapf)];
         }
         dst[i] = v;
+    }
+}
+
+// grad [Cout][tap][Cin] -> OIHW, dst += src
+__global__ void unpack_wgrad_fewout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int T, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % T);
+        const long long t1 = i / T;
+        const int ci = (int)(t1 % Cin);
+        const int co = (int)(t1 / Cin);
+        dst[i] += src[((size_t)co * T + tap) * Cin + ci];
     }
 }
 
@@ -122,6 +145,13 @@ extern "C" int mrfa_pack_conv_weight(void* stream, const float* src, float* dst,
         hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, T, total);
         MRFA_CHECK_LAUNCH("unpack_wgrad");
         return 0;
+    } else if (mode == 6) {
+        total = (long long)Cout * Cin * T;
+        hipLaunchKernelGGL(unpack_wgrad_fewout_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, T, total);
+        MRFA_CHECK_LAUNCH("unpack_wgrad_fewout");
+        return 0;
+    } else if (mode == 5 || mode == 7) {
+        total = (long long)Cout * Cin * T;
     } else { mrfa_set_error("pack_conv_weight: unknown mode %d", mode); return 1; }
     hipLaunchKernelGGL(pack_weight_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, R, S, mode, CoP, CiP,
                        KP, total);

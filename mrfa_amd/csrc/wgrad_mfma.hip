@@ -339,11 +339,11 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     const int NTOT = flat ? p.kflat : p.Cin;
     // tile selection: (BM over Cout) x (BN over Cin or taps*Cin)
     auto pick = [](int n) {                 // padded size x small-tile penalty (loads ~ BM+BN, MFMAs ~ BM*BN)
-        const int cands[3] = {128, 64, 32};
-        const double pen[3] = {1.0, 1.35, 1.8};
+        const int cands[4] = {128, 96, 64, 32};
+        const double pen[4] = {1.0, 1.12, 1.35, 1.8};
         int best_t = 128;
         double best = 1e18;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const double cost = (double)cdiv(n, cands[i]) * cands[i] * pen[i];
             if (cost < best) { best = cost; best_t = cands[i]; }
         }
@@ -355,6 +355,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
         else if (BM <= BN) BN = 128;
         else BM = 128;
     }
+    if (flat && (BM == 96 || BN == 96)) { BM = BM == 96 ? 128 : BM; BN = BN == 96 ? 128 : BN; }
     const int tiles_m = cdiv(p.Cout, BM), tiles_n = cdiv(NTOT, BN);
     const long long base = (long long)tiles_m * tiles_n * taps * nb;
     int nsplit = p.ksplit;
@@ -399,6 +400,8 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     else WCFG(64, 64, 2, 2)
     else WCFG(32, 128, 1, 4)
     else WCFG(128, 32, 4, 1)
+    else WCFG(128, 96, 4, 1)
+    else WCFG(96, 128, 1, 4)
     else { mrfa_set_error("wgrad: no tile config"); return 1; }
 #undef WCFG
 #undef WLAUNCH

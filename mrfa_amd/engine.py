@@ -96,6 +96,12 @@ class ConvW:
         self.fwd_flat = (self.Cin % 32) != 0
         self.dgrad_flat = (self.Cout % 32) != 0
         self.wgrad_flat = self.Cin < 32
+        # direct VALU kernels for <= 4 output channels (forward + weight gradient) and for the data gradient of
+        # convs with <= 4 input channels (= a few-output conv over dY)
+        self.fewout = self.Cout <= 4 and self.Cin % 4 == 0 and self.R == self.S
+        self.fewin = self.Cin <= 4 and self.Cout % 4 == 0 and self.R == self.S
+        self._fo = self._fi = None
+        self._ver_fo = self._ver_fi = None
         self._fwd = None
         self._dg = None
         self._ver_f = self._ver_d = None
@@ -159,6 +165,24 @@ class ConvW:
             self._ver_d = self._key()
         return self._dg
 
+    def _simple_pack(self, attr, ver_attr, mode):
+        if getattr(self, attr) is None or getattr(self, ver_attr) != self._key():
+            w = self.conv.weight.detach()
+            buf = getattr(self, attr)
+            if buf is None or buf.device != w.device:
+                buf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+                setattr(self, attr, buf)
+            hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), w.contiguous().data_ptr(), buf.data_ptr(), self.Cout, self.Cin,
+                                                      self.R, self.S, mode), f"pack(mode {mode})")
+            setattr(self, ver_attr, self._key())
+        return getattr(self, attr)
+
+    def fewout_pack(self) -> torch.Tensor:          # [Cout][tap][Cin]
+        return self._simple_pack("_fo", "_ver_fo", 5)
+
+    def fewin_dgrad_pack(self) -> torch.Tensor:     # [Cin][tap'][Cout]
+        return self._simple_pack("_fi", "_ver_fi", 7)
+
     def grad_acc(self):
         if self.dw_acc is None:
             dev = self.conv.weight.device
@@ -172,7 +196,7 @@ class ConvW:
             return None, None
         dw = torch.zeros_like(self.conv.weight)
         hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), self.dw_acc.data_ptr(), dw.data_ptr(), self.Cout, self.Cin,
-                                                  self.R, self.S, 4), "unpack(wgrad)")
+                                                  self.R, self.S, 6 if self.fewout else 4), "unpack(wgrad)")
         db = self.db_acc
         self.dw_acc = self.db_acc = None
         return dw, db
@@ -333,6 +357,27 @@ class Ctx:
         Ho, Wo = Hv + 2 * cw.pad - cw.R + 1, Wv + 2 * cw.pad - cw.S + 1
         out = out or self.new(x.N, Ho, Wo, cw.Cout)
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cw.Cout)
+        bias = conv.bias if use_bias else None
+        direct = (cw.fewout and not ups and pre is None and res is None and stats is None and not relu
+                  and x.ld % 4 == 0 and x.coff % 4 == 0)
+        if direct:
+            self._chk(self.L.mrfa_conv_fewout_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, cw.fewout_pack().data_ptr(),
+                                                  bias.data_ptr() if bias is not None else None, out.ptr, out.ld, cw.Cout, cw.R, cw.pad, 0),
+                      "conv_fewout_fwd")
+            if self.record:
+                def bwd_direct():
+                    if not out.has_grad:
+                        return
+                    dw, db = cw.grad_acc()
+                    self._chk(self.L.mrfa_conv_fewout_wgrad(self.s, x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, out.gptr, out.ld, cw.Cout, cw.R,
+                                                            cw.pad, dw.data_ptr(), db.data_ptr() if (bias is not None and db is not None) else None),
+                              "conv_fewout_wgrad")
+                    if need_dx:
+                        self._conv_dgrad(x, cw, out, ups, pre)
+                self.tape.append(bwd_direct)
+                if cw not in self.touched_convs:
+                    self.touched_convs.append(cw)
+            return out
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
         wp = cw.fwd_pack()
@@ -349,7 +394,6 @@ class Ctx:
         p.R, p.S, p.pad = cw.R, cw.S, cw.pad
         if pre is not None:
             p.in_scale, p.in_shift, p.in_relu = pre[0].data_ptr(), pre[1].data_ptr(), 1
-        bias = conv.bias if use_bias else None
         p.bias = bias.data_ptr() if bias is not None else None
         p.relu = int(relu)
         if res is not None:
@@ -396,6 +440,11 @@ class Ctx:
         through the pre-activation BN+ReLU by the caller-registered closure (see prebn)."""
         Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
         direct = (not ups) and pre is None
+        if direct and cw.fewin and out.ld % 4 == 0 and out.coff % 4 == 0:
+            # few input channels: the data gradient is a few-output conv over dY
+            self._chk(self.L.mrfa_conv_fewout_fwd(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewin_dgrad_pack().data_ptr(),
+                                                  None, x.gptr, x.ld, cw.Cin, cw.R, cw.R - 1 - cw.pad, 1), "conv_fewout(dgrad)")
+            return
         tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.gptr, out.ld, out.H, out.W, 0, out.N, cw.Cout

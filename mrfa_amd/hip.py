@@ -80,6 +80,8 @@ _SIGNATURES = {
     "mrfa_conv2d_nhwc": ([_V, C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_last_config": ([], C.c_int),
     "mrfa_conv2d_wgrad_nhwc": ([_V, C.POINTER(WgradParams)], C.c_int),
+    "mrfa_conv_fewout_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_conv_fewout_wgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _V], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_build_ktab": ([c_int_p, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_bn_stats": ([_V, _V, _I, _L, _I, _V], C.c_int),

@@ -71,7 +71,18 @@ class Emulator:
             d = _flat(dst, Cout * Cin * T).view(Cout, Cin, T)
             d += g.permute(1, 2, 0)
             return 0
+        if mode == 6:
+            g = _flat(src, T * Cout * Cin).view(Cout, T, Cin)
+            d = _flat(dst, Cout * Cin * T).view(Cout, Cin, T)
+            d += g.permute(0, 2, 1)
+            return 0
         w = _flat(src, Cout * Cin * T).view(Cout, Cin, T)
+        if mode == 5:
+            _flat(dst, Cout * T * Cin).view(Cout, T, Cin).copy_(w.permute(0, 2, 1))
+            return 0
+        if mode == 7:
+            _flat(dst, Cin * T * Cout).view(Cin, T, Cout).copy_(w.flip(2).permute(1, 2, 0))
+            return 0
         if mode == 0:
             cop, cip = (Cout + 127) // 128 * 128, (Cin + 31) // 32 * 32
             d = _flat(dst, T * cop * cip).view(T, cop, cip)
@@ -163,6 +174,29 @@ class Emulator:
             dw += p.alpha * gw.reshape(p.Cout, p.Cin, T).permute(2, 0, 1)
             if p.dbias:
                 vec(p.dbias, p.Cout).add_(dy.sum(dim=(0, 2, 3)))
+        return 0
+
+    def mrfa_conv_fewout_fwd(self, stream, x, ldx, N, H, W, Cin, w, bias, y, ldy, Cout, R, pad, accumulate):
+        T = R * R
+        xx = nhwc(x, N, H, W, ldx, Cin).permute(0, 3, 1, 2)
+        ww = _flat(w, Cout * T * Cin).view(Cout, T, Cin).permute(0, 2, 1).reshape(Cout, Cin, R, R)
+        v = F.conv2d(xx, ww.contiguous(), vec(bias, Cout) if bias else None, padding=pad).permute(0, 2, 3, 1)
+        Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+        o = nhwc(y, N, Ho, Wo, ldy, Cout)
+        o.copy_(o + v if accumulate else v)
+        return 0
+
+    def mrfa_conv_fewout_wgrad(self, stream, x, ldx, N, H, W, Cin, dy, lddy, Cout, R, pad, dw, dbias):
+        T = R * R
+        Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+        xx = nhwc(x, N, H, W, ldx, Cin).permute(0, 3, 1, 2).contiguous()
+        g = nhwc(dy, N, Ho, Wo, lddy, Cout).permute(0, 3, 1, 2).contiguous()
+        with torch.enable_grad():
+            ww = torch.zeros(Cout, Cin, R, R, requires_grad=True)
+            (gw,) = torch.autograd.grad(F.conv2d(xx, ww, None, padding=pad), ww, g)
+        _flat(dw, Cout * T * Cin).view(Cout, T, Cin).add_(gw.reshape(Cout, Cin, T).permute(0, 2, 1))
+        if dbias:
+            vec(dbias, Cout).add_(g.sum(dim=(0, 2, 3)))
         return 0
 
     # ---------------------------------------------------------------- batch norm

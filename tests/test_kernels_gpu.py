@@ -135,6 +135,8 @@ CONV_CASES = {
     "basic": dict(),
     "t128x128_oddM": dict(N=1, H=9, W=11, Cin=64, Cout=130, tile=(128 << 16) | 128),
     "t128x64": dict(Cout=96, tile=(128 << 16) | 64),
+    "t128x96": dict(Cout=192, tile=(128 << 16) | 96),
+    "t128x96_auto": dict(N=4, H=32, W=32, Cin=64, Cout=192, R=1, pad=0),
     "t128x32": dict(Cout=24, tile=(128 << 16) | 32),
     "t64x128": dict(Cout=126, tile=(64 << 16) | 128),
     "t64x64": dict(Cout=64, tile=(64 << 16) | 64),
@@ -259,7 +261,9 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
                                  dict(Cin=3, Cout=64, R=7, pad=3), dict(Cin=2, Cout=128, R=7, pad=3), dict(Cin=128, Cout=2),
                                  dict(Cin=64, Cout=3, R=7, pad=3), dict(Cin=35, Cout=10, R=7, pad=0), dict(Cin=13, Cout=64, pro=True),
                                  dict(R=1, pad=0, Cin=98, Cout=128), dict(N=4, H=32, W=32, Cin=64, Cout=64, ksplit=7),
-                                 dict(Cin=128, Cout=1, dy_off=2), dict(Cin=128, Cout=64, dy_off=3)])
+                                 dict(Cin=128, Cout=1, dy_off=2), dict(Cin=128, Cout=64, dy_off=3),
+                                 dict(N=2, H=32, W=32, Cin=192, Cout=128), dict(N=2, H=32, W=32, Cin=128, Cout=96),
+                                 dict(N=2, H=32, W=32, Cin=160, Cout=126, pro=True), dict(N=1, H=32, W=64, Cin=64, Cout=128, ups=1)])
 def test_wgrad(cfg):
     tag = "wgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
     ref, got = both(lambda s: wgrad_case(s, tag=tag, **cfg))
@@ -462,3 +466,41 @@ def test_layout_and_elementwise():
         return side.done(*outs)
     ref, got = both(run)
     assert_close(ref, got, what="elementwise")
+
+
+@pytest.mark.parametrize("cfg", [dict(Cin=64, Cout=3, R=7, pad=3), dict(Cin=128, Cout=2, R=3, pad=1), dict(Cin=128, Cout=1, R=3, pad=1),
+                                 dict(Cin=108, Cout=1, R=7, pad=3, H=20, W=17), dict(Cin=128, Cout=2, R=7, pad=3, mode7=True),
+                                 dict(Cin=36, Cout=4, R=7, pad=0, H=24, W=24)])
+def test_conv_fewout(cfg):
+    """direct <=4-output-channel kernels (forward incl. accumulate, weight/bias gradient, pack modes 5/6/7)"""
+    c = dict(N=2, H=33, W=40, mode7=False)
+    c.update(cfg)
+    tag = "fo/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+
+    def run(side):
+        N, H, W, Cin, Cout, R, pad = c["N"], c["H"], c["W"], c["Cin"], c["Cout"], c["R"], c["pad"]
+        T = R * R
+        Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+        x = side.t(f"{tag}/x", (N * H * W, Cin + 4))
+        if c["mode7"]:      # weights of a conv with Cout(here)=its Cin: OIHW (Cin_here, Cout_here, R, R) packed flipped
+            woihw = side.t(f"{tag}/w", (Cin, Cout, R, R), -0.2, 0.2)
+            wp = side.garbage((Cout * T * Cin,))
+            side.call("mrfa_pack_conv_weight", woihw.data_ptr(), wp.data_ptr(), Cin, Cout, R, R, 7)
+        else:
+            woihw = side.t(f"{tag}/w", (Cout, Cin, R, R), -0.2, 0.2)
+            wp = side.garbage((Cout * T * Cin,))
+            side.call("mrfa_pack_conv_weight", woihw.data_ptr(), wp.data_ptr(), Cout, Cin, R, R, 5)
+        bias = side.t(f"{tag}/b", (Cout,))
+        y = side.t(f"{tag}/y0", (N * Ho * Wo, 4))
+        side.call("mrfa_conv_fewout_fwd", x.data_ptr(), Cin + 4, N, H, W, Cin, wp.data_ptr(), bias.data_ptr(), y.data_ptr(), 4, Cout, R, pad, 1)
+        y2 = side.garbage((N * Ho * Wo, 4))
+        side.call("mrfa_conv_fewout_fwd", x.data_ptr(), Cin + 4, N, H, W, Cin, wp.data_ptr(), None, y2.data_ptr(), 4, Cout, R, pad, 0)
+        dy = side.t(f"{tag}/dy", (N * Ho * Wo, 4))
+        dw = side.z((Cout * T * Cin,))
+        db = side.z((Cout,))
+        side.call("mrfa_conv_fewout_wgrad", x.data_ptr(), Cin + 4, N, H, W, Cin, dy.data_ptr(), 4, Cout, R, pad, dw.data_ptr(), db.data_ptr())
+        g = side.t(f"{tag}/g0", (Cout, Cin, R, R))
+        side.call("mrfa_pack_conv_weight", dw.data_ptr(), g.data_ptr(), Cout, Cin, R, R, 6)
+        return side.done(y[:, :Cout], y2[:, :Cout], dw, db, g, wp)
+    ref, got = both(run)
+    assert_close(ref, got, tol=5e-4, what=tag)
