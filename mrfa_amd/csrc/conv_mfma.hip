@@ -81,41 +81,50 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
 
     f32x4 ra[RA], rb[RB];
 
+    // (tap, channel-chunk) of the NEXT k-tile to load, advanced incrementally: no integer divisions in the k-loop
+    int l_r = 0, l_s = 0, l_c = 0;           // tap row / col, chunk index
+    const float* l_w = w;                    // packed-weight pointer of the current tap
+    const int a_koff = kq * 4;
+
     auto load_tiles = [&](int kt) {
         if constexpr (!FLAT) {
-            const int tap = kt / KC;
-            const int c0 = (kt - tap * KC) * 32 + kq * 4;
-            const int r = tap / p.S;
-            const int s = tap - r * p.S;
+            const int c0 = l_c * 32 + a_koff;
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
             if (p.in_scale) {
                 sc = *reinterpret_cast<const f32x4*>(p.in_scale + c0);
                 sh = *reinterpret_cast<const f32x4*>(p.in_shift + c0);
             }
+            const int dr = l_r - p.pad, ds = l_s - p.pad;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
-                const int iy = a_oy[j] + r - p.pad;
-                const int ix = a_ox[j] + s - p.pad;
+                const int iy = a_oy[j] + dr;
+                const int ix = a_ox[j] + ds;
                 const bool inb = a_ok[j] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (inb) {
-                    const size_t pix = (size_t)(a_base[j] + (iy >> p.ups) * p.Win + (ix >> p.ups));
-                    v = *reinterpret_cast<const f32x4*>(x + pix * p.ldx + c0);
-                    if (p.in_scale) {
-                        v = v * sc + sh;
-                        if (p.in_relu) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        }
+                // branch-free: out-of-bounds rows read a valid address (pixel 0 of their image) and are zeroed afterwards
+                const int pix = inb ? (a_base[j] + (iy >> p.ups) * p.Win + (ix >> p.ups)) : a_base[j];
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)pix * p.ldx + c0);
+                if (p.in_scale) {
+                    v = v * sc + sh;
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                 }
-                ra[j] = v;
+                const float m = inb ? 1.f : 0.f;
+                ra[j] = inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                (void)m;
             }
-            const float* wt = w + (size_t)tap * p.w_tap + c0;
+            const float* wt = l_w + c0;
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(wt + (size_t)(n0 + lrow + 32 * j) * p.w_ld);
-                rb[j] = v;
+                const int row = b_ok[j] ? (n0 + lrow + 32 * j) : 0;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(wt + (size_t)row * p.w_ld);
+                rb[j] = b_ok[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // advance (chunk, s, r)
+            if (++l_c == KC) {
+                l_c = 0;
+                l_w += p.w_tap;
+                if (++l_s == p.S) { l_s = 0; ++l_r; }
             }
         } else {
             const int k0 = kt * 32 + kq * 4;
@@ -172,6 +181,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
     const int kt_begin = blockIdx.z * kt_per_split;
     const int kt_end = min(KT, kt_begin + kt_per_split);
 
+    if constexpr (!FLAT) {
+        const int tap0 = kt_begin / KC;
+        l_c = kt_begin - tap0 * KC;
+        l_r = tap0 / p.S;
+        l_s = tap0 - l_r * p.S;
+        l_w = w + (size_t)tap0 * p.w_tap;
+    }
     if (kt_begin < kt_end) {
         load_tiles(kt_begin);
         store_tiles(0);

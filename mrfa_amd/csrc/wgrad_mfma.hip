@@ -150,20 +150,21 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
             if constexpr (!FLAT) {
                 const int iy = t_oy + r - p.pad;
                 const bool rowok = b_any && (unsigned)iy < (unsigned)Hv;
-                const float* bp = x + ((size_t)t_n * p.Hin + (iy >> p.ups)) * p.Win * p.ldx + ci0 + b_col;
+                const int iyc = rowok ? (iy >> p.ups) : 0;
+                const int colc = b_any ? (ci0 + b_col) : 0;
+                const float* bp = x + ((size_t)t_n * p.Hin + iyc) * p.Win * p.ldx + colc;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int ix = ox + rr + s - p.pad;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (rowok && (unsigned)ix < (unsigned)Wv) {
-                        v = *reinterpret_cast<const f32x4*>(bp + (size_t)(ix >> p.ups) * p.ldx);
-                        if (p.in_scale) {
-                            v = v * sc + sh;
-                            if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) if (!cmask[q]) v[q] = 0.f;
+                    const bool ok = rowok && (unsigned)ix < (unsigned)Wv;
+                    // branch-free: out-of-bounds taps read column 0 of the row and are zeroed afterwards
+                    f32x4 v = *reinterpret_cast<const f32x4*>(bp + (size_t)(ok ? (ix >> p.ups) : 0) * p.ldx);
+                    if (p.in_scale) {
+                        v = v * sc + sh;
+                        if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (!cmask[q] || !ok) v[q] = 0.f;
                     rb[rr] = v;
                 }
             } else {

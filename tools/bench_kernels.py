@@ -31,6 +31,8 @@ def time_it(fn, iters=10, warmup=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=8)
+    ap.add_argument("--only", type=str, default="", help="substring filter on the layer name; skips the HBM kernels")
+    ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -57,6 +59,8 @@ def main():
     ]
     print(f"{'layer':42s} {'fwd ms':>8s} {'TF/s':>7s} {'%pk':>5s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
     for name, ci, co, k, res, ups in shapes:
+        if a.only and a.only not in name:
+            continue
         conv = torch.nn.Conv2d(ci, co, k, padding=k // 2).to(dev)
         x = e.new(B, res, res, ci)
         x.st.data.normal_()
@@ -65,14 +69,16 @@ def main():
         cw = convw(conv)
         flops = 2.0 * B * ro * ro * co * ci * k * k
         e.record = False
-        t_f = time_it(lambda: e.conv(x, conv, out=out, relu=True, ups=bool(ups)))
+        t_f = time_it(lambda: e.conv(x, conv, out=out, relu=True, ups=bool(ups)), iters=a.iters)
         out.st.grad_buf().normal_()
         x.st.grad_buf()
-        t_d = time_it(lambda: e._conv_dgrad(x, cw, out, bool(ups), None))
-        t_w = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True))
+        t_d = time_it(lambda: e._conv_dgrad(x, cw, out, bool(ups), None), iters=a.iters)
+        t_w = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True), iters=a.iters)
         cw.dw_acc = None
         tf = lambda t: flops / t / 1e9
         print(f"{name:42s} {t_f:8.3f} {tf(t_f):7.1f} {100*tf(t_f)/PEAK_TF:5.1f} | {t_d:8.3f} {tf(t_d):7.1f} | {t_w:8.3f} {tf(t_w):7.1f}", flush=True)
+    if a.only:
+        return
     # HBM-bound kernels
     print("\nHBM-bound kernels (GB/s of algorithmic bytes)")
     for cch, res in ((64, 256), (128, 128), (256, 64)):
