@@ -6,7 +6,7 @@ vox1.yaml shapes with the FOMM prior and RAFT refinement, B=8 per GPU, synthetic
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant kernel
-(the 128x128-tile fp32 MFMA implicit-GEMM convolution, forward + data-gradient launches) inside the timed region;
+(the 128x128-tile, 8-wave fp32 MFMA implicit-GEMM convolution, forward + data-gradient launches) inside the timed region;
 `cpu_baseline` times the CPU oracle (the reference restated, oracle/mrfa_oracle.py) on a bounded sample on rank 0."""
 import argparse
 import json
@@ -136,7 +136,7 @@ def main():
                 achieved = fl / (ms * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                        "kernel": "conv_mfma_kernel<128,128,2,2,false> (fwd + dgrad launches)",
+                        "kernel": "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)",
                         "launches_per_step": len(sel) / a.steps, "avg_launch_ms": round(ms / len(sel), 4),
                         "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
                         "kernel_ms_per_step": round(ms / a.steps, 2),

@@ -24,13 +24,16 @@ constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // 36 floats = 144 B row stride: 16-B slots (9*i + h) mod 16 are distinct per lane group
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split,
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split,
                                                        const long long M, const int tiles_n, const int total_tiles) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
-    constexpr int RA = BM / 32;   // float4 global loads per thread per k-tile (A)
-    constexpr int RB = BN / 32;   // (B)
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int NT = WAVES_M * WAVES_N * 64;       // threads per workgroup (256 or 512)
+    constexpr int RSTEP = NT / 8;                    // rows covered by one pass of the loader (8 float4 per 32-wide row)
+    constexpr int RA = BM / RSTEP;                   // float4 global loads per thread per k-tile (A)
+    constexpr int RB = BN / RSTEP;                   // (B)
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
+    static_assert(RA >= 1 && RB >= 1, "tile too small for the workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
     bool a_ok[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        const long long m = m0 + lrow + 32 * j;
+        const long long m = m0 + lrow + RSTEP * j;
         a_ok[j] = m < M;
         const long long mm = a_ok[j] ? m : 0;
         const int n_img = (int)(mm / HWo);
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
     }
     bool b_ok[RB];
 #pragma unroll
-    for (int j = 0; j < RB; ++j) b_ok[j] = (n0 + lrow + 32 * j) < p.w_rows;
+    for (int j = 0; j < RB; ++j) b_ok[j] = (n0 + lrow + RSTEP * j) < p.w_rows;
 
     f32x4 ra[RA], rb[RB];
 
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
             const float* wt = l_w + c0;
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                const int row = b_ok[j] ? (n0 + lrow + 32 * j) : 0;
+                const int row = b_ok[j] ? (n0 + lrow + RSTEP * j) : 0;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(wt + (size_t)row * p.w_ld);
                 rb[j] = b_ok[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(w + (size_t)(n0 + lrow + 32 * j) * p.w_ld + k0);
+                if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(w + (size_t)(n0 + lrow + RSTEP * j) * p.w_ld + k0);
                 rb[j] = v;
             }
         }
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const mrfa_conv_params p
         float* As = smem + buf * (BM + BN) * LDK;
         float* Bs = As + BM * LDK;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDK + kq * 4) = ra[j];
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<f32x4*>(As + (lrow + RSTEP * j) * LDK + kq * 4) = ra[j];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDK + kq * 4) = rb[j];
+        for (int j = 0; j < RB; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + RSTEP * j) * LDK + kq * 4) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -311,9 +314,9 @@ int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, i
     mrfa_conv_params q = p;
     q.splitk = splitk;
     if (p.kflat > 0)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, true>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, true>), grid, dim3(WM_ * WN_ * 64), 0, st, q, KT, kps, M, tiles_n, total_tiles);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, false>), grid, dim3(256), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM_, WN_, false>), grid, dim3(WM_ * WN_ * 64), 0, st, q, KT, kps, M, tiles_n, total_tiles);
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc");
     return 0;
 }
@@ -365,7 +368,8 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     } else if (BN == 64) {
         if (ntiles(128, 64) < 384) BM = 64;
     }
-    if (p.tile) { BM = p.tile >> 16; BN = p.tile & 0xffff; }
+    bool w8 = false;                                         // 8-wave (512-thread) variant of the 128x128 tile
+    if (p.tile) { BM = p.tile >> 16; BN = p.tile & 0x7fff; w8 = (p.tile & 0x8000) != 0; }
 
     int splitk = 1;
     if (p.splitk > 1) {
@@ -390,7 +394,9 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     g_last_tile = (BM << 16) | (BN << 4) | ((flat ? 1 : 0) << 1) | (splitk > 1 ? 1 : 0);
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
-    CFG(128, 128, 2, 2);
+    if (!p.tile && BM == 128 && BN == 128 && !flat) w8 = true;      // 8 waves: 4 waves/SIMD hide the load/barrier phases (+4..13 %)
+    if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, p, KT, M, splitk);
+    else CFG(128, 128, 2, 2);
     else CFG(128, 96, 4, 1);
     else CFG(128, 64, 2, 2);
     else CFG(128, 32, 4, 1);

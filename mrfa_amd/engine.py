@@ -19,6 +19,7 @@ import torch
 from . import hip
 
 BN_EPS = 1e-5
+FORCE_TILE = 0          # tuning hook: non-zero forces mrfa_conv_params.tile for every MFMA conv launch
 BN_MOMENTUM = 0.1
 
 
@@ -297,6 +298,8 @@ class Ctx:
             self.tape.append(fn)
 
     def _launch_conv(self, p, what: str):
+        if FORCE_TILE:
+            p.tile = FORCE_TILE
         prof = Ctx.profile
         if prof is None:
             self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), what)

@@ -134,6 +134,7 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
 CONV_CASES = {
     "basic": dict(),
     "t128x128_oddM": dict(N=1, H=9, W=11, Cin=64, Cout=130, tile=(128 << 16) | 128),
+    "t128x128_8wave": dict(N=1, H=9, W=11, Cin=64, Cout=130, tile=(128 << 16) | 0x8000 | 128, pro=True),
     "t128x64": dict(Cout=96, tile=(128 << 16) | 64),
     "t128x96": dict(Cout=192, tile=(128 << 16) | 96),
     "t128x96_auto": dict(N=4, H=32, W=32, Cin=64, Cout=192, R=1, pad=0),
