@@ -360,27 +360,37 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
         }
     }
     auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * cdiv(p.Cout, bn) * nb; };
+    // Few output tiles (low-resolution hourglass / generator levels): every M-tile re-reads the whole weight tensor, so
+    // keep the tile tall and split K across workgroups first; shrink BM only when K is too short to split.
     int BM = 128;
     if (BN == 96 && ntiles(128, 96) < 384) BN = 128;     // few tiles: the 128-wide family has the 64/32-row variants
-    if (BN == 128) {
-        if (ntiles(128, 128) < 384) BM = 64;
-        if (ntiles(64, 128) < 384) BM = 32;
-    } else if (BN == 64) {
-        if (ntiles(128, 64) < 384) BM = 64;
-    }
-    bool w8 = false;                                         // 8-wave (512-thread) variant of the 128x128 tile
-    if (p.tile) { BM = p.tile >> 16; BN = p.tile & 0x7fff; w8 = (p.tile & 0x8000) != 0; }
-
+    if (BN == 128) { if (M <= 32) BM = 32; else if (M <= 64) BM = 64; }
+    else if (BN == 64 && M <= 64) BM = 64;
     int splitk = 1;
-    if (p.splitk > 1) {
-        splitk = p.splitk;
-    } else if (p.splitk == 0) {
-        const long long t = ntiles(BM, BN);
-        if (t < 192 && KT >= 8) {
-            splitk = (int)((512 + t - 1) / t);
-            if (splitk > KT / 4) splitk = KT / 4;
+    const bool auto_split = (p.splitk == 0);
+    if (p.splitk > 1) splitk = p.splitk;
+    {
+        const int max_split = auto_split ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
+        long long t = ntiles(BM, BN);
+        if (t < 384) {
+            int want = (int)((512 + t - 1) / t);
+            if (auto_split) splitk = want <= max_split ? want : max_split;
+            const int min_bm = (BN == 128) ? 32 : (BN == 64 ? 64 : 128);
+            while (ntiles(BM, BN) * splitk < 384 && BM > min_bm) {
+                BM >>= 1;
+                if (auto_split) {
+                    t = ntiles(BM, BN);
+                    want = (int)((512 + t - 1) / t);
+                    splitk = want <= max_split ? want : max_split;
+                }
+            }
             if (splitk < 1) splitk = 1;
         }
+    }
+    bool w8 = false;                                         // 8-wave (512-thread) variant of the 128x128 tile
+    if (p.tile) {
+        BM = p.tile >> 16; BN = p.tile & 0x7fff; w8 = (p.tile & 0x8000) != 0;
+        if (p.splitk >= 1) splitk = p.splitk;
     }
     if (splitk > 1) {
         if (!p.accumulate) {

@@ -46,11 +46,14 @@ class Storage:
 
 class View:
     """NHWC activation view: C channels starting at channel offset `coff` of a Storage with leading dimension ld."""
-    __slots__ = ("st", "N", "H", "W", "C", "coff")
+    __slots__ = ("st", "N", "H", "W", "C", "coff", "zpad")
 
-    def __init__(self, st: Storage, N: int, H: int, W: int, C_: int, coff: int = 0):
+    def __init__(self, st: Storage, N: int, H: int, W: int, C_: int, coff: int = 0, zpad: bool = False):
         assert N * H * W == st.rows and coff + C_ <= st.ld, (N, H, W, C_, coff, st.rows, st.ld)
         self.st, self.N, self.H, self.W, self.C, self.coff = st, N, H, W, C_, coff
+        # zpad: the channels [C, roundup32(C)) exist inside ld and hold zeros, so a conv may read the view as if it had
+        # roundup32(C) channels (with zero-padded weights) and stay on the vectorised "chunked" MFMA path
+        self.zpad = zpad
 
     @property
     def rows(self) -> int:
@@ -134,11 +137,17 @@ class ConvW:
         w = self.conv.weight
         return (w._version, w.data_ptr())
 
-    def fwd_pack(self) -> torch.Tensor:
+    def fwd_pack(self, padded: bool = False) -> torch.Tensor:
+        """padded: chunked layout with Cin zero-padded to a multiple of 32 even though Cin % 32 != 0 (zpad inputs)"""
+        if padded != getattr(self, "_fwd_padded", False):
+            self._fwd = None
+            self._fwd_padded = padded
         if self._fwd is None or self._ver_f != self._key():
             w = self.conv.weight.detach()
             cop = (self.Cout + 127) // 128 * 128
-            if self.fwd_flat:
+            if padded:
+                n, mode = self.T * cop * ((self.Cin + 31) // 32 * 32), 0
+            elif self.fwd_flat:
                 kp = (self.T * self.Cin + 31) // 32 * 32
                 n, mode = cop * kp, 1
             else:
@@ -150,11 +159,16 @@ class ConvW:
             self._ver_f = self._key()
         return self._fwd
 
-    def dgrad_pack(self) -> torch.Tensor:
+    def dgrad_pack(self, padded: bool = False) -> torch.Tensor:
+        if padded != getattr(self, "_dg_padded", False):
+            self._dg = None
+            self._dg_padded = padded
         if self._dg is None or self._ver_d != self._key():
             w = self.conv.weight.detach()
             cip = (self.Cin + 127) // 128 * 128
-            if self.dgrad_flat:
+            if padded:
+                n, mode = self.T * cip * ((self.Cout + 31) // 32 * 32), 2
+            elif self.dgrad_flat:
                 kp = (self.T * self.Cout + 31) // 32 * 32
                 n, mode = cip * kp, 3
             else:
@@ -297,7 +311,7 @@ class Ctx:
         if self.record:
             self.tape.append(fn)
 
-    def _launch_conv(self, p, what: str):
+    def _launch_conv(self, p, what: str, alg_cin: Optional[int] = None):
         if FORCE_TILE:
             p.tile = FORCE_TILE
         prof = Ctx.profile
@@ -309,10 +323,13 @@ class Ctx:
         self._chk(self.L.mrfa_conv2d_nhwc(self.s, C.byref(p)), what)
         e1.record()
         nb = max(p.nbatch, 1)
-        flops = 2.0 * nb * p.N * p.Hout * p.Wout * p.Cout * p.Cin * p.R * p.S
+        flops = 2.0 * nb * p.N * p.Hout * p.Wout * p.Cout * (alg_cin or p.Cin) * p.R * p.S      # algorithmic (unpadded)
         prof.append((self.L.mrfa_conv2d_last_config(), flops, e0, e1))
 
-    def new(self, N, H, W, C_, ld=None, zero=False) -> View:
+    def new(self, N, H, W, C_, ld=None, zero=False, pad32=False) -> View:
+        if pad32 and C_ % 32 != 0:
+            ld = (C_ + 31) // 32 * 32
+            return View(Storage(torch.zeros((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_, 0, True)
         ld = _r4(C_) if ld is None else ld
         alloc = torch.zeros if zero else torch.empty
         return View(Storage(alloc((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_)
@@ -383,10 +400,15 @@ class Ctx:
             return out
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
-        wp = cw.fwd_pack()
+        padded = cw.fwd_flat and x.zpad and x.coff % 4 == 0 and pre is None
+        wp = cw.fwd_pack(padded)
         cop = (cw.Cout + 127) // 128 * 128
         p.w = wp.data_ptr()
-        if cw.fwd_flat:
+        if padded:
+            cip32 = (cw.Cin + 31) // 32 * 32
+            p.Cin = cip32
+            p.w_ld, p.w_tap, p.kflat = cip32, cop * cip32, 0
+        elif cw.fwd_flat:
             kp = (cw.T * cw.Cin + 31) // 32 * 32
             p.w_ld, p.w_tap, p.kflat = kp, 0, cw.T * cw.Cin
             p.ktab = cw.ktab_fwd().data_ptr()
@@ -404,7 +426,7 @@ class Ctx:
         if stats is not None:
             p.stats = stats.data_ptr()
         p.alpha, p.nbatch = 1.0, 1
-        self._launch_conv(p, "conv2d")
+        self._launch_conv(p, "conv2d", cw.Cin)
 
         if self.record:
             def bwd():
@@ -451,10 +473,17 @@ class Ctx:
         tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.gptr, out.ld, out.H, out.W, 0, out.N, cw.Cout
-        wp = cw.dgrad_pack()
+        co32 = (cw.Cout + 31) // 32 * 32
+        # Cout % 32 != 0 but the dY view sits in a wider (zero-initialised, finite) gradient buffer: read it as co32
+        # channels against zero-padded weights instead of taking the scalar-gather flat path
+        padded = cw.dgrad_flat and out.coff % 4 == 0 and out.ld % 4 == 0 and out.coff + co32 <= out.ld
+        wp = cw.dgrad_pack(padded)
         cip = (cw.Cin + 127) // 128 * 128
         p.w = wp.data_ptr()
-        if cw.dgrad_flat:
+        if padded:
+            p.Cin = co32
+            p.w_ld, p.w_tap, p.kflat = co32, cip * co32, 0
+        elif cw.dgrad_flat:
             kp = (cw.T * cw.Cout + 31) // 32 * 32
             p.w_ld, p.w_tap, p.kflat = kp, 0, cw.T * cw.Cout
             p.ktab = cw.ktab_dgrad().data_ptr()
@@ -466,7 +495,7 @@ class Ctx:
         p.R, p.S, p.pad = cw.R, cw.S, cw.R - 1 - cw.pad
         p.alpha, p.nbatch = 1.0, 1
         p.accumulate = 1 if direct else 0
-        self._launch_conv(p, "dgrad")
+        self._launch_conv(p, "dgrad", cw.Cout)
         if direct:
             return
         cur = tgt            # holds d(pre(ups(x))) as DATA
@@ -583,7 +612,7 @@ class Ctx:
         return out
 
     def resize(self, x: View, Ho: int, Wo: int, mul: float = 1.0, out: Optional[View] = None, acc: bool = False) -> View:
-        out = out or self.new(x.N, Ho, Wo, x.C)
+        out = out or self.new(x.N, Ho, Wo, x.C, pad32=x.zpad)
         self._chk(self.L.mrfa_resize_bilinear_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld, Ho, Wo, mul, int(acc)),
                   "resize_fwd")
         if self.record:
@@ -600,7 +629,7 @@ class Ctx:
         """vol0 (Q,Hs*Ws), vol1 (Q,Hs/2*Ws/2) torch tensors; dvols: callable returning (dvol0, dvol1) grad tensors or None."""
         Q = coords.rows
         nwin = (2 * radius + 1) ** 2
-        out = out or self.new(coords.N, coords.H, coords.W, 2 * nwin)
+        out = out or self.new(coords.N, coords.H, coords.W, 2 * nwin, pad32=True)
         self._chk(self.L.mrfa_corr_lookup_fwd(self.s, vol0.data_ptr(), vol1.data_ptr(), Hs, Ws, coords.ptr, coords.ld, Q, radius,
                                               out.ptr, out.ld), "corr_lookup_fwd")
         if self.record:

@@ -203,7 +203,7 @@ class Hourglass(_Block):
         for k in range(nb):
             j = nb - 1 - k
             c_up = ups[k].conv.out_channels
-            cats.append(e.new(x.N, sizes[j][0], sizes[j][1], c_up + chans[j]))
+            cats.append(e.new(x.N, sizes[j][0], sizes[j][1], c_up + chans[j], pad32=True))
         # skip slot of feats[0] (the input itself)
         c_up_last = ups[nb - 1].conv.out_channels
         e.copy(x, out=cats[nb - 1].slice(c_up_last, c_up_last + chans[0])) if need_dx else \
