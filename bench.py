@@ -61,14 +61,20 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE config: bs=8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel (RCCL) even with one rank")
+    ap.add_argument("--no-forward", action="store_true", help="skip the extra forward-only (inference) measurement")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (reference train.py:43) instead of per-GPU statistics")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or a.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", init_method="env://")
     dev = torch.device("cuda", local_rank)
@@ -91,8 +97,10 @@ def main():
             if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
                 sd[k] = sd[k] * 0.3
         mod.load_state_dict(sd)
+    if a.sync_bn:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.to(dev).train(True)
-    if world > 1:
+    if world > 1 or a.force_ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                           broadcast_buffers=False, gradient_as_bucket_view=True)
     opt = make_optimizer(model, lr=VOX1["train_params"]["lr"])
@@ -102,7 +110,7 @@ def main():
     drv = det_uniform(f"bench/drv/r{rank}", (B, 3, 256, 256), 0, 1).to(dev)
 
     def barrier():
-        if world > 1:
+        if world > 1 or a.force_ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -123,6 +131,26 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    fwd = None
+    if not a.no_forward:
+        # extra (outside the timed region): inference forward only, eval-mode BN, no autograd -- the quantity the
+        # north_star's ">= 0.5 x MFMA roofline on the DenseMotion+Generator forward" target is stated on
+        m = model.module if hasattr(model, "module") else model
+        m.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                m(src, drv)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nf = max(3, a.steps)
+            for _ in range(nf):
+                m(src, drv)
+            torch.cuda.synchronize()
+            fdt = (time.perf_counter() - t1) / nf
+        m.train(True)
+        gflop = 375.2 * B                       # whole pair incl. 2x KPDetector, forward
+        fwd = {"ms_per_batch": round(1e3 * fdt, 3), "pairs_per_s_per_gpu": round(B / fdt, 2),
+               "algorithmic_tflops": round(gflop / fdt / 1e3, 2), "frac_of_fp32_mfma_peak": round(gflop / fdt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)}
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
         value = world * B * a.steps / dt
@@ -154,12 +182,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "vox1.yaml shapes, FOMM KPDetector prior + DenseMotion + RaftFlow refinement, 256x256, "
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "loss": float(f"{loss_val:.6f}")},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "loss": float(f"{loss_val:.6f}")},
+            "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    else:
+        line = None
+    if world > 1 or a.force_ddp:
         torch.distributed.destroy_process_group()
+    if line is not None:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

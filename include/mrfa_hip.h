@@ -96,7 +96,8 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * mode 4: grad [tap][Cout][Cin] -> OIHW, accumulating (dst += src)
  * mode 5: OIHW -> [Cout][tap][Cin]            (few-output direct kernels)
  * mode 6: grad [Cout][tap][Cin] -> OIHW, accumulating
- * mode 7: OIHW -> [Cin][tap'][Cout] flipped   (data gradient of a few-INPUT conv run as a few-output conv over dY)    */
+ * mode 7: OIHW -> [Cin][tap'][Cout] flipped   (data gradient of a few-INPUT conv run as a few-output conv over dY)
+ * modes 4|16 and 6|16: as 4 / 6 but overwriting (dst = ...) instead of accumulating                                   */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 /* host-side helper: fills tab[KPad] for flat mode; entry = (dy+128) | (dx+128)<<8 | c<<16, invalid k -> -1      */
 int mrfa_build_ktab(int* tab_host, int C, int R, int S, int pad, int flip);

@@ -56,24 +56,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 }
 
 // grad [Cout][tap][Cin] -> OIHW, dst += src
-__global__ void unpack_wgrad_fewout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int T, long long total) {
+__global__ void unpack_wgrad_fewout_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int T, long long total,
+                                           int overwrite) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % T);
         const long long t1 = i / T;
         const int ci = (int)(t1 % Cin);
         const int co = (int)(t1 / Cin);
-        dst[i] += src[((size_t)co * T + tap) * Cin + ci];
+        const float v = src[((size_t)co * T + tap) * Cin + ci];
+        dst[i] = overwrite ? v : dst[i] + v;
     }
 }
 
 // grad [tap][Cout][Cin] -> OIHW, dst += src   (one thread per OIHW element)
-__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int T, long long total) {
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int T, long long total,
+                                    int overwrite) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % T);
         const long long t1 = i / T;
         const int ci = (int)(t1 % Cin);
         const int co = (int)(t1 / Cin);
-        dst[i] += src[((size_t)tap * Cout + co) * Cin + ci];
+        const float v = src[((size_t)tap * Cout + co) * Cin + ci];
+        dst[i] = overwrite ? v : dst[i] + v;
     }
 }
 
@@ -136,18 +140,20 @@ extern "C" int mrfa_pack_conv_weight(void* stream, const float* src, float* dst,
     const int T = R * S;
     long long total;
     int CoP = 0, CiP = 0, KP = 0;
+    const int overwrite = (mode & 16) ? 1 : 0;      // modes 4|16, 6|16: dst = unpacked gradient instead of dst += ...
+    mode &= 15;
     if (mode == 0) { CoP = cdiv(Cout, 128) * 128; CiP = cdiv(Cin, 32) * 32; total = (long long)T * CoP * CiP; }
     else if (mode == 1) { CoP = cdiv(Cout, 128) * 128; KP = cdiv((long long)T * Cin, 32) * 32; total = (long long)CoP * KP; }
     else if (mode == 2) { CiP = cdiv(Cin, 128) * 128; CoP = cdiv(Cout, 32) * 32; total = (long long)T * CiP * CoP; }
     else if (mode == 3) { CiP = cdiv(Cin, 128) * 128; KP = cdiv((long long)T * Cout, 32) * 32; total = (long long)CiP * KP; }
     else if (mode == 4) {
         total = (long long)Cout * Cin * T;
-        hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, T, total);
+        hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, T, total, overwrite);
         MRFA_CHECK_LAUNCH("unpack_wgrad");
         return 0;
     } else if (mode == 6) {
         total = (long long)Cout * Cin * T;
-        hipLaunchKernelGGL(unpack_wgrad_fewout_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, T, total);
+        hipLaunchKernelGGL(unpack_wgrad_fewout_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, src, dst, Cout, Cin, T, total, overwrite);
         MRFA_CHECK_LAUNCH("unpack_wgrad_fewout");
         return 0;
     } else if (mode == 5 || mode == 7) {

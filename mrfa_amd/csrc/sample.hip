@@ -179,6 +179,43 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dout, int lddo, int 
     }
 }
 
+// Up-sampling backward as a GATHER (no atomics): one thread per (input pixel, channel) visits the output pixels whose
+// two source taps include it.  Used when Ho >= Hi and Wo >= Wi (the x2 / x4 resizes of the flow recomposition and the
+// 98-channel correlation features, raft.py:243,279-295); the scatter version above remains for down-sampling.
+__global__ void resize_bwd_gather_kernel(const float* __restrict__ dout, int lddo, int N, int Hi, int Wi, int C, float* __restrict__ din,
+                                         int lddi, int Ho, int Wo, float mul, long long total) {
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long ipix = i / C;
+        const int c = (int)(i - ipix * C);
+        const int ix = (int)(ipix % Wi);
+        const long long t = ipix / Wi;
+        const int iy = (int)(t % Hi);
+        const long long n = t / Hi;
+        // candidate output range: src in (i-1, i+1)  (one extra on each side against rounding)
+        int oy_lo = sy > 0.f ? (int)floorf((float)(iy - 1) / sy) - 1 : 0, oy_hi = sy > 0.f ? (int)ceilf((float)(iy + 1) / sy) + 1 : Ho - 1;
+        int ox_lo = sx > 0.f ? (int)floorf((float)(ix - 1) / sx) - 1 : 0, ox_hi = sx > 0.f ? (int)ceilf((float)(ix + 1) / sx) + 1 : Wo - 1;
+        oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1); ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+        const float* g = dout + (size_t)n * Ho * Wo * lddo + c;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float fy;
+            resize_src(oy, Hi, Ho, y0, y1, fy);
+            const float wy = (y0 == iy ? 1.f - fy : 0.f) + (y1 == iy ? fy : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float fx;
+                resize_src(ox, Wi, Wo, x0, x1, fx);
+                const float wx = (x0 == ix ? 1.f - fx : 0.f) + (x1 == ix ? fx : 0.f);
+                if (wx != 0.f) row += wx * g[((size_t)oy * Wo + ox) * lddo];
+            }
+            acc += wy * row;
+        }
+        din[(size_t)ipix * lddi + c] += acc * mul;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- correlation window lookup
 // One wave per query pixel.  Lane e < (2r+1)^2 owns window element (a,b) = (e / (2r+1), e % (2r+1)) sampled at
 // (x + a - r, y + b - r) on its level's source map; all 49 lanes share the fractional offsets, so the wave touches an
@@ -282,6 +319,13 @@ extern "C" int mrfa_resize_bilinear_fwd(void* stream, const float* in, int ldi, 
 extern "C" int mrfa_resize_bilinear_bwd(void* stream, const float* dout, int lddo, int N, int Hi, int Wi, int C, float* din, int lddi,
                                         int Ho, int Wo, float scale_mul) {
     MRFA_CHECK_ARG(dout && din && C > 0 && N > 0, "resize_bwd: bad args");
+    if (Ho >= Hi && Wo >= Wi) {
+        const long long total_in = (long long)N * Hi * Wi * C;
+        hipLaunchKernelGGL(resize_bwd_gather_kernel, dim3(stream_grid(total_in, 256)), dim3(256), 0, (hipStream_t)stream, dout, lddo, N, Hi,
+                           Wi, C, din, lddi, Ho, Wo, scale_mul, total_in);
+        MRFA_CHECK_LAUNCH("resize_bwd_gather");
+        return 0;
+    }
     const long long total = (long long)N * Ho * Wo * C;
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, lddo, N, Hi, Wi, C, din,
                        lddi, Ho, Wo, scale_mul, total);

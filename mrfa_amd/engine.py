@@ -87,6 +87,27 @@ class View:
         return self.st.grad_buf().view(self.N, self.H, self.W, self.ld)[..., self.coff:self.coff + self.C]
 
 
+class ZeroPool:
+    """Hands out zero-filled 1-D slices carved from large zero chunks: one memset per chunk instead of one tiny fill
+    kernel per statistics / gradient-accumulator buffer (~1000 fills per training step otherwise)."""
+
+    def __init__(self, dev, dtype, chunk_elems: int):
+        self.dev, self.dtype, self.chunk = dev, dtype, chunk_elems
+        self.cur: Optional[torch.Tensor] = None
+        self.off = 0
+
+    def take(self, n: int) -> torch.Tensor:
+        n4 = (n + 3) // 4 * 4
+        if n4 > self.chunk // 4:
+            return torch.zeros(n, dtype=self.dtype, device=self.dev)
+        if self.cur is None or self.off + n4 > self.chunk:
+            self.cur = torch.zeros(self.chunk, dtype=self.dtype, device=self.dev)
+            self.off = 0
+        v = self.cur[self.off:self.off + n]
+        self.off += n4
+        return v
+
+
 # ------------------------------------------------------------------------------------------------- parameters
 class ConvW:
     """Packed-weight cache + packed-gradient accumulator for one nn.Conv2d parameter pair (OIHW weight, bias)."""
@@ -198,20 +219,21 @@ class ConvW:
     def fewin_dgrad_pack(self) -> torch.Tensor:     # [Cin][tap'][Cout]
         return self._simple_pack("_fi", "_ver_fi", 7)
 
-    def grad_acc(self):
+    def grad_acc(self, pool: Optional[ZeroPool] = None):
         if self.dw_acc is None:
             dev = self.conv.weight.device
-            self.dw_acc = torch.zeros(self.T * self.Cout * self.Cin, dtype=torch.float32, device=dev)
-            self.db_acc = torch.zeros(self.Cout, dtype=torch.float32, device=dev) if self.conv.bias is not None else None
+            z = pool.take if pool is not None else (lambda n: torch.zeros(n, dtype=torch.float32, device=dev))
+            self.dw_acc = z(self.T * self.Cout * self.Cin)
+            self.db_acc = z(self.Cout) if self.conv.bias is not None else None
         return self.dw_acc, self.db_acc
 
     def take_grads(self):
         """-> (dW OIHW or None, dbias or None); clears the accumulators."""
         if self.dw_acc is None:
             return None, None
-        dw = torch.zeros_like(self.conv.weight)
+        dw = torch.empty_like(self.conv.weight)
         hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), self.dw_acc.data_ptr(), dw.data_ptr(), self.Cout, self.Cin,
-                                                  self.R, self.S, 6 if self.fewout else 4), "unpack(wgrad)")
+                                                  self.R, self.S, (6 if self.fewout else 4) | 16), "unpack(wgrad)")
         db = self.db_acc
         self.dw_acc = self.db_acc = None
         return dw, db
@@ -233,10 +255,13 @@ class BNGrad:
         self.dg: Optional[torch.Tensor] = None
         self.db: Optional[torch.Tensor] = None
 
-    def acc(self):
+    def acc(self, pool: Optional[ZeroPool] = None):
         if self.dg is None:
-            self.dg = torch.zeros_like(self.bn.weight)
-            self.db = torch.zeros_like(self.bn.bias)
+            if pool is not None:
+                self.dg, self.db = pool.take(self.bn.weight.numel()), pool.take(self.bn.bias.numel())
+            else:
+                self.dg = torch.zeros_like(self.bn.weight)
+                self.db = torch.zeros_like(self.bn.bias)
         return self.dg, self.db
 
     def take(self):
@@ -294,9 +319,13 @@ class Ctx:
         self.record = record
         self.tape: List[Callable[[], None]] = []
         self.L = hip.lib()
+        self.in_backward = False
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
         self.ext_grads = {}              # id(tensor) -> grad for module inputs / parameters touched by islands
+        self.storages: List[Storage] = []            # forward activations whose gradients live in one zero arena
+        self.pool32 = ZeroPool(device, torch.float32, 32 << 20)     # 128 MiB chunks
+        self.pool64 = ZeroPool(device, torch.float64, 1 << 18)      # 2 MiB chunks
 
     # -- plumbing
     @property
@@ -329,10 +358,16 @@ class Ctx:
     def new(self, N, H, W, C_, ld=None, zero=False, pad32=False) -> View:
         if pad32 and C_ % 32 != 0:
             ld = (C_ + 31) // 32 * 32
-            return View(Storage(torch.zeros((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_, 0, True)
+            v = View(Storage(torch.zeros((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_, 0, True)
+            if self.record and not self.in_backward:
+                self.storages.append(v.st)
+            return v
         ld = _r4(C_) if ld is None else ld
         alloc = torch.zeros if zero else torch.empty
-        return View(Storage(alloc((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_)
+        v = View(Storage(alloc((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_)
+        if self.record and not self.in_backward:
+            self.storages.append(v.st)
+        return v
 
     def wrap_nhwc(self, t: torch.Tensor) -> View:
         """Zero-copy view of a contiguous (N,H,W,C) fp32 tensor."""
@@ -365,7 +400,7 @@ class Ctx:
         return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.dev)
 
     def f64z(self, n):
-        return torch.zeros(n, dtype=torch.float64, device=self.dev)
+        return self.pool64.take(n)
 
     # -- convolution ------------------------------------------------------------------------------------------
     def conv(self, x: View, conv: torch.nn.Conv2d, out: Optional[View] = None, *, relu=False, ups=False, pre=None,
@@ -388,7 +423,7 @@ class Ctx:
                 def bwd_direct():
                     if not out.has_grad:
                         return
-                    dw, db = cw.grad_acc()
+                    dw, db = cw.grad_acc(self.pool32)
                     self._chk(self.L.mrfa_conv_fewout_wgrad(self.s, x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, out.gptr, out.ld, cw.Cout, cw.R,
                                                             cw.pad, dw.data_ptr(), db.data_ptr() if (bias is not None and db is not None) else None),
                               "conv_fewout_wgrad")
@@ -446,7 +481,7 @@ class Ctx:
         return out
 
     def _conv_wgrad(self, x: View, cw: ConvW, out: View, ups, pre, has_bias):
-        dw, db = cw.grad_acc()
+        dw, db = cw.grad_acc(self.pool32)
         q = hip.WgradParams()
         q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
         if pre is not None:
@@ -508,10 +543,23 @@ class Ctx:
         self._chk(self.L.mrfa_sumpool2_acc(self.s, cur.ptr, cur.ld, x.N, x.H, x.W, x.C, x.gptr, x.ld, 1.0), "sumpool2")
 
     # -- batch norm -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _sync_world(bn) -> int:
+        """>1 when `bn` is a SyncBatchNorm (torch.nn.SyncBatchNorm.convert_sync_batchnorm, reference train.py:43) in an
+        initialised process group: batch statistics are then reduced over all ranks (RCCL all-reduce of 2C doubles)."""
+        if isinstance(bn, torch.nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_world_size()
+        return 1
+
     def _bn_finalize(self, bn, stats, count):
         Cn = bn.num_features
         scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
         train = self.train
+        if train and stats is not None:
+            world = self._sync_world(bn)
+            if world > 1:
+                torch.distributed.all_reduce(stats)          # sum / sum-of-squares over every rank's pixels
+                count = count * world
         self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
                                           bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                           BN_MOMENTUM, BN_EPS, Cn, int(train), scale.data_ptr(), shift.data_ptr(),
@@ -551,7 +599,7 @@ class Ctx:
         bg = bngrad(bn)
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
-        dg, db = bg.acc()
+        dg, db = bg.acc(self.pool32)
         red = self.f64z(2 * x.C)
         q = hip.BnBwdParams()
         q.x, q.ldx, q.N, q.H, q.W, q.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
@@ -568,6 +616,17 @@ class Ctx:
         q.train = int(train)
         q.phase = 1
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
+        world = self._sync_world(bn) if train else 1
+        if world > 1:
+            # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums
+            Cn = x.C
+            db.add_(red[:Cn].float())
+            dg.add_(red[Cn:].float())
+            red_g = red.clone()
+            torch.distributed.all_reduce(red_g)
+            red_g.div_(world)                                # kernel divides by the LOCAL row count
+            q.red = red_g.data_ptr()
+            q.dgamma = q.dbeta = None
         q.phase = 2
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(2)")
 
@@ -775,6 +834,18 @@ class Ctx:
 
     # -- backward driver --------------------------------------------------------------------------------------
     def run_backward(self):
+        # one zero arena for the gradients of every forward activation (single memset instead of ~500 fills)
+        self.in_backward = True
+        todo = [st for st in self.storages if st.grad is None]
+        total = sum(st.data.numel() for st in todo)
+        if total:
+            arena = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            off = 0
+            for st in todo:
+                n = st.data.numel()
+                st.grad = arena[off:off + n].view(st.rows, st.ld)
+                off += n
+        self.storages = []
         for fn in reversed(self.tape):
             fn()
         self.tape = []

@@ -66,15 +66,17 @@ class Emulator:
 
     def mrfa_pack_conv_weight(self, stream, src, dst, Cout, Cin, R, S, mode):
         T = R * S
+        overwrite = bool(mode & 16)
+        mode &= 15
         if mode == 4:
             g = _flat(src, T * Cout * Cin).view(T, Cout, Cin)
             d = _flat(dst, Cout * Cin * T).view(Cout, Cin, T)
-            d += g.permute(1, 2, 0)
+            d.copy_(g.permute(1, 2, 0) if overwrite else d + g.permute(1, 2, 0))
             return 0
         if mode == 6:
             g = _flat(src, T * Cout * Cin).view(Cout, T, Cin)
             d = _flat(dst, Cout * Cin * T).view(Cout, Cin, T)
-            d += g.permute(0, 2, 1)
+            d.copy_(g.permute(0, 2, 1) if overwrite else d + g.permute(0, 2, 1))
             return 0
         w = _flat(src, Cout * Cin * T).view(Cout, Cin, T)
         if mode == 5:

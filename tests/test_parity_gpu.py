@@ -155,3 +155,20 @@ def test_batch_independence_at_bench_size():
             assert (o8[i:i + 1] - o1).abs().max().item() <= 2e-4
             assert (w8[i:i + 1] - w1).abs().max().item() <= 2e-4
     assert torch.isfinite(o8).all() and o8.min() >= 0 and o8.max() <= 1
+
+
+def test_raft_flow_512_inference_vs_oracle():
+    """BASELINE config 5 (512x512 inference, the grid_sample / 1 GiB-per-sample correlation-volume stress): B=1 against
+    the CPU oracle on fresh inputs."""
+    size, b = 512, 1
+    rf = RaftFlow(**cases.raft_cfg(size))
+    sd = cases.weights_for(rf.state_dict(), "rf")
+    rf.load_state_dict(sd)
+    rf.to(DEV).eval()
+    kp_s, kp_d, dmo, img, img_full = raft_inputs(size, b, "c5/raft")
+    with torch.no_grad():
+        o, w, s = rf(kp_s.to(DEV), kp_d.to(DEV), {k: v.to(DEV) for k, v in dmo.items()}, img.to(DEV), img_full.to(DEV))
+        oo, ow, os_ = O.raft_flow(kp_s, kp_d, dmo, img, img_full, {k: v.clone() for k, v in sd.items()}, "", size=size)
+    _cmp(o, oo.numpy(), what="out 512")
+    _cmp(w, ow.numpy(), what="warp 512")
+    assert s.shape == (b, 1, size, 7 * size)

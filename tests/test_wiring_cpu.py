@@ -147,6 +147,59 @@ def test_raft_flow_backward_through_emulator(golden_dir):
             assert np.abs(P[key[6:]].grad.numpy() - g[key]).max() <= 1e-5 + 1e-3 * np.abs(g[key]).max(), key
 
 
+SYNCBN_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from tests.emu import emulated_hip
+from mrfa_amd.modules.util import Hourglass
+from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+with emulated_hip():
+    m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+    m.load_state_dict(fill_state_dict(m.state_dict(), "sbn"))
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)       # reference train.py:43
+    m.train(True)
+    # (DDP refuses CPU modules that contain SyncBatchNorm, so its gradient averaging is done by hand here)
+    x = det_uniform("sbn/x", (4, 5, 8, 8))[rank * 2:(rank + 1) * 2]
+    y = m(x)
+    (y * det_uniform("sbn/w", (4, 13, 8, 8))[rank * 2:(rank + 1) * 2]).sum().div(4.0).mul(world).backward()
+    for p in m.parameters():
+        dist.all_reduce(p.grad)
+        p.grad.div_(world)
+    if rank == 0:
+        torch.save({"grads": {n: p.grad for n, p in m.named_parameters()}, "y": y.detach(),
+                    "rm": m.encoder.down_blocks[0].norm.running_mean.clone()}, out)
+dist.destroy_process_group()
+"""
+
+
+def test_sync_batchnorm_world2_matches_big_batch(tmp_path):
+    """SyncBatchNorm semantics (reference train.py:43): 2 ranks x 2 samples with statistics all-reduced inside the
+    engine == 1 process on the 4-sample batch, for outputs, running stats and every gradient (gloo, CPU, emulated)."""
+    from mrfa_amd.modules.util import Hourglass
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    script = tmp_path / "worker.py"
+    script.write_text(SYNCBN_WORKER)
+    out = tmp_path / "res.pt"
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = torch.load(out)
+    with emulated_hip():
+        m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+        m.load_state_dict(fill_state_dict(m.state_dict(), "sbn"))
+        m.train(True)
+        y = m(det_uniform("sbn/x", (4, 5, 8, 8)))
+        (y * det_uniform("sbn/w", (4, 13, 8, 8))).sum().div(4.0).backward()
+    assert torch.allclose(got["y"], y.detach()[:2], atol=1e-5)
+    assert torch.allclose(got["rm"], m.encoder.down_blocks[0].norm.running_mean, atol=1e-6)
+    for n, p in m.named_parameters():
+        assert torch.allclose(got["grads"][n], p.grad, atol=2e-5, rtol=1e-4), n
+
+
 DDP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
