@@ -83,6 +83,7 @@ typedef struct {
     int ksplit;            /* 0 = auto: number of pixel-range splits                                            */
     const int* ktab;       /* flat mode (small / odd Cin): GEMM N axis = taps*Cin gathered through the table      */
     int kflat;             /* R*S*Cin in flat mode, else 0                                                      */
+    int tile8_off;         /* tuning: 1 disables the 8-wave variant of the 128x128 tile                         */
 } mrfa_wgrad_params;
 
 int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);

@@ -23,12 +23,13 @@ constexpr int WBK = 32;      // pixels per k-tile
 constexpr int KG = WBK / 4;  // k-groups (planes) per tile
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT, bool ROWAL>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void wgrad_mfma_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
                                                         const int tiles_n, const int nsplit, const int dy_scalar,
                                                         const int inner, const int total_splits, const int taps) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;   // per-wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    static_assert((NT == 256 || NT == 512) && TM >= 1 && TN >= 1, "tile");
     constexpr int SA = BM / 4 + 4, SB = BN / 4 + 4;         // float4 stride between the four (m%4) groups of a plane
     constexpr int PLA = 4 * SA, PLB = 4 * SB;               // float4 per plane
     constexpr int IA = (BM / 4) * KG, IB = (BN / 4) * KG;   // (column-group, k-group) work items per tile
@@ -68,9 +69,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const mrfa_wgrad_params
     const int ke = (int)min(M, (long long)kb + k_per_split);
 
     // loader work item of this thread: column group (4 columns) x k-group (4 pixels)
-    const bool a_item = tid < IA, b_item = tid < IB;
+    // 512-thread variant: threads 0-255 stage A, threads 256-511 stage B (4 loads each instead of 8)
+    const int btid = NT == 512 ? tid - 256 : tid;
+    const bool a_item = tid < IA, b_item = btid >= 0 && btid < IB;
     const int a_cg = tid % (BM / 4), a_kg = tid / (BM / 4);
-    const int b_cg = tid % (BN / 4), b_kg = tid / (BN / 4);
+    const int b_cg = (btid & 0x3ff) % (BN / 4), b_kg = (btid & 0x3ff) / (BN / 4);
     const int a_col = a_cg * 4, b_col = b_cg * 4;
     const bool do_bias = (p.dbias != nullptr) && tap == 0 && tile_n == 0;
 
@@ -386,7 +389,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     dim3 grid((unsigned)(cdiv(total_splits, 8) * 8 * inner));
     const bool rowal = (p.Wout % WBK) == 0;
 #define WLAUNCH(bm, bn, wm, wn, fl, ra)                                                                                     \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, fl, ra>), grid, dim3(256), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar, \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, fl, ra>), grid, dim3((wm) * (wn) * 64), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar, \
                        inner, total_splits, taps)
 #define WCFG(bm, bn, wm, wn)                                              \
     if (BM == bm && BN == bn) {                                           \
@@ -395,7 +398,8 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
         else if (rowal) WLAUNCH(bm, bn, wm, wn, false, true);             \
         else WLAUNCH(bm, bn, wm, wn, false, false);                       \
     }
-    WCFG(128, 128, 2, 2)
+    if (BM == 128 && BN == 128 && !flat && rowal && !p.tile8_off) { WLAUNCH(128, 128, 2, 4, false, true); }
+    else WCFG(128, 128, 2, 2)
     else WCFG(128, 64, 2, 2)
     else WCFG(64, 128, 2, 2)
     else WCFG(64, 64, 2, 2)

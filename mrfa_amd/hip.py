@@ -46,7 +46,7 @@ class WgradParams(C.Structure):
         ("R", C.c_int), ("S", C.c_int), ("pad", C.c_int),
         ("dw", C.c_void_p), ("dbias", C.c_void_p), ("alpha", C.c_float),
         ("nbatch", C.c_int), ("x_bs", C.c_longlong), ("dy_bs", C.c_longlong), ("dw_bs", C.c_longlong),
-        ("ksplit", C.c_int), ("ktab", C.c_void_p), ("kflat", C.c_int),
+        ("ksplit", C.c_int), ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile8_off", C.c_int),
     ]
 
 
