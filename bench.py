@@ -156,14 +156,20 @@ def main():
         value = world * B * a.steps / dt
         roof = None
         if prof:
-            dom = (128 << 16) | (128 << 4)           # BM=128, BN=128, chunked, no split-K
-            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof if cfg == dom]
+            dom = (128 << 16) | (128 << 4)           # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel)
+            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof if (cfg & ~1) == dom]
             allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof]
             if sel:
                 fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
                 achieved = fl / (ms * 1e-3) / 1e12
+                traffic = None
+                try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
+                    with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
+                        traffic = round(json.load(tf)["hbm_bytes_per_launch"] / 1e9, 4)
+                except Exception:
+                    pass
                 roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
                         "kernel": "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)",
                         "launches_per_step": len(sel) / a.steps, "avg_launch_ms": round(ms / len(sel), 4),
                         "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
