@@ -157,8 +157,8 @@ def main():
         roof = None
         if prof:
             dom = (128 << 16) | (128 << 4)           # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel)
-            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof if (cfg & ~1) == dom]
-            allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1 in prof]
+            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if (cfg & ~1) == dom]
+            allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0]
             if sel:
                 fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
                 achieved = fl / (ms * 1e-3) / 1e12

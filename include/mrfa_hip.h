@@ -84,6 +84,8 @@ typedef struct {
     const int* ktab;       /* flat mode (small / odd Cin): GEMM N axis = taps*Cin gathered through the table      */
     int kflat;             /* R*S*Cin in flat mode, else 0                                                      */
     int tile8_off;         /* tuning: 1 disables the 8-wave variant of the 128x128 tile                         */
+    float* ws;             /* optional scratch for the two-stage split reduction (used when many splits hit few   */
+    long long ws_bytes;    /*   weights: 1x1 / few-channel layers); NULL => atomics only                          */
 } mrfa_wgrad_params;
 
 int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);

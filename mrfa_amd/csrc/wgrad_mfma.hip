@@ -25,7 +25,8 @@ constexpr int KG = WBK / 4;  // k-groups (planes) per tile
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT, bool ROWAL>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void wgrad_mfma_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
                                                         const int tiles_n, const int nsplit, const int dy_scalar,
-                                                        const int inner, const int total_splits, const int taps) {
+                                                        const int inner, const int total_splits, const int taps,
+                                                        const long long partial_stride) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;   // per-wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -315,14 +316,47 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void wgrad_mfma_kernel(cons
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int co = co0 + wm * WTM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-                if (co < p.Cout) atomicAdd(dw + ((size_t)otap * p.Cout + co) * p.Cin + ci, acc[i][j][q] * p.alpha);
+                if (co < p.Cout) {
+                    const size_t idx = ((size_t)otap * p.Cout + co) * p.Cin + ci;
+                    if (partial_stride) p.ws[(size_t)split * partial_stride + idx] = acc[i][j][q] * p.alpha;   // two-stage reduction
+                    else atomicAdd(dw + idx, acc[i][j][q] * p.alpha);
+                }
             }
         }
     }
-    if (do_bias) {
+    // bias gradient: reduce the 8 k-group partials of every channel through LDS first, so a workgroup issues ONE atomic per
+    // channel (per-thread atomics put 2048 x nsplit adds on each of the <= 128 addresses: ~0.6 ms on the 1x1 layers)
+    if (p.dbias != nullptr && tap == 0 && tile_n == 0) {        // workgroup-uniform
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        if (a_item) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (amask[q]) atomicAdd(p.dbias + co0 + a_col + q, bias_acc[q]);
+            for (int q = 0; q < 4; ++q) red[a_kg * BM + a_col + q] = bias_acc[q];
+        }
+        __syncthreads();
+        if (tid < BM && co0 + tid < p.Cout) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) sacc += red[g * BM + tid];
+            atomicAdd(p.dbias + co0 + tid, sacc);
+        }
+    }
+}
+
+
+// second stage of the two-stage split reduction: dw[i] += sum_s ws[s][i].  One thread per (i, group of 16 splits):
+// 16 independent coalesced loads, then one atomic per group (<= nsplit/16-way contention instead of nsplit-way).
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int nsplit) {
+    const int groups = (nsplit + 15) / 16;
+    const long long total = n * groups;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(t / n);
+        const long long i = t - (long long)g * n;
+        const int k0 = g * 16, k1 = min(nsplit, k0 + 16);
+        float s = 0.f;
+#pragma unroll 16
+        for (int k = k0; k < k1; ++k) s += ws[(size_t)k * n + i];
+        atomicAdd(dw + i, s);
     }
 }
 
@@ -386,11 +420,15 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     nsplit = (int)((M + kps - 1) / kps);
     const int inner = tiles_m * tiles_n * taps;
     const int total_splits = nsplit * nb;
+    // Many splits of few tiles (1x1 and few-channel layers) would hammer the same few thousand addresses with hundreds of
+    // atomics each: write per-split partial tiles with plain stores instead and reduce them in a second kernel.
+    const long long wn = (long long)(flat ? 1 : taps) * 0 + (long long)p.R * p.S * p.Cout * p.Cin;
+    const long long partial_stride = (nb == 1 && nsplit >= 24 && p.ws && wn * nsplit * 4 <= p.ws_bytes) ? wn : 0;
     dim3 grid((unsigned)(cdiv(total_splits, 8) * 8 * inner));
     const bool rowal = (p.Wout % WBK) == 0;
 #define WLAUNCH(bm, bn, wm, wn, fl, ra)                                                                                     \
     hipLaunchKernelGGL((wgrad_mfma_kernel<bm, bn, wm, wn, fl, ra>), grid, dim3((wm) * (wn) * 64), 0, st, p, M, kps, tiles_n, nsplit, dy_scalar, \
-                       inner, total_splits, taps)
+                       inner, total_splits, taps, partial_stride)
 #define WCFG(bm, bn, wm, wn)                                              \
     if (BM == bm && BN == bn) {                                           \
         if (flat && rowal) WLAUNCH(bm, bn, wm, wn, true, true);           \
@@ -411,5 +449,9 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
 #undef WCFG
 #undef WLAUNCH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc");
+    if (partial_stride) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(wn * ((nsplit + 15) / 16), 256)), dim3(256), 0, st, p.ws, p.dw, wn, nsplit);
+        MRFA_CHECK_LAUNCH("wgrad_reduce");
+    }
     return 0;
 }

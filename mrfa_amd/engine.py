@@ -120,7 +120,8 @@ class ConvW:
         self.T = self.R * self.S
         self.fwd_flat = (self.Cin % 32) != 0
         self.dgrad_flat = (self.Cout % 32) != 0
-        self.wgrad_flat = self.Cin < 32
+        # flat wgrad (GEMM N axis = taps*Cin, gathered): few input channels, or big kernels over an odd channel count
+        self.wgrad_flat = self.Cin < 32 or (self.T >= 25 and self.Cin % 32 != 0 and self.Cin < 64)
         # direct VALU kernels for <= 4 output channels (forward + weight gradient) and for the data gradient of
         # convs with <= 4 input channels (= a few-output conv over dY)
         self.fewout = self.Cout <= 4 and self.Cin % 4 == 0 and self.R == self.S
@@ -312,6 +313,7 @@ class IslandOut:
 class Ctx:
     # bench.py sets this to a list to collect (config, flops, start_event, end_event) per MFMA conv/GEMM launch
     profile: Optional[list] = None
+    _wgrad_ws: Optional[torch.Tensor] = None          # scratch for the two-stage wgrad split reduction
 
     def __init__(self, device: torch.device, train: bool, record: bool):
         self.dev = device
@@ -353,7 +355,8 @@ class Ctx:
         e1.record()
         nb = max(p.nbatch, 1)
         flops = 2.0 * nb * p.N * p.Hout * p.Wout * p.Cout * (alg_cin or p.Cin) * p.R * p.S      # algorithmic (unpadded)
-        prof.append((self.L.mrfa_conv2d_last_config(), flops, e0, e1))
+        prof.append((self.L.mrfa_conv2d_last_config(), flops, e0, e1,
+                     f"{what} {p.Cin}->{p.Cout} {p.R}x{p.S} @{p.Hout}x{p.Wout} N={p.N} nb={nb} ups={p.ups}"))
 
     def new(self, N, H, W, C_, ld=None, zero=False, pad32=False) -> View:
         if pad32 and C_ % 32 != 0:
@@ -493,7 +496,20 @@ class Ctx:
         q.alpha, q.nbatch, q.ksplit = 1.0, 1, 0
         if cw.wgrad_flat:
             q.ktab, q.kflat = cw.ktab_fwd().data_ptr(), cw.T * cw.Cin
-        self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "wgrad")
+        ws = Ctx._wgrad_ws
+        if ws is None or ws.device != self.dev:
+            ws = Ctx._wgrad_ws = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)      # 64 MiB scratch
+        q.ws, q.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        prof = Ctx.profile
+        if prof is None:
+            self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "wgrad")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "wgrad")
+            e1.record()
+            flops = 2.0 * q.N * q.Hout * q.Wout * q.Cout * q.Cin * q.R * q.S
+            prof.append((-1, flops, e0, e1, f"wgrad {q.Cin}->{q.Cout} {q.R}x{q.S} @{q.Hout}x{q.Wout} N={q.N} ups={q.ups} flat={int(q.kflat > 0)} ldx={q.ldx} ldy={q.ldy} xal={x.ptr % 16} dyal={out.gptr % 16} bias={int(bool(q.dbias))} pre={int(pre is not None)}"))
 
     def _conv_dgrad(self, x: View, cw: ConvW, out: View, ups, pre):
         """x.grad += conv_transpose(out.grad); with ups the hi-res gradient is sum-pooled; with pre it is pushed

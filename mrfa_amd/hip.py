@@ -47,6 +47,7 @@ class WgradParams(C.Structure):
         ("dw", C.c_void_p), ("dbias", C.c_void_p), ("alpha", C.c_float),
         ("nbatch", C.c_int), ("x_bs", C.c_longlong), ("dy_bs", C.c_longlong), ("dw_bs", C.c_longlong),
         ("ksplit", C.c_int), ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile8_off", C.c_int),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
     ]
 
 

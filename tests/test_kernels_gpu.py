@@ -231,7 +231,7 @@ def test_dgrad_matches_autograd(cfg):
     assert_close([gx.permute(0, 2, 3, 1).reshape(-1, c["Cin"])], [got], what=tag)
 
 
-def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, tag="w"):
+def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, tag="w"):
     x = side.t(f"{tag}/x", (N * H * W, (Cin + 3) // 4 * 4))
     Hv, Wv = H << ups, W << ups
     Ho, Wo = Hv + 2 * pad - R + 1, Wv + 2 * pad - R + 1
@@ -250,6 +250,10 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     q.dw = dw.data_ptr()
     q.dbias = db.data_ptr() if dbias else None
     q.alpha, q.nbatch, q.ksplit = 1.0, 1, ksplit
+    if ws:
+        wsb = side.garbage((4 << 20,))
+        keep.append(wsb)
+        q.ws, q.ws_bytes = wsb.data_ptr(), wsb.numel() * 4
     if Cin < 32:
         kt = ktab(side, Cin, R, R, pad)
         keep.append(kt)
@@ -264,7 +268,9 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
                                  dict(R=1, pad=0, Cin=98, Cout=128), dict(N=4, H=32, W=32, Cin=64, Cout=64, ksplit=7),
                                  dict(Cin=128, Cout=1, dy_off=2), dict(Cin=128, Cout=64, dy_off=3),
                                  dict(N=2, H=32, W=32, Cin=192, Cout=128), dict(N=2, H=32, W=32, Cin=128, Cout=96),
-                                 dict(N=2, H=32, W=32, Cin=160, Cout=126, pro=True), dict(N=1, H=32, W=64, Cin=64, Cout=128, ups=1)])
+                                 dict(N=2, H=32, W=32, Cin=160, Cout=126, pro=True), dict(N=1, H=32, W=64, Cin=64, Cout=128, ups=1),
+                                 dict(N=4, H=64, W=64, Cin=98, Cout=128, R=1, pad=0, ksplit=40, ws=True),
+                                 dict(N=2, H=64, W=64, Cin=2, Cout=128, R=7, pad=3, ksplit=32, ws=True)])
 def test_wgrad(cfg):
     tag = "wgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
     ref, got = both(lambda s: wgrad_case(s, tag=tag, **cfg))
