@@ -5,8 +5,12 @@ vox1.yaml shapes with the FOMM prior and RAFT refinement, B=8 per GPU, synthetic
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant kernel
-(the 128x128-tile, 8-wave fp32 MFMA implicit-GEMM convolution, forward + data-gradient launches) inside the timed region;
+Rank 0 prints ONE JSON line.  A step = pack + forward + backward + (flat RCCL all-reduce, N > 1) + clip + Adam, replayed
+as hipGraphs (mrfa_amd/graph.py; `--no-graph` launches every kernel eagerly, with DistributedDataParallel for N > 1).
+`roofline` is measured live with HIP events around every launch of the dominant kernel (the 128x128-tile, 8-wave fp32
+MFMA implicit-GEMM convolution, forward + data-gradient launches): inside the timed region for eager launches, and on
+the same step re-issued eagerly right after the timed region when it was a graph replay (events cannot be recorded
+inside a replayed graph; the kernels, shapes and stream are identical).
 `cpu_baseline` times the CPU oracle (the reference restated, oracle/mrfa_oracle.py) on a bounded sample on rank 0."""
 import argparse
 import json
@@ -64,6 +68,7 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel (RCCL) even with one rank")
     ap.add_argument("--no-forward", action="store_true", help="skip the extra forward-only (inference) measurement")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (reference train.py:43) instead of per-GPU statistics")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (DDP for N>1) instead of replaying hipGraphs")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,11 +105,14 @@ def main():
     if a.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.to(dev).train(True)
-    if world > 1 or a.force_ddp:
+    use_graph = not (a.no_graph or a.sync_bn or a.force_ddp)
+    ddp = (world > 1 or a.force_ddp) and not use_graph
+    if ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                           broadcast_buffers=False, gradient_as_bucket_view=True)
-    opt = make_optimizer(model, lr=VOX1["train_params"]["lr"])
+    opt = make_optimizer(model, lr=VOX1["train_params"]["lr"], capturable=use_graph)
     B = a.batch
+    clip = VOX1["train_params"]["clip"]
     # synthetic pairs, different per rank (weak scaling: per-GPU work fixed), resident in HBM before timing
     src = det_uniform(f"bench/src/r{rank}", (B, 3, 256, 256), 0, 1).to(dev)
     drv = det_uniform(f"bench/drv/r{rank}", (B, 3, 256, 256), 0, 1).to(dev)
@@ -114,14 +122,42 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    step = lambda: train_step(model, opt, src, drv, clip=clip)
+    launch = "eager"
+    if use_graph:
+        # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
+        # (mrfa_amd/graph.py): graph A = pack + fwd + bwd, one flat RCCL all-reduce when N > 1, graph B = clip + Adam
+        from mrfa_amd.graph import GraphedTrainStep
+        loss = step()
+        ok = 1
+        try:
+            gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world)
+        except Exception as ex:                       # keep the bench alive on a capture problem: eager path
+            print(f"[bench] hipGraph capture failed on rank {rank}: {ex!r}; falling back to eager launches", file=sys.stderr)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            step = lambda: gstep(src, drv)
+            launch = "hipGraph"
+        else:
+            for prm in model.parameters():
+                prm.grad = None
+            if world > 1:
+                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                                  broadcast_buffers=False, gradient_as_bucket_view=True)
+                step = lambda: train_step(model, opt, src, drv, clip=clip)
+
     for _ in range(a.warmup):
-        loss = train_step(model, opt, src, drv, clip=VOX1["train_params"]["clip"])
+        loss = step()
     barrier()
-    if not a.no_roofline:
+    if launch == "eager" and not a.no_roofline:
         Ctx.profile = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = train_step(model, opt, src, drv, clip=VOX1["train_params"]["clip"])
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     prof, Ctx.profile = Ctx.profile, None
@@ -130,6 +166,20 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    nprof = a.steps
+    if launch == "hipGraph" and not a.no_roofline and rank == 0:
+        # roofline of the dominant kernel: the SAME step launched eagerly on the same stream with a HIP event pair
+        # around every MFMA launch (events cannot be recorded inside a replayed graph); no collective in here
+        bare = model
+        for prm in bare.parameters():
+            prm.grad = None
+        nprof = max(2, min(a.steps, 4))
+        train_step(bare, opt, src, drv, clip=clip)
+        Ctx.profile = []
+        for _ in range(nprof):
+            train_step(bare, opt, src, drv, clip=clip)
+        torch.cuda.synchronize()
+        prof, Ctx.profile = Ctx.profile, None
 
     fwd = None
     if not a.no_forward:
@@ -138,13 +188,21 @@ def main():
         m = model.module if hasattr(model, "module") else model
         m.eval()
         with torch.no_grad():
+            fstep = lambda: m(src, drv)
+            if launch == "hipGraph":
+                try:
+                    from mrfa_amd.graph import GraphedForward
+                    gf = GraphedForward(m, src, drv)
+                    fstep = lambda: gf(src, drv)
+                except Exception as ex:
+                    print(f"[bench] forward hipGraph capture failed: {ex!r}", file=sys.stderr)
             for _ in range(2):
-                m(src, drv)
+                fstep()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             nf = max(3, a.steps)
             for _ in range(nf):
-                m(src, drv)
+                fstep()
             torch.cuda.synchronize()
             fdt = (time.perf_counter() - t1) / nf
         m.train(True)
@@ -171,10 +229,10 @@ def main():
                 roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
                         "kernel": "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)",
-                        "launches_per_step": len(sel) / a.steps, "avg_launch_ms": round(ms / len(sel), 4),
+                        "launches_per_step": len(sel) / nprof, "avg_launch_ms": round(ms / len(sel), 4),
                         "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
-                        "kernel_ms_per_step": round(ms / a.steps, 2),
-                        "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / a.steps, 2),
+                        "kernel_ms_per_step": round(ms / nprof, 2),
+                        "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / nprof, 2),
                         "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
         cpu = None
         if not a.no_cpu_baseline:
@@ -188,7 +246,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "vox1.yaml shapes, FOMM KPDetector prior + DenseMotion + RaftFlow refinement, 256x256, "
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "loss": float(f"{loss_val:.6f}")},
+                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "launch": launch, "loss": float(f"{loss_val:.6f}")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd,
         }
     else:

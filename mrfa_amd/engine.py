@@ -21,6 +21,9 @@ from . import hip
 BN_EPS = 1e-5
 FORCE_TILE = 0          # tuning hook: non-zero forces mrfa_conv_params.tile for every MFMA conv launch
 BN_MOMENTUM = 0.1
+# non-zero while mrfa_amd.graph captures a TRAINING step into a hipGraph: part of every weight-pack cache key, so that
+# each pack kernel is recorded (once) inside the graph and re-runs on replay, after the optimizer changed the weights
+CAPTURE_KEY = 0
 
 
 def _r4(c: int) -> int:
@@ -157,7 +160,7 @@ class ConvW:
     # -- packs (re-done whenever the parameter was modified in place, e.g. by the optimizer)
     def _key(self):
         w = self.conv.weight
-        return (w._version, w.data_ptr())
+        return (w._version, w.data_ptr(), CAPTURE_KEY)
 
     def fwd_pack(self, padded: bool = False) -> torch.Tensor:
         """padded: chunked layout with Cin zero-padded to a multiple of 32 even though Cin % 32 != 0 (zpad inputs)"""
@@ -314,6 +317,7 @@ class Ctx:
     # bench.py sets this to a list to collect (config, flops, start_event, end_event) per MFMA conv/GEMM launch
     profile: Optional[list] = None
     _wgrad_ws: Optional[torch.Tensor] = None          # scratch for the two-stage wgrad split reduction
+    debug_backward: Optional[list] = None             # list -> run_backward appends per-closure gradient fingerprints
 
     def __init__(self, device: torch.device, train: bool, record: bool):
         self.dev = device
@@ -862,8 +866,25 @@ class Ctx:
                 st.grad = arena[off:off + n].view(st.rows, st.ld)
                 off += n
         self.storages = []
-        for fn in reversed(self.tape):
-            fn()
+        dbg = Ctx.debug_backward
+        if dbg is None:
+            for fn in reversed(self.tape):
+                fn()
+        else:
+            # determinism debugging (tools/graph_bisect.py): fingerprint of every activation gradient after each closure
+            rec = []
+            for i, fn in enumerate(reversed(self.tape)):
+                fn()
+                fv = dict(zip(fn.__code__.co_freevars, (c.cell_contents for c in (fn.__closure__ or ()))))
+                desc = fn.__qualname__.replace("Ctx.", "").replace(".<locals>", "")
+                o, cw = fv.get("out"), fv.get("cw")
+                if isinstance(o, View):
+                    desc += f" out=({o.N},{o.H},{o.W},{o.C})"
+                if cw is not None and hasattr(cw, "Cin"):
+                    desc += f" conv {cw.Cin}->{cw.Cout} {cw.R}x{cw.S}"
+                fp = float(arena.abs().sum(dtype=torch.float64)) if total else 0.0
+                rec.append((i, desc, fp))
+            dbg.append(rec)
         self.tape = []
 
 
@@ -883,7 +904,10 @@ class _ProgramFn(torch.autograd.Function):
         outs, seeders, in_grad_fns = program(ectx, *inputs)
         actx.ectx, actx.seeders, actx.in_grad_fns = ectx, seeders, in_grad_fns
         actx.params, actx.n_in = params, n_in
-        return tuple(outs)
+        # return ALIASES: autograd stamps grad_fn (= this node) on the returned tensor objects, and the seeders held
+        # by this node reference the program's own output tensors -- handing those out would close a reference
+        # cycle through C++ (node -> seeders -> tensor -> grad_fn -> node) that no garbage collector can break
+        return tuple(o.detach() for o in outs)
 
     @staticmethod
     def backward(actx, *gouts):
@@ -908,7 +932,7 @@ class _ProgramFn(torch.autograd.Function):
         in_grads = [fn() if (fn is not None and need) else None
                     for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[3:3 + actx.n_in])]
         out = [None, None, None] + in_grads + [pgrads.get(id(p)) for p in actx.params]
-        actx.ectx = None
+        actx.ectx = actx.seeders = actx.in_grad_fns = actx.params = None
         return tuple(out)
 
 

@@ -1,0 +1,157 @@
+"""hipGraph capture of the hot path.
+
+A training step of the path is ~2 900 kernel launches (the reference issues more: one ATen op per layer op); issued
+one by one from Python they cost 100-130 ms of host time, which is the same order as the 135 ms of device time -- on a
+slow host core the step becomes launch-bound.  The programs the engine runs are static (fixed shapes, no
+data-dependent control flow, no host synchronisation), so a whole step is captured ONCE into hipGraphs
+(torch.cuda.CUDAGraph is the HIP graph object on ROCm; torch is only the owner of the capture stream and of the graph's
+private memory pool) and replayed with one launch per step:
+
+  graph A   zero the flat gradient buffer, re-pack the weights, forward, loss, backward (every kernel of mrfa_hip.h)
+  (eager)   N > 1 only: ONE RCCL all-reduce of the flat gradient buffer (all parameters, ~60 M floats) -- the only
+            exchange step of the data-parallel path; it is 2 ms of a 135 ms step on xGMI, so it is not overlapped
+  graph B   inf-norm clipping of the encoder / dense_motion gradients + Adam (reference train.py:21-25, 58-70)
+
+`GraphedForward` is the inference counterpart (one graph, weights packed once outside it).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import engine
+
+
+def _params(model):
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+class FlatGradients:
+    """Every parameter's .grad as a view of ONE fp32 buffer (each slice 16-byte aligned): one memset instead of ~700
+    zero fills, and the data-parallel exchange of the path is ONE all-reduce (RCCL on the GPU, gloo in the CPU tests)
+    of the whole buffer instead of DistributedDataParallel's buckets.  autograd accumulates into existing .grad tensors
+    in place, so the views survive backward passes."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        self.total = sum((p.numel() + 3) // 4 * 4 for p in self.params)
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+
+    def bind(self):
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += (p.numel() + 3) // 4 * 4
+
+    def bound(self) -> bool:
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.total
+        return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
+
+    def all_reduce(self):
+        """sum over ranks (the mean's 1/world is applied by the caller: GraphedTrainStep folds it into graph B)"""
+        torch.distributed.all_reduce(self.flat)
+
+
+class GraphedForward:
+    """Replay of `model(source, driving)` (eval mode, no autograd) as one hipGraph.
+
+    Weights are packed once before capture: call `recapture()` after changing them."""
+
+    def __init__(self, model: nn.Module, source: torch.Tensor, driving: torch.Tensor):
+        self.model = model
+        self.src = source.clone()
+        self.drv = driving.clone()
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out = None
+        self.recapture()
+
+    def recapture(self):
+        m = self.model
+        was_training = m.training
+        m.eval()
+        try:
+            with torch.no_grad():
+                m(self.src, self.drv)                   # packs weights / builds gather tables outside the graph
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = m(self.src, self.drv)
+            self.graph = g
+        finally:
+            m.train(was_training)
+
+    def __call__(self, source: torch.Tensor, driving: torch.Tensor):
+        if source.data_ptr() != self.src.data_ptr():
+            self.src.copy_(source)
+        if driving.data_ptr() != self.drv.data_ptr():
+            self.drv.copy_(driving)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedTrainStep:
+    """fwd + bwd + (all-reduce) + clip + Adam of mrfa_amd.train.train_step as two hipGraphs (see module docstring).
+
+    `model` is the bare HotPath (NOT wrapped in DistributedDataParallel: the gradient exchange is the single flat
+    all-reduce issued here); `optimizer` must have been built with capturable=True and stepped at least once."""
+    _captures = 0
+
+    def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
+                 clip: float = 10.0, world: int = 1):
+        self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
+        self.src, self.drv = source.clone(), driving.clone()
+        self.grads = FlatGradients(model.parameters())
+        ps, dev = self.grads.params, self.grads.flat.device
+        self.flat = self.grads.flat
+        # capture stream: autograd's AccumulateGrad nodes remember the stream they were created on, so one eager
+        # fwd+bwd is issued on the capture stream first (no optimizer step: the weights are left untouched)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for p in ps:
+                p.grad = None
+            saved = [b.clone() for b in model.buffers()]            # BN running statistics: this pass must not count
+            (model(self.src, self.drv) - self.drv).abs().mean().backward()
+            for b, sv in zip(model.buffers(), saved):
+                b.copy_(sv)
+            self.grads.bind()
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        GraphedTrainStep._captures += 1
+        engine.CAPTURE_KEY = GraphedTrainStep._captures
+        try:
+            with torch.cuda.graph(self.g_fb, stream=self.stream):
+                self.flat.zero_()
+                gen = model(self.src, self.drv)
+                loss = (gen - self.drv).abs().mean()
+                loss.backward()
+                # detached handles: a static output that still referenced its autograd graph would keep the graph (and
+                # the parameters' AccumulateGrad nodes bound to the capture stream) alive for the life of this object
+                self.loss, self.gen = loss.detach(), gen.detach()
+        finally:
+            engine.CAPTURE_KEY = 0
+        assert self.grads.bound(), "a gradient left the flat buffer"
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), stream=self.stream):
+            if world > 1:
+                self.flat.mul_(1.0 / world)
+            if clip:
+                nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
+                nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
+            optimizer.step()
+
+    def __call__(self, source: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
+        if source.data_ptr() != self.src.data_ptr():
+            self.src.copy_(source)
+        if driving.data_ptr() != self.drv.data_ptr():
+            self.drv.copy_(driving)
+        self.g_fb.replay()
+        if self.world > 1:
+            self.grads.all_reduce()
+        self.g_opt.replay()
+        return self.loss

@@ -42,7 +42,12 @@ class DenseMotionNetwork(nn.Module):
             ident = make_coordinate_grid((h, w), kd_).view(1, 1, h, w, 2)
             z = ident - kd_.view(b, -1, 1, 1, 2)
             if jd_ is not None:
-                jac = torch.matmul(js_, torch.inverse(jd_))
+                # closed-form 2x2 inverse (reference: torch.inverse, dense_motion.py:54): no solver library call, so the
+                # island stays free of host synchronisation and can be captured in a hipGraph
+                a, b_, c_, d = jd_[..., 0, 0], jd_[..., 0, 1], jd_[..., 1, 0], jd_[..., 1, 1]
+                det = a * d - b_ * c_
+                inv = torch.stack([torch.stack([d, -b_], dim=-1), torch.stack([-c_, a], dim=-1)], dim=-2) / det[..., None, None]
+                jac = torch.matmul(js_, inv)
                 z = torch.einsum("bkij,bkhwj->bkhwi", jac, z)
             d2s = z + ks_.view(b, -1, 1, 1, 2)
             motions = torch.cat([ident.expand(b, 1, h, w, 2), d2s], dim=1)                         # (B,K1,h,w,2)

@@ -48,14 +48,18 @@ class HotPath(nn.Module):
         return gen
 
 
-def make_optimizer(model: HotPath, lr=2.0e-4):
+def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False):
+    """capturable=True keeps Adam's step counters on the device so that the update can live in a hipGraph
+    (mrfa_amd.graph.GraphedTrainStep)"""
     m = model.module if hasattr(model, "module") else model
     return torch.optim.Adam([{"params": m.encoder.parameters()}, {"params": m.decoder.parameters()},
-                             {"params": m.dense_motion.parameters()}], lr=lr, betas=(0.5, 0.999))
+                             {"params": m.dense_motion.parameters()}], lr=lr, betas=(0.5, 0.999), capturable=capturable)
 
 
 def train_step(model, optimizer, source, driving, clip=10.0):
-    """one fwd + bwd + clip + Adam step; returns the (device) loss tensor"""
+    """one fwd + bwd + clip + Adam step; returns the (device) loss tensor, detached: a loss that still references its
+    autograd graph would keep the parameters' AccumulateGrad nodes -- and the stream they were created on -- alive,
+    which breaks a later hipGraph capture on another stream"""
     optimizer.zero_grad(set_to_none=True)
     gen = model(source, driving)
     loss = (gen - driving).abs().mean()
@@ -65,4 +69,4 @@ def train_step(model, optimizer, source, driving, clip=10.0):
         nn.utils.clip_grad_norm_(m.encoder.parameters(), max_norm=clip, norm_type=math.inf)
         nn.utils.clip_grad_norm_(m.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
     optimizer.step()
-    return loss
+    return loss.detach()

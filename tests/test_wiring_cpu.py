@@ -102,6 +102,27 @@ def test_prior_modules_through_emulator(golden_dir, train):
         assert o["sparse_deformed"].shape == (2, 11, 3, 64, 64) and o["logit_mask"].shape == (2, 11, 64, 64)
 
 
+@pytest.mark.parametrize("run_backward", [False, True])
+def test_autograd_node_is_released(run_backward):
+    """The per-module autograd node holds the engine context (arenas, tapes); it must die with the outputs -- with or
+    without a backward pass -- and must not keep the parameters' AccumulateGrad nodes (and their stream) alive, which
+    is also what makes the step capturable into a hipGraph on another stream."""
+    import gc
+    import weakref
+    with emulated_hip():
+        kp = KPDetector(**cases.KP_DETECTOR_CFG)
+        kp.load_state_dict(cases.weights_for(kp.state_dict(), "kp"))
+        kp.train(True)
+        o = kp(cases.images("leak/src", 1, 256))
+        node = weakref.ref(o["kp"].grad_fn)
+        assert node() is not None
+        if run_backward:
+            (o["kp"].sum() + o["jacobian"].sum()).backward()
+        del o
+        gc.collect()
+        assert node() is None
+
+
 @pytest.mark.parametrize("prior_only", [False, True])
 def test_raft_flow_through_emulator(golden_dir, prior_only):
     size, b = 64, 2
@@ -232,6 +253,59 @@ def test_ddp_gloo_world2_matches_single_process(tmp_path):
     script.write_text(DDP_WORKER)
     out = tmp_path / "grads.pt"
     port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = torch.load(out)
+    with emulated_hip():
+        m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+        m.load_state_dict(fill_state_dict(m.state_dict(), "ddp"))
+        m.eval()
+        y = m(det_uniform("ddp/x", (4, 5, 8, 8)))
+        (y * det_uniform("ddp/w", (4, 13, 8, 8))).sum().div(4.0).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(got[n], p.grad, atol=1e-5, rtol=1e-4), n
+
+
+FLAT_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from tests.emu import emulated_hip
+from mrfa_amd.graph import FlatGradients
+from mrfa_amd.modules.util import Hourglass
+from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+with emulated_hip():
+    m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+    m.load_state_dict(fill_state_dict(m.state_dict(), "ddp"))
+    m.eval()
+    fg = FlatGradients(m.parameters())
+    fg.bind()
+    for it in range(2):                          # second pass: the views must have survived backward + exchange
+        fg.flat.zero_()
+        x = det_uniform("ddp/x", (4, 5, 8, 8))[rank * 2:(rank + 1) * 2]
+        y = m(x)
+        (y * det_uniform("ddp/w", (4, 13, 8, 8))[rank * 2:(rank + 1) * 2]).sum().div(4.0).mul(world).backward()
+        assert fg.bound()
+        fg.all_reduce()
+        fg.flat.mul_(1.0 / world)
+    if rank == 0:
+        torch.save({n: p.grad.clone() for n, p in m.named_parameters()}, out)
+dist.destroy_process_group()
+"""
+
+
+def test_flat_gradient_exchange_world2_matches_single_process(tmp_path):
+    """The hipGraph step's data-parallel exchange (mrfa_amd/graph.py: every .grad a view of one buffer, ONE all-reduce,
+    1/world) on 2 gloo ranks x 2 samples == the 1-process gradients on the 4-sample batch."""
+    from mrfa_amd.modules.util import Hourglass
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    script = tmp_path / "worker.py"
+    script.write_text(FLAT_WORKER)
+    out = tmp_path / "grads.pt"
+    port = str(33500 + os.getpid() % 2000)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)]) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
