@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-forward", action="store_true", help="skip the extra forward-only (inference) measurement")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (reference train.py:43) instead of per-GPU statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (DDP for N>1) instead of replaying hipGraphs")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of the flat K20 optimizer kernels")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,7 +111,8 @@ def main():
     if ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                           broadcast_buffers=False, gradient_as_bucket_view=True)
-    opt = make_optimizer(model, lr=VOX1["train_params"]["lr"], capturable=use_graph)
+    fused = use_graph and not a.torch_adam           # FlatAdam re-homes parameters/gradients/moments into flat buffers
+    opt = make_optimizer(model, lr=VOX1["train_params"]["lr"], capturable=use_graph, fused=fused, clip=VOX1["train_params"]["clip"])
     B = a.batch
     clip = VOX1["train_params"]["clip"]
     # synthetic pairs, different per rank (weak scaling: per-GPU work fixed), resident in HBM before timing
@@ -145,9 +147,9 @@ def main():
         else:
             for prm in model.parameters():
                 prm.grad = None
-            if world > 1:
+            if world > 1:                         # (bucket views would unbind FlatAdam's flat .grad views)
                 model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
-                                                                  broadcast_buffers=False, gradient_as_bucket_view=True)
+                                                                  broadcast_buffers=False, gradient_as_bucket_view=not fused)
                 step = lambda: train_step(model, opt, src, drv, clip=clip)
 
     for _ in range(a.warmup):
@@ -246,7 +248,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "vox1.yaml shapes, FOMM KPDetector prior + DenseMotion + RaftFlow refinement, 256x256, "
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "launch": launch, "loss": float(f"{loss_val:.6f}")},
+                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "launch": launch,
+                       "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "loss": float(f"{loss_val:.6f}")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd,
         }
     else:

@@ -203,6 +203,26 @@ int mrfa_antialias_down(void* stream, const float* x_nchw, int N, int C, int H, 
                         int stride, float* y, int ldy);
 int mrfa_colsum(void* stream, const float* x, int ldx, long long rows, int C, float* out /*+=*/);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K20: optimizer step of the data-parallel path on FLAT fp32 buffers (every parameter / gradient / Adam moment of a
+ * parameter group in one allocation, 16-byte aligned slices).  Replaces torch.optim.Adam(betas=(0.5, 0.999)).step()
+ * (reference train.py:21, 70) and nn.utils.clip_grad_norm_(.., norm_type=inf) (train.py:65-67); the 1/world of the
+ * data-parallel gradient mean is folded in as `gscale`.
+ * state: MRFA_ADAM_STATE_FLOATS device floats per parameter group:
+ *   [0] t (steps taken)  [1] lr / (1 - beta1^t)  [2] 1 / sqrt(1 - beta2^t)  [3] lr (written by the host, read by
+ *   mrfa_adam_prepare, so a hipGraph replay follows an LR scheduler)  [4..8) inf-norm slots of this step's gradients */
+#define MRFA_ADAM_STATE_FLOATS 8
+#define MRFA_ADAM_CLIP_SLOTS 4
+/* for every group g < ngroups: t += 1, recompute [1], [2] from [3], zero the inf-norm slots                      */
+int mrfa_adam_prepare(void* stream, float* state, int ngroups, double beta1, double beta2);
+/* state[4 + clip_slot] = max(state[4 + clip_slot], max_i |g[i]|)   (n % 4 == 0, g 16-byte aligned)                */
+int mrfa_grad_absmax(void* stream, const float* g, long long n, float* state, int clip_slot);
+/* g' = gscale * g * (clip_slot < 0 ? 1 : min(1, max_norm / (gscale * state[4 + clip_slot] + 1e-6)));
+ * m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;  w -= state[1] * m / (sqrt(v) * state[2] + eps)     */
+int mrfa_adam_flat(void* stream, float* w, const float* g, float* m, float* v, long long n, const float* state,
+                   double beta1, double beta2, float eps, float gscale, int clip_slot, float max_norm);
+/* (betas are doubles: torch.optim.Adam forms 1 - beta and beta^t in double precision before rounding to fp32)    */
+
 #ifdef __cplusplus
 }
 #endif

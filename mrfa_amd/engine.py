@@ -24,6 +24,26 @@ BN_MOMENTUM = 0.1
 # non-zero while mrfa_amd.graph captures a TRAINING step into a hipGraph: part of every weight-pack cache key, so that
 # each pack kernel is recorded (once) inside the graph and re-runs on replay, after the optimizer changed the weights
 CAPTURE_KEY = 0
+# True (see direct_param_grads()): parameter gradients are accumulated by the backward kernels straight into existing
+# .grad tensors (the flat gradient buffer of mrfa_amd.graph / mrfa_amd.optim) and autograd is handed None for them: no
+# per-parameter staging tensor, zero fill and AccumulateGrad add (~900 small launches per step).  Gradient hooks do not
+# fire in this mode, so DistributedDataParallel must not be wrapped around the model (the flat all-reduce replaces it).
+DIRECT_PARAM_GRADS = False
+
+
+class direct_param_grads:
+    def __enter__(self):
+        global DIRECT_PARAM_GRADS
+        self.prev, DIRECT_PARAM_GRADS = DIRECT_PARAM_GRADS, True
+
+    def __exit__(self, *exc):
+        global DIRECT_PARAM_GRADS
+        DIRECT_PARAM_GRADS = self.prev
+
+
+def _direct_ok(*params) -> bool:
+    return DIRECT_PARAM_GRADS and all(p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32)
+                                      for p in params)
 
 
 def _r4(c: int) -> int:
@@ -227,17 +247,28 @@ class ConvW:
         if self.dw_acc is None:
             dev = self.conv.weight.device
             z = pool.take if pool is not None else (lambda n: torch.zeros(n, dtype=torch.float32, device=dev))
+            self._direct = _direct_ok(self.conv.weight, self.conv.bias)
             self.dw_acc = z(self.T * self.Cout * self.Cin)
-            self.db_acc = z(self.Cout) if self.conv.bias is not None else None
+            if self.conv.bias is None:
+                self.db_acc = None
+            else:                                  # direct mode: the bias gradient is atomically added where it belongs
+                self.db_acc = self.conv.bias.grad if self._direct else z(self.Cout)
         return self.dw_acc, self.db_acc
 
     def take_grads(self):
-        """-> (dW OIHW or None, dbias or None); clears the accumulators."""
+        """-> (dW OIHW or None, dbias or None); clears the accumulators.  Direct mode: the packed [tap][Cout][Cin]
+        accumulator is un-packed INTO weight.grad (+=) and (None, None) is returned."""
         if self.dw_acc is None:
+            return None, None
+        mode = 6 if self.fewout else 4
+        if self._direct:
+            hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), self.dw_acc.data_ptr(), self.conv.weight.grad.data_ptr(), self.Cout,
+                                                      self.Cin, self.R, self.S, mode), "unpack(wgrad, +=)")
+            self.dw_acc = self.db_acc = None
             return None, None
         dw = torch.empty_like(self.conv.weight)
         hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), self.dw_acc.data_ptr(), dw.data_ptr(), self.Cout, self.Cin,
-                                                  self.R, self.S, (6 if self.fewout else 4) | 16), "unpack(wgrad)")
+                                                  self.R, self.S, mode | 16), "unpack(wgrad)")
         db = self.db_acc
         self.dw_acc = self.db_acc = None
         return dw, db
@@ -261,7 +292,10 @@ class BNGrad:
 
     def acc(self, pool: Optional[ZeroPool] = None):
         if self.dg is None:
-            if pool is not None:
+            self._direct = _direct_ok(self.bn.weight, self.bn.bias)
+            if self._direct:                       # the kernels accumulate (+=) straight into the existing gradients
+                self.dg, self.db = self.bn.weight.grad, self.bn.bias.grad
+            elif pool is not None:
                 self.dg, self.db = pool.take(self.bn.weight.numel()), pool.take(self.bn.bias.numel())
             else:
                 self.dg = torch.zeros_like(self.bn.weight)
@@ -271,7 +305,7 @@ class BNGrad:
     def take(self):
         dg, db = self.dg, self.db
         self.dg = self.db = None
-        return dg, db
+        return (None, None) if self._direct else (dg, db)
 
 
 def bngrad(bn) -> BNGrad:
@@ -928,7 +962,13 @@ class _ProgramFn(torch.autograd.Function):
             if dg is not None:
                 pgrads[id(bg.bn.weight)] = dg
                 pgrads[id(bg.bn.bias)] = db
-        pgrads.update(ectx.ext_grads)
+        for p in actx.params:                      # parameters touched by torch glue islands
+            g = ectx.ext_grads.get(id(p))
+            if g is not None:
+                if _direct_ok(p):
+                    p.grad.add_(g)
+                else:
+                    pgrads[id(p)] = g
         in_grads = [fn() if (fn is not None and need) else None
                     for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[3:3 + actx.n_in])]
         out = [None, None, None] + in_grads + [pgrads.get(id(p)) for p in actx.params]

@@ -25,8 +25,15 @@ from torch import nn
 from . import engine
 
 
-def _params(model):
-    return [p for p in model.parameters() if p.requires_grad]
+def _increment_version(tensors):
+    """kernels and graph replays write parameters behind autograd's back: bump the version counters so that every
+    cache keyed on them (the engine's packed-weight cache) sees the change"""
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        inc(tensors)
+    else:
+        for t in tensors:
+            torch._C._increment_version(t)
 
 
 class FlatGradients:
@@ -40,6 +47,7 @@ class FlatGradients:
         dev = self.params[0].device
         self.total = sum((p.numel() + 3) // 4 * 4 for p in self.params)
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        assert self.flat.data_ptr() % 16 == 0
 
     def bind(self):
         off = 0
@@ -104,7 +112,8 @@ class GraphedTrainStep:
                  clip: float = 10.0, world: int = 1):
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         self.src, self.drv = source.clone(), driving.clone()
-        self.grads = FlatGradients(model.parameters())
+        self.fused = getattr(optimizer, "fused_clip", False)      # mrfa_amd.optim.FlatAdam: owns the flat buffers
+        self.grads = optimizer.grads if self.fused else FlatGradients(model.parameters())
         ps, dev = self.grads.params, self.grads.flat.device
         self.flat = self.grads.flat
         # capture stream: autograd's AccumulateGrad nodes remember the stream they were created on, so one eager
@@ -115,7 +124,8 @@ class GraphedTrainStep:
             for p in ps:
                 p.grad = None
             saved = [b.clone() for b in model.buffers()]            # BN running statistics: this pass must not count
-            (model(self.src, self.drv) - self.drv).abs().mean().backward()
+            with engine.direct_param_grads():
+                (model(self.src, self.drv) - self.drv).abs().mean().backward()
             for b, sv in zip(model.buffers(), saved):
                 b.copy_(sv)
             self.grads.bind()
@@ -125,7 +135,7 @@ class GraphedTrainStep:
         GraphedTrainStep._captures += 1
         engine.CAPTURE_KEY = GraphedTrainStep._captures
         try:
-            with torch.cuda.graph(self.g_fb, stream=self.stream):
+            with torch.cuda.graph(self.g_fb, stream=self.stream), engine.direct_param_grads():
                 self.flat.zero_()
                 gen = model(self.src, self.drv)
                 loss = (gen - self.drv).abs().mean()
@@ -137,21 +147,32 @@ class GraphedTrainStep:
             engine.CAPTURE_KEY = 0
         assert self.grads.bound(), "a gradient left the flat buffer"
         self.g_opt = torch.cuda.CUDAGraph()
+        if self.fused:
+            optimizer.grad_scale = 1.0 / world
+            optimizer.sync_lr()
         with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), stream=self.stream):
-            if world > 1:
-                self.flat.mul_(1.0 / world)
-            if clip:
-                nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
-                nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
-            optimizer.step()
+            if self.fused:
+                optimizer.step()                                      # 1/world, clipping and Adam: 6 launches
+            else:
+                if world > 1:
+                    self.flat.mul_(1.0 / world)
+                if clip:
+                    nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
+                    nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
+                optimizer.step()
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
         if source.data_ptr() != self.src.data_ptr():
             self.src.copy_(source)
         if driving.data_ptr() != self.drv.data_ptr():
             self.drv.copy_(driving)
+        if self.fused:
+            self.opt.sync_lr()                                        # an LR scheduler may have edited param_groups
         self.g_fb.replay()
         if self.world > 1:
             self.grads.all_reduce()
         self.g_opt.replay()
+        # the replay changed the weights behind autograd's back: bump the version counters, on which the engine's
+        # packed-weight cache is keyed, so that an eager forward after this step re-packs
+        _increment_version(self.grads.params)
         return self.loss

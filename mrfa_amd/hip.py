@@ -107,6 +107,9 @@ _SIGNATURES = {
     "mrfa_blend_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I, _V, _I, _V, _I], C.c_int),
     "mrfa_antialias_down": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V, _I], C.c_int),
     "mrfa_colsum": ([_V, _V, _I, _L, _I, _V], C.c_int),
+    "mrfa_adam_prepare": ([_V, _V, _I, C.c_double, C.c_double], C.c_int),
+    "mrfa_grad_absmax": ([_V, _V, _L, _V, _I], C.c_int),
+    "mrfa_adam_flat": ([_V, _V, _V, _V, _V, _L, _V, C.c_double, C.c_double, _F, _F, _I, _F], C.c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -7,6 +7,7 @@ The reference's real losses (VGG19 perceptual pyramid, equivariance) need torchv
 fwd+bwd metric."""
 from __future__ import annotations
 
+import contextlib
 import math
 
 import torch
@@ -48,10 +49,17 @@ class HotPath(nn.Module):
         return gen
 
 
-def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False):
-    """capturable=True keeps Adam's step counters on the device so that the update can live in a hipGraph
-    (mrfa_amd.graph.GraphedTrainStep)"""
+def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False, fused=False, clip=10.0):
+    """The reference's optimizer (train.py:21): Adam(lr, betas=(0.5, 0.999)) over three parameter groups.
+
+    fused=False  torch.optim.Adam (capturable=True keeps its step counters on the device for hipGraph capture);
+    fused=True   mrfa_amd.optim.FlatAdam: parameters, gradients and moments re-homed into flat HBM buffers, inf-norm
+                 clipping of the encoder / dense_motion groups (train.py:65-67) + Adam as 6 HIP launches."""
     m = model.module if hasattr(model, "module") else model
+    if fused:
+        from .optim import FlatAdam
+        return FlatAdam([{"params": list(m.encoder.parameters()), "clip": clip}, {"params": list(m.decoder.parameters())},
+                         {"params": list(m.dense_motion.parameters()), "clip": clip}], lr=lr, betas=(0.5, 0.999))
     return torch.optim.Adam([{"params": m.encoder.parameters()}, {"params": m.decoder.parameters()},
                              {"params": m.dense_motion.parameters()}], lr=lr, betas=(0.5, 0.999), capturable=capturable)
 
@@ -60,12 +68,16 @@ def train_step(model, optimizer, source, driving, clip=10.0):
     """one fwd + bwd + clip + Adam step; returns the (device) loss tensor, detached: a loss that still references its
     autograd graph would keep the parameters' AccumulateGrad nodes -- and the stream they were created on -- alive,
     which breaks a later hipGraph capture on another stream"""
+    from . import engine
     optimizer.zero_grad(set_to_none=True)
-    gen = model(source, driving)
-    loss = (gen - driving).abs().mean()
-    loss.backward()
-    m = model.module if hasattr(model, "module") else model
-    if clip:
+    wrapped = hasattr(model, "module")                 # DistributedDataParallel needs autograd's gradient hooks
+    fused = getattr(optimizer, "fused_clip", False)
+    with (engine.direct_param_grads() if (fused and not wrapped) else contextlib.nullcontext()):
+        gen = model(source, driving)
+        loss = (gen - driving).abs().mean()
+        loss.backward()
+    m = model.module if wrapped else model
+    if clip and not fused:
         nn.utils.clip_grad_norm_(m.encoder.parameters(), max_norm=clip, norm_type=math.inf)
         nn.utils.clip_grad_norm_(m.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
     optimizer.step()

@@ -477,3 +477,34 @@ class Emulator:
         v = F.conv2d(F.pad(img, (ka, ka, ka, ka)), ker, groups=Cc)[:, :, ::stride, ::stride]
         nhwc(y, N, H // stride, W // stride, ldy, Cc).copy_(v.permute(0, 2, 3, 1))
         return 0
+
+    # ---------------------------------------------------------------- K20: flat clip + Adam
+    def mrfa_adam_prepare(self, stream, state, ngroups, beta1, beta2):
+        st = _flat(state, 8 * ngroups).view(ngroups, 8)
+        for g in range(ngroups):
+            t = float(st[g, 0]) + 1.0
+            st[g, 0] = t
+            st[g, 1] = float(st[g, 3]) / (1.0 - beta1 ** t)
+            st[g, 2] = 1.0 / (1.0 - beta2 ** t) ** 0.5
+            st[g, 4:8] = 0.0
+        return 0
+
+    def mrfa_grad_absmax(self, stream, g, n, state, clip_slot):
+        if n:
+            st = _flat(state, 8)
+            st[4 + clip_slot] = max(float(st[4 + clip_slot]), float(_flat(g, n).abs().max()))
+        return 0
+
+    def mrfa_adam_flat(self, stream, w, g, m, v, n, state, beta1, beta2, eps, gscale, clip_slot, max_norm):
+        if not n:
+            return 0
+        st = _flat(state, 8)
+        coef = gscale
+        if clip_slot >= 0:
+            coef = coef * min(1.0, max_norm / (float(st[4 + clip_slot]) * gscale + 1e-6))
+        W, G, M, V = _flat(w, n), _flat(g, n) * coef, _flat(m, n), _flat(v, n)
+        M.lerp_(G, 1.0 - beta1)
+        V.mul_(beta2).addcmul_(G, G, value=1.0 - beta2)
+        W.addcdiv_(M, V.sqrt() * float(st[2]) + eps, value=-float(st[1]))
+        return 0
+

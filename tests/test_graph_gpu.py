@@ -61,8 +61,20 @@ def _fwd_bwd(model, src, drv):
     return float(loss.detach()), _grads(model)
 
 
-def test_graphed_train_step_equals_eager():
-    """graph A (pack + fwd + bwd into the flat gradient buffer) against an eager fwd + bwd at the SAME weights, and graph B
+def _fwd_bwd_direct(model, opt, src, drv):
+    from mrfa_amd import engine
+    opt.zero_grad()
+    with engine.direct_param_grads():
+        loss = (model(src, drv) - drv).abs().mean()
+        loss.backward()
+    return float(loss.detach()), _grads(model)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_train_step_equals_eager(fused):
+    """fused=False: torch.optim.Adam(capturable) + clip_grad_norm_ captured; fused=True: mrfa_amd.optim.FlatAdam (flat
+    buffers, K20 kernels, parameter gradients written directly by the backward kernels).
+    graph A (pack + fwd + bwd into the flat gradient buffer) against an eager fwd + bwd at the SAME weights, and graph B
     (clip + Adam) against eager clip + Adam on the SAME gradients.  (Whole trajectories are not comparable: the fp32
     atomics of the split reductions make even two eager runs drift apart by ~1e-3 in the loss after one Adam step.)"""
     import copy
@@ -71,7 +83,7 @@ def test_graphed_train_step_equals_eager():
     from mrfa_amd.train import make_optimizer, train_step
     src, drv = _pairs(2, "g/t")
     ma, mb = _hotpath().train(), _hotpath().train()
-    oa, ob = make_optimizer(ma, capturable=True), make_optimizer(mb, capturable=True)
+    oa, ob = make_optimizer(ma, capturable=True), make_optimizer(mb, capturable=True, fused=fused)
     l0 = float(train_step(ma, oa, src, drv))
     train_step(mb, ob, src, drv)
     mb.load_state_dict(ma.state_dict())                   # identical weights, BN buffers and Adam state from here on
@@ -106,20 +118,25 @@ def test_graphed_train_step_equals_eager():
     for n in gb:                                           # parameters eager leaves without a gradient get exact zeros
         if n not in ga:
             assert float(gb[n].abs().max()) == 0.0, n
+    lb2, gb2 = _fwd_bwd_direct(mb, ob, src, drv) if fused else (lb, gb)    # eager direct-gradient mode == the replay
+    assert abs(lb2 - lb) <= 2e-6
+    num2 = sum(float(((gb2[n] - gb[n]) ** 2).sum()) for n in ga)
+    assert math.sqrt(num2 / den) <= max(3.0 * math.sqrt(noise / den), 0.15)
 
     # --- graph B vs eager clip + Adam on the same gradients
+    gcur = _grads(mb)                                      # what the flat buffer holds now (fused: the eager direct pass)
     for n, p in ma.named_parameters():
-        p.grad = gb[n].clone() if n in ga else None
+        p.grad = gcur[n].clone() if n in ga else None
     torch.nn.utils.clip_grad_norm_(ma.encoder.parameters(), max_norm=10.0, norm_type=math.inf)
     torch.nn.utils.clip_grad_norm_(ma.dense_motion.parameters(), max_norm=10.0, norm_type=math.inf)
     oa.step()
     step.g_opt.replay()
     torch.cuda.synchronize()
     for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
-        assert (pa - pb).abs().max().item() <= 1e-7, n
+        assert (pa - pb).abs().max().item() <= (2e-7 if fused else 1e-7), n
     for (n, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
         if n.endswith("num_batches_tracked"):
-            assert 0 < int(bb) < int(ba), n                 # the replay counts batches; ma ran one eager forward more
+            assert 0 < int(bb) <= int(ba), n                # the replay counts batches like an eager forward
         elif n.endswith(("running_mean", "running_var")):
             assert torch.isfinite(bb).all()
 

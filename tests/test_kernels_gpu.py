@@ -511,3 +511,33 @@ def test_conv_fewout(cfg):
         return side.done(y[:, :Cout], y2[:, :Cout], dw, db, g, wp)
     ref, got = both(run)
     assert_close(ref, got, tol=5e-4, what=tag)
+
+
+@pytest.mark.parametrize("gmag,clip_slot", [(1.0, -1), (1.0, 0), (500.0, 0), (500.0, 2)])
+def test_flat_clip_adam(gmag, clip_slot):
+    """K20: mrfa_adam_prepare / mrfa_grad_absmax / mrfa_adam_flat over three steps on two parameter groups (odd sizes
+    padded to 4), clipping inactive (|g|_inf < max_norm), active, and off; gscale = 1/8 as with 8 data-parallel ranks."""
+    n0, n1 = 4 * 12345, 4 * 777
+
+    def run(side):
+        w = side.t("k20/w", (n0 + n1,))
+        m, v = side.z((n0 + n1,)), side.z((n0 + n1,))
+        state = side.z((2, 8))
+        state[:, 3] = torch.tensor([2e-4, 1e-3], device=side.dev)
+        outs = []
+        for step in range(3):
+            g = side.t(f"k20/g{step}", (n0 + n1,), -gmag, gmag)
+            side.call("mrfa_adam_prepare", state.data_ptr(), 2, 0.5, 0.999)
+            if clip_slot >= 0:
+                side.call("mrfa_grad_absmax", g.data_ptr(), n0, state.data_ptr(), clip_slot)
+            side.call("mrfa_adam_flat", w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n0, state.data_ptr(), 0.5, 0.999, 1e-8,
+                      0.125, clip_slot, 10.0)
+            side.call("mrfa_adam_flat", w.data_ptr() + 4 * n0, g.data_ptr() + 4 * n0, m.data_ptr() + 4 * n0, v.data_ptr() + 4 * n0, n1,
+                      state.data_ptr() + 32, 0.5, 0.999, 1e-8, 0.125, -1, 0.0)
+            outs += [w.clone(), state.clone()]
+        return side.done(*outs, m, v)
+    ref, got = both(run)
+    assert_close(ref, got, tol=2e-6, what="flat clip+adam")
+    assert float(ref[1][0, 0]) == 1.0 and float(got[-3][0, 0]) == 3.0          # step counters
+    if clip_slot >= 0:
+        assert abs(float(got[1][0, 4 + clip_slot]) - float(ref[1][0, 4 + clip_slot])) == 0.0   # |g|_inf is exact

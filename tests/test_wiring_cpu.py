@@ -141,8 +141,14 @@ def test_raft_flow_through_emulator(golden_dir, prior_only):
     assert s.shape == (b, 1, size, (6 if prior_only else 7) * size)
 
 
-def test_raft_flow_backward_through_emulator(golden_dir):
-    """the hand-written backward tape (every op's gradient wiring) against the reference's autograd gradients"""
+@pytest.mark.parametrize("direct", [False, True])
+def test_raft_flow_backward_through_emulator(golden_dir, direct):
+    """the hand-written backward tape (every op's gradient wiring) against the reference's autograd gradients.
+    direct=True: engine.direct_param_grads() -- the backward kernels accumulate straight into pre-bound .grad tensors
+    (the flat gradient buffer of the hipGraph step) and autograd is handed None for the parameters."""
+    import contextlib
+    from mrfa_amd import engine
+    from mrfa_amd.graph import FlatGradients
     g = _g(golden_dir, "grads_64.npz")
     names = json.load(open(os.path.join(golden_dir, "grads_64_param_names.json")))
     size, b = 64, 2
@@ -153,9 +159,14 @@ def test_raft_flow_backward_through_emulator(golden_dir):
         kp_s, kp_d, dmo, img, img_full = raft_inputs(size, b, "g4/raft")
         leaves = [t.clone().requires_grad_(True) for t in (kp_s, kp_d, dmo["deformation"], dmo["occlusion"])]
         driving = cases.images("g4/drv", b, size)
-        o, _, _ = rf(leaves[0], leaves[1], {"deformation": leaves[2], "occlusion": leaves[3]}, img, img_full)
-        loss = (o - driving).abs().mean()
-        loss.backward()
+        if direct:
+            fg = FlatGradients(rf.parameters())
+            fg.bind()
+        with (engine.direct_param_grads() if direct else contextlib.nullcontext()):
+            o, _, _ = rf(leaves[0], leaves[1], {"deformation": leaves[2], "occlusion": leaves[3]}, img, img_full)
+            loss = (o - driving).abs().mean()
+            loss.backward()
+        assert not direct or fg.bound()
     assert abs(loss.item() - float(g["loss"][0])) < 1e-6
     for n, t in zip(("kp_s", "kp_d", "deformation", "occlusion"), leaves):
         assert np.abs(t.grad.numpy() - g[f"grad_{n}"]).max() < 1e-4, n
@@ -318,3 +329,53 @@ def test_flat_gradient_exchange_world2_matches_single_process(tmp_path):
         (y * det_uniform("ddp/w", (4, 13, 8, 8))).sum().div(4.0).backward()
     for n, p in m.named_parameters():
         assert torch.allclose(got[n], p.grad, atol=1e-5, rtol=1e-4), n
+
+
+def test_flat_adam_matches_torch_adam_and_clip():
+    """mrfa_amd.optim.FlatAdam (flat buffers + K20 entry points, emulated here) against torch.optim.Adam(betas=(0.5, 0.999))
+    + clip_grad_norm_(norm_type=inf) as the reference's train.py:21,65-70 uses them: same weights after every step, with
+    clipping active and inactive, across an LR change, and through state_dict round trips in both directions."""
+    import copy
+    import math
+    from mrfa_amd.modules.util import Hourglass
+    from mrfa_amd.optim import FlatAdam
+    from mrfa_amd.utils.prng import det_normal, fill_state_dict
+
+    def model():
+        m = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+        m.load_state_dict(fill_state_dict(m.state_dict(), "fa"))
+        return m
+    with emulated_hip():
+        ma, mb = model(), model()
+        ga_, gb_ = [list(ma.encoder.parameters()), list(ma.decoder.parameters())], [list(mb.encoder.parameters()), list(mb.decoder.parameters())]
+        oa = torch.optim.Adam([{"params": ga_[0]}, {"params": ga_[1]}], lr=2e-4, betas=(0.5, 0.999))
+        ob = FlatAdam([{"params": gb_[0], "clip": 10.0}, {"params": gb_[1]}], lr=2e-4, betas=(0.5, 0.999))
+        assert all(p.data_ptr() >= ob.flat_w.data_ptr() for p in mb.parameters())       # parameters re-homed
+        sd0 = {k: v.clone() for k, v in mb.state_dict().items()}
+        assert all(torch.equal(v, ma.state_dict()[k]) for k, v in sd0.items())            # ... with their values
+
+        def one(step, gain):
+            oa.zero_grad()
+            ob.zero_grad()
+            for i, (pa, pb) in enumerate(zip(ma.parameters(), mb.parameters())):
+                g = det_normal(f"fa/g{step}/{i}", tuple(pa.shape)) * gain
+                pa.grad = g.clone()
+                pb.grad.add_(g)                                                           # into the bound flat view
+            torch.nn.utils.clip_grad_norm_(ga_[0], max_norm=10.0, norm_type=math.inf)
+            oa.step()
+            ob.step()
+            for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+                assert (pa - pb).abs().max().item() <= 2e-7, (step, n)
+        one(0, 1.0)
+        one(1, 300.0)                                   # |g|_inf >> 10: clipping active on group 0 only
+        for g in oa.param_groups + ob.param_groups:     # MultiStepLR-style edit of param_groups
+            g["lr"] = 2e-5
+        one(2, 1e-3)
+        # torch Adam resumes from a FlatAdam checkpoint and vice versa
+        oa2 = torch.optim.Adam([{"params": ga_[0]}, {"params": ga_[1]}], lr=1.0, betas=(0.9, 0.9))
+        oa2.load_state_dict(copy.deepcopy(ob.state_dict()))
+        oa = oa2
+        one(3, 1.0)
+        ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+        one(4, 1.0)
+        assert float(ob.state[gb_[0][0]]["step"]) == 5.0
