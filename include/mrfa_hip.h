@@ -102,6 +102,28 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * mode 7: OIHW -> [Cin][tap'][Cout] flipped   (data gradient of a few-INPUT conv run as a few-output conv over dY)
  * modes 4|16 and 6|16: as 4 / 6 but overwriting (dst = ...) instead of accumulating                                   */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
+
+/* Batched forms: all layouts of many convolutions per launch (descriptor table passed by value in the kernel
+ * arguments, MRFA_PACK_MAX_DESCS per launch), used once per training step for all ~90 convolutions of the path.
+ * mrfa_pack_conv_weights_multi: for every desc, src (OIHW) -> dst[k] in layout mode[k] (0,1,2,3,5,7 as above).  Padding
+ *   elements of the destinations are NOT written: allocate those buffers zero-filled.
+ * mrfa_unpack_wgrads_multi: for every desc, dst (OIHW gradient) += src (accumulator, [tap][Cout][Cin], or
+ *   [Cout][tap][Cin] when fewout != 0)  -- modes 4 / 6 above.                                                         */
+#define MRFA_PACK_MAX_DESCS 48
+typedef struct {
+    const float* src;
+    float* dst[3];
+    int mode[3];
+    int ndst;
+    int Cout, Cin, R, S;
+} mrfa_pack_desc;
+typedef struct {
+    const float* src;
+    float* dst;
+    int Cout, Cin, T, fewout;
+} mrfa_unpack_desc;
+int mrfa_pack_conv_weights_multi(void* stream, const mrfa_pack_desc* descs /* host array */, int n);
+int mrfa_unpack_wgrads_multi(void* stream, const mrfa_unpack_desc* descs /* host array */, int n);
 /* host-side helper: fills tab[KPad] for flat mode; entry = (dy+128) | (dx+128)<<8 | c<<16, invalid k -> -1      */
 int mrfa_build_ktab(int* tab_host, int C, int R, int S, int pad, int flip);
 

@@ -198,7 +198,7 @@ class ConvW:
             else:
                 n, mode = self.T * cop * self.Cin, 0
             if self._fwd is None or self._fwd.numel() != n or self._fwd.device != w.device:
-                self._fwd = torch.empty(n, dtype=torch.float32, device=w.device)
+                self._fwd = torch.zeros(n, dtype=torch.float32, device=w.device)      # zero pads: PackPlan never writes them
             hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), w.contiguous().data_ptr(), self._fwd.data_ptr(),
                                                       self.Cout, self.Cin, self.R, self.S, mode), "pack(fwd)")
             self._ver_f = self._key()
@@ -219,7 +219,7 @@ class ConvW:
             else:
                 n, mode = self.T * cip * self.Cout, 2
             if self._dg is None or self._dg.numel() != n or self._dg.device != w.device:
-                self._dg = torch.empty(n, dtype=torch.float32, device=w.device)
+                self._dg = torch.zeros(n, dtype=torch.float32, device=w.device)
             hip.check(hip.lib().mrfa_pack_conv_weight(hip.stream_ptr(), w.contiguous().data_ptr(), self._dg.data_ptr(),
                                                       self.Cout, self.Cin, self.R, self.S, mode), "pack(dgrad)")
             self._ver_d = self._key()
@@ -272,6 +272,63 @@ class ConvW:
         db = self.db_acc
         self.dw_acc = self.db_acc = None
         return dw, db
+
+
+class PackPlan:
+    """Every packed layout that exists so far (i.e. after one forward + backward) of every convolution of `model`,
+    refreshed from the current weights by ONE batched launch per 48 convolutions (mrfa_pack_conv_weights_multi) instead
+    of ~180 single-layout launches; run() also marks the per-convolution caches valid, so the engine's own
+    fwd_pack()/dgrad_pack() calls of the same step find nothing to do."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.cws: List[ConvW] = [m._mrfa_convw for m in model.modules() if getattr(m, "_mrfa_convw", None) is not None]
+        descs = []
+        self._keep = []
+        for cw in self.cws:
+            w = cw.conv.weight
+            assert w.is_contiguous()
+            dsts = []
+            if cw._fwd is not None:
+                dsts.append((cw._fwd, 0 if (getattr(cw, "_fwd_padded", False) or not cw.fwd_flat) else 1))
+            if cw._dg is not None:
+                dsts.append((cw._dg, 2 if (getattr(cw, "_dg_padded", False) or not cw.dgrad_flat) else 3))
+            if cw._fo is not None:
+                dsts.append((cw._fo, 5))
+            if cw._fi is not None:
+                dsts.append((cw._fi, 7))
+            for i in range(0, len(dsts), 3):
+                d = hip.PackDesc()
+                d.src, d.Cout, d.Cin, d.R, d.S = w.data_ptr(), cw.Cout, cw.Cin, cw.R, cw.S
+                part = dsts[i:i + 3]
+                d.ndst = len(part)
+                for k, (buf, mode) in enumerate(part):
+                    d.dst[k], d.mode[k] = buf.data_ptr(), mode
+                    self._keep.append(buf)
+                descs.append(d)
+        self.n = len(descs)
+        self.table = (hip.PackDesc * max(self.n, 1))(*descs)
+        self.ptrs = [(cw, cw.conv.weight.data_ptr(), id(cw._fwd), id(cw._dg)) for cw in self.cws]
+
+    def run(self):
+        if self.n:
+            hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), self.table, self.n), "pack_conv_weights_multi")
+        for cw, wptr, idf, idd in self.ptrs:
+            assert cw.conv.weight.data_ptr() == wptr and id(cw._fwd) == idf and id(cw._dg) == idd, "PackPlan is stale: rebuild it"
+            k = cw._key()
+            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = k
+
+
+def unpack_direct(cws: List["ConvW"]):
+    """direct-gradient mode: weight.grad += un-packed accumulator for all given convolutions in one batched launch"""
+    if not cws:
+        return
+    table = (hip.UnpackDesc * len(cws))()
+    for d, cw in zip(table, cws):
+        d.src, d.dst = cw.dw_acc.data_ptr(), cw.conv.weight.grad.data_ptr()
+        d.Cout, d.Cin, d.T, d.fewout = cw.Cout, cw.Cin, cw.T, int(cw.fewout)
+    hip.check(hip.lib().mrfa_unpack_wgrads_multi(hip.stream_ptr(), table, len(cws)), "unpack_wgrads_multi")
+    for cw in cws:
+        cw.dw_acc = cw.db_acc = None
 
 
 def convw(conv: torch.nn.Conv2d) -> ConvW:
@@ -951,6 +1008,7 @@ class _ProgramFn(torch.autograd.Function):
                 seed(g)
         ectx.run_backward()
         pgrads = {}
+        unpack_direct([cw for cw in ectx.touched_convs if cw.dw_acc is not None and cw._direct])
         for cw in ectx.touched_convs:
             dw, db = cw.take_grads()
             if dw is not None:

@@ -131,12 +131,14 @@ class GraphedTrainStep:
             self.grads.bind()
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize()
+        self.packs = engine.PackPlan(model)                           # every layout the warm pass packed, in one launch
         self.g_fb = torch.cuda.CUDAGraph()
         GraphedTrainStep._captures += 1
         engine.CAPTURE_KEY = GraphedTrainStep._captures
         try:
             with torch.cuda.graph(self.g_fb, stream=self.stream), engine.direct_param_grads():
                 self.flat.zero_()
+                self.packs.run()
                 gen = model(self.src, self.drv)
                 loss = (gen - self.drv).abs().mean()
                 loss.backward()

@@ -51,6 +51,15 @@ class WgradParams(C.Structure):
     ]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p * 3), ("mode", C.c_int * 3), ("ndst", C.c_int),
+                ("Cout", C.c_int), ("Cin", C.c_int), ("R", C.c_int), ("S", C.c_int)]
+
+
+class UnpackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("T", C.c_int), ("fewout", C.c_int)]
+
+
 class BnActParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("ldx", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
@@ -84,6 +93,8 @@ _SIGNATURES = {
     "mrfa_conv_fewout_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_conv_fewout_wgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _V], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_pack_conv_weights_multi": ([_V, C.POINTER(PackDesc), _I], C.c_int),
+    "mrfa_unpack_wgrads_multi": ([_V, C.POINTER(UnpackDesc), _I], C.c_int),
     "mrfa_build_ktab": ([c_int_p, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_bn_stats": ([_V, _V, _I, _L, _I, _V], C.c_int),
     "mrfa_bn_finalize": ([_V, _V, _L, _V, _V, _V, _V, _F, _F, _I, _I, _V, _V, _V, _V], C.c_int),

@@ -508,3 +508,23 @@ class Emulator:
         W.addcdiv_(M, V.sqrt() * float(st[2]) + eps, value=-float(st[1]))
         return 0
 
+    # ---------------------------------------------------------------- batched (un)packing
+    def mrfa_pack_conv_weights_multi(self, stream, descs, n):
+        for i in range(n):
+            d = descs[i]
+            for k in range(d.ndst):
+                rc = self.mrfa_pack_conv_weight(stream, d.src, d.dst[k], d.Cout, d.Cin, d.R, d.S, d.mode[k])
+                if rc:
+                    return rc
+        return 0
+
+    def mrfa_unpack_wgrads_multi(self, stream, descs, n):
+        for i in range(n):
+            d = descs[i]
+            R = int(round(d.T ** 0.5))
+            assert R * R == d.T
+            rc = self.mrfa_pack_conv_weight(stream, d.src, d.dst, d.Cout, d.Cin, R, R, 6 if d.fewout else 4)
+            if rc:
+                return rc
+        return 0
+

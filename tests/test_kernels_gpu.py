@@ -541,3 +541,48 @@ def test_flat_clip_adam(gmag, clip_slot):
     assert float(ref[1][0, 0]) == 1.0 and float(got[-3][0, 0]) == 3.0          # step counters
     if clip_slot >= 0:
         assert abs(float(got[1][0, 4 + clip_slot]) - float(ref[1][0, 4 + clip_slot])) == 0.0   # |g|_inf is exact
+
+
+def test_pack_and_unpack_multi():
+    """batched (un)packing == the single-tensor entry points, layout by layout, on the path's awkward shapes
+    (3-channel 7x7 stem, 98-channel 1x1, 126 outputs, 35-channel 7x7 head, 1024->512, few-output heads)."""
+    shapes = [(64, 3, 7), (128, 98, 1), (126, 160, 3), (10, 35, 7), (512, 1024, 3), (2, 128, 3), (128, 2, 7), (96, 128, 3), (40, 36, 5)]
+
+    def run(side):
+        outs, keep = [], []
+        descs = []
+        for i, (Cout, Cin, R) in enumerate(shapes):
+            T = R * R
+            w = side.t(f"pm/w{i}", (Cout, Cin, R, R))
+            sizes = {0: T * ((Cout + 127) // 128 * 128) * ((Cin + 31) // 32 * 32), 1: ((Cout + 127) // 128 * 128) * ((T * Cin + 31) // 32 * 32),
+                     2: T * ((Cin + 127) // 128 * 128) * ((Cout + 31) // 32 * 32), 3: ((Cin + 127) // 128 * 128) * ((T * Cout + 31) // 32 * 32),
+                     5: Cout * Cin * T, 7: Cout * Cin * T}
+            for modes in ((0, 2, 5), (1, 3, 7)):
+                d = hip.PackDesc()
+                d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, R, 3
+                for k, m in enumerate(modes):
+                    buf = side.z((sizes[m],))
+                    d.dst[k], d.mode[k] = buf.data_ptr(), m
+                    outs.append(buf)
+                descs.append(d)
+            keep.append(w)
+        table = (hip.PackDesc * len(descs))(*descs)
+        side.call("mrfa_pack_conv_weights_multi", table, len(descs))
+        # gradients back: accumulate twice into a non-zero OIHW buffer
+        ud = []
+        for i, (Cout, Cin, R) in enumerate(shapes):
+            T = R * R
+            for few in (0, 1):
+                acc = side.t(f"pm/a{i}{few}", (T * Cout * Cin,))
+                g = side.t(f"pm/g{i}{few}", (Cout, Cin, R, R))
+                u = hip.UnpackDesc()
+                u.src, u.dst, u.Cout, u.Cin, u.T, u.fewout = acc.data_ptr(), g.data_ptr(), Cout, Cin, T, few
+                ud.append(u)
+                outs.append(g)
+                keep.append(acc)
+        ut = (hip.UnpackDesc * len(ud))(*ud)
+        side.call("mrfa_unpack_wgrads_multi", ut, len(ud))
+        side.call("mrfa_unpack_wgrads_multi", ut, len(ud))
+        return side.done(*outs)
+    ref, got = both(run)
+    assert_close(ref, got, tol=1e-6, what="pack/unpack multi")
