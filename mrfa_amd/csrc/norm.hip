@@ -182,6 +182,135 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
     }
 }
 
+
+// float4 variant of the backward kernel: a lane owns 4 consecutive channels, 16 lanes cover the block's 64 channels of one
+// row, so a wave streams 4 rows (4 x 256 B) per iteration and a workgroup 16; needs C % 4 == 0 and 16-byte aligned
+// views.  Same arithmetic as the scalar kernel above, element by element.  Phase 2 also folds the parameter-gradient
+// update (dgamma += sum du*xhat, dbeta += sum du) into the first row-block instead of a separate launch.
+template <int PHASE>
+__global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+    __shared__ float red[2][16][CH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 15, rsub = lane >> 4;
+    const int slot = wave * 4 + rsub;                       // 16 row slots per workgroup
+    const int c = blockIdx.x * CH + cg * 4;
+    const bool c_ok = c < p.C;                              // C % 4 == 0: all four channels valid together
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    const int Wo = p.W / 2, Ho = p.H / 2;
+    f32x4 sc = {0, 0, 0, 0}, sh = sc, mean = sc, invstd = sc, k1 = sc, k2 = sc, gi = sc;
+    if (c_ok) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + c);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+        if (p.mean) {
+            mean = *reinterpret_cast<const f32x4*>(p.mean + c);
+            invstd = *reinterpret_cast<const f32x4*>(p.invstd + c);
+        }
+        if (PHASE == 2 && p.train) {
+            const double cnt = (double)rows;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                k1[k] = (float)(p.red[c + k] / cnt);
+                k2[k] = (float)(p.red[p.C + c + k] / cnt);
+                gi[k] = g[k] * invstd[k];
+            }
+        }
+        if (PHASE == 2 && blockIdx.y == 0 && slot == 0) {   // parameter gradients, once per channel
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (p.dbeta) p.dbeta[c + k] += (float)p.red[c + k];
+                if (p.dgamma) p.dgamma[c + k] += (float)p.red[p.C + c + k];
+            }
+        }
+    }
+    f32x4 s1 = {0, 0, 0, 0}, s2 = s1;
+    for (long long r = r0 + slot; r < r1; r += 16) {
+        long long opix = r;
+        float gmul = 1.f;
+        if (p.pool) {
+            const int xx = (int)(r % p.W);
+            const long long t = r / p.W;
+            const int yy = (int)(t % p.H);
+            const long long n = t / p.H;
+            opix = ((long long)n * Ho + (yy >> 1)) * Wo + (xx >> 1);
+            gmul = 0.25f;
+        }
+        f32x4 du = {0, 0, 0, 0}, xv = du;
+        float docc_part = 0.f;
+        if (c_ok) {
+            xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.ldx + c);
+            f32x4 da = *reinterpret_cast<const f32x4*>(p.dy + (size_t)opix * p.lddy + c);
+            float o = 0.f;
+            f32x4 A = {0, 0, 0, 0};
+            if (p.blend_a) {
+                o = p.occ[(size_t)opix * p.ldo];
+                if (PHASE == 1) A = *reinterpret_cast<const f32x4*>(p.blend_a + (size_t)opix * p.lda + c);
+            }
+            f32x4 dA = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = xv[k] * sc[k] + sh[k];
+                const float a = p.relu ? fmaxf(u, 0.f) : u;
+                float d = da[k] * gmul;
+                if (p.blend_a) {
+                    if (PHASE == 1) {
+                        dA[k] = d * o;
+                        docc_part += d * (A[k] - a);
+                    }
+                    d *= (1.f - o);
+                }
+                du[k] = (p.relu && u <= 0.f) ? 0.f : d;
+            }
+            if (PHASE == 1 && p.blend_a && p.dblend_a) {
+                f32x4* q = reinterpret_cast<f32x4*>(p.dblend_a + (size_t)opix * p.ldda + c);
+                f32x4 cur = *q;
+                cur += dA;
+                *q = cur;
+            }
+        }
+        if (PHASE == 1) {
+            if (p.blend_a && p.docc) {
+                float t = docc_part;                         // sum over the 16 lanes (64 channels) of this row
+#pragma unroll
+                for (int o2 = 8; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2, 64);
+                if (cg == 0) atomicAdd(p.docc + (size_t)opix * p.lddo, t);
+            }
+            if (c_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[k] += du[k];
+                    s2[k] += du[k] * (xv[k] - mean[k]) * invstd[k];
+                }
+            }
+        } else if (c_ok) {
+            f32x4* q = reinterpret_cast<f32x4*>(p.dx + (size_t)r * p.lddx + c);
+            f32x4 cur = *q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dx = p.train ? gi[k] * (du[k] - k1[k] - (xv[k] - mean[k]) * invstd[k] * k2[k]) : du[k] * sc[k];
+                cur[k] += dx;
+            }
+            *q = cur;
+        }
+    }
+    if (PHASE == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[0][slot][cg * 4 + k] = s1[k];
+            red[1][slot][cg * 4 + k] = s2[k];
+        }
+        __syncthreads();
+        const int cc = blockIdx.x * CH + threadIdx.x;
+        if (threadIdx.x < CH && cc < p.C) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < 16; ++w) { a += red[0][w][threadIdx.x]; b += red[1][w][threadIdx.x]; }
+            atomicAdd(p.red + cc, a);
+            atomicAdd(p.red + p.C + cc, b);
+        }
+    }
+}
+
 __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                      int train, const float* __restrict__ rmean, const float* __restrict__ rvar, float eps) {
     // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
@@ -243,6 +372,20 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     const int chunks = cdiv(p.C, CH);
     const int rpb = pick_rows_per_block(rows, chunks);
     dim3 grid(chunks, cdiv(rows, rpb));
+    const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.scale) &&
+                     aligned16(p.shift) && (!p.mean || (aligned16(p.mean) && aligned16(p.invstd))) && (!p.gamma || aligned16(p.gamma)) &&
+                     (p.phase == 1 || ((p.lddx % 4 == 0) && aligned16(p.dx))) &&
+                     (!p.blend_a || ((p.lda % 4 == 0) && aligned16(p.blend_a) && (!p.dblend_a || ((p.ldda % 4 == 0) && aligned16(p.dblend_a)))));
+    if (vec) {
+        if (p.phase == 1) {
+            hipLaunchKernelGGL((bn_act_bwd_vec_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
+        } else {
+            MRFA_CHECK_ARG(p.dx != nullptr, "bn_act_bwd: phase 2 needs dx");
+            hipLaunchKernelGGL((bn_act_bwd_vec_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
+        }
+        MRFA_CHECK_LAUNCH("bn_act_bwd(vec)");
+        return 0;
+    }
     if (p.phase == 1) {
         hipLaunchKernelGGL((bn_act_bwd_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
     } else {

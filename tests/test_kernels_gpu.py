@@ -311,9 +311,12 @@ def test_pack_modes(mode):
     assert_close(ref, got, tol=0, what=f"pack{mode}")
 
 
-def test_bn_forward_backward():
+@pytest.mark.parametrize("Cc,ld,N", [(96, 100, 2), (37, 41, 2), (132, 132, 5)])
+def test_bn_forward_backward(Cc, ld, N):
+    """(96, 100) and (132, 132): float4 backward kernels (132 = 2 channel blocks + a 4-channel tail, 5*8*6 rows = ragged
+    row blocks); (37, 41): scalar kernels"""
     def run(side):
-        N, H, W, Cc, ld = 2, 8, 6, 96, 100
+        H, W = 8, 6
         x = side.t("bn/x", (N * H * W, ld), -2, 2)
         gamma, beta = side.t("bn/g", (Cc,), 0.5, 1.5), side.t("bn/b", (Cc,))
         rm, rv = side.t("bn/rm", (Cc,)), side.t("bn/rv", (Cc,), 0.5, 1.5)
