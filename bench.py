@@ -16,6 +16,9 @@ import argparse
 import json
 import os
 import sys
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see mrfa_amd/__init__.py
+
 import time
 
 import torch
@@ -134,6 +137,7 @@ def main():
         ok = 1
         try:
             gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world)
+            replay_noise = gstep.verify()             # replays must agree with each other, or the graph is not used
         except Exception as ex:                       # keep the bench alive on a capture problem: eager path
             print(f"[bench] hipGraph capture failed on rank {rank}: {ex!r}; falling back to eager launches", file=sys.stderr)
             ok = 0

@@ -86,6 +86,26 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, int ldy, const float
     }
 }
 
+// float4 form: C % 4 == 0, 16-byte aligned views, rows * C / 4 < 2^31 (32-bit index arithmetic: no 64-bit divisions).
+// dx may alias dy (in-place ReLU backward of a conv output), hence no __restrict__.
+__global__ void act_bwd_vec_kernel(const float* y, int ldy, const float* dy, int lddy, int C4, int act, float* dx, int lddx, int acc,
+                                   unsigned total4) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / (unsigned)C4;
+        const unsigned c = (i - r * (unsigned)C4) * 4u;
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (size_t)r * ldy + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)r * lddy + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (act == 1) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+            else if (act == 2) g[k] = g[k] * yy[k] * (1.f - yy[k]);
+        }
+        f32x4* d = reinterpret_cast<f32x4*>(dx + (size_t)r * lddx + c);
+        if (acc) g += *d;
+        *d = g;
+    }
+}
+
 __global__ void blend_fwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, const float* __restrict__ occ,
                                  int ldo, int C, float* __restrict__ y, int ldy, long long total) {
     GRID_STRIDE(i, total) {
@@ -208,6 +228,13 @@ extern "C" int mrfa_act_bwd(void* stream, const float* y, int ldy, const float* 
                             int lddx, int accumulate) {
     MRFA_CHECK_ARG(y && dy && dx && rows > 0 && C > 0, "act_bwd: bad args");
     const long long total = rows * C;
+    if (C % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && aligned16(y) && aligned16(dy) && aligned16(dx) &&
+        total / 4 < (1ll << 31)) {
+        hipLaunchKernelGGL(act_bwd_vec_kernel, dim3(stream_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, ldy, dy, lddy, C / 4,
+                           act, dx, lddx, accumulate, (unsigned)(total / 4));
+        MRFA_CHECK_LAUNCH("act_bwd(vec)");
+        return 0;
+    }
     hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, ldy, dy, lddy, rows, C, act, dx,
                        lddx, accumulate, total);
     MRFA_CHECK_LAUNCH("act_bwd");

@@ -132,6 +132,18 @@ __global__ void copy_view_kernel(const float* __restrict__ x, int ldx, long long
     }
 }
 
+__global__ void copy_view_vec_kernel(const float* __restrict__ x, int ldx, int C4, float* __restrict__ y, int ldy, float mul, int acc,
+                                     unsigned total4) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / (unsigned)C4;
+        const unsigned c = (i - r * (unsigned)C4) * 4u;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + c) * mul;
+        f32x4* d = reinterpret_cast<f32x4*>(y + (size_t)r * ldy + c);
+        if (acc) v += *d;
+        *d = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode) {
@@ -198,6 +210,12 @@ extern "C" int mrfa_nhwc_to_nchw(void* stream, const float* src, int lds_, float
 extern "C" int mrfa_copy_view(void* stream, const float* x, int ldx, long long rows, int C, float* y, int ldy, float mul, int accumulate) {
     MRFA_CHECK_ARG(x && y && rows >= 0 && C > 0, "copy_view: bad args");
     if (rows == 0) return 0;
+    if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) && rows * C / 4 < (1ll << 31)) {
+        hipLaunchKernelGGL(copy_view_vec_kernel, dim3(stream_grid(rows * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, C / 4, y, ldy,
+                           mul, accumulate, (unsigned)(rows * C / 4));
+        MRFA_CHECK_LAUNCH("copy_view(vec)");
+        return 0;
+    }
     hipLaunchKernelGGL(copy_view_kernel, dim3(stream_grid(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C, y, ldy,
                        mul, accumulate);
     MRFA_CHECK_LAUNCH("copy_view");

@@ -32,8 +32,15 @@ __global__ void grad_absmax_kernel(const f32x4* __restrict__ g, long long n4, un
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    // non-negative floats order like their bit patterns: one integer atomic per wave
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(slot, __float_as_uint(m));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // non-negative floats order like their bit patterns: ONE integer atomic per workgroup (16 K same-address atomics
+    // from one per wave serialised into 0.2 ms)
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.0f) atomicMax(slot, __float_as_uint(m));
+    }
 }
 
 __global__ void adam_flat_kernel(f32x4* __restrict__ w, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
@@ -78,7 +85,9 @@ extern "C" int mrfa_grad_absmax(void* stream, const float* g, long long n, float
     MRFA_CHECK_ARG(n % 4 == 0 && aligned16(g), "grad_absmax: n %% 4 != 0 or unaligned buffer");
     MRFA_CHECK_ARG(clip_slot >= 0 && clip_slot < MRFA_ADAM_CLIP_SLOTS, "grad_absmax: clip slot %d out of range", clip_slot);
     if (n == 0) return 0;
-    hipLaunchKernelGGL(grad_absmax_kernel, dim3(stream_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+    int grid = stream_grid(n / 4, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(g), n / 4, reinterpret_cast<unsigned*>(state + 4 + clip_slot));
     MRFA_CHECK_LAUNCH("grad_absmax");
     return 0;

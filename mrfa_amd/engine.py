@@ -392,8 +392,11 @@ class IslandOut:
         return self._view
 
     def add_grad(self, g: torch.Tensor):
+        # no .clone(): nothing mutates g afterwards, and a contiguous clone is a device-to-device hipMemcpyAsync, which a
+        # stream capture records as a MEMCPY NODE -- on ROCm 7.2 memcpy / memset nodes are not reliably ordered against
+        # the kernel nodes around them when the graph is replayed (mrfa_amd/graph.py: "MEMCPY / MEMSET NODES")
         g = g.reshape(self.t.shape)
-        self.ext_grad = g.clone() if self.ext_grad is None else self.ext_grad + g
+        self.ext_grad = g if self.ext_grad is None else self.ext_grad + g
 
     def total_grad(self) -> Optional[torch.Tensor]:
         g = self.ext_grad
@@ -419,6 +422,7 @@ class Ctx:
         self.in_backward = False
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
+        self.nbt = {}                    # BatchNorm module -> forward passes in train mode during this program
         self.ext_grads = {}              # id(tensor) -> grad for module inputs / parameters touched by islands
         self.storages: List[Storage] = []            # forward activations whose gradients live in one zero arena
         self.pool32 = ZeroPool(device, torch.float32, 32 << 20)     # 128 MiB chunks
@@ -676,8 +680,17 @@ class Ctx:
                                           BN_MOMENTUM, BN_EPS, Cn, int(train), scale.data_ptr(), shift.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr()), "bn_finalize")
         if train:
-            bn.num_batches_tracked.add_(1)
+            self.nbt[bn] = self.nbt.get(bn, 0) + 1     # num_batches_tracked += 1, batched in flush_forward()
         return scale, shift, mean, invstd
+
+    def flush_forward(self):
+        """end of a program's forward: one multi-tensor launch for all BatchNorm batch counters instead of one each"""
+        by_count = {}
+        for bn, k in self.nbt.items():
+            by_count.setdefault(k, []).append(bn.num_batches_tracked)
+        for k, ts in by_count.items():
+            torch._foreach_add_(ts, k)
+        self.nbt = {}
 
     def bn_stats_buf(self, bn):
         return self.f64z(2 * bn.num_features) if self.train else None
@@ -993,6 +1006,7 @@ class _ProgramFn(torch.autograd.Function):
         need = any(actx.needs_input_grad[3:])
         ectx = Ctx(dev, train=module.training, record=need)
         outs, seeders, in_grad_fns = program(ectx, *inputs)
+        ectx.flush_forward()
         actx.ectx, actx.seeders, actx.in_grad_fns = ectx, seeders, in_grad_fns
         actx.params, actx.n_in = params, n_in
         # return ALIASES: autograd stamps grad_fn (= this node) on the returned tensor objects, and the seeders held

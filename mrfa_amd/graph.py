@@ -13,16 +13,34 @@ private memory pool) and replayed with one launch per step:
   graph B   inf-norm clipping of the encoder / dense_motion gradients + Adam (reference train.py:21-25, 58-70)
 
 `GraphedForward` is the inference counterpart (one graph, weights packed once outside it).
+
+MEMCPY / MEMSET NODES.  With ROCm 7.2's default "graph packet capture" path (kernel nodes pre-recorded as AQL packets)
+a hipMemcpyAsync / hipMemsetAsync recorded by stream capture becomes a memcpy / memset node that is NOT reliably
+ordered against the kernel nodes around it when the graph is replayed: the first replay is right, later ones read a
+source before its producer ran (observed: the 80-byte clone of d(loss)/d(keypoints) feeding the KPDetector backward, and
+the 4-byte semaphore memset of torch's multi-workgroup reductions -- the loss then reads 0.0).  Two defences:
+  * mrfa_amd sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime initialises (mrfa_amd/__init__.py; same
+    replay speed on this GPU-bound path, replays then agree with eager launches -- tools/graph_bisect.py replays);
+  * what the engine itself records is kernels only (no memcpy clones in IslandOut.add_grad, train.l1_loss reduces
+    without a semaphore memset, zero fills are fill kernels); torch's autograd inside the glue islands still emits a
+    few 8-byte memsets, which is why the first defence is needed;
+and GraphedTrainStep.verify() replays the graph against itself so a mis-ordered graph is detected, not trusted.
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
 from torch import nn
 
 from . import engine
+
+
+def l1_loss(gen, driving):
+    from .train import l1_loss as f
+    return f(gen, driving)
 
 
 def _increment_version(tensors):
@@ -125,7 +143,7 @@ class GraphedTrainStep:
                 p.grad = None
             saved = [b.clone() for b in model.buffers()]            # BN running statistics: this pass must not count
             with engine.direct_param_grads():
-                (model(self.src, self.drv) - self.drv).abs().mean().backward()
+                l1_loss(model(self.src, self.drv), self.drv).backward()
             for b, sv in zip(model.buffers(), saved):
                 b.copy_(sv)
             self.grads.bind()
@@ -140,7 +158,7 @@ class GraphedTrainStep:
                 self.flat.zero_()
                 self.packs.run()
                 gen = model(self.src, self.drv)
-                loss = (gen - self.drv).abs().mean()
+                loss = l1_loss(gen, self.drv)
                 loss.backward()
                 # detached handles: a static output that still referenced its autograd graph would keep the graph (and
                 # the parameters' AccumulateGrad nodes bound to the capture stream) alive for the life of this object
@@ -162,6 +180,33 @@ class GraphedTrainStep:
                     nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
                     nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
                 optimizer.step()
+
+    @torch.no_grad()
+    def verify(self, replays: int = 3, tol: float = 0.5) -> float:
+        """Self-check after capture: replays graph A several times at fixed weights (BatchNorm buffers restored) and
+        returns the worst relative L2 distance between the gradients of two replays; raises if it exceeds `tol` or the
+        loss moves.  Identical inputs must give identical results up to atomic-order noise -- a replay that depends on
+        what ran before it means a node of the graph is not ordered (see "kernel nodes only" above)."""
+        saved = [b.clone() for b in self.model.buffers()]
+        ref = ref_loss = None
+        worst = 0.0
+        scratch = torch.empty_like(self.flat)
+        for k in range(replays):
+            scratch.normal_()                       # unrelated device work between replays
+            float(scratch.sum())
+            self.g_fb.replay()
+            torch.cuda.synchronize()
+            g, loss = self.flat.double().cpu(), float(self.loss)
+            if ref is None:
+                ref, ref_loss = g, loss
+            else:
+                d = float((g - ref).norm() / (ref.norm() + 1e-30))
+                worst = max(worst, d)
+                if d > tol or abs(loss - ref_loss) > 1e-4 * max(1.0, abs(ref_loss)):
+                    raise RuntimeError(f"hipGraph replay {k} differs from replay 0: gradient distance {d:.3f}, loss {loss} vs {ref_loss}")
+        for b, sv in zip(self.model.buffers(), saved):
+            b.copy_(sv)
+        return worst
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
         if source.data_ptr() != self.src.data_ptr():

@@ -49,6 +49,19 @@ class HotPath(nn.Module):
         return gen
 
 
+def l1_loss(gen: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
+    """mean |gen - driving| (the surrogate loss of SURVEY.md 8(d)) as two single-workgroup-per-output reductions.
+    torch's .mean() over ~1.5 M elements is a multi-workgroup reduction that zeroes its semaphore with hipMemsetAsync;
+    captured into a hipGraph that becomes a memset node, which ROCm 7.2 does not order reliably against kernel nodes
+    on replay (the loss then reads 0.0).  Same value up to fp32 summation order."""
+    d = (gen - driving).abs()
+    n = d.numel()
+    for w in (1024, 512, 256, 128):
+        if n % w == 0 and n // w <= 4096:
+            return d.view(-1, w).sum(dim=1).sum() / n
+    return d.mean()
+
+
 def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False, fused=False, clip=10.0):
     """The reference's optimizer (train.py:21): Adam(lr, betas=(0.5, 0.999)) over three parameter groups.
 
@@ -74,7 +87,7 @@ def train_step(model, optimizer, source, driving, clip=10.0):
     fused = getattr(optimizer, "fused_clip", False)
     with (engine.direct_param_grads() if (fused and not wrapped) else contextlib.nullcontext()):
         gen = model(source, driving)
-        loss = (gen - driving).abs().mean()
+        loss = l1_loss(gen, driving)
         loss.backward()
     m = model.module if wrapped else model
     if clip and not fused:

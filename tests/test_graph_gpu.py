@@ -56,7 +56,8 @@ def _grads(model):
 def _fwd_bwd(model, src, drv):
     for p in model.parameters():
         p.grad = None
-    loss = (model(src, drv) - drv).abs().mean()
+    from mrfa_amd.train import l1_loss
+    loss = l1_loss(model(src, drv), drv)
     loss.backward()
     return float(loss.detach()), _grads(model)
 
@@ -65,7 +66,8 @@ def _fwd_bwd_direct(model, opt, src, drv):
     from mrfa_amd import engine
     opt.zero_grad()
     with engine.direct_param_grads():
-        loss = (model(src, drv) - drv).abs().mean()
+        from mrfa_amd.train import l1_loss
+        loss = l1_loss(model(src, drv), drv)
         loss.backward()
     return float(loss.detach()), _grads(model)
 
@@ -89,6 +91,7 @@ def test_graphed_train_step_equals_eager(fused):
     mb.load_state_dict(ma.state_dict())                   # identical weights, BN buffers and Adam state from here on
     ob.load_state_dict(copy.deepcopy(oa.state_dict()))    # load_state_dict shares the tensors it is given
     step = GraphedTrainStep(mb, ob, src, drv, clip=10.0, world=1)
+    assert step.verify(replays=4) <= 0.3                  # replays agree with each other (graph nodes are ordered)
     for (n, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
         assert torch.equal(ba, bb), f"capture changed buffer {n}"
     for pa, pb in zip(ma.parameters(), mb.parameters()):
@@ -139,6 +142,19 @@ def test_graphed_train_step_equals_eager(fused):
             assert 0 < int(bb) <= int(ba), n                # the replay counts batches like an eager forward
         elif n.endswith(("running_mean", "running_var")):
             assert torch.isfinite(bb).all()
+
+    # --- second and later replays (with unrelated device work in between) still match an eager pass at the same weights
+    for _ in range(3):
+        torch.randn(50_000_000, device=DEV).sum().item()
+        mb.load_state_dict(ma.state_dict())
+        la3, ga3 = _fwd_bwd(ma, src, drv)
+        step.g_fb.replay()
+        torch.cuda.synchronize()
+        gb3 = _grads(mb)
+        assert abs(la3 - float(step.loss)) <= 2e-6 * max(1.0, abs(la3))
+        num3 = sum(float(((ga3[n] - gb3[n]) ** 2).sum()) for n in ga3)
+        den3 = sum(float((ga3[n] ** 2).sum()) for n in ga3)
+        assert math.sqrt(num3 / den3) <= 0.2, math.sqrt(num3 / den3)
 
     # --- and the replayed step trains
     losses = [float(step(src, drv)) for _ in range(3)]
