@@ -72,13 +72,14 @@ def main():
     ap.add_argument("--no-forward", action="store_true", help="skip the extra forward-only (inference) measurement")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (reference train.py:43) instead of per-GPU statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (DDP for N>1) instead of replaying hipGraphs")
+    ap.add_argument("--force-exchange", action="store_true", help="graph mode: initialise RCCL and run the flat gradient all-reduce even with one rank")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of the flat K20 optimizer kernels")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or a.force_ddp:
+    if world > 1 or a.force_ddp or a.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -123,7 +124,7 @@ def main():
     drv = det_uniform(f"bench/drv/r{rank}", (B, 3, 256, 256), 0, 1).to(dev)
 
     def barrier():
-        if world > 1 or a.force_ddp:
+        if world > 1 or a.force_ddp or a.force_exchange:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +137,7 @@ def main():
         loss = step()
         ok = 1
         try:
-            gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world)
+            gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange))
             replay_noise = gstep.verify()             # replays must agree with each other, or the graph is not used
         except Exception as ex:                       # keep the bench alive on a capture problem: eager path
             print(f"[bench] hipGraph capture failed on rank {rank}: {ex!r}; falling back to eager launches", file=sys.stderr)
@@ -258,7 +259,7 @@ def main():
         }
     else:
         line = None
-    if world > 1 or a.force_ddp:
+    if world > 1 or a.force_ddp or a.force_exchange:
         torch.distributed.destroy_process_group()
     if line is not None:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout

@@ -127,8 +127,9 @@ class GraphedTrainStep:
     _captures = 0
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
-                 clip: float = 10.0, world: int = 1):
+                 clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None):
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
+        self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the two graphs
         self.src, self.drv = source.clone(), driving.clone()
         self.fused = getattr(optimizer, "fused_clip", False)      # mrfa_amd.optim.FlatAdam: owns the flat buffers
         self.grads = optimizer.grads if self.fused else FlatGradients(model.parameters())
@@ -216,7 +217,7 @@ class GraphedTrainStep:
         if self.fused:
             self.opt.sync_lr()                                        # an LR scheduler may have edited param_groups
         self.g_fb.replay()
-        if self.world > 1:
+        if self.exchange:
             self.grads.all_reduce()
         self.g_opt.replay()
         # the replay changed the weights behind autograd's back: bump the version counters, on which the engine's
