@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: BF16 dense (not the 2:1-sparsity figure)
 
 
 def cpu_baseline(batch: int, max_seconds: float = 25.0):
@@ -73,6 +74,9 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (reference train.py:43) instead of per-GPU statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (DDP for N>1) instead of replaying hipGraphs")
     ap.add_argument("--force-exchange", action="store_true", help="graph mode: initialise RCCL and run the flat gradient all-reduce even with one rank")
+    ap.add_argument("--mfma", choices=["f32", "bf16x6"], default=None,
+                    help="matrix pipe of the 128x128 conv tiles: native fp32 MFMA, or exactly split fp32 operands on the bf16 pipe "
+                         "(fp32-accurate; default: MRFA_MFMA or the library default)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of the flat K20 optimizer kernels")
     a = ap.parse_args()
 
@@ -95,6 +99,8 @@ def main():
     from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
     from mrfa_amd.utils.prng import det_uniform, fill_state_dict
     hip.lib()                                       # fail loudly if the HIP library is missing
+    if a.mfma:
+        hip.set_mfma_mode(a.mfma)
 
     model = HotPath(VOX1)
     for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
@@ -221,7 +227,9 @@ def main():
         value = world * B * a.steps / dt
         roof = None
         if prof:
-            dom = (128 << 16) | (128 << 4)           # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel)
+            split = hip.mfma_mode() == "bf16x6"
+            # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel, bit 2 = bf16x6 split-operand kernel)
+            dom = (128 << 16) | (128 << 4) | (4 if split else 0)
             sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if (cfg & ~1) == dom]
             allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0]
             if sel:
@@ -233,9 +241,15 @@ def main():
                         traffic = round(json.load(tf)["hbm_bytes_per_launch"] / 1e9, 4)
                 except Exception:
                     pass
-                roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
-                        "kernel": "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)",
+                # bf16x6: six bf16 MFMA products per fp32 multiply-add -> ceiling = bf16 dense peak / 6, in fp32-equivalent FLOPs
+                peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
+                roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": None if split else traffic, "traffic_unit": "GB/launch (PMC)",
+                        "peak_is": ("bf16 dense MFMA peak 2500 / 6 split products (fp32-equivalent FLOPs)" if split
+                                    else "fp32 dense MFMA peak"),
+                        "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "kernel": ("conv_bf16x6_kernel 128x128 (fwd + dgrad launches)" if split
+                                   else "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)"),
                         "launches_per_step": len(sel) / nprof, "avg_launch_ms": round(ms / len(sel), 4),
                         "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
                         "kernel_ms_per_step": round(ms / nprof, 2),
@@ -254,7 +268,7 @@ def main():
             "config": {"workload": "vox1.yaml shapes, FOMM KPDetector prior + DenseMotion + RaftFlow refinement, 256x256, "
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "launch": launch,
-                       "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "loss": float(f"{loss_val:.6f}")},
+                       "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd,
         }
     else:

@@ -10,6 +10,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void mrfa_set_error(const char* fmt, ...);
 
+// conv_split.hip: the 128 x 128 chunked implicit-GEMM tile on the bf16 matrix pipe with exactly split fp32 operands
+int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk);
+
 #define MRFA_CHECK_ARG(cond, ...)                      \
     do {                                               \
         if (!(cond)) {                                 \

@@ -323,6 +323,15 @@ int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, i
 
 }  // namespace
 
+// 0: v_mfma_f32_32x32x2_f32 everywhere; 1: eligible launches (chunked K, 128 x 128 tile) run the bf16x6 split-operand kernel
+static int g_mfma_mode = 0;
+extern "C" int mrfa_set_mfma_mode(int mode) {
+    if (mode != 0 && mode != 1) { mrfa_set_error("set_mfma_mode: unknown mode %d", mode); return 1; }
+    g_mfma_mode = mode;
+    return 0;
+}
+extern "C" int mrfa_get_mfma_mode(void) { return g_mfma_mode; }
+
 static thread_local int g_last_tile = 0;
 // (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) of the most recent mrfa_conv2d_nhwc launch on this thread
 extern "C" int mrfa_conv2d_last_config(void) { return g_last_tile; }
@@ -405,7 +414,10 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
     if (!p.tile && BM == 128 && BN == 128 && !flat) w8 = true;      // 8 waves: 4 waves/SIMD hide the load/barrier phases (+4..13 %)
-    if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, p, KT, M, splitk);
+    if (g_mfma_mode == 1 && BM == 128 && BN == 128 && !flat) {
+        g_last_tile |= 4;                                            // bit 2: split-operand kernel
+        rc = mrfa_conv_split_launch(st, p, KT, M, splitk);
+    } else if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, p, KT, M, splitk);
     else CFG(128, 128, 2, 2);
     else CFG(128, 96, 4, 1);
     else CFG(128, 64, 2, 2);

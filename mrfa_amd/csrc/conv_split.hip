@@ -1,0 +1,279 @@
+// fp32 implicit-GEMM convolution on the bf16 matrix pipe: operands split EXACTLY into three bf16 pieces, six products.
+//
+// A float has 24 significand bits = 3 x 8: chopping x to its top 16 bits gives a bf16 x1 with x - x1 exact, and twice
+// more gives x = x1 + x2 + x3 with NO error (bf16 has fp32's exponent range).  Then
+//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1) + [a2b3 + a3b2 + a3b3]
+// where every kept product of two 8-bit significands is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 and the
+// dropped bracket is < 2^-23 |ab| -- below the rounding of a single fp32 multiply.  The result is an fp32-accurate dot
+// product (same error class as the v_mfma_f32_32x32x2_f32 kernel of conv_mfma.hip: only accumulation order differs),
+// computed with six bf16 MFMAs per 32x32x16 block: the bf16 pipe is 16x the fp32 matrix pipe (2.5 PF vs 157 TF dense),
+// so the ceiling is 2.5 PF / 6 = 417 TF/s of fp32-equivalent work.  (Same idea as "3xTF32" / cuBLAS "BF16x9".)
+//
+// Structure (128 x 128 tile, 4 wave64, each wave 64 x 64 = 2 x 2 MFMA tiles, BK = 32):
+//   global fp32 tile -> registers (same loaders / fused prologues as conv_mfma.hip) -> split with VALU (and / sub / perm)
+//   -> LDS as three bf16 planes per operand, rows of 32 k = 64 B, 16-byte slots XOR-swizzled with (row >> 2) & 3 so that
+//   both the 4-lanes-per-row writes and the 16-rows-per-group ds_read_b128 fragment reads are bank-conflict free with no
+//   padding (48 KB per workgroup, 3 workgroups = 12 waves per CU) -> 12 fragment reads and 24 MFMAs per k16 step per wave.
+// Epilogue identical to conv_mfma.hip (C/D layout of the 32x32 MFMAs does not depend on the input type).
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int PLANE = 128 * 64;                    // bytes per (operand, piece) plane: 128 rows x 32 bf16
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {      // (bf16 chop of b) << 16 | (bf16 chop of a)
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float chop_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// 4 consecutive k of one row -> the three bf16x4 pieces (2 dwords each)
+__device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float a = x[2 * q], b = x[2 * q + 1];
+        p1[q] = pack_hi16(a, b);
+        const float ra = chop_rest(a), rb = chop_rest(b);
+        p2[q] = pack_hi16(ra, rb);
+        p3[q] = pack_hi16(chop_rest(ra), chop_rest(rb));
+    }
+}
+
+__global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split, const long long M,
+                                                            const int tiles_n, const int total_tiles) {
+    constexpr int TM = 2, TN = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLANE];          // A pieces 1..3, B pieces 1..3
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (lin >= total_tiles) return;
+    const int tile_m = lin / tiles_n;
+    const int tile_n = lin - tile_m * tiles_n;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+
+    const float* __restrict__ x = p.x + (size_t)bz * p.x_bs;
+    const float* __restrict__ w = p.w + (size_t)bz * p.w_bs;
+    float* __restrict__ y = p.y + (size_t)bz * p.y_bs;
+
+    // loader mapping as in conv_mfma.hip: 8 lanes x 16 B cover one 128-byte row of the k-tile (full cache lines per
+    // wave instruction: the L1 processes lines, and half-used lines halve its throughput), 32 rows per pass, 4 passes
+    const int lrow = tid >> 3;    // 0..31; rows lrow + 32 j
+    const int kq = tid & 7;       // which float4 (4 k) of the 32-wide k-tile
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    const int HWo = p.Hout * p.Wout;
+    const int KC = p.Cin >> 5;
+
+    int a_oy[4], a_ox[4], a_base[4];
+    bool a_ok[4], b_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long m = m0 + lrow + 32 * j;
+        a_ok[j] = m < M;
+        const long long mm = a_ok[j] ? m : 0;
+        const int n_img = (int)(mm / HWo);
+        const int rem = (int)(mm - (long long)n_img * HWo);
+        a_oy[j] = rem / p.Wout;
+        a_ox[j] = rem - a_oy[j] * p.Wout;
+        a_base[j] = n_img * p.Hin * p.Win;
+        b_ok[j] = (n0 + lrow + 32 * j) < p.w_rows;
+    }
+
+    f32x4 ra[4], rb[4], psc, psh;
+    bool a_inb[4];
+    int l_r = 0, l_s = 0, l_c = 0;
+    const float* l_w = w;
+
+    // ISSUE the global loads of the next k-tile; nothing here consumes a loaded register (masking, the fused BN+ReLU
+    // prologue and the bf16 split all happen in store_tiles, AFTER the MFMA phase), so the compiler has no reason to
+    // wait for them before the matrix work of the current tile
+    auto load_tiles = [&]() {
+        const int c0 = l_c * 32 + kq * 4;
+        if (p.in_scale) {
+            psc = *reinterpret_cast<const f32x4*>(p.in_scale + c0);
+            psh = *reinterpret_cast<const f32x4*>(p.in_shift + c0);
+        }
+        const int dr = l_r - p.pad, ds = l_s - p.pad;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_oy[j] + dr;
+            const int ix = a_ox[j] + ds;
+            const bool inb = a_ok[j] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+            a_inb[j] = inb;
+            // out-of-bounds rows read a valid address (pixel 0 of their image) and are zeroed when stored
+            const int pix = inb ? (a_base[j] + (iy >> p.ups) * p.Win + (ix >> p.ups)) : a_base[j];
+            ra[j] = *reinterpret_cast<const f32x4*>(x + (size_t)pix * p.ldx + c0);
+        }
+        const float* wt = l_w + c0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = b_ok[j] ? (n0 + lrow + 32 * j) : 0;
+            rb[j] = *reinterpret_cast<const f32x4*>(wt + (size_t)row * p.w_ld);
+        }
+        if (++l_c == KC) {
+            l_c = 0;
+            l_w += p.w_tap;
+            if (++l_s == p.S) { l_s = 0; ++l_r; }
+        }
+    };
+
+    auto store_tiles = [&]() {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = lrow + 32 * j;
+            // 16-byte slot kq >> 1 (swizzled), 8-byte half kq & 1
+            const int off = row * 64 + ((((kq >> 1) ^ ((row >> 2) & 3)) << 4) | ((kq & 1) << 3));
+            f32x4 v = ra[j];
+            if (p.in_scale) {
+                v = v * psc + psh;
+                if (p.in_relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+            v = a_inb[j] ? v : z;
+            u32x2 p1, p2, p3;
+            split3(v, p1, p2, p3);
+            *reinterpret_cast<u32x2*>(smem + 0 * PLANE + off) = p1;
+            *reinterpret_cast<u32x2*>(smem + 1 * PLANE + off) = p2;
+            *reinterpret_cast<u32x2*>(smem + 2 * PLANE + off) = p3;
+            split3(b_ok[j] ? rb[j] : z, p1, p2, p3);
+            *reinterpret_cast<u32x2*>(smem + 3 * PLANE + off) = p1;
+            *reinterpret_cast<u32x2*>(smem + 4 * PLANE + off) = p2;
+            *reinterpret_cast<u32x2*>(smem + 5 * PLANE + off) = p3;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kt_begin = blockIdx.z * kt_per_split;
+    const int kt_end = min(KT, kt_begin + kt_per_split);
+    {
+        const int tap0 = kt_begin / KC;
+        l_c = kt_begin - tap0 * KC;
+        l_r = tap0 / p.S;
+        l_s = tap0 - l_r * p.S;
+        l_w = w + (size_t)tap0 * p.w_tap;
+    }
+    if (kt_begin < kt_end) {
+        load_tiles();
+        store_tiles();
+    }
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_half = lane >> 5;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tiles();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * 64 + i * 32 + frag_row;
+                const int off = row * 64 + (((s * 2 + frag_half) ^ ((row >> 2) & 3)) << 4);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) a[pc][i] = *reinterpret_cast<const bf16x8*>(smem + pc * PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * 64 + j * 32 + frag_row;
+                const int off = row * 64 + (((s * 2 + frag_half) ^ ((row >> 2) & 3)) << 4);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const bf16x8*>(smem + (3 + pc) * PLANE + off);
+            }
+            // six products, smallest first; the four accumulators interleave so no MFMA waits for its predecessor
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                 // every wave is done reading this k-tile
+        if (more) store_tiles();
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue (as conv_mfma.hip)
+    const int half = lane >> 5;
+    const bool splitk = p.splitk > 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool c_ok = c < p.Cout;
+        float bias = 0.f, osc = 1.f, osh = 0.f;
+        if (c_ok && !splitk) {
+            if (p.bias) bias = p.bias[c];
+            if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c_ok && m < M) {
+                    float v = acc[i][j][r] * p.alpha;
+                    float* dst = y + (size_t)m * p.ldy + c;
+                    if (splitk) {
+                        atomicAdd(dst, v);
+                    } else {
+                        v += bias;
+                        v = v * osc + osh;
+                        if (p.res) v += p.res[(size_t)m * p.ldr + c];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+            }
+        }
+        if (p.stats && !splitk) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (half == 0 && c_ok) {
+                atomicAdd(p.stats + c, (double)s1);
+                atomicAdd(p.stats + p.Cout + c, (double)s2);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// called by mrfa_conv2d_nhwc when the split-operand mode is on and the launch is a chunked 128 x 128 tile
+int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk) {
+    const int tiles_n = cdiv(p.Cout, BN);
+    const long long tiles_m = (M + BM - 1) / BM;
+    const int total_tiles = (int)(tiles_m * tiles_n);
+    dim3 grid((unsigned)(cdiv(total_tiles, 8) * 8), (unsigned)(p.nbatch > 1 ? p.nbatch : 1), (unsigned)splitk);
+    const int kps = cdiv(KT, splitk);
+    mrfa_conv_params q = p;
+    q.splitk = splitk;
+    hipLaunchKernelGGL(conv_bf16x6_kernel, grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+    MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(bf16x6)");
+    return 0;
+}

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "mrfa_last_error": ([], C.c_char_p),
     "mrfa_conv2d_nhwc": ([_V, C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_last_config": ([], C.c_int),
+    "mrfa_set_mfma_mode": ([_I], C.c_int),
+    "mrfa_get_mfma_mode": ([], C.c_int),
     "mrfa_conv2d_wgrad_nhwc": ([_V, C.POINTER(WgradParams)], C.c_int),
     "mrfa_conv_fewout_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_conv_fewout_wgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _V], C.c_int),
@@ -146,7 +148,28 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = restype
         _lib = L
+        mode = os.environ.get("MRFA_MFMA", DEFAULT_MFMA)
+        if mode not in MFMA_MODES:
+            raise ValueError(f"MRFA_MFMA={mode!r}: expected one of {sorted(MFMA_MODES)}")
+        check(L.mrfa_set_mfma_mode(MFMA_MODES[mode]), "mrfa_set_mfma_mode")
     return _lib
+
+
+# matrix-pipe selection for the 128 x 128 chunked conv tiles (include/mrfa_hip.h, mrfa_set_mfma_mode):
+#   "f32"     v_mfma_f32_32x32x2_f32 on fp32 operands
+#   "bf16x6"  fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate
+#             (fp32-accurate, csrc/conv_split.hip)
+MFMA_MODES = {"f32": 0, "bf16x6": 1}
+DEFAULT_MFMA = "f32"
+
+
+def set_mfma_mode(mode: str):
+    check(lib().mrfa_set_mfma_mode(MFMA_MODES[mode]), "mrfa_set_mfma_mode")
+
+
+def mfma_mode() -> str:
+    m = lib().mrfa_get_mfma_mode()
+    return next(k for k, v in MFMA_MODES.items() if v == m)
 
 
 def check(rc: int, what: str):

@@ -52,6 +52,13 @@ class Emulator:
     def mrfa_conv2d_last_config(self):
         return 0
 
+    def mrfa_set_mfma_mode(self, mode):
+        self._mfma = mode            # the specification is the same fp32 convolution in every mode
+        return 0
+
+    def mrfa_get_mfma_mode(self):
+        return getattr(self, "_mfma", 0)
+
     def mrfa_build_ktab(self, tab, Cc, R, S, pad, flip):
         K = R * S * Cc
         KP = (K + 31) // 32 * 32

@@ -167,6 +167,66 @@ def test_conv2d(name):
     assert_close(ref, got, what=name)
 
 
+SPLIT_CASES = {
+    "oddM_c130": dict(N=1, H=9, W=11, Cin=64, Cout=130, tile=(128 << 16) | 128),
+    "pro_relu": dict(N=2, H=16, W=16, Cin=96, Cout=128, pro=True, tile=(128 << 16) | 128),
+    "ups_res_stats": dict(ups=1, H=6, W=5, Cin=128, Cout=256, res=True, stats=True, relu=False, tile=(128 << 16) | 128),
+    "conv1x1_affine": dict(R=1, pad=0, Cin=256, Cout=128, oaff=True, N=4, H=16, W=16, tile=(128 << 16) | 128),
+    "splitk4": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, tile=(128 << 16) | 128),
+    "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False, Cin=64, Cout=128, tile=(128 << 16) | 128),
+    "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128),
+}
+
+
+@pytest.mark.parametrize("name", list(SPLIT_CASES))
+def test_conv2d_split_operand_mode(name):
+    """mrfa_set_mfma_mode(1): fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate --
+    must satisfy the SAME fp32 tolerance against the CPU specification as the native fp32 MFMA kernel"""
+    L = hip.lib()
+    ref = conv_case(Side(False), tag=f"split/{name}", **SPLIT_CASES[name])
+    assert L.mrfa_set_mfma_mode(1) == 0
+    try:
+        got = conv_case(Side(True), tag=f"split/{name}", **SPLIT_CASES[name])
+        assert L.mrfa_conv2d_last_config() & 4, "the split-operand kernel did not run"
+    finally:
+        L.mrfa_set_mfma_mode(0)
+    assert_close(ref, got, what="split " + name)
+
+
+def test_split_operand_mode_is_fp32_accurate():
+    """error against an fp64 convolution: the bf16x6 kernel must be as accurate as the native fp32 MFMA kernel (K = 2304
+    products per output, operands with a wide dynamic range so that all three bf16 pieces matter)"""
+    L = hip.lib()
+    N, H, W, Cin, Cout = 1, 24, 24, 256, 128
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64) * torch.exp(2.0 * torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))).float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) * 0.05).float()
+    exact = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    side = Side(True)
+    xd, wd = x.reshape(-1, Cin).to(side.dev).contiguous(), w.to(side.dev)
+    wp = pack(side, wd, 0)
+    errs = {}
+    for mode in (0, 1):
+        y = side.garbage((N * H * W, Cout))
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = xd.data_ptr(), Cin, H, W, 0, N, Cin
+        p.w, p.w_ld, p.w_tap, p.kflat, p.w_rows = wp.data_ptr(), Cin, 128 * Cin, 0, 128
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), Cout, Cout, H, W
+        p.R, p.S, p.pad, p.alpha, p.nbatch, p.splitk, p.tile = 3, 3, 1, 1.0, 1, 1, (128 << 16) | 128
+        assert L.mrfa_set_mfma_mode(mode) == 0
+        try:
+            side.call("mrfa_conv2d_nhwc", C.byref(p))
+            assert bool(L.mrfa_conv2d_last_config() & 4) == bool(mode)
+        finally:
+            L.mrfa_set_mfma_mode(0)
+        torch.cuda.synchronize()
+        d = (y.double().cpu() - exact)
+        errs[mode] = (float(d.abs().max()), float(d.pow(2).mean().sqrt()))
+    scale = float(exact.abs().max())
+    assert errs[1][0] <= max(2.0 * errs[0][0], 1e-6 * scale), (errs, scale)       # max error no worse than native fp32 (x2 slack)
+    assert errs[1][1] <= max(2.0 * errs[0][1], 1e-7 * scale), (errs, scale)       # rms error likewise
+
+
 def test_gemm_nt_batched():
     def run(side):
         B, M, Nn, K = 3, 100, 72, 64

@@ -33,11 +33,14 @@ def main():
     ap.add_argument("--b", type=int, default=8)
     ap.add_argument("--only", type=str, default="", help="substring filter on the layer name; skips the HBM kernels")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--mfma", type=int, default=0, help="mrfa_set_mfma_mode: 0 native fp32 MFMA, 1 bf16x6 split-operand kernel")
     ap.add_argument("--tile", type=lambda v: int(v, 0), default=0, help="force mrfa_conv_params.tile, e.g. 0x808080 = 128x128 8-wave")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import mrfa_amd.engine as eng
     eng.FORCE_TILE = a.tile
+    from mrfa_amd import hip as _hip
+    _hip.check(_hip.lib().mrfa_set_mfma_mode(a.mfma), "set_mfma_mode")
     torch.manual_seed(0)
     e = Ctx(dev, train=True, record=True)
     B = a.b
