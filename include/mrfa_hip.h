@@ -66,7 +66,7 @@ typedef struct {
 } mrfa_conv_params;
 
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
-/* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc (process-wide):
+/* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
  *   1  fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate
  *      (fp32-accurate: the dropped cross terms are < 2^-23 of each product; 2.5 PF/s pipe / 6)                    */

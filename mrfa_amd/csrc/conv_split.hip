@@ -23,7 +23,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, NT = 256;
-constexpr int PLANE = 128 * 64;                    // bytes per (operand, piece) plane: 128 rows x 32 bf16
+constexpr int PLANE = 128 * 32;                    // bytes per (operand, piece) plane of one k16 slab: 128 rows x 16 bf16
+constexpr int SLAB = 6 * PLANE;                    // A pieces 1..3, B pieces 1..3
 
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) {      // (bf16 chop of b) << 16 | (bf16 chop of a)
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
@@ -43,10 +44,11 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     }
 }
 
+template <bool PRO>
 __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split, const long long M,
                                                             const int tiles_n, const int total_tiles) {
     constexpr int TM = 2, TN = 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLANE];          // A pieces 1..3, B pieces 1..3
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB];           // two k16 slab buffers (48 KB)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,19 +67,20 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     const float* __restrict__ w = p.w + (size_t)bz * p.w_bs;
     float* __restrict__ y = p.y + (size_t)bz * p.y_bs;
 
-    // loader mapping as in conv_mfma.hip: 8 lanes x 16 B cover one 128-byte row of the k-tile (full cache lines per
-    // wave instruction: the L1 processes lines, and half-used lines halve its throughput), 32 rows per pass, 4 passes
-    const int lrow = tid >> 3;    // 0..31; rows lrow + 32 j
-    const int kq = tid & 7;       // which float4 (4 k) of the 32-wide k-tile
+    // Loader mapping: thread (lrow = tid >> 2, q = tid & 3) owns, for rows lrow and lrow + 64, the float4 chunks q
+    // (k = 4q..4q+3, first k16 slab of the 32-wide k-tile) and q + 4 (second slab): every thread has the same amount of
+    // split / LDS-store work in both slabs.
+    const int lrow = tid >> 2;    // 0..63
+    const int q4 = tid & 3;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
     const int HWo = p.Hout * p.Wout;
     const int KC = p.Cin >> 5;
 
-    int a_oy[4], a_ox[4], a_base[4];
-    bool a_ok[4], b_ok[4];
+    int a_oy[2], a_ox[2], a_base[2];
+    bool a_ok[2], b_ok[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long m = m0 + lrow + 32 * j;
+    for (int j = 0; j < 2; ++j) {
+        const long long m = m0 + lrow + 64 * j;
         a_ok[j] = m < M;
         const long long mm = a_ok[j] ? m : 0;
         const int n_img = (int)(mm / HWo);
@@ -85,39 +88,45 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         a_oy[j] = rem / p.Wout;
         a_ox[j] = rem - a_oy[j] * p.Wout;
         a_base[j] = n_img * p.Hin * p.Win;
-        b_ok[j] = (n0 + lrow + 32 * j) < p.w_rows;
+        b_ok[j] = (n0 + lrow + 64 * j) < p.w_rows;
     }
 
-    f32x4 ra[4], rb[4], psc, psh;
-    bool a_inb[4];
+    f32x4 ra[2][2], rb[2][2], psc[2], psh[2];      // [row j][slab h]
+    bool a_inb[2];
     int l_r = 0, l_s = 0, l_c = 0;
     const float* l_w = w;
 
-    // ISSUE the global loads of the next k-tile; nothing here consumes a loaded register (masking, the fused BN+ReLU
-    // prologue and the bf16 split all happen in store_tiles, AFTER the MFMA phase), so the compiler has no reason to
-    // wait for them before the matrix work of the current tile
-    auto load_tiles = [&]() {
-        const int c0 = l_c * 32 + kq * 4;
-        if (p.in_scale) {
-            psc = *reinterpret_cast<const f32x4*>(p.in_scale + c0);
-            psh = *reinterpret_cast<const f32x4*>(p.in_shift + c0);
+    // ISSUE the global loads of one 32-wide k-tile; nothing here consumes a loaded register (masking, the fused BN+ReLU
+    // prologue and the bf16 split happen in store_slab), so the loads stay in flight across the matrix work
+    auto load_tile = [&]() {
+        const int c0 = l_c * 32 + q4 * 4;
+        if constexpr (PRO) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                psc[h] = *reinterpret_cast<const f32x4*>(p.in_scale + c0 + 16 * h);
+                psh[h] = *reinterpret_cast<const f32x4*>(p.in_shift + c0 + 16 * h);
+            }
         }
         const int dr = l_r - p.pad, ds = l_s - p.pad;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int iy = a_oy[j] + dr;
             const int ix = a_ox[j] + ds;
             const bool inb = a_ok[j] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
             a_inb[j] = inb;
             // out-of-bounds rows read a valid address (pixel 0 of their image) and are zeroed when stored
             const int pix = inb ? (a_base[j] + (iy >> p.ups) * p.Win + (ix >> p.ups)) : a_base[j];
-            ra[j] = *reinterpret_cast<const f32x4*>(x + (size_t)pix * p.ldx + c0);
+            const float* src = x + (size_t)pix * p.ldx + c0;
+            ra[j][0] = *reinterpret_cast<const f32x4*>(src);
+            ra[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
         }
         const float* wt = l_w + c0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = b_ok[j] ? (n0 + lrow + 32 * j) : 0;
-            rb[j] = *reinterpret_cast<const f32x4*>(wt + (size_t)row * p.w_ld);
+        for (int j = 0; j < 2; ++j) {
+            const int row = b_ok[j] ? (n0 + lrow + 64 * j) : 0;
+            const float* src = wt + (size_t)row * p.w_ld;
+            rb[j][0] = *reinterpret_cast<const f32x4*>(src);
+            rb[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
         }
         if (++l_c == KC) {
             l_c = 0;
@@ -126,31 +135,32 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         }
     };
 
-    auto store_tiles = [&]() {
+    // LDS: two slab buffers (k16 each), each 6 planes (A pieces 1..3, B pieces 1..3) of 128 rows x 16 bf16 = 32 B per row;
+    // the two 16-byte halves of a row are swapped for rows with bit 3 set, so the 16 rows of a ds_read_b128 lane group
+    // (and the 4-lanes-per-row ds_write_b64 groups) hit 16 distinct 16-byte bank slots
+    auto store_slab = [&](int h, int buf) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        unsigned char* base = smem + buf * SLAB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = lrow + 32 * j;
-            // 16-byte slot kq >> 1 (swizzled), 8-byte half kq & 1
-            const int off = row * 64 + ((((kq >> 1) ^ ((row >> 2) & 3)) << 4) | ((kq & 1) << 3));
-            f32x4 v = ra[j];
-            if (p.in_scale) {
-                v = v * psc + psh;
-                if (p.in_relu) {
+        for (int j = 0; j < 2; ++j) {
+            const int row = lrow + 64 * j;
+            const int off = row * 32 + ((((q4 >> 1) ^ (row >> 3)) & 1) << 4) + ((q4 & 1) << 3);
+            f32x4 v = ra[j][h];
+            if constexpr (PRO) {                   // fused pre-activation BN + ReLU (in_relu is always set with in_scale)
+                v = v * psc[h] + psh[h];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             v = a_inb[j] ? v : z;
             u32x2 p1, p2, p3;
             split3(v, p1, p2, p3);
-            *reinterpret_cast<u32x2*>(smem + 0 * PLANE + off) = p1;
-            *reinterpret_cast<u32x2*>(smem + 1 * PLANE + off) = p2;
-            *reinterpret_cast<u32x2*>(smem + 2 * PLANE + off) = p3;
-            split3(b_ok[j] ? rb[j] : z, p1, p2, p3);
-            *reinterpret_cast<u32x2*>(smem + 3 * PLANE + off) = p1;
-            *reinterpret_cast<u32x2*>(smem + 4 * PLANE + off) = p2;
-            *reinterpret_cast<u32x2*>(smem + 5 * PLANE + off) = p3;
+            *reinterpret_cast<u32x2*>(base + 0 * PLANE + off) = p1;
+            *reinterpret_cast<u32x2*>(base + 1 * PLANE + off) = p2;
+            *reinterpret_cast<u32x2*>(base + 2 * PLANE + off) = p3;
+            split3(b_ok[j] ? rb[j][h] : z, p1, p2, p3);
+            *reinterpret_cast<u32x2*>(base + 3 * PLANE + off) = p1;
+            *reinterpret_cast<u32x2*>(base + 4 * PLANE + off) = p2;
+            *reinterpret_cast<u32x2*>(base + 5 * PLANE + off) = p3;
         }
     };
 
@@ -162,6 +172,37 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int frag_row = lane & 31;
+    const int frag_half = lane >> 5;
+    auto compute_slab = [&](int buf) {
+        const unsigned char* base = smem + buf * SLAB;
+        bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * 64 + i * 32 + frag_row;
+            const int off = row * 32 + (((frag_half ^ (row >> 3)) & 1) << 4);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a[pc][i] = *reinterpret_cast<const bf16x8*>(base + pc * PLANE + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * 64 + j * 32 + frag_row;
+            const int off = row * 32 + (((frag_half ^ (row >> 3)) & 1) << 4);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + off);
+        }
+        // six products, smallest first; the four accumulators interleave so no MFMA waits for its predecessor
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+    };
+
     const int kt_begin = blockIdx.z * kt_per_split;
     const int kt_end = min(KT, kt_begin + kt_per_split);
     {
@@ -171,47 +212,24 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         l_s = tap0 - l_r * p.S;
         l_w = w + (size_t)tap0 * p.w_tap;
     }
+    // Software pipeline over k16 slabs u = 2 kt + h, LDS buffer u & 1:
+    //   iteration kt:   compute(slab 2kt)   | split + store slab 2kt+1 (registers of tile kt)   ; issue loads of tile kt+1 ; barrier
+    //                   compute(slab 2kt+1) | split + store slab 2kt+2 (registers of tile kt+1) ; barrier
+    // one barrier per slab; the VALU split / LDS stores of the next slab sit in the same basic block as the 24 MFMAs of
+    // the current one, and the global loads have a whole slab of matrix work to land.
     if (kt_begin < kt_end) {
-        load_tiles();
-        store_tiles();
+        load_tile();
+        store_slab(0, 0);
     }
     __syncthreads();
-
-    const int frag_row = lane & 31;
-    const int frag_half = lane >> 5;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
-        if (more) load_tiles();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 a[3][TM], b[3][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * 64 + i * 32 + frag_row;
-                const int off = row * 64 + (((s * 2 + frag_half) ^ ((row >> 2) & 3)) << 4);
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) a[pc][i] = *reinterpret_cast<const bf16x8*>(smem + pc * PLANE + off);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * 64 + j * 32 + frag_row;
-                const int off = row * 64 + (((s * 2 + frag_half) ^ ((row >> 2) & 3)) << 4);
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const bf16x8*>(smem + (3 + pc) * PLANE + off);
-            }
-            // six products, smallest first; the four accumulators interleave so no MFMA waits for its predecessor
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();                 // every wave is done reading this k-tile
-        if (more) store_tiles();
+        compute_slab(0);
+        store_slab(1, 1);
+        if (more) load_tile();
+        __syncthreads();
+        compute_slab(1);
+        store_slab(0, 0);            // (after the last tile: stale registers into a buffer nobody reads again)
         __syncthreads();
     }
 
@@ -273,7 +291,12 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
     const int kps = cdiv(KT, splitk);
     mrfa_conv_params q = p;
     q.splitk = splitk;
-    hipLaunchKernelGGL(conv_bf16x6_kernel, grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+    if (p.in_scale) {
+        if (!p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
+        hipLaunchKernelGGL(conv_bf16x6_kernel<true>, grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+    } else {
+        hipLaunchKernelGGL(conv_bf16x6_kernel<false>, grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+    }
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(bf16x6)");
     return 0;
 }

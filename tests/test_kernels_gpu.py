@@ -337,6 +337,23 @@ def test_wgrad(cfg):
     assert_close(ref, got, tol=5e-4, what=tag)
 
 
+@pytest.mark.parametrize("cfg", [dict(N=2, H=32, W=32, Cin=256, Cout=128), dict(N=2, H=32, W=64, Cin=128, Cout=256, pro=True),
+                                 dict(N=1, H=32, W=64, Cin=128, Cout=126, ups=1), dict(N=2, H=32, W=32, Cin=128, Cout=128, R=1, pad=0, dbias=False),
+                                 dict(N=4, H=64, W=64, Cin=128, Cout=128, ksplit=40, ws=True), dict(N=2, H=32, W=32, Cin=100, Cout=130)])
+def test_wgrad_split_operand_mode(cfg):
+    """mrfa_set_mfma_mode(1): the bf16x6 weight-gradient kernel (128 x 128 tiles, Wout % 32 == 0) against the CPU specification
+    at the tolerance of the native fp32 MFMA kernel"""
+    L = hip.lib()
+    tag = "wsplit/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+    ref = wgrad_case(Side(False), tag=tag, **cfg)
+    assert L.mrfa_set_mfma_mode(1) == 0
+    try:
+        got = wgrad_case(Side(True), tag=tag, **cfg)
+    finally:
+        L.mrfa_set_mfma_mode(0)
+    assert_close(ref, got, tol=5e-4, what=tag)
+
+
 def test_gemm_tn_batched():
     def run(side):
         B, K, M, Nn = 2, 300, 96, 64
