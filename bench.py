@@ -194,6 +194,27 @@ def main():
         torch.cuda.synchronize()
         prof, Ctx.profile = Ctx.profile, None
 
+    alt = None
+    if launch == "hipGraph" and hip.mfma_mode() == "bf16x6" and not a.no_forward:
+        # for the record (outside the timed region): the same step with every conv on the native fp32 matrix pipe
+        try:
+            hip.set_mfma_mode("f32")
+            g2 = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange))
+            for _ in range(2):
+                g2(src, drv)
+            barrier()
+            t2 = time.perf_counter()
+            n2 = max(3, min(a.steps, 5))
+            for _ in range(n2):
+                g2(src, drv)
+            barrier()
+            d2 = (time.perf_counter() - t2) / n2
+            alt = {"mfma": "f32", "ms_per_step": round(1e3 * d2, 3), "pairs_per_s": round(world * B / d2, 3)}
+            del g2
+        except Exception as ex:
+            print(f"[bench] fp32-MFMA comparison run failed: {ex!r}", file=sys.stderr)
+        finally:
+            hip.set_mfma_mode("bf16x6")
     fwd = None
     if not a.no_forward:
         # extra (outside the timed region): inference forward only, eval-mode BN, no autograd -- the quantity the
@@ -269,7 +290,7 @@ def main():
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}")},
-            "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd,
+            "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt,
         }
     else:
         line = None

@@ -160,7 +160,7 @@ def lib():
 #   "bf16x6"  fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate
 #             (fp32-accurate, csrc/conv_split.hip)
 MFMA_MODES = {"f32": 0, "bf16x6": 1}
-DEFAULT_MFMA = "f32"
+DEFAULT_MFMA = "bf16x6"
 
 
 def set_mfma_mode(mode: str):
