@@ -259,13 +259,16 @@ def main():
                 traffic = None
                 try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
                     with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
-                        traffic = round(json.load(tf)["hbm_bytes_per_launch"] / 1e9, 4)
+                        tj = json.load(tf)
+                        if split:
+                            tj = tj["split_operand"]["conv_bf16x6_kernel"]
+                        traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 4)
                 except Exception:
                     pass
                 # bf16x6: six bf16 MFMA products per fp32 multiply-add -> ceiling = bf16 dense peak / 6, in fp32-equivalent FLOPs
                 peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
                 roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": None if split else traffic, "traffic_unit": "GB/launch (PMC)",
+                        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
                         "peak_is": ("bf16 dense MFMA peak 2500 / 6 split products (fp32-equivalent FLOPs)" if split
                                     else "fp32 dense MFMA peak"),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
