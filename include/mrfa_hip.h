@@ -63,6 +63,8 @@ typedef struct {
     const int* ktab;       /* flat-K mode (Cin % 32 != 0): table of (dy,dx,ci) per k, see mrfa_build_ktab       */
     int kflat;             /* R*S*Cin in flat mode, 0 in chunked mode                                           */
     int tile;              /* 0 = auto; else force a tile config (tests / tuning)                               */
+    const void* w_split;   /* optional (chunked mode): the same weights pre-split into three bf16 pieces (pack modes 8 / 9);  */
+    long long w_piece;     /*   bf16 elements between consecutive pieces.  Used by the split-operand kernel when present.     */
 } mrfa_conv_params;
 
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
@@ -106,7 +108,10 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * mode 5: OIHW -> [Cout][tap][Cin]            (few-output direct kernels)
  * mode 6: grad [Cout][tap][Cin] -> OIHW, accumulating
  * mode 7: OIHW -> [Cin][tap'][Cout] flipped   (data gradient of a few-INPUT conv run as a few-output conv over dY)
- * modes 4|16 and 6|16: as 4 / 6 but overwriting (dst = ...) instead of accumulating                                   */
+ * modes 4|16 and 6|16: as 4 / 6 but overwriting (dst = ...) instead of accumulating
+ * mode 8: as mode 0 but split for the bf16x6 kernels: three planes [piece][tap][CoutPad][CinPad] of bf16 with
+ *         w = piece0 + piece1 + piece2 exactly (piece_k = top 16 bits of the residual); mode 9: likewise for mode 2
+ *         (modes 8 / 9: batched entry point only)                                                                         */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 
 /* Batched forms: all layouts of many convolutions per launch (descriptor table passed by value in the kernel

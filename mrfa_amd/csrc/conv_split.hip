@@ -44,7 +44,7 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     }
 }
 
-template <bool PRO>
+template <bool PRO, bool WS>
 __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split, const long long M,
                                                             const int tiles_n, const int total_tiles) {
     constexpr int TM = 2, TN = 2;
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     }
 
     f32x4 ra[2][2], rb[2][2], psc[2], psh[2];      // [row j][slab h]
+    // WS: weights arrive pre-split (pack modes 8 / 9): thread (brow = tid >> 1, bhalf = tid & 1) copies, per slab and piece,
+    // the 8 bf16 of row brow that form one MFMA fragment half -- no VALU work on the B operand at all
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 wsp[2][3];
+    const int brow = tid >> 1, bhalf = tid & 1;
+    const unsigned short* l_ws = reinterpret_cast<const unsigned short*>(p.w_split) + (size_t)bz * p.w_bs;
     bool a_inb[2];
     int l_r = 0, l_s = 0, l_c = 0;
     const float* l_w = w;
@@ -120,17 +126,26 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             ra[j][0] = *reinterpret_cast<const f32x4*>(src);
             ra[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
         }
-        const float* wt = l_w + c0;
+        if constexpr (WS) {
+            const unsigned short* src = l_ws + (size_t)(n0 + brow) * p.w_ld + l_c * 32 + bhalf * 8;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = b_ok[j] ? (n0 + lrow + 64 * j) : 0;
-            const float* src = wt + (size_t)row * p.w_ld;
-            rb[j][0] = *reinterpret_cast<const f32x4*>(src);
-            rb[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) wsp[h][pc] = *reinterpret_cast<const u32x4*>(src + (size_t)pc * p.w_piece + h * 16);
+        } else {
+            const float* wt = l_w + c0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = b_ok[j] ? (n0 + lrow + 64 * j) : 0;
+                const float* src = wt + (size_t)row * p.w_ld;
+                rb[j][0] = *reinterpret_cast<const f32x4*>(src);
+                rb[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
+            }
         }
         if (++l_c == KC) {
             l_c = 0;
             l_w += p.w_tap;
+            l_ws += p.w_tap;
             if (++l_s == p.S) { l_s = 0; ++l_r; }
         }
     };
@@ -157,10 +172,17 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             *reinterpret_cast<u32x2*>(base + 0 * PLANE + off) = p1;
             *reinterpret_cast<u32x2*>(base + 1 * PLANE + off) = p2;
             *reinterpret_cast<u32x2*>(base + 2 * PLANE + off) = p3;
-            split3(b_ok[j] ? rb[j][h] : z, p1, p2, p3);
-            *reinterpret_cast<u32x2*>(base + 3 * PLANE + off) = p1;
-            *reinterpret_cast<u32x2*>(base + 4 * PLANE + off) = p2;
-            *reinterpret_cast<u32x2*>(base + 5 * PLANE + off) = p3;
+            if constexpr (!WS) {
+                split3(b_ok[j] ? rb[j][h] : z, p1, p2, p3);
+                *reinterpret_cast<u32x2*>(base + 3 * PLANE + off) = p1;
+                *reinterpret_cast<u32x2*>(base + 4 * PLANE + off) = p2;
+                *reinterpret_cast<u32x2*>(base + 5 * PLANE + off) = p3;
+            }
+        }
+        if constexpr (WS) {
+            const int off = brow * 32 + (((bhalf ^ (brow >> 3)) & 1) << 4);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(base + (3 + pc) * PLANE + off) = wsp[h][pc];
         }
     };
 
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         l_r = tap0 / p.S;
         l_s = tap0 - l_r * p.S;
         l_w = w + (size_t)tap0 * p.w_tap;
+        l_ws += (size_t)tap0 * p.w_tap;
     }
     // Software pipeline over k16 slabs u = 2 kt + h, LDS buffer u & 1:
     //   iteration kt:   compute(slab 2kt)   | split + store slab 2kt+1 (registers of tile kt)   ; issue loads of tile kt+1 ; barrier
@@ -293,9 +316,11 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
     q.splitk = splitk;
     if (p.in_scale) {
         if (!p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
-        hipLaunchKernelGGL(conv_bf16x6_kernel<true>, grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        if (p.w_split) hipLaunchKernelGGL((conv_bf16x6_kernel<true, true>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        else hipLaunchKernelGGL((conv_bf16x6_kernel<true, false>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
     } else {
-        hipLaunchKernelGGL(conv_bf16x6_kernel<false>, grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        if (p.w_split) hipLaunchKernelGGL((conv_bf16x6_kernel<false, true>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        else hipLaunchKernelGGL((conv_bf16x6_kernel<false, false>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
     }
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(bf16x6)");
     return 0;

@@ -70,6 +70,25 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
     for (int k = 0; k < d.ndst; ++k) {
         const int mode = d.mode[k];
         float* __restrict__ dst = d.dst[k];
+        if (mode == 8 || mode == 9) {                              // bf16 pieces for the split-operand kernels
+            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(dst);
+            const long long piece = mode == 8 ? (long long)T * rup(Cout, 128) * rup(Cin, 32) : (long long)T * rup(Cin, 128) * rup(Cout, 32);
+            for (int i = threadIdx.x; i < nco * T * nci; i += 256) {
+                int co_l, ci_l, t;
+                if (mode == 8) { ci_l = i % nci; const int q = i / nci; t = q % T; co_l = q / T; }
+                else { co_l = i % nco; const int q = i / nco; ci_l = q % nci; t = q / nci; }
+                const float v = lds[co_l * row + ci_l * T + t];
+                const unsigned b1 = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(b1);
+                const unsigned b2 = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(b2);
+                const long long idx = dst_index(mode == 8 ? 0 : 2, co0 + co_l, ci0 + ci_l, t, Cout, Cin, T);
+                d16[idx] = (unsigned short)(b1 >> 16);
+                d16[piece + idx] = (unsigned short)(b2 >> 16);
+                d16[2 * piece + idx] = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
+            continue;
+        }
         if (mode == 0 || mode == 1 || mode == 5) {                 // ci fastest
             for (int i = threadIdx.x; i < nco * T * nci; i += 256) {
                 const int ci_l = i % nci, q = i / nci;
@@ -153,7 +172,7 @@ extern "C" int mrfa_pack_conv_weights_multi(void* stream, const mrfa_pack_desc* 
                        descs[i].ndst);
         for (int k = 0; k < descs[i].ndst; ++k) {
             const int m = descs[i].mode[k];
-            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7),
+            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9),
                            "pack_conv_weights_multi: desc %d: null dst or mode %d", i, m);
         }
     }

@@ -225,6 +225,30 @@ class ConvW:
             self._ver_d = self._key()
         return self._dg
 
+    def split_pack(self, which: str, padded: bool) -> tuple:
+        """(buffer, elements per piece) of the weights pre-split into three bf16 pieces for the bf16x6 kernels (pack mode 8
+        = forward layout, 9 = data-gradient layout); chunked layouts only"""
+        fwd = which == "f"
+        attr, ver = ("_fwd_s", "_ver_fs") if fwd else ("_dg_s", "_ver_ds")
+        if fwd:
+            rows, cols = (self.Cout + 127) // 128 * 128, (self.Cin + 31) // 32 * 32
+        else:
+            rows, cols = (self.Cin + 127) // 128 * 128, (self.Cout + 31) // 32 * 32
+        piece = self.T * rows * cols
+        buf = getattr(self, attr, None)
+        w = self.conv.weight.detach()
+        if buf is None or buf.numel() != 3 * piece or buf.device != w.device:
+            buf = torch.zeros(3 * piece, dtype=torch.int16, device=w.device)
+            setattr(self, attr, buf)
+            setattr(self, ver, None)
+        if getattr(self, ver, None) != self._key():
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.contiguous().data_ptr(), self.Cout, self.Cin, self.R, self.S, 1
+            d.dst[0], d.mode[0] = buf.data_ptr(), 8 if fwd else 9
+            hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack(split)")
+            setattr(self, ver, self._key())
+        return buf, piece
+
     def _simple_pack(self, attr, ver_attr, mode):
         if getattr(self, attr) is None or getattr(self, ver_attr) != self._key():
             w = self.conv.weight.detach()
@@ -292,6 +316,10 @@ class PackPlan:
                 dsts.append((cw._fwd, 0 if (getattr(cw, "_fwd_padded", False) or not cw.fwd_flat) else 1))
             if cw._dg is not None:
                 dsts.append((cw._dg, 2 if (getattr(cw, "_dg_padded", False) or not cw.dgrad_flat) else 3))
+            if getattr(cw, "_fwd_s", None) is not None:
+                dsts.append((cw._fwd_s, 8))
+            if getattr(cw, "_dg_s", None) is not None:
+                dsts.append((cw._dg_s, 9))
             if cw._fo is not None:
                 dsts.append((cw._fo, 5))
             if cw._fi is not None:
@@ -307,15 +335,17 @@ class PackPlan:
                 descs.append(d)
         self.n = len(descs)
         self.table = (hip.PackDesc * max(self.n, 1))(*descs)
-        self.ptrs = [(cw, cw.conv.weight.data_ptr(), id(cw._fwd), id(cw._dg)) for cw in self.cws]
+        self.ptrs = [(cw, cw.conv.weight.data_ptr(), id(cw._fwd), id(cw._dg), id(getattr(cw, "_fwd_s", None)), id(getattr(cw, "_dg_s", None)))
+                     for cw in self.cws]
 
     def run(self):
         if self.n:
             hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), self.table, self.n), "pack_conv_weights_multi")
-        for cw, wptr, idf, idd in self.ptrs:
-            assert cw.conv.weight.data_ptr() == wptr and id(cw._fwd) == idf and id(cw._dg) == idd, "PackPlan is stale: rebuild it"
+        for cw, wptr, idf, idd, idfs, idds in self.ptrs:
+            assert (cw.conv.weight.data_ptr() == wptr and id(cw._fwd) == idf and id(cw._dg) == idd and
+                    id(getattr(cw, "_fwd_s", None)) == idfs and id(getattr(cw, "_dg_s", None)) == idds), "PackPlan is stale: rebuild it"
             k = cw._key()
-            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = k
+            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = k
 
 
 def unpack_direct(cws: List["ConvW"]):
@@ -419,6 +449,7 @@ class Ctx:
         self.record = record
         self.tape: List[Callable[[], None]] = []
         self.L = hip.lib()
+        self.split = self.L.mrfa_get_mfma_mode() == 1        # bf16x6 kernels: also hand over pre-split weights
         self.in_backward = False
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
@@ -545,12 +576,18 @@ class Ctx:
             cip32 = (cw.Cin + 31) // 32 * 32
             p.Cin = cip32
             p.w_ld, p.w_tap, p.kflat = cip32, cop * cip32, 0
+            if self.split:
+                ws, p.w_piece = cw.split_pack("f", True)
+                p.w_split = ws.data_ptr()
         elif cw.fwd_flat:
             kp = (cw.T * cw.Cin + 31) // 32 * 32
             p.w_ld, p.w_tap, p.kflat = kp, 0, cw.T * cw.Cin
             p.ktab = cw.ktab_fwd().data_ptr()
         else:
             p.w_ld, p.w_tap, p.kflat = cw.Cin, cop * cw.Cin, 0
+            if self.split:
+                ws, p.w_piece = cw.split_pack("f", False)
+                p.w_split = ws.data_ptr()
         p.w_rows = cop
         p.y, p.ldy, p.Cout, p.Hout, p.Wout = out.ptr, out.ld, cw.Cout, Ho, Wo
         p.R, p.S, p.pad = cw.R, cw.S, cw.pad
@@ -633,12 +670,18 @@ class Ctx:
         if padded:
             p.Cin = co32
             p.w_ld, p.w_tap, p.kflat = co32, cip * co32, 0
+            if self.split:
+                ws, p.w_piece = cw.split_pack("d", True)
+                p.w_split = ws.data_ptr()
         elif cw.dgrad_flat:
             kp = (cw.T * cw.Cout + 31) // 32 * 32
             p.w_ld, p.w_tap, p.kflat = kp, 0, cw.T * cw.Cout
             p.ktab = cw.ktab_dgrad().data_ptr()
         else:
             p.w_ld, p.w_tap, p.kflat = cw.Cout, cip * cw.Cout, 0
+            if self.split:
+                ws, p.w_piece = cw.split_pack("d", False)
+                p.w_split = ws.data_ptr()
         p.w_rows = cip
         p.y, p.ldy = (tgt.gptr if direct else tgt.ptr), tgt.ld
         p.Cout, p.Hout, p.Wout = cw.Cin, Hv, Wv

@@ -34,6 +34,7 @@ class ConvParams(C.Structure):
         ("nbatch", C.c_int), ("x_bs", C.c_longlong), ("w_bs", C.c_longlong), ("y_bs", C.c_longlong),
         ("splitk", C.c_int),
         ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile", C.c_int),
+        ("w_split", C.c_void_p), ("w_piece", C.c_longlong),
     ]
 
 

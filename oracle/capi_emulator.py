@@ -520,6 +520,23 @@ class Emulator:
         for i in range(n):
             d = descs[i]
             for k in range(d.ndst):
+                if d.mode[k] in (8, 9):              # three bf16 pieces of the mode 0 / 2 layout (exact split by chopping)
+                    T = d.R * d.S
+                    if d.mode[k] == 8:
+                        n = T * ((d.Cout + 127) // 128 * 128) * ((d.Cin + 31) // 32 * 32)
+                    else:
+                        n = T * ((d.Cin + 127) // 128 * 128) * ((d.Cout + 31) // 32 * 32)
+                    tmp = torch.zeros(n, dtype=torch.float32)
+                    rc = self.mrfa_pack_conv_weight(stream, d.src, tmp.data_ptr(), d.Cout, d.Cin, d.R, d.S, d.mode[k] - 8 if d.mode[k] == 8 else 2)
+                    if rc:
+                        return rc
+                    out = torch.frombuffer((C.c_short * (3 * n)).from_address(d.dst[k]), dtype=torch.int16).view(3, n)
+                    r = tmp
+                    for pc in range(3):
+                        bits = r.view(torch.int32) & -65536
+                        out[pc] = (bits >> 16).to(torch.int16)
+                        r = r - bits.view(torch.float32)
+                    continue
                 rc = self.mrfa_pack_conv_weight(stream, d.src, d.dst[k], d.Cout, d.Cin, d.R, d.S, d.mode[k])
                 if rc:
                     return rc

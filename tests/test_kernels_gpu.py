@@ -81,7 +81,7 @@ def ktab(side, Cc, R, S, pad):
 
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
-              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, tag="c"):
+              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -103,6 +103,15 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     else:
         wp = pack(side, w, 0)
         p.w, p.w_ld, p.w_tap, p.kflat = wp.data_ptr(), Cin, cop * Cin, 0
+        if wsplit:                  # weights pre-split into three bf16 pieces (pack mode 8)
+            piece = R * S * cop * Cin
+            wsb = torch.zeros(3 * piece, dtype=torch.int16, device=side.dev)
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, S, 1
+            d.dst[0], d.mode[0] = wsb.data_ptr(), 8
+            side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
+            keep.append(wsb)
+            p.w_split, p.w_piece = wsb.data_ptr(), piece
     p.w_rows = cop
     p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), ldy, Cout, Ho, Wo
     p.R, p.S, p.pad = R, S, pad
@@ -178,15 +187,16 @@ SPLIT_CASES = {
 }
 
 
+@pytest.mark.parametrize("wsplit", [False, True])
 @pytest.mark.parametrize("name", list(SPLIT_CASES))
-def test_conv2d_split_operand_mode(name):
+def test_conv2d_split_operand_mode(name, wsplit):
     """mrfa_set_mfma_mode(1): fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate --
     must satisfy the SAME fp32 tolerance against the CPU specification as the native fp32 MFMA kernel"""
     L = hip.lib()
     ref = conv_case(Side(False), tag=f"split/{name}", **SPLIT_CASES[name])
     assert L.mrfa_set_mfma_mode(1) == 0
     try:
-        got = conv_case(Side(True), tag=f"split/{name}", **SPLIT_CASES[name])
+        got = conv_case(Side(True), tag=f"split/{name}", wsplit=wsplit, **SPLIT_CASES[name])
         assert L.mrfa_conv2d_last_config() & 4, "the split-operand kernel did not run"
     finally:
         L.mrfa_set_mfma_mode(0)
@@ -621,6 +631,33 @@ def test_flat_clip_adam(gmag, clip_slot):
     assert float(ref[1][0, 0]) == 1.0 and float(got[-3][0, 0]) == 3.0          # step counters
     if clip_slot >= 0:
         assert abs(float(got[1][0, 4 + clip_slot]) - float(ref[1][0, 4 + clip_slot])) == 0.0   # |g|_inf is exact
+
+
+def test_pack_split_pieces():
+    """pack modes 8 / 9: three bf16 pieces whose sum is the fp32 weight exactly, in the mode 0 / 2 layouts"""
+    shapes = [(130, 64, 3), (128, 100, 1), (96, 256, 3)]
+
+    def run(side):
+        outs = []
+        for i, (Cout, Cin, R) in enumerate(shapes):
+            T = R * R
+            w = side.t(f"ps/w{i}", (Cout, Cin, R, R))
+            n8 = T * ((Cout + 127) // 128 * 128) * ((Cin + 31) // 32 * 32)
+            n9 = T * ((Cin + 127) // 128 * 128) * ((Cout + 31) // 32 * 32)
+            b8 = torch.zeros(3 * n8, dtype=torch.int16, device=side.dev)
+            b9 = torch.zeros(3 * n9, dtype=torch.int16, device=side.dev)
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, R, 2
+            d.dst[0], d.mode[0], d.dst[1], d.mode[1] = b8.data_ptr(), 8, b9.data_ptr(), 9
+            side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
+            for b, n, mode in ((b8, n8, 0), (b9, n9, 2)):
+                pieces = (b.view(3, n).to(torch.int32) << 16).view(torch.float32)
+                outs += [pieces[0], pieces[1], pieces[2], pieces.double().sum(0).float() - pack(side, w, mode)]
+        return side.done(*outs)
+    ref, got = both(run)
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)
+    assert all(float(x.abs().max()) == 0.0 for x in got[3::4])          # piece sum == packed fp32 weight, exactly
 
 
 def test_pack_and_unpack_multi():
