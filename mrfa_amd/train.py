@@ -95,3 +95,24 @@ def train_step(model, optimizer, source, driving, clip=10.0):
         nn.utils.clip_grad_norm_(m.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
     optimizer.step()
     return loss.detach()
+
+
+def save_checkpoint(path: str, model, optimizer, epoch: int):
+    """The reference's checkpoint file (logger.py:50-58, train.py:94): {'model': state_dict with DDP's 'module.' prefix,
+    'optimizer': optimizer.state_dict(), 'epoch': int} -- readable by the reference's Logger.load_cpk and by load_checkpoint."""
+    m = model.module if hasattr(model, "module") else model
+    sd = {"module." + k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    torch.save({"model": sd, "optimizer": optimizer.state_dict(), "epoch": int(epoch)}, path)
+
+
+def load_checkpoint(path: str, model, optimizer=None) -> int:
+    """Logger.load_cpk (logger.py:60-66) for either side's files: accepts keys with or without the 'module.' prefix and an
+    optimizer state written by torch.optim.Adam or by FlatAdam; returns the epoch to resume from."""
+    cpk = torch.load(path, map_location="cpu")
+    m = model.module if hasattr(model, "module") else model
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in cpk["model"].items()}
+    own = m.state_dict()
+    m.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=set(own) <= set(sd))
+    if optimizer is not None and "optimizer" in cpk:
+        optimizer.load_state_dict(cpk["optimizer"])
+    return int(cpk.get("epoch", 0))

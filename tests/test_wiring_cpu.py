@@ -379,3 +379,80 @@ def test_flat_adam_matches_torch_adam_and_clip():
         ob.load_state_dict(copy.deepcopy(oa.state_dict()))
         one(4, 1.0)
         assert float(ob.state[gb_[0][0]]["step"]) == 5.0
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path):
+    """save_checkpoint writes the reference's file layout ({'model': 'module.'-prefixed state_dict, 'optimizer', 'epoch'},
+    logger.py:50-66); a torch.optim.Adam training loop and a FlatAdam one both resume from it, and FlatAdam resumes from a
+    file written with torch.optim.Adam (the reference's own checkpoints)."""
+    from mrfa_amd.modules.util import Hourglass
+    from mrfa_amd.optim import FlatAdam
+    from mrfa_amd.train import load_checkpoint, save_checkpoint
+    from mrfa_amd.utils.prng import det_normal, fill_state_dict
+
+    class Tiny(torch.nn.Module):                     # encoder / decoder / dense_motion attributes as in the reference's MRFA
+        def __init__(self, tag):
+            super().__init__()
+            self.encoder = Hourglass(block_expansion=8, in_features=3, num_blocks=2, max_features=32)
+            self.decoder = Hourglass(block_expansion=8, in_features=5, num_blocks=2, max_features=32)
+            self.dense_motion = Hourglass(block_expansion=8, in_features=4, num_blocks=2, max_features=32)
+            self.load_state_dict(fill_state_dict(self.state_dict(), tag))
+
+    def groups(m):
+        return [{"params": list(m.encoder.parameters()), "clip": 10.0}, {"params": list(m.decoder.parameters())},
+                {"params": list(m.dense_motion.parameters()), "clip": 10.0}]
+
+    def fake_step(m, opt, k):
+        opt.zero_grad()
+        for i, p in enumerate(m.parameters()):
+            g = det_normal(f"ck/g{k}/{i}", tuple(p.shape))
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        opt.step()
+    with emulated_hip():
+        a = Tiny("ck")
+        oa = FlatAdam(groups(a), lr=2e-4, betas=(0.5, 0.999))
+        fake_step(a, oa, 0)
+        f1 = str(tmp_path / "00000003-checkpoint.pth")
+        save_checkpoint(f1, a, oa, epoch=3)
+        raw = torch.load(f1)
+        assert set(raw) == {"model", "optimizer", "epoch"} and all(k.startswith("module.") for k in raw["model"])
+        # reference-style resume: torch.optim.Adam
+        b = Tiny("other")
+        ob = torch.optim.Adam([{"params": g["params"]} for g in groups(b)], lr=2e-4, betas=(0.5, 0.999))
+        assert load_checkpoint(f1, b, ob) == 3
+        # FlatAdam resume
+        c = Tiny("other2")
+        oc = FlatAdam(groups(c), lr=2e-4, betas=(0.5, 0.999))
+        assert load_checkpoint(f1, c, oc) == 3
+        for m in (b, c):
+            for (n, p), (_, q) in zip(a.named_parameters(), m.named_parameters()):
+                assert torch.equal(p, q), n
+        fake_step(a, oa, 1)
+        for g in ob.param_groups:
+            pass
+        for m, o in ((b, ob), (c, oc)):
+            if o is ob:                                            # the reference clips encoder / dense_motion by hand
+                o.zero_grad()
+                for i, p in enumerate(m.parameters()):
+                    p.grad = det_normal(f"ck/g1/{i}", tuple(p.shape))
+                import math
+                torch.nn.utils.clip_grad_norm_(m.encoder.parameters(), 10.0, norm_type=math.inf)
+                torch.nn.utils.clip_grad_norm_(m.dense_motion.parameters(), 10.0, norm_type=math.inf)
+                o.step()
+            else:
+                fake_step(m, o, 1)
+            for (n, p), (_, q) in zip(a.named_parameters(), m.named_parameters()):
+                assert (p - q).abs().max().item() <= 2e-7, n      # resumed optimizers continue identically
+        # and the other direction: a checkpoint written with torch.optim.Adam (the reference's) into FlatAdam
+        f2 = str(tmp_path / "00000004-checkpoint.pth")
+        save_checkpoint(f2, b, ob, epoch=4)
+        d = Tiny("other3")
+        od = FlatAdam(groups(d), lr=2e-4, betas=(0.5, 0.999))
+        assert load_checkpoint(f2, d, od) == 4
+        fake_step(a, oa, 2)
+        fake_step(d, od, 2)
+        for (n, p), (_, q) in zip(a.named_parameters(), d.named_parameters()):
+            assert (p - q).abs().max().item() <= 4e-7, n
