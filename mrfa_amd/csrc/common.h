@@ -11,10 +11,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 void mrfa_set_error(const char* fmt, ...);
 
 // conv_split.hip: the 128 x 128 chunked implicit-GEMM tile on the bf16 matrix pipe with exactly split fp32 operands
-int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk);
+int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk, int BN);
 // wgrad_split.hip: the 128 x 128 chunked, row-aligned weight-gradient tile in the same arithmetic
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
-                            int total_splits, int taps, long long partial_stride);
+                            int total_splits, int taps, long long partial_stride, int BM, int BN);
 
 #define MRFA_CHECK_ARG(cond, ...)                      \
     do {                                               \

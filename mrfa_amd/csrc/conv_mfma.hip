@@ -370,7 +370,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     }
     // split-operand mode: the bf16x6 kernel only exists as a 128-wide tile and is ~1.5x faster than the fp32-MFMA tiles, which
     // outweighs the padding of 64 / 96 / 160 / 192-channel outputs to a multiple of 128
-    if (g_mfma_mode == 1 && !flat && p.Cout >= 48) BN = 128;
+    if (g_mfma_mode == 1 && !flat && p.Cout >= 48) BN = p.Cout <= 64 ? 64 : 128;
     auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * cdiv(p.Cout, bn) * nb; };
     // Few output tiles (low-resolution hourglass / generator levels): every M-tile re-reads the whole weight tensor, so
     // keep the tile tall and split K across workgroups first; shrink BM only when K is too short to split.
@@ -417,9 +417,9 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
     if (!p.tile && BM == 128 && BN == 128 && !flat) w8 = true;      // 8 waves: 4 waves/SIMD hide the load/barrier phases (+4..13 %)
-    if (g_mfma_mode == 1 && BM == 128 && BN == 128 && !flat) {
+    if (g_mfma_mode == 1 && BM == 128 && (BN == 128 || BN == 64) && !flat) {
         g_last_tile |= 4;                                            // bit 2: split-operand kernel
-        rc = mrfa_conv_split_launch(st, p, KT, M, splitk);
+        rc = mrfa_conv_split_launch(st, p, KT, M, splitk, BN);
     } else if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, p, KT, M, splitk);
     else CFG(128, 128, 2, 2);
     else CFG(128, 96, 4, 1);

@@ -22,7 +22,7 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int BM = 128, NT = 256;
 constexpr int PLANE = 128 * 32;                    // bytes per (operand, piece) plane of one k16 slab: 128 rows x 16 bf16
 constexpr int SLAB = 6 * PLANE;                    // A pieces 1..3, B pieces 1..3
 
@@ -44,10 +44,12 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     }
 }
 
-template <bool PRO, bool WS>
+// BN = 128: waves 2 x 2, each 64 x 64.  BN = 64 (layers with 64 output channels: half of a 128-wide tile would be padding):
+// waves 2 x 2, each 64 x 32 -- same loaders, the B operand simply has 64 rows.
+template <bool PRO, bool WS, int BN>
 __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split, const long long M,
                                                             const int tiles_n, const int total_tiles) {
-    constexpr int TM = 2, TN = 2;
+    constexpr int TM = 2, TN = BN / 64;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB];           // two k16 slab buffers (48 KB)
 
     const int tid = threadIdx.x;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         a_oy[j] = rem / p.Wout;
         a_ox[j] = rem - a_oy[j] * p.Wout;
         a_base[j] = n_img * p.Hin * p.Win;
-        b_ok[j] = (n0 + lrow + 64 * j) < p.w_rows;
+        b_ok[j] = (lrow + 64 * j) < BN && (n0 + lrow + 64 * j) < p.w_rows;
     }
 
     f32x4 ra[2][2], rb[2][2], psc[2], psh[2];      // [row j][slab h]
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 wsp[2][3];
     const int brow = tid >> 1, bhalf = tid & 1;
+    const bool b_loader = brow < BN;
     const unsigned short* l_ws = reinterpret_cast<const unsigned short*>(p.w_split) + (size_t)bz * p.w_bs;
     bool a_inb[2];
     int l_r = 0, l_s = 0, l_c = 0;
@@ -127,11 +130,13 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             ra[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
         }
         if constexpr (WS) {
-            const unsigned short* src = l_ws + (size_t)(n0 + brow) * p.w_ld + l_c * 32 + bhalf * 8;
+            if (b_loader) {
+                const unsigned short* src = l_ws + (size_t)(n0 + brow) * p.w_ld + l_c * 32 + bhalf * 8;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) wsp[h][pc] = *reinterpret_cast<const u32x4*>(src + (size_t)pc * p.w_piece + h * 16);
+                    for (int pc = 0; pc < 3; ++pc) wsp[h][pc] = *reinterpret_cast<const u32x4*>(src + (size_t)pc * p.w_piece + h * 16);
+            }
         } else {
             const float* wt = l_w + c0;
 #pragma unroll
@@ -180,9 +185,11 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             }
         }
         if constexpr (WS) {
-            const int off = brow * 32 + (((bhalf ^ (brow >> 3)) & 1) << 4);
+            if (b_loader) {
+                const int off = brow * 32 + (((bhalf ^ (brow >> 3)) & 1) << 4);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(base + (3 + pc) * PLANE + off) = wsp[h][pc];
+                for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(base + (3 + pc) * PLANE + off) = wsp[h][pc];
+            }
         }
     };
 
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int row = wn * 64 + j * 32 + frag_row;
+            const int row = wn * (TN * 32) + j * 32 + frag_row;
             const int off = row * 32 + (((frag_half ^ (row >> 3)) & 1) << 4);
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + off);
@@ -305,8 +312,8 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
 
 }  // namespace
 
-// called by mrfa_conv2d_nhwc when the split-operand mode is on and the launch is a chunked 128 x 128 tile
-int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk) {
+// called by mrfa_conv2d_nhwc when the split-operand mode is on and the launch is a chunked 128 x {128, 64} tile
+int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk, int BN) {
     const int tiles_n = cdiv(p.Cout, BN);
     const long long tiles_m = (M + BM - 1) / BM;
     const int total_tiles = (int)(tiles_m * tiles_n);
@@ -314,14 +321,17 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
     const int kps = cdiv(KT, splitk);
     mrfa_conv_params q = p;
     q.splitk = splitk;
-    if (p.in_scale) {
-        if (!p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
-        if (p.w_split) hipLaunchKernelGGL((conv_bf16x6_kernel<true, true>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
-        else hipLaunchKernelGGL((conv_bf16x6_kernel<true, false>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+    if (p.in_scale && !p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
+#define SPLIT_LAUNCH(PRO_, WS_, BN_) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles)
+    const bool pro = p.in_scale != nullptr, ws = p.w_split != nullptr;
+    if (BN == 64) {
+        if (pro && ws) SPLIT_LAUNCH(true, true, 64); else if (pro) SPLIT_LAUNCH(true, false, 64);
+        else if (ws) SPLIT_LAUNCH(false, true, 64); else SPLIT_LAUNCH(false, false, 64);
     } else {
-        if (p.w_split) hipLaunchKernelGGL((conv_bf16x6_kernel<false, true>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
-        else hipLaunchKernelGGL((conv_bf16x6_kernel<false, false>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);
+        if (pro && ws) SPLIT_LAUNCH(true, true, 128); else if (pro) SPLIT_LAUNCH(true, false, 128);
+        else if (ws) SPLIT_LAUNCH(false, true, 128); else SPLIT_LAUNCH(false, false, 128);
     }
+#undef SPLIT_LAUNCH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(bf16x6)");
     return 0;
 }

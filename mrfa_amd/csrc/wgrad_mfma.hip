@@ -396,7 +396,8 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     if (flat && (BM == 96 || BN == 96)) { BM = BM == 96 ? 128 : BM; BN = BN == 96 ? 128 : BN; }
     // split-operand mode: the bf16x6 kernel is a 128 x 128 tile and ~1.6x faster than the fp32-MFMA tiles: prefer it over the
     // 64 / 96-wide tiles even at the cost of padding (eligibility: chunked K, Wout % 32 == 0, aligned dY)
-    if (mrfa_get_mfma_mode() == 1 && !flat && (p.Wout % WBK) == 0 && !dy_scalar && p.Cout >= 48 && NTOT >= 48) BM = BN = 128;
+    const bool split_mode = mrfa_get_mfma_mode() == 1 && !flat && (p.Wout % WBK) == 0 && !dy_scalar && p.Cout >= 48 && NTOT >= 48;
+    if (split_mode) { BM = p.Cout <= 64 ? 64 : 128; BN = NTOT <= 64 ? 64 : 128; if (BM == 64 && BN == 64) BN = 128; }
     const int tiles_m = cdiv(p.Cout, BM), tiles_n = cdiv(NTOT, BN);
     const long long base = (long long)tiles_m * tiles_n * taps * nb;
     int nsplit = p.ksplit;
@@ -439,8 +440,8 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
         else if (rowal) WLAUNCH(bm, bn, wm, wn, false, true);             \
         else WLAUNCH(bm, bn, wm, wn, false, false);                       \
     }
-    if (BM == 128 && BN == 128 && !flat && rowal && !dy_scalar && mrfa_get_mfma_mode() == 1) {
-        const int rc = mrfa_wgrad_split_launch(st, p, grid, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    if (split_mode) {
+        const int rc = mrfa_wgrad_split_launch(st, p, grid, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride, BM, BN);
         if (rc) return rc;
     }
     else if (BM == 128 && BN == 128 && !flat && rowal && !p.tile8_off) { WLAUNCH(128, 128, 2, 4, false, true); }

@@ -19,7 +19,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WBK = 32;                       // pixels per k-tile (two k16 slabs)
-constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int NT = 256;
 constexpr int ROWB = 48;                      // LDS bytes per channel row (32 data + 16 pad)
 constexpr int PLANE = 128 * ROWB;             // one piece of one operand of one slab
 constexpr int SLAB = 6 * PLANE + 32;          // A pieces 1..3, B pieces 1..3 (+ skew: SLAB % 128 == 32)
@@ -41,10 +41,13 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& p1, u32x4& 
     }
 }
 
+// BM x BN in {128 x 128, 64 x 128, 128 x 64}: waves 2 x 2, each (BM/2) x (BN/2); the 64-wide variants serve the layers with 64
+// output or input channels (half of a 128-wide tile would be padding); loader items beyond the tile width stay idle
+template <int BM, int BN>
 __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
                                                              const int tiles_n, const int nsplit, const int inner, const int total_splits,
                                                              const int taps, const long long partial_stride) {
-    constexpr int TM = 2, TN = 2;
+    constexpr int TM = BM / 64, TN = BN / 64;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,11 +85,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     const int kg = it & 3;                   // 8-pixel group 0..3 of the 32-pixel k-tile
     const int cg = it >> 2;                  // channel quad 0..31
     const int col = cg * 4;
+    const bool item = col < (is_a ? BM : BN);   // this thread has a column quad inside the tile
     const bool do_bias = (p.dbias != nullptr) && tap == 0 && tile_n == 0;
 
     bool cm[4];                              // channel masks of this thread's quad
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cm[q] = is_a ? (co0 + col + q) < p.Cout : (ci0 + col + q) < p.Cin;
+    for (int q = 0; q < 4; ++q) cm[q] = item && (is_a ? (co0 + col + q) < p.Cout : (ci0 + col + q) < p.Cin);
     const bool any = cm[0];
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (!is_a && p.in_scale) {
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     }
 
     auto load_tile = [&](int k0) {
-        if (is_a) {
+        if (!item) {
+        } else if (is_a) {
             const float* ap = dy + (size_t)(k0 + 8 * kg) * p.ldy + (any ? co0 + col : 0);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     };
 
     auto store_tile = [&]() {
+        if (!item) return;
         // prologue / masks on the fp32 values, then transpose + split + store
         float v[4][8];
 #pragma unroll
@@ -187,12 +193,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
-                a[pc][i] = *reinterpret_cast<const bf16x8*>(base + pc * PLANE + (wm * 64 + i * 32 + fi) * ROWB);
+                a[pc][i] = *reinterpret_cast<const bf16x8*>(base + pc * PLANE + (wm * (TM * 32) + i * 32 + fi) * ROWB);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
-                b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + (wn * 64 + j * 32 + fi) * ROWB);
+                b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + (wn * (TN * 32) + j * 32 + fi) * ROWB);
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -222,13 +228,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     // ------------------------------------------------------------------ epilogue (as wgrad_mfma.hip)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+        const int ci = ci0 + wn * (TN * 32) + j * 32 + (lane & 31);
         if (ci >= p.Cin) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int co = co0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+                const int co = co0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
                 if (co < p.Cout) {
                     const size_t idx = ((size_t)tap * p.Cout + co) * p.Cin + ci;
                     if (partial_stride) p.ws[(size_t)split * partial_stride + idx] = acc[i][j][q] * p.alpha;
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     if (do_bias) {                                               // workgroup-uniform
         float* red = reinterpret_cast<float*>(smem);
         __syncthreads();
-        if (is_a) {
+        if (is_a && item) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[kg * BM + col + q] = bias_acc[q];
         }
@@ -257,8 +263,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
 }  // namespace
 
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
-                            int total_splits, int taps, long long partial_stride) {
-    hipLaunchKernelGGL(wgrad_bf16x6_kernel, grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+                            int total_splits, int taps, long long partial_stride, int BM, int BN) {
+    if (BM == 128 && BN == 128)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 128>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (BM == 64 && BN == 128)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<64, 128>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (BM == 128 && BN == 64)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 64>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else { mrfa_set_error("wgrad(bf16x6): no %dx%d tile", BM, BN); return 1; }
     MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc(bf16x6)");
     return 0;
 }

@@ -184,6 +184,9 @@ SPLIT_CASES = {
     "splitk4": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, tile=(128 << 16) | 128),
     "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False, Cin=64, Cout=128, tile=(128 << 16) | 128),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128),
+    "bn64_c64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True),
+    "bn64_c50_pro": dict(N=2, H=16, W=48, Cin=64, Cout=50, tile=(128 << 16) | 64, pro=True),
+    "bn64_auto": dict(N=4, H=128, W=128, Cin=128, Cout=64, ups=0),
 }
 
 
@@ -349,7 +352,9 @@ def test_wgrad(cfg):
 
 @pytest.mark.parametrize("cfg", [dict(N=2, H=32, W=32, Cin=256, Cout=128), dict(N=2, H=32, W=64, Cin=128, Cout=256, pro=True),
                                  dict(N=1, H=32, W=64, Cin=128, Cout=126, ups=1), dict(N=2, H=32, W=32, Cin=128, Cout=128, R=1, pad=0, dbias=False),
-                                 dict(N=4, H=64, W=64, Cin=128, Cout=128, ksplit=40, ws=True), dict(N=2, H=32, W=32, Cin=100, Cout=130)])
+                                 dict(N=4, H=64, W=64, Cin=128, Cout=128, ksplit=40, ws=True), dict(N=2, H=32, W=32, Cin=100, Cout=130),
+                                 dict(N=2, H=32, W=64, Cin=64, Cout=128), dict(N=2, H=32, W=32, Cin=128, Cout=64, pro=True),
+                                 dict(N=2, H=32, W=32, Cin=60, Cout=50), dict(N=1, H=32, W=64, Cin=128, Cout=64, ups=1)])
 def test_wgrad_split_operand_mode(cfg):
     """mrfa_set_mfma_mode(1): the bf16x6 weight-gradient kernel (128 x 128 tiles, Wout % 32 == 0) against the CPU specification
     at the tolerance of the native fp32 MFMA kernel"""
