@@ -298,6 +298,7 @@ def main():
     else:
         line = None
     if world > 1 or a.force_ddp or a.force_exchange:
+        torch.distributed.barrier()               # rank 0 may arrive ~15 s late (CPU baseline): tear down together
         torch.distributed.destroy_process_group()
     if line is not None:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
