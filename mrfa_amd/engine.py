@@ -1043,10 +1043,12 @@ class _ProgramFn(torch.autograd.Function):
     input_grad_fns[j]() returns the gradient of inputs[j] (or None) after the tape ran."""
 
     @staticmethod
-    def forward(actx, program, module, n_in, *args):
+    def forward(actx, program, module, n_in, want_grad, *args):
         inputs, params = args[:n_in], args[n_in:]
         dev = inputs[0].device
-        need = any(actx.needs_input_grad[3:])
+        # want_grad: grad mode of the CALLER (inside Function.forward it is always off, and needs_input_grad reports the
+        # parameters' requires_grad even under torch.no_grad()): no tape, no retained activations for inference
+        need = want_grad and any(actx.needs_input_grad[4:])
         ectx = Ctx(dev, train=module.training, record=need)
         outs, seeders, in_grad_fns = program(ectx, *inputs)
         ectx.flush_forward()
@@ -1085,12 +1087,12 @@ class _ProgramFn(torch.autograd.Function):
                 else:
                     pgrads[id(p)] = g
         in_grads = [fn() if (fn is not None and need) else None
-                    for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[3:3 + actx.n_in])]
-        out = [None, None, None] + in_grads + [pgrads.get(id(p)) for p in actx.params]
+                    for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[4:4 + actx.n_in])]
+        out = [None, None, None, None] + in_grads + [pgrads.get(id(p)) for p in actx.params]
         actx.ectx = actx.seeders = actx.in_grad_fns = actx.params = None
         return tuple(out)
 
 
 def run_program(module: torch.nn.Module, program, inputs: Sequence[torch.Tensor]):
     params = [p for p in module.parameters()]
-    return _ProgramFn.apply(program, module, len(inputs), *inputs, *params)
+    return _ProgramFn.apply(program, module, len(inputs), torch.is_grad_enabled(), *inputs, *params)

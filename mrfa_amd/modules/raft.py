@@ -2,6 +2,7 @@
 reference: modules/raft.py:12-311 (CorrBlock, BasicMotionEncoder, RefineFlow, RaftFlow)."""
 from __future__ import annotations
 
+import functools
 import math
 from typing import List
 
@@ -135,10 +136,33 @@ class RaftFlow(nn.Module):
             maps = [F.interpolate(o.tensor().permute(0, 3, 1, 2), size=self.size, mode='bilinear', align_corners=True) for o in occs]
             return torch.cat(maps, dim=3)
 
-    def _program(self, e: Ctx, kp_s, kp_d, deformation, occlusion, img, img_full):
+    def encode_source(self, kp_s, img, img_full):
+        """Source-only half of the forward (inference): the generator's 6-level feature pyramid of the source image and
+        the source structure keys k_s / pooled k_s (raft.py:143,179,181) -- ~38 GF per frame that an animation loop over
+        ONE source re-computes for every driving frame (demo.py:47-73).  Returns an opaque cache for forward(source_cache=)."""
+        assert not self.training, "source caching is an inference feature (eval-mode BatchNorm)"
+        with torch.no_grad():
+            e = Ctx(img_full.device, train=False, record=False)
+            gen = self.generator
+            imgf = e.from_nchw(img_full)
+            cache = {"imgf": imgf, "feature": gen.run_encode(e, imgf), "shape": tuple(img_full.shape)}
+            if not self.prior_only:
+                h, w = img.shape[2], img.shape[3]
+                (in_s,) = e.island(lambda ks_, pos_, img_: [torch.cat([(kp2gaussian(ks_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1),
+                                                                        img_.permute(0, 2, 3, 1)], dim=-1)], [kp_s, self.pos_embedding, img])
+                k_s = e.conv(self.kp_img.run(e, in_s.view()), self.kp_img_head)
+                cache["k_s"], cache["k_pool"] = k_s, e.avgpool2(k_s)
+            e.flush_forward()
+        return cache
+
+    def _program(self, e: Ctx, kp_s, kp_d, deformation, occlusion, img, img_full, cache=None):
         gen = self.generator
-        imgf = e.from_nchw(img_full)
-        feature = gen.run_encode(e, imgf)
+        if cache is not None:
+            assert not e.record and cache["shape"] == tuple(img_full.shape), "source cache: inference only, same source batch"
+            imgf, feature = cache["imgf"], cache["feature"]
+        else:
+            imgf = e.from_nchw(img_full)
+            feature = gen.run_encode(e, imgf)
         b, h, w = img.shape[0], img.shape[2], img.shape[3]
         size = self.size
         deform = e.wrap_nhwc(deformation.contiguous())                          # (B,h,w,2) normalised sampling grid
@@ -171,13 +195,16 @@ class RaftFlow(nn.Module):
             hs = (kp2gaussian(ks_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)
             hd = (kp2gaussian(kd_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)
             return [torch.cat([hs, img_.permute(0, 2, 3, 1)], dim=-1), hd]
-        in_s, in_d = e.island(heatmaps, [kp_s, kp_d, pos, img])
+        if cache is not None:
+            (in_d,) = e.island(lambda kd_, pos_: [(kp2gaussian(kd_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)], [kp_d, pos])
+            k_s, k_pool = cache["k_s"], cache["k_pool"]
+        else:
+            in_s, in_d = e.island(heatmaps, [kp_s, kp_d, pos, img])
+            k_s = e.conv(self.kp_img.run(e, in_s.view()), self.kp_img_head)    # (B,h,w,dim)
+            k_pool = e.avgpool2(k_s)
         in_grads = ((lambda: e.ext_grads.get(id(kp_s))), (lambda: e.ext_grads.get(id(kp_d)))) + in_grads[2:]
-        fe_s = self.kp_img.run(e, in_s.view())
         fe_d = self.kp.run(e, in_d.view())
-        k_s = e.conv(fe_s, self.kp_img_head)                                   # (B,h,w,dim)
         q_d = e.conv(fe_d, self.kp_head)
-        k_pool = e.avgpool2(k_s)
         base = self.basic_res_index
         q_levels = {base: q_d}
         for i in range(base - 1, -1, -1):                                       # pooled queries == volume pooled over driving dims
@@ -254,10 +281,12 @@ class RaftFlow(nn.Module):
         seed = ((lambda g: e.seed_grad_nchw(out, g)), (lambda g: e.seed_grad_nchw(warp_img, g)), None)
         return outs, seed, in_grads
 
-    def forward(self, kp_s, kp_d, dense_motion, img, img_full):
+    def forward(self, kp_s, kp_d, dense_motion, img, img_full, source_cache=None):
+        """source_cache (extension, inference only): the result of encode_source(kp_s, img, img_full) for this source"""
         if img is None:
             raise ValueError("RaftFlow.forward needs `img` (the 1/4-resolution source); the reference crashes on None too "
                              "(raft.py:144-145 uses a commented-out self.down)")
         ins = [kp_s, kp_d, dense_motion['deformation'], dense_motion['occlusion'], img, img_full]
-        out, warp_img, strip = run_program(self, self._program, ins)
+        program = self._program if source_cache is None else functools.partial(self._program, cache=source_cache)
+        out, warp_img, strip = run_program(self, program, ins)
         return out, warp_img, strip

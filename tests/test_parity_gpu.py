@@ -172,3 +172,31 @@ def test_raft_flow_512_inference_vs_oracle():
     _cmp(o, oo.numpy(), what="out 512")
     _cmp(w, ow.numpy(), what="warp 512")
     assert s.shape == (b, 1, size, 7 * size)
+
+
+def test_animator_source_cache_equals_full_forward():
+    """mrfa_amd.infer.Animator (source-side work computed once) == the full per-pair forward, eagerly and as a hipGraph"""
+    from mrfa_amd.infer import Animator
+    from mrfa_amd.train import VOX1, HotPath
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    model = HotPath(VOX1)
+    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+        sd = fill_state_dict(mod.state_dict(), tag="anim/" + pfx)
+        for k in list(sd):
+            if k.endswith("jacobian.weight"):
+                sd[k] = sd[k] * 0.05
+            if k.endswith("jacobian.bias"):
+                sd[k] = torch.tensor([1.0, 0.0, 0.0, 1.0]) + sd[k] * 0.5
+            if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
+                sd[k] = sd[k] * 0.3
+        mod.load_state_dict(sd)
+    model.to(DEV).eval()
+    src = det_uniform("anim/src", (2, 3, 256, 256), 0, 1).to(DEV)
+    frames = [det_uniform(f"anim/drv{i}", (2, 3, 256, 256), 0, 1).to(DEV) for i in range(3)]
+    with torch.no_grad():
+        ref = [model(src, f).clone() for f in frames]
+    for graph in (False, True):
+        an = Animator(model, graph=graph)
+        an.set_source(src)
+        for f, r in zip(frames, ref):
+            assert (an(f) - r).abs().max().item() <= 1e-4, graph
