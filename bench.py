@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--mfma", choices=["f32", "bf16x6"], default=None,
                     help="matrix pipe of the 128x128 conv tiles: native fp32 MFMA, or exactly split fp32 operands on the bf16 pipe "
                          "(fp32-accurate; default: MRFA_MFMA or the library default)")
+    ap.add_argument("--wgrad-stream", action="store_true", help="graph mode: weight-gradient kernels as a parallel graph branch (measured slower)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of the flat K20 optimizer kernels")
     a = ap.parse_args()
 
@@ -143,7 +144,8 @@ def main():
         loss = step()
         ok = 1
         try:
-            gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange))
+            gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange),
+                                     overlap_wgrad=a.wgrad_stream)
             replay_noise = gstep.verify()             # replays must agree with each other, or the graph is not used
         except Exception as ex:                       # keep the bench alive on a capture problem: eager path
             print(f"[bench] hipGraph capture failed on rank {rank}: {ex!r}; falling back to eager launches", file=sys.stderr)

@@ -29,6 +29,12 @@ CAPTURE_KEY = 0
 # per-parameter staging tensor, zero fill and AccumulateGrad add (~900 small launches per step).  Gradient hooks do not
 # fire in this mode, so DistributedDataParallel must not be wrapped around the model (the flat all-reduce replaces it).
 DIRECT_PARAM_GRADS = False
+# True: weight-gradient kernels are issued on a second HIP stream (forked after dY is final, joined at the end of each
+# program's backward).  The weight gradients are a side chain of the backward pass -- nothing downstream reads them before
+# the optimizer -- so the ~130 wgrad launches of a step can overlap the data-gradient / BN / elementwise chain; captured
+# into a hipGraph this becomes a parallel branch.  Correct (tests/test_graph_gpu.py passes with it) but measured SLOWER on
+# the benchmark step (97.0 vs 93.3 ms: the big kernels already fill the chip and then compete for L2), so it is off by default.
+WGRAD_STREAM = False
 
 
 class direct_param_grads:
@@ -441,6 +447,7 @@ class Ctx:
     # bench.py sets this to a list to collect (config, flops, start_event, end_event) per MFMA conv/GEMM launch
     profile: Optional[list] = None
     _wgrad_ws: Optional[torch.Tensor] = None          # scratch for the two-stage wgrad split reduction
+    _side: Optional["torch.cuda.Stream"] = None        # second stream for the weight-gradient side chain (WGRAD_STREAM)
     debug_backward: Optional[list] = None             # list -> run_backward appends per-closure gradient fingerprints
 
     def __init__(self, device: torch.device, train: bool, record: bool):
@@ -637,7 +644,16 @@ class Ctx:
             ws = Ctx._wgrad_ws = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)      # 64 MiB scratch
         q.ws, q.ws_bytes = ws.data_ptr(), ws.numel() * 4
         prof = Ctx.profile
-        if prof is None:
+        if prof is None and WGRAD_STREAM:
+            main = torch.cuda.current_stream(self.dev)
+            if Ctx._side is None or Ctx._side.device != self.dev:
+                Ctx._side = torch.cuda.Stream(device=self.dev)
+            side = Ctx._side
+            side.wait_stream(main)                    # dY, the zeroed accumulators and everything before are ordered first
+            with torch.cuda.stream(side):
+                self._chk(self.L.mrfa_conv2d_wgrad_nhwc(hip.stream_ptr(), C.byref(q)), "wgrad")
+            self.side_used = True
+        elif prof is None:
             self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "wgrad")
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1032,6 +1048,9 @@ class Ctx:
                 fp = float(arena.abs().sum(dtype=torch.float64)) if total else 0.0
                 rec.append((i, desc, fp))
             dbg.append(rec)
+        if getattr(self, "side_used", False):         # join the weight-gradient side chain before anyone reads dW
+            torch.cuda.current_stream(self.dev).wait_stream(Ctx._side)
+            self.side_used = False
         self.tape = []
 
 

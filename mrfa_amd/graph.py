@@ -127,7 +127,7 @@ class GraphedTrainStep:
     _captures = 0
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
-                 clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None):
+                 clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False):
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the two graphs
         self.src, self.drv = source.clone(), driving.clone()
@@ -143,8 +143,12 @@ class GraphedTrainStep:
             for p in ps:
                 p.grad = None
             saved = [b.clone() for b in model.buffers()]            # BN running statistics: this pass must not count
-            with engine.direct_param_grads():
-                l1_loss(model(self.src, self.drv), self.drv).backward()
+            engine.WGRAD_STREAM = overlap_wgrad
+            try:
+                with engine.direct_param_grads():
+                    l1_loss(model(self.src, self.drv), self.drv).backward()
+            finally:
+                engine.WGRAD_STREAM = False
             for b, sv in zip(model.buffers(), saved):
                 b.copy_(sv)
             self.grads.bind()
@@ -154,6 +158,7 @@ class GraphedTrainStep:
         self.g_fb = torch.cuda.CUDAGraph()
         GraphedTrainStep._captures += 1
         engine.CAPTURE_KEY = GraphedTrainStep._captures
+        engine.WGRAD_STREAM = overlap_wgrad
         try:
             with torch.cuda.graph(self.g_fb, stream=self.stream), engine.direct_param_grads():
                 self.flat.zero_()
@@ -166,6 +171,7 @@ class GraphedTrainStep:
                 self.loss, self.gen = loss.detach(), gen.detach()
         finally:
             engine.CAPTURE_KEY = 0
+            engine.WGRAD_STREAM = False
         assert self.grads.bound(), "a gradient left the flat buffer"
         self.g_opt = torch.cuda.CUDAGraph()
         if self.fused:
