@@ -369,6 +369,42 @@ def test_wgrad_split_operand_mode(cfg):
     assert_close(ref, got, tol=5e-4, what=tag)
 
 
+def test_wgrad_split_operand_mode_is_fp32_accurate():
+    """weight gradient against fp64 (K = 2 x 32 x 64 = 4096 pixels per output, wide dynamic range): the bf16x6 kernel is as accurate as
+    the native fp32 MFMA kernel"""
+    L = hip.lib()
+    N, H, W, Cin, Cout = 2, 32, 64, 128, 128
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64) * torch.exp(2.0 * torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))).float()
+    dy = (torch.randn(N, H, W, Cout, generator=g, dtype=torch.float64) * torch.exp(2.0 * torch.randn(N, H, W, Cout, generator=g, dtype=torch.float64))).float()
+    xp = torch.nn.functional.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1))
+    exact = torch.zeros(9, Cout, Cin, dtype=torch.float64)
+    dyd = dy.double().reshape(-1, Cout)
+    for r in range(3):
+        for s_ in range(3):
+            exact[r * 3 + s_] = dyd.t() @ xp[:, :, r:r + H, s_:s_ + W].permute(0, 2, 3, 1).reshape(-1, Cin)
+    side = Side(True)
+    xd, dyd32 = x.reshape(-1, Cin).to(side.dev).contiguous(), dy.reshape(-1, Cout).to(side.dev).contiguous()
+    errs = {}
+    for mode in (0, 1):
+        dw = side.z((9 * Cout * Cin,))
+        q = hip.WgradParams()
+        q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = xd.data_ptr(), Cin, H, W, 0, N, Cin
+        q.dy, q.ldy, q.Cout, q.Hout, q.Wout = dyd32.data_ptr(), Cout, Cout, H, W
+        q.R, q.S, q.pad, q.dw, q.alpha, q.nbatch, q.ksplit = 3, 3, 1, dw.data_ptr(), 1.0, 1, 1
+        assert L.mrfa_set_mfma_mode(mode) == 0
+        try:
+            side.call("mrfa_conv2d_wgrad_nhwc", C.byref(q))
+        finally:
+            L.mrfa_set_mfma_mode(0)
+        torch.cuda.synchronize()
+        d = dw.double().cpu().view(9, Cout, Cin) - exact
+        errs[mode] = (float(d.abs().max()), float(d.pow(2).mean().sqrt()))
+    scale = float(exact.abs().max())
+    assert errs[1][0] <= max(2.0 * errs[0][0], 1e-6 * scale), (errs, scale)
+    assert errs[1][1] <= max(2.0 * errs[0][1], 1e-7 * scale), (errs, scale)
+
+
 def test_gemm_tn_batched():
     def run(side):
         B, K, M, Nn = 2, 300, 96, 64
