@@ -492,7 +492,7 @@ def test_bn_forward_backward(Cc, ld, N):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("Cc,in_rep", [(64, 1), (3, 1), (96, 1), (3, 11), (130, 1)])
+@pytest.mark.parametrize("Cc,in_rep", [(64, 1), (3, 1), (96, 1), (3, 11), (130, 1), (128, 1), (256, 2), (512, 1)])
 def test_grid_sample(mode, Cc, in_rep):
     def run(side):
         Nin, Hi, Wi, Ho, Wo = 2, 9, 7, 6, 8
