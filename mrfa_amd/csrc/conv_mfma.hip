@@ -370,7 +370,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     }
     // split-operand mode: the bf16x6 kernel only exists as a 128-wide tile and is ~1.5x faster than the fp32-MFMA tiles, which
     // outweighs the padding of 64 / 96 / 160 / 192-channel outputs to a multiple of 128
-    if (g_mfma_mode == 1 && !flat && p.Cout >= 48) BN = p.Cout <= 64 ? 64 : 128;
+    if (g_mfma_mode == 1 && !flat && p.Cout >= 32) BN = p.Cout <= 64 ? 64 : 128;
     auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * cdiv(p.Cout, bn) * nb; };
     // Few output tiles (low-resolution hourglass / generator levels): every M-tile re-reads the whole weight tensor, so
     // keep the tile tall and split K across workgroups first; shrink BM only when K is too short to split.
