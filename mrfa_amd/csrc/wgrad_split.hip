@@ -9,8 +9,8 @@
 // ds_write_b128 per (piece, channel).  LDS image per k16 slab and piece: [channel m][2 halves x 16 B] with a 48-byte row
 // stride and a 32-byte skew between the two slabs: the 8 lanes of a ds_write_b128 group (4 k-groups x 2 channel quads)
 // and the 16 rows of a ds_read_b128 fragment group both fall on distinct 16-byte bank slots.
-// Covers the case that dominates the step: 128 x 128 tile, chunked (not flat) K, Wout % 32 == 0 (a k-tile of 32 pixels
-// lies in one image row); everything else stays on wgrad_mfma.hip.
+// Covers the cases that dominate the step: 128/64-wide tiles, chunked (not flat) K, Wout % 8 == 0 and N*Hout*Wout % 32 == 0 (every
+// 8-pixel k-group lies in one image row, no partial k-tiles); everything else stays on wgrad_mfma.hip.
 #include "common.h"
 
 namespace {
@@ -103,10 +103,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     bool rok[8];
     f32x4 bias_acc = {0.f, 0.f, 0.f, 0.f};
 
-    // a k-tile is 32 consecutive pixels of ONE image row (Wout % 32 == 0): (n, oy, ox0) advance with scalar adds
-    int t_n = kb / HWo, t_oy, t_ox0;
+    // Wout % 8 == 0: this thread's 8 consecutive pixels (k-group kg of the tile) lie in ONE image row; their (n, oy, ox0) advance
+    // by one k-tile = 32 pixels per iteration (for Wout % 32 == 0 the whole tile stays in one row and the wrap never loops)
+    int t_n, t_oy, t_ox0;
     {
-        const int rem = kb - t_n * HWo;
+        const int p0 = kb + 8 * kg;
+        t_n = p0 / HWo;
+        const int rem = p0 - t_n * HWo;
         t_oy = rem / p.Wout;
         t_ox0 = rem - t_oy * p.Wout;
     }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
                 rok[rr] = true;
             }
         } else {
-            const int ox = t_ox0 + 8 * kg;
+            const int ox = t_ox0;
             const int iy = t_oy + r - p.pad;
             const bool rowok = (unsigned)iy < (unsigned)Hv;
             const int iyc = rowok ? (iy >> p.ups) : 0;
@@ -136,7 +139,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
             }
         }
         t_ox0 += WBK;
-        if (t_ox0 == p.Wout) { t_ox0 = 0; if (++t_oy == p.Hout) { t_oy = 0; ++t_n; } }
+        while (t_ox0 >= p.Wout) {
+            t_ox0 -= p.Wout;
+            if (++t_oy == p.Hout) { t_oy = 0; ++t_n; }
+        }
     };
 
     auto store_tile = [&]() {
