@@ -112,9 +112,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                 }
-                const float m = inb ? 1.f : 0.f;
                 ra[j] = inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-                (void)m;
             }
             const float* wt = l_w + c0;
 #pragma unroll
