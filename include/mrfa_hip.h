@@ -179,6 +179,8 @@ typedef struct {
     float* dgamma; float* dbeta;                 /* += (phase 2)                                                 */
     int train;                                   /* 0: eval-mode BN (no batch-statistics terms)                  */
     int phase;                                   /* 1: reductions, 2: apply                                      */
+    int dx_overwrite;                            /* phase 2: dx = ... instead of dx += ... (this BN is the only writer
+                                                    of its input's gradient: no zero fill, no read of dx)              */
 } mrfa_bnbwd_params;
 int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
 

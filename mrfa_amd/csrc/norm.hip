@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
             float dx;
             if (p.train) dx = gi * (du - k1 - (xv - mean) * invstd * k2);
             else dx = du * sc;
-            p.dx[(size_t)r * p.lddx + c] += dx;
+            float* q = p.dx + (size_t)r * p.lddx + c;
+            *q = p.dx_overwrite ? dx : *q + dx;
         }
     }
     if (PHASE == 1) {
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
             }
         } else if (c_ok) {
             f32x4* q = reinterpret_cast<f32x4*>(p.dx + (size_t)r * p.lddx + c);
-            f32x4 cur = *q;
+            f32x4 cur = {0.f, 0.f, 0.f, 0.f};
+            if (!p.dx_overwrite) cur = *q;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dx = p.train ? gi[k] * (du[k] - k1[k] - (xv[k] - mean[k]) * invstd[k] * k2[k]) : du[k] * sc[k];

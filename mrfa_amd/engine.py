@@ -59,13 +59,16 @@ def _r4(c: int) -> int:
 # ------------------------------------------------------------------------------------------------- storage / views
 class Storage:
     """[rows, ld] fp32 buffer + lazily allocated gradient buffer of the same geometry."""
-    __slots__ = ("data", "grad", "rows", "ld")
+    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit")
 
     def __init__(self, data: torch.Tensor):
         assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
         self.data = data
         self.rows, self.ld = data.shape
         self.grad: Optional[torch.Tensor] = None
+        # True: the gradient buffer has exactly one writer that overwrites all of it (a raw conv output whose only consumer
+        # is its BatchNorm): allocated uninitialised, outside the zero arena
+        self.grad_noinit = False
 
     def grad_buf(self) -> torch.Tensor:
         if self.grad is None:
@@ -754,7 +757,8 @@ class Ctx:
     def bn_stats_buf(self, bn):
         return self.f64z(2 * bn.num_features) if self.train else None
 
-    def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None) -> View:
+    def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None,
+               sole_consumer: bool = False) -> View:
         """out = [blend_a*occ +] act(bn(x)) [*(1-occ)], optional 2x2 avg-pool.  x = raw conv output, stats = its
         epilogue-accumulated sums (train) or None (eval)."""
         scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
@@ -770,6 +774,8 @@ class Ctx:
         self._chk(self.L.mrfa_bn_act_fwd(self.s, C.byref(p)), "bn_act_fwd")
         if self.record:
             train = self.train
+            if sole_consumer and x.coff == 0 and x.ld == x.C and x.st.grad is None and not self.in_backward:
+                x.st.grad_noinit = True               # this BN's backward is the only writer of x.grad and covers all of it
 
             def bwd():
                 if not out.has_grad:
@@ -795,6 +801,7 @@ class Ctx:
             q.dblend_a, q.ldda, q.docc, q.lddo = a.gptr, a.ld, occ.gptr, occ.ld
         q.red = red.data_ptr()
         q.dx, q.lddx = dx_view.gptr, dx_view.ld
+        q.dx_overwrite = int(dx_view.st.grad_noinit)
         q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
         q.train = int(train)
         q.phase = 1
@@ -1019,6 +1026,9 @@ class Ctx:
     def run_backward(self):
         # one zero arena for the gradients of every forward activation (single memset instead of ~500 fills)
         self.in_backward = True
+        for st in self.storages:
+            if st.grad is None and st.grad_noinit:
+                st.grad = torch.empty_like(st.data)
         todo = [st for st in self.storages if st.grad is None]
         total = sum(st.data.numel() for st in todo)
         if total:

@@ -79,7 +79,7 @@ class BnBwdParams(C.Structure):
         ("blend_a", C.c_void_p), ("lda", C.c_int), ("occ", C.c_void_p), ("ldo", C.c_int),
         ("dblend_a", C.c_void_p), ("ldda", C.c_int), ("docc", C.c_void_p), ("lddo", C.c_int),
         ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
-        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int),
+        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int), ("dx_overwrite", C.c_int),
     ]
 
 

@@ -90,7 +90,7 @@ class DownBlock2d(_Block):
     def run(self, e: Ctx, x: View, out: Optional[View] = None, need_dx=True) -> View:
         st = e.bn_stats_buf(self.norm)
         raw = e.conv(x, self.conv, stats=st, need_dx=need_dx)
-        return e.bn_act(raw, self.norm, st, relu=True, pool=True, out=out)
+        return e.bn_act(raw, self.norm, st, relu=True, pool=True, out=out, sole_consumer=True)
 
 
 class UpBlock2d(_Block):
@@ -105,7 +105,7 @@ class UpBlock2d(_Block):
     def run(self, e: Ctx, x: View, out: Optional[View] = None, blend=None) -> View:
         st = e.bn_stats_buf(self.norm)
         raw = e.conv(x, self.conv, stats=st, ups=True)
-        return e.bn_act(raw, self.norm, st, relu=True, blend=blend, out=out)
+        return e.bn_act(raw, self.norm, st, relu=True, blend=blend, out=out, sole_consumer=True)
 
 
 class SameBlock2d(_Block):
@@ -120,7 +120,7 @@ class SameBlock2d(_Block):
     def run(self, e: Ctx, x: View, out: Optional[View] = None, need_dx=True) -> View:
         st = e.bn_stats_buf(self.norm)
         raw = e.conv(x, self.conv, stats=st, need_dx=need_dx)
-        return e.bn_act(raw, self.norm, st, relu=True, out=out)
+        return e.bn_act(raw, self.norm, st, relu=True, out=out, sole_consumer=True)
 
 
 class ResBlock2d(_Block):

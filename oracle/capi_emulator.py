@@ -296,7 +296,11 @@ class Emulator:
             dx = vec(p.gamma, Cc) * invstd * (du - k1 - xhat * k2)
         else:
             dx = du * sc
-        nhwc(p.dx, p.N, p.H, p.W, p.lddx, Cc).add_(dx)
+        tgt = nhwc(p.dx, p.N, p.H, p.W, p.lddx, Cc)
+        if getattr(p, "dx_overwrite", 0):
+            tgt.copy_(dx)
+        else:
+            tgt.add_(dx)
         if p.dbeta:
             vec(p.dbeta, Cc).add_(red[:Cc].float())
         if p.dgamma:

@@ -487,6 +487,11 @@ def test_bn_forward_backward(Cc, ld, N):
                     q.phase = ph
                     side.call("mrfa_bn_act_bwd", C.byref(q))
                 outs += [y[:, :Cc], dx, da, docc, dg, dbt]
+                # sole-writer form: phase 2 overwrites an UNINITIALISED dx (no zero fill, no read)
+                dx2 = side.garbage((N * H * W, Cc))
+                q.dx, q.dx_overwrite, q.dgamma, q.dbeta, q.phase = dx2.data_ptr(), 1, None, None, 2
+                side.call("mrfa_bn_act_bwd", C.byref(q))
+                outs.append(dx2)
             outs += [rm.clone(), rv.clone(), sc, sh]
         return side.done(*outs)
     ref, got = both(run)
