@@ -163,6 +163,8 @@ typedef struct {
     const float* blend_a; int lda;   /* optional: y = a*occ + act(x)*(1-occ)  (generator.py:57)                  */
     const float* occ; int ldo;       /* occ: one channel per pixel                                               */
     float* y; int ldy;
+    const float* res; int ldr;       /* optional residual added BEFORE the activation: y = act(bn(x) + res) (HRNet
+                                        BasicBlock / Bottleneck, transformer/hr_base.py:50-51,92-93); not with pool/blend */
 } mrfa_bnact_params;
 int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* p);
 
@@ -181,6 +183,8 @@ typedef struct {
     int phase;                                   /* 1: reductions, 2: apply                                      */
     int dx_overwrite;                            /* phase 2: dx = ... instead of dx += ... (this BN is the only writer
                                                     of its input's gradient: no zero fill, no read of dx)              */
+    const float* res; int ldr;                   /* the forward's residual (needed for the ReLU mask)            */
+    float* dres; int lddr;                       /* += gradient wrt the residual (phase 1), may be null          */
 } mrfa_bnbwd_params;
 int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
 
@@ -237,6 +241,37 @@ int mrfa_blend_bwd(void* stream, const float* a, int lda, const float* b, int ld
 int mrfa_antialias_down(void* stream, const float* x_nchw, int N, int C, int H, int W, const float* kern, int k,
                         int stride, float* y, int ldy);
 int mrfa_colsum(void* stream, const float* x, int ldx, long long rows, int C, float* out /*+=*/);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * K21: the MTIA prior, TokenPose_B (reference modules/transformer/pose_tokenpose_b.py:16-50,
+ * hr_base.py:294-450, tokenpose_base.py:33-94,137-158,406-468).  Its convolutions, Linear layers (1x1 convolutions over
+ * token rows) and BatchNorms run on K1-K8; these are the remaining ops.  All views NHWC / row-major fp32, C % 4 == 0 and
+ * 16-byte aligned unless noted; every *_bwd ACCUMULATES (+=) into its gradient outputs.                          */
+/* y[n,oy,ox,:] = x[n,oy*stride,ox*stride,:]: a stride-2 3x3 pad-1 convolution (hr_base.py:231,312,316,357) is the
+ * stride-1 convolution kept at the even pixels                                                                   */
+int mrfa_subsample_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, int stride, float* y, int ldy);
+int mrfa_subsample_bwd(void* stream, const float* dy, int lddy, int N, int H, int W, int C, int stride, float* dx /*+=*/, int lddx);
+/* y = act(base + nearest_upsample(lo, factor)): the branch fusion of HighResolutionModule.forward (hr_base.py:278-289;
+ * nn.Upsample(mode='nearest') at :218); factor 1 = plain add (+ReLU).  lo is (N,Hl,Wl,C), base / y (N,Hl*f,Wl*f,C)  */
+int mrfa_upsample_add_act_fwd(void* stream, const float* lo, int ldl, int N, int Hl, int Wl, int C, int factor, const float* base, int ldb,
+                              int relu, float* y, int ldy);
+int mrfa_upsample_add_act_bwd(void* stream, const float* y, int ldy, const float* dy, int lddy, int N, int Hl, int Wl, int C, int factor,
+                              int relu, float* dlo /*+=, may be null*/, int lddl, float* dbase /*+=, may be null*/, int lddb);
+/* torch.nn.LayerNorm over the last dimension (tokenpose_base.py:33,38; any C <= 1024, no alignment needs); mean / rstd
+ * [rows] are saved for the backward                                                                               */
+int mrfa_layernorm_fwd(void* stream, const float* x, int ldx, long long rows, int C, const float* gamma, const float* beta, float eps,
+                       float* y, int ldy, float* mean, float* rstd);
+int mrfa_layernorm_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, const float* gamma,
+                       const float* mean, const float* rstd, float* dx /*+=*/, int lddx, float* dgamma /*+=*/, float* dbeta /*+=*/);
+/* exact (erf) GELU, nn.GELU() at tokenpose_base.py:51                                                             */
+int mrfa_gelu_fwd(void* stream, const float* x, int ldx, long long rows, int C, float* y, int ldy);
+int mrfa_gelu_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, float* dx /*+=*/, int lddx);
+/* softmax(scale * q k^T) v per (sample, head), Attention.forward tokenpose_base.py:72-94 without mask.  qkv: (B*n) rows
+ * of [q | k | v], each heads*d wide with head h at columns [h*d, (h+1)*d) ('b n (h d)'); out: (B*n) x (heads*d);
+ * lse / delta: [B*heads*n] (log-sum-exp saved by the forward; scratch of the backward).  d in {16, 24, 32}.      */
+int mrfa_attention_fwd(void* stream, const float* qkv, int ld, int B, int n, int heads, int d, float scale, float* out, int ldo, float* lse);
+int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const float* out, int ldo, const float* dout, int lddo, const float* lse,
+                       float* delta, int B, int n, int heads, int d, float scale, float* dqkv /*+=*/, int lddq);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K20: optimizer step of the data-parallel path on FLAT fp32 buffers (every parameter / gradient / Adam moment of a

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params
         float v;
         if (!p.pool) {
             v = p.x[(size_t)opix * p.ldx + c] * sc + sh;
+            if (p.res) v += p.res[(size_t)opix * p.ldr + c];
             if (p.relu) v = fmaxf(v, 0.f);
         } else {
             const int ox = (int)(opix % Wo);
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
         float du = 0.f, xv = 0.f, docc_part = 0.f;
         if (c_ok) {
             xv = p.x[(size_t)r * p.ldx + c];
-            const float u = xv * sc + sh;
+            float u = xv * sc + sh;
+            if (p.res) u += p.res[(size_t)r * p.ldr + c];
             const float a = p.relu ? fmaxf(u, 0.f) : u;
             float da = p.dy[(size_t)opix * p.lddy + c] * gmul;
             if (p.blend_a) {
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
                 da *= (1.f - o);
             }
             du = (p.relu && u <= 0.f) ? 0.f : da;
+            if (PHASE == 1 && p.dres) p.dres[(size_t)r * p.lddr + c] += du;
         }
         if (PHASE == 1) {
             if (p.blend_a && p.docc) {
@@ -248,10 +251,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
                 o = p.occ[(size_t)opix * p.ldo];
                 if (PHASE == 1) A = *reinterpret_cast<const f32x4*>(p.blend_a + (size_t)opix * p.lda + c);
             }
-            f32x4 dA = {0, 0, 0, 0};
+            f32x4 dA = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
+            if (p.res) rs = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float u = xv[k] * sc[k] + sh[k];
+                const float u = xv[k] * sc[k] + sh[k] + rs[k];
                 const float a = p.relu ? fmaxf(u, 0.f) : u;
                 float d = da[k] * gmul;
                 if (p.blend_a) {
@@ -262,6 +266,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
                     d *= (1.f - o);
                 }
                 du[k] = (p.relu && u <= 0.f) ? 0.f : d;
+            }
+            if (PHASE == 1 && p.dres) {
+                f32x4* q = reinterpret_cast<f32x4*>(p.dres + (size_t)r * p.lddr + c);
+                f32x4 cur = *q;
+                cur += du;
+                *q = cur;
             }
             if (PHASE == 1 && p.blend_a && p.dblend_a) {
                 f32x4* q = reinterpret_cast<f32x4*>(p.dblend_a + (size_t)opix * p.ldda + c);
@@ -359,6 +369,7 @@ extern "C" int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* pp) {
     MRFA_CHECK_ARG(p.x && p.y && p.scale && p.shift, "bn_act_fwd: null pointer");
     MRFA_CHECK_ARG(!p.pool || ((p.H % 2) == 0 && (p.W % 2) == 0), "bn_act_fwd: pool needs even H,W");
     MRFA_CHECK_ARG(!(p.pool && p.blend_a), "bn_act_fwd: pool and blend are exclusive");
+    MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)), "bn_act_fwd: residual excludes pool and blend");
     const long long opix = (long long)p.N * (p.pool ? p.H / 2 : p.H) * (p.pool ? p.W / 2 : p.W);
     const long long total = opix * p.C;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p, total);
@@ -370,6 +381,7 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     const mrfa_bnbwd_params& p = *pp;
     MRFA_CHECK_ARG(p.x && p.dy && p.scale && p.shift && p.red, "bn_act_bwd: null pointer");
     MRFA_CHECK_ARG(!p.train || (p.mean && p.invstd && p.gamma), "bn_act_bwd: train mode needs mean/invstd/gamma");
+    MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)) && !(p.dres && !p.res), "bn_act_bwd: residual excludes pool and blend");
     const long long rows = (long long)p.N * p.H * p.W;
     const int chunks = cdiv(p.C, CH);
     const int rpb = pick_rows_per_block(rows, chunks);
@@ -377,6 +389,7 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.scale) &&
                      aligned16(p.shift) && (!p.mean || (aligned16(p.mean) && aligned16(p.invstd))) && (!p.gamma || aligned16(p.gamma)) &&
                      (p.phase == 1 || ((p.lddx % 4 == 0) && aligned16(p.dx))) &&
+                     (!p.res || ((p.ldr % 4 == 0) && aligned16(p.res) && (!p.dres || ((p.lddr % 4 == 0) && aligned16(p.dres))))) &&
                      (!p.blend_a || ((p.lda % 4 == 0) && aligned16(p.blend_a) && (!p.dblend_a || ((p.ldda % 4 == 0) && aligned16(p.dblend_a)))));
     if (vec) {
         if (p.phase == 1) {

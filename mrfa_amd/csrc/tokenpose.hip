@@ -1,0 +1,535 @@
+// K21: the kernels the MTIA prior (TokenPose_B = HRNet-W32 stem + 12-layer ViT; reference
+// modules/transformer/{hr_base,tokenpose_base,pose_tokenpose_b}.py) needs beyond the convolution / BatchNorm kernels
+// it shares with the rest of the path:
+//   * stride-2 pixel subsampling (a stride-2 3x3 conv = the stride-1 conv kept at even pixels, hr_base.py:231,312,316),
+//   * nearest-neighbour upsample fused with the branch sum and the ReLU of HighResolutionModule.forward
+//     (hr_base.py:278-289), also used with factor 1 as a plain add + ReLU,
+//   * LayerNorm over token rows (tokenpose_base.py:33,38), exact-erf GELU (tokenpose_base.py:51),
+//   * multi-head attention over 276 tokens x 8 heads x 24 (tokenpose_base.py:72-94) computed per (sample, head) from the
+//     packed qkv rows, softmax never materialised in HBM.
+// All of it is HBM- or latency-bound work on <= 4 MB tensors; float4 accesses, one pass per tensor.
+#include "common.h"
+
+namespace {
+
+#define GRID_STRIDE_U(i, n) for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------------------------- subsample
+// y[n,oy,ox,:] = x[n,oy*s,ox*s,:]        (ACC: dx[n,oy*s,ox*s,:] += dy[n,oy,ox,:], called with the roles swapped)
+template <bool SCATTER>
+__global__ void subsample_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int H, int W, int Ho, int Wo,
+                                 int C4, int s, unsigned total4) {
+    GRID_STRIDE_U(i, total4) {
+        const unsigned opix = i / (unsigned)C4;
+        const unsigned c = (i - opix * (unsigned)C4) * 4u;
+        const unsigned ox = opix % (unsigned)Wo, t = opix / (unsigned)Wo;
+        const unsigned oy = t % (unsigned)Ho, n = t / (unsigned)Ho;
+        const size_t big = ((size_t)n * H + oy * s) * W + ox * s;
+        if (!SCATTER) {
+            *reinterpret_cast<f32x4*>(dst + (size_t)opix * ldd + c) = *reinterpret_cast<const f32x4*>(src + big * lds + c);
+        } else {
+            f32x4* q = reinterpret_cast<f32x4*>(dst + big * ldd + c);
+            f32x4 v = *q;
+            v += *reinterpret_cast<const f32x4*>(src + (size_t)opix * lds + c);
+            *q = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- upsample + add + act
+__global__ void ups_add_act_fwd_kernel(const float* __restrict__ lo, int ldl, int Hl, int Wl, int C4, int f, const float* __restrict__ base,
+                                       int ldb, int relu, float* __restrict__ y, int ldy, unsigned total4) {
+    const int H = Hl * f, W = Wl * f;
+    GRID_STRIDE_U(i, total4) {
+        const unsigned pix = i / (unsigned)C4;
+        const unsigned c = (i - pix * (unsigned)C4) * 4u;
+        const unsigned xx = pix % (unsigned)W, t = pix / (unsigned)W;
+        const unsigned yy = t % (unsigned)H, n = t / (unsigned)H;
+        const size_t lp = ((size_t)n * Hl + yy / f) * Wl + xx / f;
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)pix * ldb + c);
+        v += *reinterpret_cast<const f32x4*>(lo + lp * ldl + c);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)pix * ldy + c) = v;
+    }
+}
+
+// one thread per low-resolution float4: walks its f x f block of the output gradient
+__global__ void ups_add_act_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dy, int lddy, int Hl, int Wl, int C4,
+                                       int f, int relu, float* __restrict__ dlo, int lddl, float* dbase, int lddb, unsigned total4) {
+    const int W = Wl * f, H = Hl * f;
+    GRID_STRIDE_U(i, total4) {
+        const unsigned lp = i / (unsigned)C4;
+        const unsigned c = (i - lp * (unsigned)C4) * 4u;
+        const unsigned xl = lp % (unsigned)Wl, t = lp / (unsigned)Wl;
+        const unsigned yl = t % (unsigned)Hl, n = t / (unsigned)Hl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < f; ++a) {
+            for (int b = 0; b < f; ++b) {
+                const size_t pix = ((size_t)n * H + yl * f + a) * W + xl * f + b;
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + pix * lddy + c);
+                if (relu) {
+                    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + pix * ldy + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+                }
+                acc += g;
+                if (dbase) {
+                    f32x4* q = reinterpret_cast<f32x4*>(dbase + pix * lddb + c);
+                    f32x4 cur = *q;
+                    cur += g;
+                    *q = cur;
+                }
+            }
+        }
+        if (dlo) {
+            f32x4* q = reinterpret_cast<f32x4*>(dlo + (size_t)lp * lddl + c);
+            f32x4 cur = *q;
+            cur += acc;
+            *q = cur;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+// one wave per row, C <= 1024; biased variance, eps inside the square root (torch.nn.LayerNorm)
+constexpr int LN_MAXK = 16;
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, long long rows, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ y, int ldy, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * ldx;
+    float v[LN_MAXK];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+        const int c = k * 64 + lane;
+        v[k] = c < C ? xr[c] : 0.f;
+        s += v[k];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+        const int c = k * 64 + lane;
+        const float d = c < C ? v[k] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) {
+        const int c = k * 64 + lane;
+        if (c < C) y[(size_t)r * ldy + c] = (v[k] - mean) * rstd * gamma[c] + beta[c];
+    }
+    if (lane == 0) {
+        mean_out[r] = mean;
+        rstd_out[r] = rstd;
+    }
+}
+
+// dx += rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma ; dgamma += sum_r dy*xhat ; dbeta += sum_r dy
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                           long long rows, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int rows_per_wave) {
+    __shared__ float red[2][4][64 * 4];            // per wave partials for up to 256 channels at a time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long w_id = (long long)blockIdx.x * 4 + wave;
+    const long long r0 = w_id * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+    float pg[LN_MAXK], pb[LN_MAXK];
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) pg[k] = pb[k] = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        const float m = mean[r], rs = rstd[r];
+        float xh[LN_MAXK], g[LN_MAXK];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int c = k * 64 + lane;
+            if (c < C) {
+                const float d = dy[(size_t)r * lddy + c];
+                xh[k] = (x[(size_t)r * ldx + c] - m) * rs;
+                g[k] = d * gamma[c];
+                pg[k] += d * xh[k];
+                pb[k] += d;
+                s1 += g[k];
+                s2 += g[k] * xh[k];
+            } else {
+                xh[k] = g[k] = 0.f;
+            }
+        }
+        const float k1 = wave_sum(s1) / (float)C, k2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int c = k * 64 + lane;
+            if (c < C) dx[(size_t)r * lddx + c] += rs * (g[k] - k1 - xh[k] * k2);
+        }
+    }
+    // parameter gradients: waves of the block -> LDS -> one atomic per channel per block, 256 channels per round
+    for (int k0 = 0; k0 * 64 < C; k0 += 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_MAXK; ++k)
+                if (k == k0 + kk) { a = pg[k]; b = pb[k]; }
+            red[0][wave][kk * 64 + lane] = a;
+            red[1][wave][kk * 64 + lane] = b;
+        }
+        __syncthreads();
+        const int c = k0 * 64 + threadIdx.x;
+        if (c < C) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[0][w][threadIdx.x]; b += red[1][w][threadIdx.x]; }
+            if (dgamma) atomicAdd(dgamma + c, a);
+            if (dbeta) atomicAdd(dbeta + c, b);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- GELU (exact, erf)
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, int ldx, int C4, float* __restrict__ y, int ldy, unsigned total4) {
+    GRID_STRIDE_U(i, total4) {
+        const unsigned r = i / (unsigned)C4;
+        const unsigned c = (i - r * (unsigned)C4) * 4u;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752440f));
+        *reinterpret_cast<f32x4*>(y + (size_t)r * ldy + c) = v;
+    }
+}
+
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, int C4, float* __restrict__ dx,
+                                int lddx, unsigned total4) {
+    GRID_STRIDE_U(i, total4) {
+        const unsigned r = i / (unsigned)C4;
+        const unsigned c = (i - r * (unsigned)C4) * 4u;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)r * lddy + c);
+        f32x4* q = reinterpret_cast<f32x4*>(dx + (size_t)r * lddx + c);
+        f32x4 cur = *q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float cdf = 0.5f * (1.f + erff(v[k] * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * v[k] * v[k]);
+            cur[k] += g[k] * (cdf + v[k] * pdf);
+        }
+        *q = cur;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- attention
+// qkv: (B*n) rows x (3*heads*d) floats, q | k | v thirds, head h = columns [h*d, (h+1)*d) of its third ('b n (h d)',
+// tokenpose_base.py:77-78).  One workgroup = one (sample, head) x 128 query rows; K and V of the head live in LDS
+// (2 x n x d floats: 53 KB for 276 x 24), a thread owns one query row and reads K_j / V_j as LDS broadcasts.
+constexpr int ATT_ROWS = 128;
+constexpr int ATT_MAXD = 32;
+
+template <int D>
+__global__ __launch_bounds__(ATT_ROWS) void attention_fwd_kernel(const float* __restrict__ qkv, int ld, int n, int heads, float scale,
+                                                               float* __restrict__ out, int ldo, float* __restrict__ lse) {
+    extern __shared__ float sm[];
+    float* Ks = sm;
+    float* Vs = sm + (size_t)n * D;
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+    const float* base = qkv + (size_t)b * n * ld;
+    const int inner = heads * D;
+    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_ROWS) {
+        const int j = i / (D / 4), c = (i - j * (D / 4)) * 4;
+        *reinterpret_cast<f32x4*>(Ks + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + inner + h * D + c);
+        *reinterpret_cast<f32x4*>(Vs + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + 2 * inner + h * D + c);
+    }
+    __syncthreads();
+    const int i = blockIdx.y * ATT_ROWS + threadIdx.x;
+    if (i >= n) return;
+    float q[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) q[c] = base[(size_t)i * ld + h * D + c] * scale;
+    float m = -3.0e38f;
+    for (int j = 0; j < n; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) s += q[c] * Ks[j * D + c];
+        m = fmaxf(m, s);
+    }
+    float l = 0.f, acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int j = 0; j < n; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) s += q[c] * Ks[j * D + c];
+        const float p = __expf(s - m);
+        l += p;
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] += p * Vs[j * D + c];
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int c = 0; c < D; ++c) out[((size_t)b * n + i) * ldo + h * D + c] = acc[c] * inv;
+    lse[(size_t)bh * n + i] = m + __logf(l);
+}
+
+// backward, query side: dq_i += scale * sum_j dS_ij K_j ; delta_i = dO_i . O_i is also written for the key side
+template <int D>
+__global__ __launch_bounds__(ATT_ROWS) void attention_bwd_q_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ o, int ldo,
+                                                                 const float* __restrict__ dout, int lddo, const float* __restrict__ lse,
+                                                                 float* __restrict__ delta, int n, int heads, float scale,
+                                                                 float* __restrict__ dqkv, int lddq) {
+    extern __shared__ float sm[];
+    float* Ks = sm;
+    float* Vs = sm + (size_t)n * D;
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+    const float* base = qkv + (size_t)b * n * ld;
+    const int inner = heads * D;
+    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_ROWS) {
+        const int j = i / (D / 4), c = (i - j * (D / 4)) * 4;
+        *reinterpret_cast<f32x4*>(Ks + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + inner + h * D + c);
+        *reinterpret_cast<f32x4*>(Vs + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + 2 * inner + h * D + c);
+    }
+    __syncthreads();
+    const int i = blockIdx.y * ATT_ROWS + threadIdx.x;
+    if (i >= n) return;
+    float q[D], dO[D], dq[D];
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        q[c] = base[(size_t)i * ld + h * D + c] * scale;
+        dO[c] = dout[((size_t)b * n + i) * lddo + h * D + c];
+        dl += dO[c] * o[((size_t)b * n + i) * ldo + h * D + c];
+        dq[c] = 0.f;
+    }
+    const float L = lse[(size_t)bh * n + i];
+    delta[(size_t)bh * n + i] = dl;
+    for (int j = 0; j < n; ++j) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            s += q[c] * Ks[j * D + c];
+            dp += dO[c] * Vs[j * D + c];
+        }
+        const float ds = __expf(s - L) * (dp - dl);
+#pragma unroll
+        for (int c = 0; c < D; ++c) dq[c] += ds * Ks[j * D + c];
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) dqkv[((size_t)b * n + i) * lddq + h * D + c] += dq[c] * scale;
+}
+
+// backward, key side: a thread owns key/value row j; Q and dO of the head live in LDS
+template <int D>
+__global__ __launch_bounds__(ATT_ROWS) void attention_bwd_kv_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dout,
+                                                                  int lddo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  int n, int heads, float scale, float* __restrict__ dqkv, int lddq) {
+    extern __shared__ float sm[];
+    float* Qs = sm;
+    float* Gs = sm + (size_t)n * D;
+    float* Ls = sm + (size_t)2 * n * D;
+    float* Ds = Ls + n;
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+    const float* base = qkv + (size_t)b * n * ld;
+    const int inner = heads * D;
+    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_ROWS) {
+        const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+        *reinterpret_cast<f32x4*>(Qs + r * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + h * D + c);
+        *reinterpret_cast<f32x4*>(Gs + r * D + c) = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * n + r) * lddo + h * D + c);
+    }
+    for (int i = threadIdx.x; i < n; i += ATT_ROWS) {
+        Ls[i] = lse[(size_t)bh * n + i];
+        Ds[i] = delta[(size_t)bh * n + i];
+    }
+    __syncthreads();
+    const int j = blockIdx.y * ATT_ROWS + threadIdx.x;
+    if (j >= n) return;
+    float k[D], v[D], dk[D], dv[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        k[c] = base[(size_t)j * ld + inner + h * D + c] * scale;
+        v[c] = base[(size_t)j * ld + 2 * inner + h * D + c];
+        dk[c] = dv[c] = 0.f;
+    }
+    for (int i = 0; i < n; ++i) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            s += Qs[i * D + c] * k[c];
+            dp += Gs[i * D + c] * v[c];
+        }
+        const float p = __expf(s - Ls[i]);
+        const float ds = p * (dp - Ds[i]);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            dv[c] += p * Gs[i * D + c];
+            dk[c] += ds * Qs[i * D + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        dqkv[((size_t)b * n + j) * lddq + inner + h * D + c] += dk[c] * scale;
+        dqkv[((size_t)b * n + j) * lddq + 2 * inner + h * D + c] += dv[c];
+    }
+}
+
+bool vec_ok(const void* p, int ld) { return aligned16(p) && (ld % 4) == 0; }
+
+}  // namespace
+
+extern "C" int mrfa_subsample_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, int stride, float* y, int ldy) {
+    MRFA_CHECK_ARG(x && y && N > 0 && C > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, "subsample_fwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && vec_ok(x, ldx) && vec_ok(y, ldy), "subsample_fwd: needs C %% 4 == 0 and 16-byte aligned views");
+    const int Ho = H / stride, Wo = W / stride;
+    const long long total4 = (long long)N * Ho * Wo * (C / 4);
+    MRFA_CHECK_ARG(total4 < (1ll << 31), "subsample_fwd: tensor too large");
+    hipLaunchKernelGGL((subsample_kernel<false>), dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, H, W, Ho, Wo,
+                       C / 4, stride, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("subsample_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_subsample_bwd(void* stream, const float* dy, int lddy, int N, int H, int W, int C, int stride, float* dx, int lddx) {
+    MRFA_CHECK_ARG(dy && dx && N > 0 && C > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, "subsample_bwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && vec_ok(dy, lddy) && vec_ok(dx, lddx), "subsample_bwd: needs C %% 4 == 0 and 16-byte aligned views");
+    const int Ho = H / stride, Wo = W / stride;
+    const long long total4 = (long long)N * Ho * Wo * (C / 4);
+    MRFA_CHECK_ARG(total4 < (1ll << 31), "subsample_bwd: tensor too large");
+    hipLaunchKernelGGL((subsample_kernel<true>), dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, H, W, Ho, Wo,
+                       C / 4, stride, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("subsample_bwd");
+    return 0;
+}
+
+extern "C" int mrfa_upsample_add_act_fwd(void* stream, const float* lo, int ldl, int N, int Hl, int Wl, int C, int factor, const float* base,
+                                         int ldb, int relu, float* y, int ldy) {
+    MRFA_CHECK_ARG(lo && base && y && N > 0 && C > 0 && factor >= 1, "upsample_add_act_fwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && vec_ok(lo, ldl) && vec_ok(base, ldb) && vec_ok(y, ldy), "upsample_add_act_fwd: needs C %% 4 == 0, aligned views");
+    const long long total4 = (long long)N * Hl * factor * Wl * factor * (C / 4);
+    MRFA_CHECK_ARG(total4 < (1ll << 31), "upsample_add_act_fwd: tensor too large");
+    hipLaunchKernelGGL(ups_add_act_fwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, lo, ldl, Hl, Wl, C / 4, factor,
+                       base, ldb, relu, y, ldy, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("upsample_add_act_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_upsample_add_act_bwd(void* stream, const float* y, int ldy, const float* dy, int lddy, int N, int Hl, int Wl, int C,
+                                         int factor, int relu, float* dlo, int lddl, float* dbase, int lddb) {
+    MRFA_CHECK_ARG(dy && (y || !relu) && N > 0 && C > 0 && factor >= 1, "upsample_add_act_bwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && vec_ok(dy, lddy) && (!relu || vec_ok(y, ldy)) && (!dlo || vec_ok(dlo, lddl)) && (!dbase || vec_ok(dbase, lddb)),
+                   "upsample_add_act_bwd: needs C %% 4 == 0, aligned views");
+    const long long total4 = (long long)N * Hl * Wl * (C / 4);
+    MRFA_CHECK_ARG(total4 * factor * factor < (1ll << 31), "upsample_add_act_bwd: tensor too large");
+    hipLaunchKernelGGL(ups_add_act_bwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, y, ldy, dy, lddy, Hl, Wl, C / 4,
+                       factor, relu, dlo, lddl, dbase, lddb, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("upsample_add_act_bwd");
+    return 0;
+}
+
+extern "C" int mrfa_layernorm_fwd(void* stream, const float* x, int ldx, long long rows, int C, const float* gamma, const float* beta, float eps,
+                                  float* y, int ldy, float* mean, float* rstd) {
+    MRFA_CHECK_ARG(x && y && gamma && beta && mean && rstd && rows > 0 && C > 0 && C <= 64 * LN_MAXK, "layernorm_fwd: bad args (C <= 1024)");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C, gamma, beta, eps, y, ldy,
+                       mean, rstd);
+    MRFA_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_layernorm_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, const float* gamma,
+                                  const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta) {
+    MRFA_CHECK_ARG(x && dy && gamma && mean && rstd && dx && rows > 0 && C > 0 && C <= 64 * LN_MAXK, "layernorm_bwd: bad args (C <= 1024)");
+    const int rpw = rows >= 4096 ? 8 : 2;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4 * rpw)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, rows, C, gamma, mean,
+                       rstd, dx, lddx, dgamma, dbeta, rpw);
+    MRFA_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+}
+
+extern "C" int mrfa_gelu_fwd(void* stream, const float* x, int ldx, long long rows, int C, float* y, int ldy) {
+    MRFA_CHECK_ARG(x && y && rows > 0 && C > 0, "gelu_fwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && vec_ok(x, ldx) && vec_ok(y, ldy) && rows * (C / 4) < (1ll << 31), "gelu_fwd: needs C %% 4 == 0, aligned views");
+    const long long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, C / 4, y, ldy, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("gelu_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_gelu_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, float* dx, int lddx) {
+    MRFA_CHECK_ARG(x && dy && dx && rows > 0 && C > 0, "gelu_bwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && vec_ok(x, ldx) && vec_ok(dy, lddy) && vec_ok(dx, lddx) && rows * (C / 4) < (1ll << 31),
+                   "gelu_bwd: needs C %% 4 == 0, aligned views");
+    const long long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, C / 4, dx, lddx,
+                       (unsigned)total4);
+    MRFA_CHECK_LAUNCH("gelu_bwd");
+    return 0;
+}
+
+#define ATT_DISPATCH(D_, KERNEL, ...)                                                                                         \
+    do {                                                                                                                      \
+        if (d == 24) hipLaunchKernelGGL((KERNEL<24>), grid, dim3(ATT_ROWS), lds, (hipStream_t)stream, __VA_ARGS__);           \
+        else if (d == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(ATT_ROWS), lds, (hipStream_t)stream, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<32>), grid, dim3(ATT_ROWS), lds, (hipStream_t)stream, __VA_ARGS__);                   \
+    } while (0)
+
+static int att_check(const char* what, int B, int n, int heads, int d, size_t lds_floats) {
+    if (B <= 0 || n <= 0 || heads <= 0 || !(d == 16 || d == 24 || d == 32)) {
+        mrfa_set_error("%s: bad shape B=%d n=%d heads=%d d=%d (d in {16, 24, 32})", what, B, n, heads, d);
+        return 1;
+    }
+    if (lds_floats * 4 > 160 * 1024) {
+        mrfa_set_error("%s: %d tokens x %d do not fit the 160 KB LDS", what, n, d);
+        return 1;
+    }
+    return 0;
+}
+
+template <typename K>
+static int att_attr(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return 0;                     // within the default dynamic-LDS limit: nothing to raise
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : 1;
+}
+
+extern "C" int mrfa_attention_fwd(void* stream, const float* qkv, int ld, int B, int n, int heads, int d, float scale, float* out, int ldo,
+                                  float* lse) {
+    MRFA_CHECK_ARG(qkv && out && lse && vec_ok(qkv, ld), "attention_fwd: null or misaligned pointer");
+    if (att_check("attention_fwd", B, n, heads, d, (size_t)2 * n * d)) return 1;
+    const size_t lds = (size_t)2 * n * d * sizeof(float);
+    const dim3 grid(B * heads, cdiv(n, ATT_ROWS));
+    int rc = d == 24 ? att_attr(attention_fwd_kernel<24>, lds) : d == 16 ? att_attr(attention_fwd_kernel<16>, lds) : att_attr(attention_fwd_kernel<32>, lds);
+    MRFA_CHECK_ARG(rc == 0, "attention_fwd: cannot reserve %zu bytes of LDS", lds);
+    ATT_DISPATCH(d, attention_fwd_kernel, qkv, ld, n, heads, scale, out, ldo, lse);
+    MRFA_CHECK_LAUNCH("attention_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const float* out, int ldo, const float* dout, int lddo, const float* lse,
+                                  float* delta, int B, int n, int heads, int d, float scale, float* dqkv, int lddq) {
+    MRFA_CHECK_ARG(qkv && out && dout && lse && delta && dqkv && vec_ok(qkv, ld) && vec_ok(dout, lddo),
+                   "attention_bwd: null or misaligned pointer");
+    if (att_check("attention_bwd", B, n, heads, d, (size_t)2 * n * d + 2 * n)) return 1;
+    const dim3 grid(B * heads, cdiv(n, ATT_ROWS));
+    {
+        const size_t lds = (size_t)2 * n * d * sizeof(float);
+        int rc = d == 24 ? att_attr(attention_bwd_q_kernel<24>, lds) : d == 16 ? att_attr(attention_bwd_q_kernel<16>, lds)
+                                                                                 : att_attr(attention_bwd_q_kernel<32>, lds);
+        MRFA_CHECK_ARG(rc == 0, "attention_bwd: cannot reserve %zu bytes of LDS", lds);
+        ATT_DISPATCH(d, attention_bwd_q_kernel, qkv, ld, out, ldo, dout, lddo, lse, delta, n, heads, scale, dqkv, lddq);
+        MRFA_CHECK_LAUNCH("attention_bwd(q)");
+    }
+    {
+        const size_t lds = ((size_t)2 * n * d + 2 * n) * sizeof(float);
+        int rc = d == 24 ? att_attr(attention_bwd_kv_kernel<24>, lds) : d == 16 ? att_attr(attention_bwd_kv_kernel<16>, lds)
+                                                                                  : att_attr(attention_bwd_kv_kernel<32>, lds);
+        MRFA_CHECK_ARG(rc == 0, "attention_bwd: cannot reserve %zu bytes of LDS", lds);
+        ATT_DISPATCH(d, attention_bwd_kv_kernel, qkv, ld, dout, lddo, lse, delta, n, heads, scale, dqkv, lddq);
+        MRFA_CHECK_LAUNCH("attention_bwd(kv)");
+    }
+    return 0;
+}

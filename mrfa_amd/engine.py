@@ -147,8 +147,13 @@ class ConvW:
     def __init__(self, conv: torch.nn.Conv2d):
         self.conv = conv
         w = conv.weight
-        self.Cout, self.Cin, self.R, self.S = w.shape
-        self.pad = conv.padding[0] if isinstance(conv.padding, tuple) else int(conv.padding)
+        if w.dim() == 2:                       # nn.Linear = 1x1 convolution over token rows (same OI memory layout)
+            (self.Cout, self.Cin), self.R, self.S, self.pad, self.stride = w.shape, 1, 1, 0, 1
+        else:
+            self.Cout, self.Cin, self.R, self.S = w.shape
+            self.pad = conv.padding[0] if isinstance(conv.padding, tuple) else int(conv.padding)
+            st = getattr(conv, "stride", 1)
+            self.stride = st[0] if isinstance(st, tuple) else int(st)
         self.T = self.R * self.S
         self.fwd_flat = (self.Cin % 32) != 0
         self.dgrad_flat = (self.Cout % 32) != 0
@@ -758,7 +763,7 @@ class Ctx:
         return self.f64z(2 * bn.num_features) if self.train else None
 
     def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None,
-               sole_consumer: bool = False) -> View:
+               sole_consumer: bool = False, res: Optional[View] = None) -> View:
         """out = [blend_a*occ +] act(bn(x)) [*(1-occ)], optional 2x2 avg-pool.  x = raw conv output, stats = its
         epilogue-accumulated sums (train) or None (eval)."""
         scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
@@ -770,6 +775,9 @@ class Ctx:
         if blend is not None:
             a, occ = blend
             p.blend_a, p.lda, p.occ, p.ldo = a.ptr, a.ld, occ.ptr, occ.ld
+        if res is not None:                           # y = act(bn(x) + res): HRNet residual blocks
+            assert (res.N, res.H, res.W, res.C) == (x.N, x.H, x.W, x.C) and not pool and blend is None
+            p.res, p.ldr = res.ptr, res.ld
         p.y, p.ldy = out.ptr, out.ld
         self._chk(self.L.mrfa_bn_act_fwd(self.s, C.byref(p)), "bn_act_fwd")
         if self.record:
@@ -780,11 +788,11 @@ class Ctx:
             def bwd():
                 if not out.has_grad:
                     return
-                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x)
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res)
             self.tape.append(bwd)
         return out
 
-    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view):
+    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None):
         bg = bngrad(bn)
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
@@ -799,6 +807,8 @@ class Ctx:
             a, occ = blend
             q.blend_a, q.lda, q.occ, q.ldo = a.ptr, a.ld, occ.ptr, occ.ld
             q.dblend_a, q.ldda, q.docc, q.lddo = a.gptr, a.ld, occ.gptr, occ.ld
+        if res is not None:
+            q.res, q.ldr, q.dres, q.lddr = res.ptr, res.ld, res.gptr, res.ld
         q.red = red.data_ptr()
         q.dx, q.lddx = dx_view.gptr, dx_view.ld
         q.dx_overwrite = int(dx_view.st.grad_noinit)
@@ -953,6 +963,99 @@ class Ctx:
         out = out or self.new(N, H // stride, W // stride, C_)
         self._chk(self.L.mrfa_antialias_down(self.s, img_nchw.data_ptr(), N, C_, H, W, kern2d.data_ptr(), k, stride, out.ptr, out.ld),
                   "antialias_down")
+        return out
+
+    # -- MTIA prior (TokenPose_B): include/mrfa_hip.h K21 ------------------------------------------------------
+    def bn_stats(self, x: View, bn):
+        """batch statistics of x by a separate pass (train mode; None in eval): for raw conv outputs whose epilogue could
+        not accumulate them (the stride-2 convolutions, which are sub-sampled after the conv)"""
+        if not self.train:
+            return None
+        stats = self.f64z(2 * bn.num_features)
+        self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
+        return stats
+
+    def subsample(self, x: View, stride: int = 2, out: Optional[View] = None) -> View:
+        """out[n,y,x] = x[n,y*stride,x*stride]"""
+        out = out or self.new(x.N, x.H // stride, x.W // stride, x.C)
+        self._chk(self.L.mrfa_subsample_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, stride, out.ptr, out.ld), "subsample_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_subsample_bwd(self.s, out.gptr, out.ld, x.N, x.H, x.W, x.C, stride, x.gptr, x.ld), "subsample_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def conv_bn_raw(self, x: View, conv, bn, need_dx=True):
+        """raw = conv(x) for a conv of stride 1 or 2 that a BatchNorm follows -> (raw, batch statistics of raw)"""
+        cw = convw(conv)
+        if cw.stride == 1:
+            st = self.bn_stats_buf(bn)
+            return self.conv(x, conv, stats=st, need_dx=need_dx), st
+        raw = self.subsample(self.conv(x, conv, need_dx=need_dx), cw.stride)
+        return raw, self.bn_stats(raw, bn)
+
+    def ups_add(self, lo: View, base: View, factor: int = 1, relu: bool = False, out: Optional[View] = None) -> View:
+        """out = act(base + nearest_upsample(lo, factor))"""
+        assert (base.N, base.H, base.W, base.C) == (lo.N, lo.H * factor, lo.W * factor, lo.C)
+        out = out or self.new(base.N, base.H, base.W, base.C)
+        self._chk(self.L.mrfa_upsample_add_act_fwd(self.s, lo.ptr, lo.ld, lo.N, lo.H, lo.W, lo.C, factor, base.ptr, base.ld, int(relu),
+                                                   out.ptr, out.ld), "upsample_add_act_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_upsample_add_act_bwd(self.s, out.ptr, out.ld, out.gptr, out.ld, lo.N, lo.H, lo.W, lo.C, factor, int(relu),
+                                                           lo.gptr, lo.ld, base.gptr, base.ld), "upsample_add_act_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def layernorm(self, x: View, ln: torch.nn.LayerNorm, out: Optional[View] = None) -> View:
+        out = out or self.new(x.N, x.H, x.W, x.C)
+        mean, rstd = self.f32(x.rows), self.f32(x.rows)
+        self._chk(self.L.mrfa_layernorm_fwd(self.s, x.ptr, x.ld, x.rows, x.C, ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps),
+                                            out.ptr, out.ld, mean.data_ptr(), rstd.data_ptr()), "layernorm_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                bg = bngrad(ln)
+                if bg not in self.touched_bns:
+                    self.touched_bns.append(bg)
+                dg, db = bg.acc(self.pool32)
+                self._chk(self.L.mrfa_layernorm_bwd(self.s, x.ptr, x.ld, out.gptr, out.ld, x.rows, x.C, ln.weight.data_ptr(), mean.data_ptr(),
+                                                    rstd.data_ptr(), x.gptr, x.ld, dg.data_ptr(), db.data_ptr()), "layernorm_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def gelu(self, x: View, out: Optional[View] = None) -> View:
+        out = out or self.new(x.N, x.H, x.W, x.C)
+        self._chk(self.L.mrfa_gelu_fwd(self.s, x.ptr, x.ld, x.rows, x.C, out.ptr, out.ld), "gelu_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_gelu_bwd(self.s, x.ptr, x.ld, out.gptr, out.ld, x.rows, x.C, x.gptr, x.ld), "gelu_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def attention(self, qkv: View, heads: int, scale: float) -> View:
+        """qkv: (B,1,n,3*heads*d) token rows [q | k | v] -> (B,1,n,heads*d)"""
+        B, n = qkv.N, qkv.H * qkv.W
+        inner = qkv.C // 3
+        d = inner // heads
+        out = self.new(B, qkv.H, qkv.W, inner)
+        lse = self.f32(B * heads * n)
+        self._chk(self.L.mrfa_attention_fwd(self.s, qkv.ptr, qkv.ld, B, n, heads, d, scale, out.ptr, out.ld, lse.data_ptr()), "attention_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                delta = self.f32(B * heads * n)
+                self._chk(self.L.mrfa_attention_bwd(self.s, qkv.ptr, qkv.ld, out.ptr, out.ld, out.gptr, out.ld, lse.data_ptr(), delta.data_ptr(),
+                                                    B, n, heads, d, scale, qkv.gptr, qkv.ld), "attention_bwd")
+            self.tape.append(bwd)
         return out
 
     # -- GEMMs for the correlation volume -----------------------------------------------------------------------

@@ -67,6 +67,7 @@ class BnActParams(C.Structure):
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int), ("pool", C.c_int),
         ("blend_a", C.c_void_p), ("lda", C.c_int), ("occ", C.c_void_p), ("ldo", C.c_int),
         ("y", C.c_void_p), ("ldy", C.c_int),
+        ("res", C.c_void_p), ("ldr", C.c_int),
     ]
 
 
@@ -80,6 +81,7 @@ class BnBwdParams(C.Structure):
         ("dblend_a", C.c_void_p), ("ldda", C.c_int), ("docc", C.c_void_p), ("lddo", C.c_int),
         ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
         ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int), ("dx_overwrite", C.c_int),
+        ("res", C.c_void_p), ("ldr", C.c_int), ("dres", C.c_void_p), ("lddr", C.c_int),
     ]
 
 
@@ -121,6 +123,16 @@ _SIGNATURES = {
     "mrfa_blend_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I, _V, _I, _V, _I], C.c_int),
     "mrfa_antialias_down": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V, _I], C.c_int),
     "mrfa_colsum": ([_V, _V, _I, _L, _I, _V], C.c_int),
+    "mrfa_subsample_fwd": ([_V, _V, _I, _I, _I, _I, _I, _I, _V, _I], C.c_int),
+    "mrfa_subsample_bwd": ([_V, _V, _I, _I, _I, _I, _I, _I, _V, _I], C.c_int),
+    "mrfa_upsample_add_act_fwd": ([_V, _V, _I, _I, _I, _I, _I, _I, _V, _I, _I, _V, _I], C.c_int),
+    "mrfa_upsample_add_act_bwd": ([_V, _V, _I, _V, _I, _I, _I, _I, _I, _I, _I, _V, _I, _V, _I], C.c_int),
+    "mrfa_layernorm_fwd": ([_V, _V, _I, _L, _I, _V, _V, _F, _V, _I, _V, _V], C.c_int),
+    "mrfa_layernorm_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _V, _V, _V, _I, _V, _V], C.c_int),
+    "mrfa_gelu_fwd": ([_V, _V, _I, _L, _I, _V, _I], C.c_int),
+    "mrfa_gelu_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
+    "mrfa_attention_fwd": ([_V, _V, _I, _I, _I, _I, _I, _F, _V, _I, _V], C.c_int),
+    "mrfa_attention_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _V, _I, _I, _I, _I, _F, _V, _I], C.c_int),
     "mrfa_adam_prepare": ([_V, _V, _I, C.c_double, C.c_double], C.c_int),
     "mrfa_grad_absmax": ([_V, _V, _L, _V, _I], C.c_int),
     "mrfa_adam_flat": ([_V, _V, _V, _V, _V, _L, _V, C.c_double, C.c_double, _F, _F, _I, _F], C.c_int),

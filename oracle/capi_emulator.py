@@ -42,6 +42,90 @@ class Emulator:
     def __init__(self):
         self._err = b""
 
+    # ---------------------------------------------------------------- K21: MTIA prior (TokenPose_B)
+    def mrfa_subsample_fwd(self, stream, x, ldx, N, H, W, Cc, stride, y, ldy):
+        nhwc(y, N, H // stride, W // stride, ldy, Cc).copy_(nhwc(x, N, H, W, ldx, Cc)[:, ::stride, ::stride])
+        return 0
+
+    def mrfa_subsample_bwd(self, stream, dy, lddy, N, H, W, Cc, stride, dx, lddx):
+        nhwc(dx, N, H, W, lddx, Cc)[:, ::stride, ::stride].add_(nhwc(dy, N, H // stride, W // stride, lddy, Cc))
+        return 0
+
+    def mrfa_upsample_add_act_fwd(self, stream, lo, ldl, N, Hl, Wl, Cc, f, base, ldb, relu, y, ldy):
+        v = nhwc(lo, N, Hl, Wl, ldl, Cc).repeat_interleave(f, dim=1).repeat_interleave(f, dim=2) + nhwc(base, N, Hl * f, Wl * f, ldb, Cc)
+        nhwc(y, N, Hl * f, Wl * f, ldy, Cc).copy_(F.relu(v) if relu else v)
+        return 0
+
+    def mrfa_upsample_add_act_bwd(self, stream, y, ldy, dy, lddy, N, Hl, Wl, Cc, f, relu, dlo, lddl, dbase, lddb):
+        g = nhwc(dy, N, Hl * f, Wl * f, lddy, Cc).clone()
+        if relu:
+            g = torch.where(nhwc(y, N, Hl * f, Wl * f, ldy, Cc) > 0, g, torch.zeros_like(g))
+        if dbase:
+            nhwc(dbase, N, Hl * f, Wl * f, lddb, Cc).add_(g)
+        if dlo:
+            nhwc(dlo, N, Hl, Wl, lddl, Cc).add_(g.view(N, Hl, f, Wl, f, Cc).sum(dim=(2, 4)))
+        return 0
+
+    def mrfa_layernorm_fwd(self, stream, x, ldx, rows, Cc, gamma, beta, eps, y, ldy, mean, rstd):
+        xx = mat(x, rows, ldx, Cc)
+        m = xx.mean(1)
+        r = 1.0 / torch.sqrt(xx.var(1, unbiased=False) + eps)
+        mat(y, rows, ldy, Cc).copy_((xx - m[:, None]) * r[:, None] * vec(gamma, Cc) + vec(beta, Cc))
+        vec(mean, rows).copy_(m)
+        vec(rstd, rows).copy_(r)
+        return 0
+
+    def mrfa_layernorm_bwd(self, stream, x, ldx, dy, lddy, rows, Cc, gamma, mean, rstd, dx, lddx, dgamma, dbeta):
+        xh = (mat(x, rows, ldx, Cc) - vec(mean, rows)[:, None]) * vec(rstd, rows)[:, None]
+        d = mat(dy, rows, lddy, Cc)
+        g = d * vec(gamma, Cc)
+        mat(dx, rows, lddx, Cc).add_(vec(rstd, rows)[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True)))
+        if dgamma:
+            vec(dgamma, Cc).add_((d * xh).sum(0))
+        if dbeta:
+            vec(dbeta, Cc).add_(d.sum(0))
+        return 0
+
+    def mrfa_gelu_fwd(self, stream, x, ldx, rows, Cc, y, ldy):
+        mat(y, rows, ldy, Cc).copy_(F.gelu(mat(x, rows, ldx, Cc)))
+        return 0
+
+    def mrfa_gelu_bwd(self, stream, x, ldx, dy, lddy, rows, Cc, dx, lddx):
+        v = mat(x, rows, ldx, Cc)
+        cdf = 0.5 * (1 + torch.erf(v * 0.7071067811865476))
+        pdf = 0.3989422804014327 * torch.exp(-0.5 * v * v)
+        mat(dx, rows, lddx, Cc).add_(mat(dy, rows, lddy, Cc) * (cdf + v * pdf))
+        return 0
+
+    @staticmethod
+    def _qkv(qkv, ld, B, n, heads, d):
+        t = mat(qkv, B * n, ld, 3 * heads * d).view(B, n, 3, heads, d)
+        return [t[:, :, i].permute(0, 2, 1, 3) for i in range(3)]            # (B, heads, n, d) each
+
+    def mrfa_attention_fwd(self, stream, qkv, ld, B, n, heads, d, scale, out, ldo, lse):
+        q, k, v = self._qkv(qkv, ld, B, n, heads, d)
+        s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+        vec(lse, B * heads * n).copy_(torch.logsumexp(s, -1).reshape(-1))
+        o = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v)
+        mat(out, B * n, ldo, heads * d).copy_(o.permute(0, 2, 1, 3).reshape(B * n, heads * d))
+        return 0
+
+    def mrfa_attention_bwd(self, stream, qkv, ld, out, ldo, dout, lddo, lse, delta, B, n, heads, d, scale, dqkv, lddq):
+        q, k, v = self._qkv(qkv, ld, B, n, heads, d)
+        p = (torch.einsum("bhid,bhjd->bhij", q, k) * scale).softmax(-1)
+        do = mat(dout, B * n, lddo, heads * d).view(B, n, heads, d).permute(0, 2, 1, 3)
+        o = mat(out, B * n, ldo, heads * d).view(B, n, heads, d).permute(0, 2, 1, 3)
+        dl = (do * o).sum(-1)
+        vec(delta, B * heads * n).copy_(dl.reshape(-1))
+        dp = torch.einsum("bhid,bhjd->bhij", do, v)
+        ds = p * (dp - dl[..., None])
+        dq = torch.einsum("bhij,bhjd->bhid", ds, k) * scale
+        dk = torch.einsum("bhij,bhid->bhjd", ds, q) * scale
+        dv = torch.einsum("bhij,bhid->bhjd", p, do)
+        g = torch.stack([t.permute(0, 2, 1, 3) for t in (dq, dk, dv)], dim=2).reshape(B * n, 3 * heads * d)
+        mat(dqkv, B * n, lddq, 3 * heads * d).add_(g)
+        return 0
+
     # ---------------------------------------------------------------- misc
     def mrfa_version(self):
         return 1
@@ -246,6 +330,8 @@ class Emulator:
         p = _obj(pref)
         x = nhwc(p.x, p.N, p.H, p.W, p.ldx, p.C)
         u = x * vec(p.scale, p.C) + vec(p.shift, p.C)
+        if getattr(p, "res", None):
+            u = u + nhwc(p.res, p.N, p.H, p.W, p.ldr, p.C)
         if p.relu:
             u = F.relu(u)
         Ho, Wo = p.H, p.W
@@ -264,6 +350,8 @@ class Emulator:
         x = nhwc(p.x, p.N, p.H, p.W, p.ldx, Cc)
         sc, sh = vec(p.scale, Cc), vec(p.shift, Cc)
         u = x * sc + sh
+        if getattr(p, "res", None):
+            u = u + nhwc(p.res, p.N, p.H, p.W, p.ldr, Cc)
         a = F.relu(u) if p.relu else u
         Ho, Wo = (p.H // 2, p.W // 2) if p.pool else (p.H, p.W)
         dy = nhwc(p.dy, p.N, Ho, Wo, p.lddy, Cc)
@@ -281,6 +369,8 @@ class Emulator:
                     nhwc(p.docc, p.N, Ho, Wo, p.lddo, 1).add_((da * (A - a)).sum(-1, keepdim=True))
             da = da * (1 - o)
         du = torch.where(u > 0, da, torch.zeros_like(da)) if p.relu else da
+        if p.phase == 1 and getattr(p, "dres", None):
+            nhwc(p.dres, p.N, p.H, p.W, p.lddr, Cc).add_(du)
         mean = vec(p.mean, Cc) if p.mean else torch.zeros(Cc)
         invstd = vec(p.invstd, Cc) if p.invstd else torch.zeros(Cc)
         xhat = (x - mean) * invstd

@@ -751,3 +751,127 @@ def test_pack_and_unpack_multi():
         return side.done(*outs)
     ref, got = both(run)
     assert_close(ref, got, tol=1e-6, what="pack/unpack multi")
+
+
+# ---------------------------------------------------------------------------------------------- K21 (MTIA prior)
+@pytest.mark.parametrize("Cc,ld", [(64, 64), (37, 41)])
+def test_bn_residual(Cc, ld):
+    """y = relu(bn(x) + res) and its backward incl. the residual gradient (float4 and scalar kernels)"""
+    def run(side):
+        N, H, W = 2, 8, 6
+        rows = N * H * W
+        x = side.t("bnr/x", (rows, ld), -2, 2)
+        res = side.t("bnr/res", (rows, ld))
+        gamma, beta = side.t("bnr/g", (Cc,), 0.5, 1.5), side.t("bnr/b", (Cc,))
+        rm, rv = side.t("bnr/rm", (Cc,)), side.t("bnr/rv", (Cc,), 0.5, 1.5)
+        st = side.z((2 * Cc,), torch.float64)
+        side.call("mrfa_bn_stats", x.data_ptr(), ld, rows, Cc, st.data_ptr())
+        sc, sh, mean, inv = (side.z((Cc,)) for _ in range(4))
+        side.call("mrfa_bn_finalize", st.data_ptr(), rows, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, Cc, 1,
+                  sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr())
+        outs = []
+        for relu in (1, 0):
+            y = side.garbage((rows, ld))
+            p = hip.BnActParams()
+            p.x, p.ldx, p.N, p.H, p.W, p.C = x.data_ptr(), ld, N, H, W, Cc
+            p.scale, p.shift, p.relu, p.pool = sc.data_ptr(), sh.data_ptr(), relu, 0
+            p.res, p.ldr = res.data_ptr(), ld
+            p.y, p.ldy = y.data_ptr(), ld
+            side.call("mrfa_bn_act_fwd", C.byref(p))
+            dy = side.t("bnr/dy", (rows, ld))
+            dx, dres = side.t("bnr/dx0", (rows, ld)), side.t("bnr/dr0", (rows, ld))
+            dg, dbt = side.z((Cc,)), side.z((Cc,))
+            red = side.z((2 * Cc,), torch.float64)
+            q = hip.BnBwdParams()
+            q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), ld, N, H, W, Cc
+            q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), relu, 0
+            q.mean, q.invstd, q.gamma = mean.data_ptr(), inv.data_ptr(), gamma.data_ptr()
+            q.dy, q.lddy = dy.data_ptr(), ld
+            q.res, q.ldr, q.dres, q.lddr = res.data_ptr(), ld, dres.data_ptr(), ld
+            q.red, q.dx, q.lddx, q.dgamma, q.dbeta, q.train = red.data_ptr(), dx.data_ptr(), ld, dg.data_ptr(), dbt.data_ptr(), 1
+            for ph in (1, 2):
+                q.phase = ph
+                side.call("mrfa_bn_act_bwd", C.byref(q))
+            outs += [y[:, :Cc], dx[:, :Cc], dres[:, :Cc], dg, dbt]
+        return side.done(*outs)
+    ref, got = both(run)
+    assert_close(ref, got, tol=5e-4, what="bn_residual")
+
+
+def test_subsample_and_upsample_add():
+    def run(side):
+        N, H, W, Cc, ld = 2, 8, 12, 32, 36
+        x = side.t("ss/x", (N * H * W, ld))
+        y = side.garbage((N * (H // 2) * (W // 2), Cc))
+        side.call("mrfa_subsample_fwd", x.data_ptr(), ld, N, H, W, Cc, 2, y.data_ptr(), Cc)
+        dy = side.t("ss/dy", (N * (H // 2) * (W // 2), Cc))
+        dx = side.t("ss/dx0", (N * H * W, ld))
+        side.call("mrfa_subsample_bwd", dy.data_ptr(), Cc, N, H, W, Cc, 2, dx.data_ptr(), ld)
+        outs = [y, dx[:, :Cc]]
+        for f, relu in ((2, 1), (4, 1), (1, 1), (2, 0)):
+            Hl, Wl = 4, 3
+            lo = side.t("ua/lo", (N * Hl * Wl, Cc))
+            base = side.t("ua/base", (N * Hl * f * Wl * f, ld))
+            out = side.garbage((N * Hl * f * Wl * f, Cc))
+            side.call("mrfa_upsample_add_act_fwd", lo.data_ptr(), Cc, N, Hl, Wl, Cc, f, base.data_ptr(), ld, relu, out.data_ptr(), Cc)
+            g = side.t("ua/dy", (N * Hl * f * Wl * f, Cc))
+            dlo, dbase = side.t("ua/dlo0", (N * Hl * Wl, Cc)), side.t("ua/db0", (N * Hl * f * Wl * f, ld))
+            side.call("mrfa_upsample_add_act_bwd", out.data_ptr(), Cc, g.data_ptr(), Cc, N, Hl, Wl, Cc, f, relu, dlo.data_ptr(), Cc,
+                      dbase.data_ptr(), ld)
+            outs += [out, dlo, dbase[:, :Cc]]
+        return side.done(*outs)
+    ref, got = both(run)
+    assert_close(ref, got, tol=1e-6, what="subsample/upsample_add")
+
+
+@pytest.mark.parametrize("rows,Cc,ld", [(2208, 192, 192), (37, 70, 72), (5000, 512, 512)])
+def test_layernorm(rows, Cc, ld):
+    def run(side):
+        x = side.t("ln/x", (rows, ld), -2, 2)
+        gamma, beta = side.t("ln/g", (Cc,), 0.5, 1.5), side.t("ln/b", (Cc,))
+        y = side.garbage((rows, ld))
+        mean, rstd = side.z((rows,)), side.z((rows,))
+        side.call("mrfa_layernorm_fwd", x.data_ptr(), ld, rows, Cc, gamma.data_ptr(), beta.data_ptr(), 1e-5, y.data_ptr(), ld, mean.data_ptr(),
+                  rstd.data_ptr())
+        dy = side.t("ln/dy", (rows, ld))
+        dx = side.t("ln/dx0", (rows, ld))
+        dg, db = side.z((Cc,)), side.z((Cc,))
+        side.call("mrfa_layernorm_bwd", x.data_ptr(), ld, dy.data_ptr(), ld, rows, Cc, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  dx.data_ptr(), ld, dg.data_ptr(), db.data_ptr())
+        return side.done(y[:, :Cc], mean, rstd, dx[:, :Cc], dg, db)
+    ref, got = both(run)
+    assert_close(ref, got, tol=2e-4, what="layernorm")
+
+
+def test_gelu():
+    def run(side):
+        rows, Cc = 300, 576
+        x = side.t("gelu/x", (rows, Cc), -4, 4)
+        y = side.garbage((rows, Cc))
+        side.call("mrfa_gelu_fwd", x.data_ptr(), Cc, rows, Cc, y.data_ptr(), Cc)
+        dy, dx = side.t("gelu/dy", (rows, Cc)), side.t("gelu/dx0", (rows, Cc))
+        side.call("mrfa_gelu_bwd", x.data_ptr(), Cc, dy.data_ptr(), Cc, rows, Cc, dx.data_ptr(), Cc)
+        return side.done(y, dx)
+    ref, got = both(run)
+    assert_close(ref, got, tol=1e-5, what="gelu")
+
+
+@pytest.mark.parametrize("B,n,heads,d", [(2, 276, 8, 24), (1, 50, 2, 16), (1, 130, 3, 32)])
+def test_attention(B, n, heads, d):
+    """softmax(scale q k^T) v per (sample, head) and its backward against the einsum / softmax formulation of the reference
+    (tokenpose_base.py:77-91)"""
+    def run(side):
+        inner = heads * d
+        qkv = side.t("att/qkv", (B * n, 3 * inner), -2, 2)
+        out = side.garbage((B * n, inner))
+        lse = side.z((B * heads * n,))
+        scale = d ** -0.5
+        side.call("mrfa_attention_fwd", qkv.data_ptr(), 3 * inner, B, n, heads, d, scale, out.data_ptr(), inner, lse.data_ptr())
+        dout = side.t("att/do", (B * n, inner))
+        dqkv = side.t("att/dq0", (B * n, 3 * inner))
+        delta = side.z((B * heads * n,))
+        side.call("mrfa_attention_bwd", qkv.data_ptr(), 3 * inner, out.data_ptr(), inner, dout.data_ptr(), inner, lse.data_ptr(),
+                  delta.data_ptr(), B, n, heads, d, scale, dqkv.data_ptr(), 3 * inner)
+        return side.done(out, lse, dqkv)
+    ref, got = both(run)
+    assert_close(ref, got, tol=2e-4, what="attention")

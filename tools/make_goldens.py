@@ -276,8 +276,69 @@ def g4():
     print("G4 gradient goldens:", len(out))
 
 
+# ----------------------------------------------------------------------------------------------- G5 MTIA prior
+def g5_tokenpose():
+    """TokenPose_B (modules/transformer/pose_tokenpose_b.py) at vox1.yaml's mtia_kp_detector: state_dict manifest, eval and
+    train-mode outputs + BatchNorm buffers after the train forward, eval-mode gradients (strict: well conditioned) and
+    train-mode gradients (loose: batch-statistics cancellation makes fp32 itself ~1e-2 relative, measured vs fp64)."""
+    import contextlib
+    import io
+    from modules.transformer.pose_tokenpose_b import get_pose_net
+    from modules.util import convert_dict_to_attrit_dict
+    from oracle import tokenpose_oracle as TO
+    with contextlib.redirect_stdout(io.StringIO()):          # the reference prints its config
+        net = get_pose_net(convert_dict_to_attrit_dict(cases.tokenpose_cfg()), is_train=True)
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))
+    man["TokenPose_B"] = manifest(net)
+    with open(os.path.join(GOLD, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0)
+    sd = cases.tokenpose_weights(net.state_dict(), "tp")
+    b = 2
+    x = cases.images("g5/img", b, 256)
+    gk, gj = det_uniform("g5/gk", (b, 10, 2)), det_uniform("g5/gj", (b, 10, 2, 2))
+    out, names = {}, [n for n, _ in net.named_parameters()]
+    for train in (False, True):
+        sfx = "train" if train else "eval"
+        net.load_state_dict(sd)
+        net.train(train)
+        net.zero_grad()
+        r = net(x)
+        ((r["kp"] * gk).sum() + (r["jacobian"] * gj).sum()).backward()
+        out[f"kp_{sfx}"], out[f"jac_{sfx}"] = npy(r["kp"]), npy(r["jacobian"])
+        out[f"param_grad_norms_{sfx}"] = np.array([0.0 if p.grad is None else p.grad.norm().item() for _, p in net.named_parameters()],
+                                                  np.float32)
+        for n in ("pre_feature.conv1.weight", "pre_feature.layer1.0.downsample.0.weight", "pre_feature.stage2.0.fuse_layers.1.0.0.0.weight",
+                  "pre_feature.stage3.2.fuse_layers.2.0.1.0.weight", "pre_feature.stage3.3.branches.2.3.bn2.weight",
+                  "transformer.keypoint_token", "transformer.patch_to_embedding.weight", "transformer.transformer.layers.0.0.fn.fn.to_qkv.weight",
+                  "transformer.transformer.layers.11.1.fn.fn.net.3.bias", "transformer.transformer.layers.5.0.fn.norm.weight",
+                  "transformer.mlp_head.1.weight", "transformer.mlp_head_jacobian.0.bias"):
+            out[f"pgrad_{sfx}_" + n] = npy(dict(net.named_parameters())[n].grad)
+        if train:
+            bufs = dict(net.named_buffers())
+            for n in ("pre_feature.bn1.running_mean", "pre_feature.bn2.running_var", "pre_feature.stage3.3.fuse_layers.0.2.1.running_var",
+                      "pre_feature.stage2.0.fuse_layers.1.0.0.1.running_mean"):
+                out["buf_" + n] = npy(bufs[n])
+            assert int(bufs["pre_feature.bn1.num_batches_tracked"]) == 1
+        # oracle
+        P = {k: v.clone().requires_grad_(v.is_floating_point() and k in names and k != "transformer.pos_embedding") for k, v in sd.items()}
+        o = TO.tokenpose_b(x, P, "", train)
+        ((o["kp"] * gk).sum() + (o["jacobian"] * gj).sum()).backward()
+        delta(f"TokenPose_B kp {sfx}", o["kp"], r["kp"])
+        delta(f"TokenPose_B jacobian {sfx}", o["jacobian"], r["jacobian"])
+        worst = max((P[n].grad - p.grad).norm().item() / (p.grad.norm().item() + 1e-12) for n, p in net.named_parameters() if p.grad is not None)
+        print(f"   worst relative param-grad error oracle-vs-ref ({sfx}): {worst:.3e}")
+        if train:
+            for n in ("pre_feature.bn1.running_mean", "pre_feature.stage3.3.fuse_layers.0.2.1.running_var"):
+                delta("buffer " + n, P[n], bufs[n])
+    print(f"   |kp| mean {np.abs(out['kp_eval']).mean():.3f}  jac spread {out['jac_eval'].std():.3f}")
+    with open(os.path.join(GOLD, "tokenpose_param_names.json"), "w") as f:
+        json.dump(names, f)
+    np.savez_compressed(os.path.join(GOLD, "tokenpose.npz"), **out)
+    print("G5 TokenPose_B goldens:", len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose"]
     for w in which:
         print("==", w)
         globals()[w]()
