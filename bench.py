@@ -30,7 +30,28 @@ PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md,
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: BF16 dense (not the 2:1-sparsity figure)
 
 
-def cpu_baseline(batch: int, max_seconds: float = 25.0):
+def init_weights(model):
+    """deterministic random-init weights of the BASELINE architecture (no checkpoints exist offline), name-keyed PRNG"""
+    from mrfa_amd.utils.prng import fill_state_dict, fill_tokenpose_state_dict
+    out = {}
+    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+        if pfx == "encoder." and model.prior == "mtia":
+            sd = fill_tokenpose_state_dict(mod.state_dict(), tag=pfx)
+        else:
+            sd = fill_state_dict(mod.state_dict(), tag=pfx)
+            for k in list(sd):
+                if k.endswith("jacobian.weight"):
+                    sd[k] = sd[k] * 0.05
+                if k.endswith("jacobian.bias"):
+                    sd[k] = torch.tensor([1.0, 0.0, 0.0, 1.0]) + sd[k] * 0.5
+                if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
+                    sd[k] = sd[k] * 0.3
+        mod.load_state_dict(sd)
+        out.update({pfx + k: v for k, v in sd.items()})
+    return out
+
+
+def cpu_baseline(batch: int, max_seconds: float = 25.0, prior: str = "mtia"):
     """Oracle fwd+bwd (train-mode BN, same loss) on the host cores: B=1 pairs until ~max_seconds are spent."""
     from mrfa_amd.train import VOX1
     from mrfa_amd.utils.prng import det_uniform
@@ -40,17 +61,15 @@ def cpu_baseline(batch: int, max_seconds: float = 25.0):
     from mrfa_amd.train import HotPath
     # oneDNN fp32 convs stop scaling (and collapse with 256 threads on the GPU box's 2-socket host): cap at 32 threads
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    model = HotPath(VOX1)
-    P = {}
-    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
-        sd = cases.weights_for(mod.state_dict(), pfx)
-        P.update({pfx + k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()})
+    model = HotPath(VOX1, prior=prior)
+    P = {k: (v.clone().requires_grad_(not k.endswith(("running_mean", "running_var", "pos_embedding", "down.weight")))
+             if v.is_floating_point() else v.clone()) for k, v in init_weights(model).items()}
     del model
     n, t0 = 0, time.time()
     while True:
         src = det_uniform(f"cpu/src{n}", (1, 3, 256, 256), 0, 1)
         drv = det_uniform(f"cpu/drv{n}", (1, 3, 256, 256), 0, 1)
-        gen, _, _, _, _ = O.mrfa_forward(src, drv, P, size=256, train=True)
+        gen, _, _, _, _ = O.mrfa_forward(src, drv, P, size=256, train=True, prior=prior)
         loss = (gen - drv).abs().mean()
         loss.backward()
         n += 1
@@ -67,6 +86,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE config: bs=8)")
+    ap.add_argument("--prior", choices=["mtia", "fomm"], default="mtia",
+                    help="keypoint prior: mtia = TokenPose_B (BASELINE config 2, `prior_model: mtia` of vox1.yaml), fomm = KPDetector")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel (RCCL) even with one rank")
@@ -103,17 +124,8 @@ def main():
     if a.mfma:
         hip.set_mfma_mode(a.mfma)
 
-    model = HotPath(VOX1)
-    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
-        sd = fill_state_dict(mod.state_dict(), tag=pfx)
-        for k in list(sd):
-            if k.endswith("jacobian.weight"):
-                sd[k] = sd[k] * 0.05
-            if k.endswith("jacobian.bias"):
-                sd[k] = torch.tensor([1.0, 0.0, 0.0, 1.0]) + sd[k] * 0.5
-            if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
-                sd[k] = sd[k] * 0.3
-        mod.load_state_dict(sd)
+    model = HotPath(VOX1, prior=a.prior)
+    init_weights(model)
     if a.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.to(dev).train(True)
@@ -242,7 +254,7 @@ def main():
             torch.cuda.synchronize()
             fdt = (time.perf_counter() - t1) / nf
         m.train(True)
-        gflop = 375.2 * B                       # whole pair incl. 2x KPDetector, forward
+        gflop = (402.4 if a.prior == "mtia" else 375.2) * B    # whole pair incl. 2x encoder (TokenPose_B | KPDetector), forward
         fwd = {"ms_per_batch": round(1e3 * fdt, 3), "pairs_per_s_per_gpu": round(B / fdt, 2),
                "algorithmic_tflops": round(gflop / fdt / 1e3, 2), "frac_of_fp32_mfma_peak": round(gflop / fdt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)}
     if rank == 0:
@@ -284,16 +296,17 @@ def main():
         cpu = None
         if not a.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(B)
+                cpu = cpu_baseline(B, prior=a.prior)
             except Exception as ex:               # the baseline must never take the GPU number down with it
                 cpu = {"error": repr(ex)}
         line = {
             "metric": "frames/sec (256x256 source+driving pair) fwd+bwd", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "vox1.yaml shapes, FOMM KPDetector prior + DenseMotion + RaftFlow refinement, 256x256, "
+            "config": {"workload": "vox1.yaml " + ("MTIA (TokenPose_B)" if a.prior == "mtia" else "FOMM KPDetector") +
+                                   " prior + DenseMotion + RaftFlow refinement, 256x256, "
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": "fomm", "sync_bn": bool(a.sync_bn), "launch": launch,
+                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "sync_bn": bool(a.sync_bn), "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt,
         }

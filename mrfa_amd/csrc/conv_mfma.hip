@@ -380,9 +380,12 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     const bool auto_split = (p.splitk == 0);
     if (p.splitk > 1) splitk = p.splitk;
     {
-        const int max_split = auto_split ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
+        // Short K loop over many pixels (HRNet's 32..64-channel 3x3 convs at 64^2 / 32^2): a K split would add a zero-init and
+        // a reduction/epilogue pass over the whole output (2 x 20 us measured) to a 20 us kernel -- keep one launch
+        const bool short_k_big_m = KT < 32 && M > 4096;
+        const int max_split = (auto_split && !short_k_big_m) ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
         long long t = ntiles(BM, BN);
-        if (t < 384) {
+        if (t < 384 && !(short_k_big_m && t >= 128)) {
             int want = (int)((512 + t - 1) / t);
             if (auto_split) splitk = want <= max_split ? want : max_split;
             const int min_bm = (BN == 128) ? 32 : (BN == 64 ? 64 : 128);

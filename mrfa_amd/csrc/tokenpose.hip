@@ -229,153 +229,200 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ x, int ldx, const floa
 
 // ---------------------------------------------------------------------------------------------- attention
 // qkv: (B*n) rows x (3*heads*d) floats, q | k | v thirds, head h = columns [h*d, (h+1)*d) of its third ('b n (h d)',
-// tokenpose_base.py:77-78).  One workgroup = one (sample, head) x 128 query rows; K and V of the head live in LDS
-// (2 x n x d floats: 53 KB for 276 x 24), a thread owns one query row and reads K_j / V_j as LDS broadcasts.
-constexpr int ATT_ROWS = 128;
-constexpr int ATT_MAXD = 32;
+// tokenpose_base.py:77-78).  One workgroup (512 threads) = one (sample, head) x 32 query rows; K and V of the head live
+// in LDS.  A query row is shared by 16 lanes ("parts"), part p owning keys j = p, p+16, ...: 8 waves per workgroup and
+// two workgroups per CU keep 4 waves on every SIMD, which hides the LDS latency a one-thread-per-row layout exposes
+// (that version ran with 1 wave per SIMD and took 146 us per launch).  The per-row partial results (max, sum, P.V) are
+// combined with xor-shuffles inside the 16-lane group.  LDS rows are padded to d+4 floats: the 16 distinct row
+// addresses of a wave's ds_read_b128 then fall into 16 disjoint 4-bank groups.
+constexpr int ATT_ROWS = 32;
+constexpr int ATT_PARTS = 16;
+constexpr int ATT_THREADS = ATT_ROWS * ATT_PARTS;
+
+__device__ __forceinline__ float part_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < ATT_PARTS; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float part_max(float v) {
+#pragma unroll
+    for (int o = 1; o < ATT_PARTS; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 template <int D>
-__global__ __launch_bounds__(ATT_ROWS) void attention_fwd_kernel(const float* __restrict__ qkv, int ld, int n, int heads, float scale,
-                                                               float* __restrict__ out, int ldo, float* __restrict__ lse) {
+__device__ __forceinline__ void att_stage(float* dst, const float* __restrict__ src, int ld, int n) {
+    constexpr int DP = D + 4;
+    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_THREADS) {
+        const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+        *reinterpret_cast<f32x4*>(dst + r * DP + c) = *reinterpret_cast<const f32x4*>(src + (size_t)r * ld + c);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ float dot_lds(const float (&a)[D], const float* row) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 k = *reinterpret_cast<const f32x4*>(row + c);
+        s += a[c] * k[0] + a[c + 1] * k[1] + a[c + 2] * k[2] + a[c + 3] * k[3];
+    }
+    return s;
+}
+
+template <int D>
+__device__ __forceinline__ void axpy_lds(float (&acc)[D], float w, const float* row) {
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+        acc[c] += w * v[0]; acc[c + 1] += w * v[1]; acc[c + 2] += w * v[2]; acc[c + 3] += w * v[3];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(const float* __restrict__ qkv, int ld, int n, int heads, float scale,
+                                                                  float* __restrict__ out, int ldo, float* __restrict__ lse) {
+    constexpr int DP = D + 4;
     extern __shared__ float sm[];
     float* Ks = sm;
-    float* Vs = sm + (size_t)n * D;
+    float* Vs = sm + (size_t)n * DP;
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
     const float* base = qkv + (size_t)b * n * ld;
     const int inner = heads * D;
-    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_ROWS) {
-        const int j = i / (D / 4), c = (i - j * (D / 4)) * 4;
-        *reinterpret_cast<f32x4*>(Ks + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + inner + h * D + c);
-        *reinterpret_cast<f32x4*>(Vs + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + 2 * inner + h * D + c);
-    }
+    att_stage<D>(Ks, base + inner + h * D, ld, n);
+    att_stage<D>(Vs, base + 2 * inner + h * D, ld, n);
     __syncthreads();
-    const int i = blockIdx.y * ATT_ROWS + threadIdx.x;
-    if (i >= n) return;
+    const int part = threadIdx.x & (ATT_PARTS - 1);
+    const int i = blockIdx.y * ATT_ROWS + (threadIdx.x >> 4);
+    const bool ok = i < n;                                   // whole 16-lane groups share i: shuffles stay inside live groups
+    const int ii = ok ? i : n - 1;
     float q[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) q[c] = base[(size_t)i * ld + h * D + c] * scale;
-    float m = -3.0e38f;
-    for (int j = 0; j < n; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < D; ++c) s += q[c] * Ks[j * D + c];
-        m = fmaxf(m, s);
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)ii * ld + h * D + c);
+        q[c] = v[0] * scale; q[c + 1] = v[1] * scale; q[c + 2] = v[2] * scale; q[c + 3] = v[3] * scale;
     }
+    float m = -3.0e38f;
+    for (int j = part; j < n; j += ATT_PARTS) m = fmaxf(m, dot_lds<D>(q, Ks + j * DP));
+    m = part_max(m);
     float l = 0.f, acc[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.f;
-    for (int j = 0; j < n; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < D; ++c) s += q[c] * Ks[j * D + c];
-        const float p = __expf(s - m);
+    for (int j = part; j < n; j += ATT_PARTS) {
+        const float p = __expf(dot_lds<D>(q, Ks + j * DP) - m);
         l += p;
-#pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] += p * Vs[j * D + c];
+        axpy_lds<D>(acc, p, Vs + j * DP);
     }
-    const float inv = 1.f / l;
+    l = part_sum(l);
 #pragma unroll
-    for (int c = 0; c < D; ++c) out[((size_t)b * n + i) * ldo + h * D + c] = acc[c] * inv;
-    lse[(size_t)bh * n + i] = m + __logf(l);
+    for (int c = 0; c < D; ++c) acc[c] = part_sum(acc[c]);
+    if (ok && part == 0) {
+        const float inv = 1.f / l;
+        float* o = out + ((size_t)b * n + i) * ldo + h * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) o[c] = acc[c] * inv;
+        lse[(size_t)bh * n + i] = m + __logf(l);
+    }
 }
 
 // backward, query side: dq_i += scale * sum_j dS_ij K_j ; delta_i = dO_i . O_i is also written for the key side
 template <int D>
-__global__ __launch_bounds__(ATT_ROWS) void attention_bwd_q_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ o, int ldo,
-                                                                 const float* __restrict__ dout, int lddo, const float* __restrict__ lse,
-                                                                 float* __restrict__ delta, int n, int heads, float scale,
-                                                                 float* __restrict__ dqkv, int lddq) {
+__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_q_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ o, int ldo,
+                                                                    const float* __restrict__ dout, int lddo, const float* __restrict__ lse,
+                                                                    float* __restrict__ delta, int n, int heads, float scale,
+                                                                    float* __restrict__ dqkv, int lddq) {
+    constexpr int DP = D + 4;
     extern __shared__ float sm[];
     float* Ks = sm;
-    float* Vs = sm + (size_t)n * D;
+    float* Vs = sm + (size_t)n * DP;
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
     const float* base = qkv + (size_t)b * n * ld;
     const int inner = heads * D;
-    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_ROWS) {
-        const int j = i / (D / 4), c = (i - j * (D / 4)) * 4;
-        *reinterpret_cast<f32x4*>(Ks + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + inner + h * D + c);
-        *reinterpret_cast<f32x4*>(Vs + j * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)j * ld + 2 * inner + h * D + c);
-    }
+    att_stage<D>(Ks, base + inner + h * D, ld, n);
+    att_stage<D>(Vs, base + 2 * inner + h * D, ld, n);
     __syncthreads();
-    const int i = blockIdx.y * ATT_ROWS + threadIdx.x;
-    if (i >= n) return;
+    const int part = threadIdx.x & (ATT_PARTS - 1);
+    const int i = blockIdx.y * ATT_ROWS + (threadIdx.x >> 4);
+    const bool ok = i < n;
+    const int ii = ok ? i : n - 1;
     float q[D], dO[D], dq[D];
     float dl = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        q[c] = base[(size_t)i * ld + h * D + c] * scale;
-        dO[c] = dout[((size_t)b * n + i) * lddo + h * D + c];
-        dl += dO[c] * o[((size_t)b * n + i) * ldo + h * D + c];
+        q[c] = base[(size_t)ii * ld + h * D + c] * scale;
+        dO[c] = dout[((size_t)b * n + ii) * lddo + h * D + c];
+        dl += dO[c] * o[((size_t)b * n + ii) * ldo + h * D + c];
         dq[c] = 0.f;
     }
-    const float L = lse[(size_t)bh * n + i];
-    delta[(size_t)bh * n + i] = dl;
-    for (int j = 0; j < n; ++j) {
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            s += q[c] * Ks[j * D + c];
-            dp += dO[c] * Vs[j * D + c];
-        }
-        const float ds = __expf(s - L) * (dp - dl);
-#pragma unroll
-        for (int c = 0; c < D; ++c) dq[c] += ds * Ks[j * D + c];
+    const float L = lse[(size_t)bh * n + ii];
+    for (int j = part; j < n; j += ATT_PARTS) {
+        const float s = dot_lds<D>(q, Ks + j * DP);
+        const float dp = dot_lds<D>(dO, Vs + j * DP);
+        axpy_lds<D>(dq, __expf(s - L) * (dp - dl), Ks + j * DP);
     }
 #pragma unroll
-    for (int c = 0; c < D; ++c) dqkv[((size_t)b * n + i) * lddq + h * D + c] += dq[c] * scale;
+    for (int c = 0; c < D; ++c) dq[c] = part_sum(dq[c]);
+    if (ok && part == 0) {
+        delta[(size_t)bh * n + i] = dl;
+        float* g = dqkv + ((size_t)b * n + i) * lddq + h * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) g[c] += dq[c] * scale;
+    }
 }
 
-// backward, key side: a thread owns key/value row j; Q and dO of the head live in LDS
+// backward, key side: 16 lanes share key/value row j, part p owning queries i = p, p+16, ...; Q and dO of the head in LDS
 template <int D>
-__global__ __launch_bounds__(ATT_ROWS) void attention_bwd_kv_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dout,
-                                                                  int lddo, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                  int n, int heads, float scale, float* __restrict__ dqkv, int lddq) {
+__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kv_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ dout,
+                                                                     int lddo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                     int n, int heads, float scale, float* __restrict__ dqkv, int lddq) {
+    constexpr int DP = D + 4;
     extern __shared__ float sm[];
     float* Qs = sm;
-    float* Gs = sm + (size_t)n * D;
-    float* Ls = sm + (size_t)2 * n * D;
+    float* Gs = sm + (size_t)n * DP;
+    float* Ls = sm + (size_t)2 * n * DP;
     float* Ds = Ls + n;
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
     const float* base = qkv + (size_t)b * n * ld;
     const int inner = heads * D;
-    for (int i = threadIdx.x; i < n * (D / 4); i += ATT_ROWS) {
-        const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
-        *reinterpret_cast<f32x4*>(Qs + r * D + c) = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + h * D + c);
-        *reinterpret_cast<f32x4*>(Gs + r * D + c) = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * n + r) * lddo + h * D + c);
-    }
-    for (int i = threadIdx.x; i < n; i += ATT_ROWS) {
+    att_stage<D>(Qs, base + h * D, ld, n);
+    att_stage<D>(Gs, dout + (size_t)b * n * lddo + h * D, lddo, n);
+    for (int i = threadIdx.x; i < n; i += ATT_THREADS) {
         Ls[i] = lse[(size_t)bh * n + i];
         Ds[i] = delta[(size_t)bh * n + i];
     }
     __syncthreads();
-    const int j = blockIdx.y * ATT_ROWS + threadIdx.x;
-    if (j >= n) return;
+    const int part = threadIdx.x & (ATT_PARTS - 1);
+    const int j = blockIdx.y * ATT_ROWS + (threadIdx.x >> 4);
+    const bool ok = j < n;
+    const int jj = ok ? j : n - 1;
     float k[D], v[D], dk[D], dv[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        k[c] = base[(size_t)j * ld + inner + h * D + c] * scale;
-        v[c] = base[(size_t)j * ld + 2 * inner + h * D + c];
+        k[c] = base[(size_t)jj * ld + inner + h * D + c] * scale;
+        v[c] = base[(size_t)jj * ld + 2 * inner + h * D + c];
         dk[c] = dv[c] = 0.f;
     }
-    for (int i = 0; i < n; ++i) {
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            s += Qs[i * D + c] * k[c];
-            dp += Gs[i * D + c] * v[c];
-        }
+    for (int i = part; i < n; i += ATT_PARTS) {
+        const float s = dot_lds<D>(k, Qs + i * DP);
+        const float dp = dot_lds<D>(v, Gs + i * DP);
         const float p = __expf(s - Ls[i]);
-        const float ds = p * (dp - Ds[i]);
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            dv[c] += p * Gs[i * D + c];
-            dk[c] += ds * Qs[i * D + c];
-        }
+        axpy_lds<D>(dv, p, Gs + i * DP);
+        axpy_lds<D>(dk, p * (dp - Ds[i]), Qs + i * DP);
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        dqkv[((size_t)b * n + j) * lddq + inner + h * D + c] += dk[c] * scale;
-        dqkv[((size_t)b * n + j) * lddq + 2 * inner + h * D + c] += dv[c];
+        dk[c] = part_sum(dk[c]);
+        dv[c] = part_sum(dv[c]);
+    }
+    if (ok && part == 0) {
+        float* gk = dqkv + ((size_t)b * n + j) * lddq + inner + h * D;
+        float* gv = dqkv + ((size_t)b * n + j) * lddq + 2 * inner + h * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            gk[c] += dk[c] * scale;
+            gv[c] += dv[c];
+        }
     }
 }
 
@@ -473,9 +520,9 @@ extern "C" int mrfa_gelu_bwd(void* stream, const float* x, int ldx, const float*
 
 #define ATT_DISPATCH(D_, KERNEL, ...)                                                                                         \
     do {                                                                                                                      \
-        if (d == 24) hipLaunchKernelGGL((KERNEL<24>), grid, dim3(ATT_ROWS), lds, (hipStream_t)stream, __VA_ARGS__);           \
-        else if (d == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(ATT_ROWS), lds, (hipStream_t)stream, __VA_ARGS__);      \
-        else hipLaunchKernelGGL((KERNEL<32>), grid, dim3(ATT_ROWS), lds, (hipStream_t)stream, __VA_ARGS__);                   \
+        if (d == 24) hipLaunchKernelGGL((KERNEL<24>), grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, __VA_ARGS__);           \
+        else if (d == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<32>), grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, __VA_ARGS__);                   \
     } while (0)
 
 static int att_check(const char* what, int B, int n, int heads, int d, size_t lds_floats) {
@@ -499,8 +546,8 @@ static int att_attr(K kernel, size_t lds) {
 extern "C" int mrfa_attention_fwd(void* stream, const float* qkv, int ld, int B, int n, int heads, int d, float scale, float* out, int ldo,
                                   float* lse) {
     MRFA_CHECK_ARG(qkv && out && lse && vec_ok(qkv, ld), "attention_fwd: null or misaligned pointer");
-    if (att_check("attention_fwd", B, n, heads, d, (size_t)2 * n * d)) return 1;
-    const size_t lds = (size_t)2 * n * d * sizeof(float);
+    if (att_check("attention_fwd", B, n, heads, d, (size_t)2 * n * (d + 4))) return 1;
+    const size_t lds = (size_t)2 * n * (d + 4) * sizeof(float);
     const dim3 grid(B * heads, cdiv(n, ATT_ROWS));
     int rc = d == 24 ? att_attr(attention_fwd_kernel<24>, lds) : d == 16 ? att_attr(attention_fwd_kernel<16>, lds) : att_attr(attention_fwd_kernel<32>, lds);
     MRFA_CHECK_ARG(rc == 0, "attention_fwd: cannot reserve %zu bytes of LDS", lds);
@@ -513,10 +560,10 @@ extern "C" int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const 
                                   float* delta, int B, int n, int heads, int d, float scale, float* dqkv, int lddq) {
     MRFA_CHECK_ARG(qkv && out && dout && lse && delta && dqkv && vec_ok(qkv, ld) && vec_ok(dout, lddo),
                    "attention_bwd: null or misaligned pointer");
-    if (att_check("attention_bwd", B, n, heads, d, (size_t)2 * n * d + 2 * n)) return 1;
+    if (att_check("attention_bwd", B, n, heads, d, (size_t)2 * n * (d + 4) + 2 * n)) return 1;
     const dim3 grid(B * heads, cdiv(n, ATT_ROWS));
     {
-        const size_t lds = (size_t)2 * n * d * sizeof(float);
+        const size_t lds = (size_t)2 * n * (d + 4) * sizeof(float);
         int rc = d == 24 ? att_attr(attention_bwd_q_kernel<24>, lds) : d == 16 ? att_attr(attention_bwd_q_kernel<16>, lds)
                                                                                  : att_attr(attention_bwd_q_kernel<32>, lds);
         MRFA_CHECK_ARG(rc == 0, "attention_bwd: cannot reserve %zu bytes of LDS", lds);
@@ -524,7 +571,7 @@ extern "C" int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const 
         MRFA_CHECK_LAUNCH("attention_bwd(q)");
     }
     {
-        const size_t lds = ((size_t)2 * n * d + 2 * n) * sizeof(float);
+        const size_t lds = ((size_t)2 * n * (d + 4) + 2 * n) * sizeof(float);
         int rc = d == 24 ? att_attr(attention_bwd_kv_kernel<24>, lds) : d == 16 ? att_attr(attention_bwd_kv_kernel<16>, lds)
                                                                                   : att_attr(attention_bwd_kv_kernel<32>, lds);
         MRFA_CHECK_ARG(rc == 0, "attention_bwd: cannot reserve %zu bytes of LDS", lds);

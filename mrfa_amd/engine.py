@@ -916,6 +916,10 @@ class Ctx:
             self.tape.append(bwd)
         return out
 
+    def add_const(self, const: View, x: View):
+        """x += const in place, const carries no gradient (d/dx is the identity: nothing goes on the tape)"""
+        self._chk(self.L.mrfa_copy_view(self.s, const.ptr, const.ld, const.rows, const.C, x.ptr, x.ld, 1.0, 1), "copy_view(+=const)")
+
     def act(self, x: View, kind: int, out: Optional[View] = None) -> View:
         """kind 1 relu, 2 sigmoid"""
         out = out or self.new(x.N, x.H, x.W, x.C)

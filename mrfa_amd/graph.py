@@ -188,31 +188,68 @@ class GraphedTrainStep:
                     nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
                 optimizer.step()
 
-    @torch.no_grad()
-    def verify(self, replays: int = 3, tol: float = 0.5) -> float:
-        """Self-check after capture: replays graph A several times at fixed weights (BatchNorm buffers restored) and
-        returns the worst relative L2 distance between the gradients of two replays; raises if it exceeds `tol` or the
-        loss moves.  Identical inputs must give identical results up to atomic-order noise -- a replay that depends on
+    def _segments(self):
+        """flat-buffer segments to compare separately: the optimizer's parameter groups (encoder / decoder / dense_motion have
+        very different conditioning) or, without FlatAdam, the whole buffer"""
+        return list(self.opt.segments) if self.fused else [(0, self.flat.numel())]
+
+    def verify(self, replays: int = 3, tol: float = 0.5, band_mult: float = 4.0) -> float:
+        """Self-check after capture.  Graph A is replayed several times at fixed weights and every replay's gradient is
+        compared, per parameter group, with replay 0 and with an eager forward+backward at the same weights.  Identical
+        inputs must give identical results up to atomic-order noise, so the allowed relative L2 distance of a group is
+        `band_mult` x the distance between two EAGER passes (the noise band, measured here: a randomly initialised model in
+        train mode amplifies summation-order noise into 0.2 % of the decoder's gradient but into tens of percent of the
+        keypoint encoder's after the first Adam steps) + `tol`/25; the best-conditioned group is therefore checked to a few
+        percent, and a gradient that is zero or stale (distance >= 1) fails wherever the band is below 1/band_mult.  The
+        loss must agree to 1e-4.  Returns the worst distance seen in the best-conditioned group.  A replay that depends on
         what ran before it means a node of the graph is not ordered (see "kernel nodes only" above)."""
-        saved = [b.clone() for b in self.model.buffers()]
+        saved = [b.detach().clone() for b in self.model.buffers()]
+        segs = self._segments()
+
+        def dist(a, b):
+            return [float((a[lo:hi] - b[lo:hi]).norm() / (b[lo:hi].norm() + 1e-30)) for lo, hi in segs]
+
+        def eager():
+            with torch.cuda.stream(self.stream):
+                self.flat.zero_()
+                with engine.direct_param_grads():
+                    loss = l1_loss(self.model(self.src, self.drv), self.drv)
+                    loss.backward()
+                loss = float(loss.detach())
+            torch.cuda.synchronize()
+            return self.flat.double().cpu(), loss
+
+        torch.cuda.synchronize()
+        e0, eloss = eager()
+        e1, _ = eager()
+        band = dist(e1, e0)
+        allow = [band_mult * b + tol / 25.0 for b in band]
+        best = min(range(len(segs)), key=lambda k: band[k])
         ref = ref_loss = None
         worst = 0.0
-        scratch = torch.empty_like(self.flat)
-        for k in range(replays):
-            scratch.normal_()                       # unrelated device work between replays
-            float(scratch.sum())
-            self.g_fb.replay()
-            torch.cuda.synchronize()
-            g, loss = self.flat.double().cpu(), float(self.loss)
-            if ref is None:
-                ref, ref_loss = g, loss
-            else:
-                d = float((g - ref).norm() / (ref.norm() + 1e-30))
-                worst = max(worst, d)
-                if d > tol or abs(loss - ref_loss) > 1e-4 * max(1.0, abs(ref_loss)):
-                    raise RuntimeError(f"hipGraph replay {k} differs from replay 0: gradient distance {d:.3f}, loss {loss} vs {ref_loss}")
-        for b, sv in zip(self.model.buffers(), saved):
-            b.copy_(sv)
+        with torch.no_grad():
+            scratch = torch.empty_like(self.flat)
+            for k in range(replays):
+                scratch.normal_()                       # unrelated device work between replays
+                float(scratch.sum())
+                self.g_fb.replay()
+                torch.cuda.synchronize()
+                g, loss = self.flat.double().cpu(), float(self.loss)
+                if abs(loss - eloss) > 1e-4 * max(1.0, abs(eloss)):
+                    raise RuntimeError(f"hipGraph replay {k}: loss {loss} differs from the eager pass {eloss}")
+                checks = [("the eager pass", dist(g, e0))]
+                if ref is None:
+                    ref, ref_loss = g, loss
+                else:
+                    checks.append(("replay 0", dist(g, ref)))
+                for what, d in checks:
+                    worst = max(worst, d[best])
+                    bad = [(i, x, a) for i, (x, a) in enumerate(zip(d, allow)) if not x <= a]
+                    if bad:
+                        raise RuntimeError(f"hipGraph replay {k} differs from {what}: per-group gradient distances {d} exceed "
+                                           f"the allowed {allow} (eager noise band {band})")
+            for b, sv in zip(self.model.buffers(), saved):
+                b.copy_(sv)
         return worst
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:

@@ -1,6 +1,6 @@
 """MRFA model assembly (inference wiring).  reference: modules/model.py:145-216.
 
-Only the hot-path wiring is reproduced: encoder (FOMM KPDetector) -> dense_motion -> decoder (RaftFlow).  The training
+Only the hot-path wiring is reproduced: encoder (FOMM KPDetector or MTIA TokenPose_B) -> dense_motion -> decoder (RaftFlow).  The training
 losses of the reference (VGG19 perceptual pyramid, equivariance, background) need torchvision + downloaded weights and
 are out of scope; bench.py trains with the surrogate L1 loss defined there."""
 from __future__ import annotations
@@ -30,10 +30,12 @@ class MRFA(nn.Module):
         if prior == 'fomm':
             self.encoder = KPDetector(**_get(cfg, 'fomm_kp_detector'))
             self.dense_motion = DenseMotionNetwork(**_get(cfg, 'dense_motion'))
+        elif prior == 'mtia':
+            from .transformer import get_pose_net
+            self.encoder = get_pose_net(_get(cfg, 'mtia_kp_detector'), is_train=True)
+            self.dense_motion = DenseMotionNetwork(**_get(cfg, 'dense_motion'))
         else:
-            raise NotImplementedError(
-                f"prior_model={prior!r}: only the FOMM KPDetector prior is built natively so far (the MTIA TokenPose_B "
-                "encoder is SURVEY.md section 8(f) rank 1; TPSM is out of scope)")
+            raise NotImplementedError(f"prior_model={prior!r}: 'fomm' and 'mtia' are built natively; TPSM is out of scope (SURVEY.md section 8)")
         self.bg_start = train_params['bg_start']
         if self.bg_start < train_params['num_epochs']:
             raise NotImplementedError("BGMotionPredictor (resnet18) is out of scope: SURVEY.md section 8(f) rank 2")

@@ -86,7 +86,7 @@ class Transformer(nn.Module):
         the keypoint-token rows"""
         for idx, (attn, ff) in enumerate(self.layers):
             if idx > 0 and self.all_attn:
-                e.copy(pos_rows, out=x, acc=True)                          # x[:, num_keypoints:] += pos   (:155)
+                e.add_const(pos_rows, x)                                   # x[:, num_keypoints:] += pos   (:155)
             a = attn.fn.fn
             h = e.layernorm(x, attn.fn.norm)
             qkv = e.conv(h, a.to_qkv)
@@ -215,10 +215,15 @@ class TokenPose_TB_base(nn.Module):
         x = e.island(assemble, [emb, self.keypoint_token] + pos_in)[0]
         pos_rows = None
         if self.all_attn:
-            dim = self.pos_embedding.shape[-1]
-            pr = torch.zeros((B, 1, nk + n, dim), dtype=torch.float32, device=e.dev)
-            pr[:, 0, nk:] = self.pos_embedding.detach()[0, :n]
-            pos_rows = e.wrap_nhwc(pr)
+            # the constant position code tiled over the batch, zero in the keypoint-token rows; cached (it is a constant and
+            # building it inside a hipGraph capture would record a memset node)
+            key = (B, str(e.dev), self.pos_embedding.data_ptr(), self.pos_embedding._version)
+            if getattr(self, "_pos_rows_key", None) != key:
+                pr = torch.zeros((B, 1, nk + n, self.pos_embedding.shape[-1]), dtype=torch.float32, device=e.dev)
+                pr[:, 0, nk:] = self.pos_embedding.detach()[0, :n]
+                object.__setattr__(self, "_pos_rows", pr)
+                object.__setattr__(self, "_pos_rows_key", key)
+            pos_rows = e.wrap_nhwc(self._pos_rows)
         xv = self.transformer.run(e, x.view(), pos_rows)
         heads = [self.mlp_head] + ([self.mlp_head_jacobian] if self.mlp_head_jacobian is not None else [])
         params = [p for hd in heads for p in hd.parameters()]

@@ -38,8 +38,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     # -- layout
     def _flatten(self):
-        ps = [p for g in self.param_groups for p in g["params"]]
-        assert all(p.requires_grad and p.dtype == torch.float32 for p in ps)
+        # frozen parameters (TokenPose_B's sine position code is an nn.Parameter(requires_grad=False)) stay in param_groups, as
+        # they do in the reference's torch.optim.Adam, so that state_dict() indices are interchangeable; they get no slot
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        assert all(p.dtype == torch.float32 for p in ps)
         dev = ps[0].device
         self.grads = FlatGradients(ps)
         self.flat_g = self.grads.flat
@@ -53,6 +55,8 @@ class FlatAdam(torch.optim.Optimizer):
         for gi, g in enumerate(self.param_groups):
             begin = off
             for p in g["params"]:
+                if not p.requires_grad:
+                    continue
                 k = p.numel()
                 w = self.flat_w[off:off + k].view_as(p)
                 w.copy_(p.data)

@@ -25,7 +25,19 @@ VOX1 = dict(
                    generator=dict(num_channels=3, block_expansion=64, max_features=512, num_up_blocks=5),
                    driving_encoder=dict(in_features=10, block_expansion=32, max_features=512, num_blocks=5),
                    source_encoder=dict(in_features=13, block_expansion=32, max_features=512, num_blocks=5)),
-    train_params=dict(lr=2.0e-4, clip=10.0),
+    # config/vox1.yaml:117-186 (the same block in celebvhq.yaml): the MTIA prior, TokenPose_B
+    mtia_kp_detector=dict(MODEL=dict(
+        ESTIMATE_JACOBIAN=True, DATA_PREPROCESS=False, FIX_IMG2MOTION_ATTENTION=False, TRANSFORMER_DEPTH=12, TRANSFORMER_HEADS=8, DIM=192,
+        INIT_WEIGHTS=False, NAME="pose_tokenpose_b", NUM_JOINTS=10, PRETRAINED="", PATCH_SIZE=[4, 4], IMAGE_SIZE=[256, 256],
+        HEATMAP_SIZE=[64, 64], TAG_PER_JOINT=True, HIDDEN_HEATMAP_DIM=-1, MULTI_TRANSFORMER_DEPTH=[12, 12],
+        MULTI_TRANSFORMER_HEADS=[16, 16], MULTI_DIM=[48, 48], NUM_BRANCHES=1, BASE_CHANNEL=32, TRANSFORMER_MLP_RATIO=3,
+        POS_EMBEDDING_TYPE="sine-full", TEMPERATURE=0.1, TARGET_TYPE="gaussian", INIT=True, SIGMA=2,
+        EXTRA=dict(PRETRAINED_LAYERS=["conv1", "bn1", "conv2", "bn2", "layer1", "transition1", "stage2", "transition2", "stage3"],
+                   FINAL_CONV_KERNEL=1,
+                   STAGE2=dict(NUM_MODULES=1, NUM_BRANCHES=2, BLOCK="BASIC", NUM_BLOCKS=[4, 4], NUM_CHANNELS=[32, 64], FUSE_METHOD="SUM"),
+                   STAGE3=dict(NUM_MODULES=4, NUM_BRANCHES=3, BLOCK="BASIC", NUM_BLOCKS=[4, 4, 4], NUM_CHANNELS=[32, 64, 128],
+                               FUSE_METHOD="SUM")))),
+    train_params=dict(lr=2.0e-4, clip=10.0, prior_model="mtia"),
 )
 
 
@@ -33,9 +45,20 @@ class HotPath(nn.Module):
     """encoder -> dense_motion -> decoder wiring of MRFA.forward (modules/model.py:185-210), attribute names as in the
     reference so checkpoints and train.py's parameter groups line up."""
 
-    def __init__(self, cfg=VOX1):
+    def __init__(self, cfg=VOX1, prior: str = "fomm"):
+        """prior: 'fomm' = KPDetector (hourglass + soft-argmax), 'mtia' = TokenPose_B (HRNet + token transformer; the
+        `prior_model` both reference YAMLs select, model.py:170-172)"""
         super().__init__()
-        self.encoder = KPDetector(**cfg["fomm_kp_detector"])
+        self.prior = prior
+        if prior == "fomm":
+            self.encoder = KPDetector(**cfg["fomm_kp_detector"])
+        elif prior == "mtia":
+            import copy
+            from .modules.transformer import get_pose_net
+            from .modules.util import convert_dict_to_attrit_dict
+            self.encoder = get_pose_net(convert_dict_to_attrit_dict(copy.deepcopy(cfg["mtia_kp_detector"])), is_train=True)
+        else:
+            raise NotImplementedError(f"prior_model={prior!r}: 'fomm' and 'mtia' are built (TPSM is out of scope, SURVEY.md section 8)")
         self.dense_motion = DenseMotionNetwork(**cfg["dense_motion"])
         self.decoder = RaftFlow(**cfg["raft_flow"])
         self.down = AntiAliasInterpolation2d(3, 0.25)

@@ -93,3 +93,22 @@ def fill_state_dict(sd: dict, tag: str = "w", bn_perturb: bool = True, gain: flo
         else:
             out[name] = det_uniform(key, shape, -0.1, 0.1)
     return out
+
+
+def fill_tokenpose_state_dict(sd_like: dict, tag: str) -> dict:
+    """Deterministic TokenPose_B (MTIA prior) weights: He-uniform convs / Linears (activations stay O(1) through the ~60-conv
+    HRNet), BatchNorm / LayerNorm scales in [0.9, 1.1] and shifts in [-0.1, 0.1], perturbed running statistics; the analytic
+    sine position code is kept; the Jacobian head (zero-initialised in the reference, tokenpose_base.py:311-312) gets a
+    small random weight around the identity so that its gradient path is exercised."""
+    sd = fill_state_dict(sd_like, tag=tag)
+    for name, t in sd_like.items():
+        shape = tuple(t.shape)
+        if name.endswith("pos_embedding"):
+            sd[name] = t.detach().clone().float()
+        elif len(shape) == 1 and name.endswith(".weight"):
+            sd[name] = det_uniform(f"{tag}:{name}", shape, 0.9, 1.1)
+        elif name.endswith("mlp_head_jacobian.1.weight"):
+            sd[name] = sd[name] * 0.3
+        elif name.endswith("mlp_head_jacobian.1.bias"):
+            sd[name] = torch.tensor([1.0, 0.0, 0.0, 1.0]) + sd[name]
+    return sd

@@ -415,10 +415,15 @@ def raft_flow(kp_s, kp_d, dm: dict, img, img_full, P, pfx="", size=256, prior_on
 
 
 # --------------------------------------------------------------------------- MRFA wiring
-def mrfa_forward(source, driving, P, size=256, prior_only=False, train=False):
-    """MRFA.forward(is_train=False) wiring with the fomm prior.  modules/model.py:185-216."""
-    kp_s = kp_detector(source, P, "encoder.", train)
-    kp_d = kp_detector(driving, P, "encoder.", train)
+def mrfa_forward(source, driving, P, size=256, prior_only=False, train=False, prior="fomm"):
+    """MRFA.forward(is_train=False) wiring with the fomm (KPDetector) or mtia (TokenPose_B) prior.  modules/model.py:185-216."""
+    if prior == "mtia":
+        from .tokenpose_oracle import tokenpose_b
+        kp_s = tokenpose_b(source, P, "encoder", train)
+        kp_d = tokenpose_b(driving, P, "encoder", train)
+    else:
+        kp_s = kp_detector(source, P, "encoder.", train)
+        kp_d = kp_detector(driving, P, "encoder.", train)
     img_down = antialias_down(source, 0.25)
     dm = dense_motion(source, kp_d, kp_s, P, "dense_motion.", train)
     gen, warp_img, occ = raft_flow(kp_s["kp"], kp_d["kp"], dm, img_down, source, P, "decoder.",
