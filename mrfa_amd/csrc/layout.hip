@@ -64,7 +64,7 @@ __global__ void unpack_wgrad_fewout_kernel(const float* __restrict__ src, float*
         const int ci = (int)(t1 % Cin);
         const int co = (int)(t1 / Cin);
         const float v = src[((size_t)co * T + tap) * Cin + ci];
-        dst[i] = overwrite ? v : dst[i] + v;
+        if (overwrite) dst[i] = v; else atomicAdd(dst + i, v);
     }
 }
 
@@ -77,7 +77,7 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
         const int ci = (int)(t1 % Cin);
         const int co = (int)(t1 / Cin);
         const float v = src[((size_t)tap * Cout + co) * Cin + ci];
-        dst[i] = overwrite ? v : dst[i] + v;
+        if (overwrite) dst[i] = v; else atomicAdd(dst + i, v);
     }
 }
 

@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
         if (PHASE == 2 && blockIdx.y == 0 && slot == 0) {   // parameter gradients, once per channel
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (p.dbeta) p.dbeta[c + k] += (float)p.red[c + k];
-                if (p.dgamma) p.dgamma[c + k] += (float)p.red[p.C + c + k];
+                if (p.dbeta) atomicAdd(p.dbeta + c + k, (float)p.red[c + k]);         // atomic: see unpack_multi_kernel
+                if (p.dgamma) atomicAdd(p.dgamma + c + k, (float)p.red[p.C + c + k]);
             }
         }
     }
@@ -328,8 +328,8 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __re
     // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (dbeta) dbeta[c] += (float)red[c];
-    if (dgamma) dgamma[c] += (float)red[C + c];
+    if (dbeta) atomicAdd(dbeta + c, (float)red[c]);
+    if (dgamma) atomicAdd(dgamma + c, (float)red[C + c]);
 }
 
 static int pick_rows_per_block(long long rows, int chunks) {

@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const UnpackArgs a) {
     __syncthreads();
     for (int i = threadIdx.x; i < nco * seg; i += 256) {
         const int co_l = i / seg, r = i - co_l * seg;
-        float* p = d.dst + ((size_t)(co0 + co_l) * Cin + ci0) * T + r;
-        *p += lds[co_l * row + r];
+        // atomic: the two keypoint-encoder passes of a training step run their backward on two streams and accumulate into
+        // the same weight.grad (mrfa_amd/train.py HotPath.encode_pair)
+        atomicAdd(d.dst + ((size_t)(co0 + co_l) * Cin + ci0) * T + r, lds[co_l * row + r]);
     }
 }
 

@@ -127,8 +127,13 @@ class GraphedTrainStep:
     _captures = 0
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
-                 clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False):
+                 clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False,
+                 concurrent_encoder: Optional[bool] = None):
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
+        if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
+            concurrent_encoder = getattr(model, "prior", "") == "mtia"
+        if hasattr(model, "concurrent_encoder"):
+            model.concurrent_encoder = bool(concurrent_encoder)
         self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the two graphs
         self.src, self.drv = source.clone(), driving.clone()
         self.fused = getattr(optimizer, "fused_clip", False)      # mrfa_amd.optim.FlatAdam: owns the flat buffers
@@ -147,6 +152,7 @@ class GraphedTrainStep:
             try:
                 with engine.direct_param_grads():
                     l1_loss(model(self.src, self.drv), self.drv).backward()
+                self._join()
             finally:
                 engine.WGRAD_STREAM = False
             for b, sv in zip(model.buffers(), saved):
@@ -166,6 +172,7 @@ class GraphedTrainStep:
                 gen = model(self.src, self.drv)
                 loss = l1_loss(gen, self.drv)
                 loss.backward()
+                self._join()
                 # detached handles: a static output that still referenced its autograd graph would keep the graph (and
                 # the parameters' AccumulateGrad nodes bound to the capture stream) alive for the life of this object
                 self.loss, self.gen = loss.detach(), gen.detach()
@@ -187,6 +194,10 @@ class GraphedTrainStep:
                     nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
                     nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
                 optimizer.step()
+
+    def _join(self):
+        if hasattr(self.model, "join"):
+            self.model.join()
 
     def _segments(self):
         """flat-buffer segments to compare separately: the optimizer's parameter groups (encoder / decoder / dense_motion have
@@ -215,6 +226,7 @@ class GraphedTrainStep:
                 with engine.direct_param_grads():
                     loss = l1_loss(self.model(self.src, self.drv), self.drv)
                     loss.backward()
+                self._join()
                 loss = float(loss.detach())
             torch.cuda.synchronize()
             return self.flat.double().cpu(), loss

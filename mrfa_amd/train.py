@@ -62,10 +62,41 @@ class HotPath(nn.Module):
         self.dense_motion = DenseMotionNetwork(**cfg["dense_motion"])
         self.decoder = RaftFlow(**cfg["raft_flow"])
         self.down = AntiAliasInterpolation2d(3, 0.25)
+        # training on a GPU: issue the driving-frame encoder pass on a second HIP stream next to the source-frame pass.  The
+        # two passes are independent chains of small, latency-bound kernels (TokenPose_B: ~2 000 launches each, 12 us
+        # average); side by side they take 39 ms instead of 58 ms (tools/graph_two_encoders.py).  Same results as the
+        # sequential order: see engine.SIDE_PASS.  mrfa_amd.graph.GraphedTrainStep switches it on for the MTIA prior.
+        self.concurrent_encoder = False
+        self._side = None
+
+    def encode_pair(self, source, driving):
+        """(kp_source, kp_driving) = (encoder(source), encoder(driving)), reference model.py:185-186"""
+        from . import engine
+        if not (self.concurrent_encoder and self.training and source.is_cuda and torch.is_grad_enabled()
+                and engine.prepare_packs(self.encoder)):
+            return self.encoder(source), self.encoder(driving)
+        main = torch.cuda.current_stream(source.device)
+        if self._side is None or self._side.device != source.device:
+            object.__setattr__(self, "_side", torch.cuda.Stream(device=source.device))
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side), engine.side_pass() as deferred:
+            driving.record_stream(side)
+            kp_d = self.encoder(driving)
+        kp_s = self.encoder(source)
+        main.wait_stream(side)
+        for t in kp_d.values():
+            t.record_stream(main)
+        engine.apply_deferred_bn(deferred)          # the driving pass's running-statistics update, after the source pass's
+        return kp_s, kp_d
+
+    def join(self):
+        """after backward(): the side stream's backward kernels are ordered before whatever the caller issues next"""
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     def forward(self, source, driving):
-        kp_s = self.encoder(source)
-        kp_d = self.encoder(driving)
+        kp_s, kp_d = self.encode_pair(source, driving)
         img_down = self.down(source)
         dm = self.dense_motion(source, kp_d, kp_s)
         gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
@@ -113,6 +144,8 @@ def train_step(model, optimizer, source, driving, clip=10.0):
         loss = l1_loss(gen, driving)
         loss.backward()
     m = model.module if wrapped else model
+    if hasattr(m, "join"):
+        m.join()
     if clip and not fused:
         nn.utils.clip_grad_norm_(m.encoder.parameters(), max_norm=clip, norm_type=math.inf)
         nn.utils.clip_grad_norm_(m.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)

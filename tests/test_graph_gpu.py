@@ -159,3 +159,53 @@ def test_graphed_train_step_equals_eager(fused):
     # --- and the replayed step trains
     losses = [float(step(src, drv)) for _ in range(3)]
     assert losses[-1] < l0, (l0, losses)
+
+
+def test_concurrent_encoder_passes_equal_sequential():
+    """MTIA prior: the driving-frame TokenPose_B pass on a side stream (HotPath.encode_pair) gives the results of the
+    sequential order -- loss, parameter gradients (within the atomic-order noise band of two sequential runs) and the
+    BatchNorm running statistics / batch counters (source update first, driving update second)."""
+    import bench
+    from mrfa_amd import engine
+    from mrfa_amd.train import VOX1, HotPath, l1_loss
+    model = HotPath(VOX1, prior="mtia")
+    bench.init_weights(model)
+    model.to(DEV).train(True)
+    src, drv = _pairs(2, "g/conc")
+    saved = [b.clone() for b in model.buffers()]
+
+    def run(concurrent):
+        for b, sv in zip(model.buffers(), saved):
+            b.copy_(sv)
+        model.concurrent_encoder = concurrent
+        for p in model.parameters():
+            p.grad = None
+        for p in model.parameters():                       # pre-bound gradients: the direct (atomic) accumulation path
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+        with engine.direct_param_grads():
+            loss = l1_loss(model(src, drv), drv)
+            loss.backward()
+        model.join()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.double().clone() for n, p in model.named_parameters() if p.grad is not None}, \
+            {n: b.clone() for n, b in model.named_buffers()}
+
+    run(False)                                             # builds packs / gather tables (a first pass never forks)
+    l0, g0, b0 = run(False)
+    l1, g1, b1 = run(False)
+    l2, g2, b2 = run(True)
+    assert model._side is not None, "the concurrent path did not run"
+    assert abs(l2 - l0) <= 1e-5 * max(1.0, abs(l0))
+    for grp in ("encoder.", "dense_motion.", "decoder."):
+        names = [n for n in g0 if n.startswith(grp)]
+
+        def dist(a, b):
+            return (sum(float((a[n] - b[n]).pow(2).sum()) for n in names) / sum(float(b[n].pow(2).sum()) for n in names)) ** 0.5
+        band = dist(g1, g0)
+        assert dist(g2, g0) <= 4 * band + 0.02, (grp, dist(g2, g0), band)
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert (b2[n] - b0[n]).abs().max().item() <= 1e-5 + 1e-5 * b0[n].abs().max().item(), n
+        else:
+            assert torch.equal(b2[n], b0[n]), n

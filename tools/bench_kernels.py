@@ -62,12 +62,30 @@ def main():
         ("convf1 2->128 7x7 @256 (flat)", 2, 128, 7, 256, 0),
         ("final 64->3 7x7 @256", 64, 3, 7, 256, 0),
         ("conv2 128->2 3x3 @256", 128, 2, 3, 256, 0),
+        # TokenPose_B's HRNet stem (MTIA prior): ~0.6 GF each, 32 of each per stage-3 pass
+        ("hr 32->32 3x3 @64", 32, 32, 3, 64, 0),
+        ("hr 64->64 3x3 @32", 64, 64, 3, 32, 0),
+        ("hr 128->128 3x3 @16", 128, 128, 3, 16, 0),
+        ("hr 64->64 3x3 @64 (layer1)", 64, 64, 3, 64, 0),
+        ("hr 64->256 1x1 @64 (layer1)", 64, 256, 1, 64, 0),
+        ("hr 256->64 1x1 @64 (layer1)", 256, 64, 1, 64, 0),
+        ("hr 64->64 3x3 @128 (stem, then ::2)", 64, 64, 3, 128, 0),
+        ("vit 192->576 1x1 tokens", 192, 576, 1, 0, 0),
     ]
     print(f"{'layer':42s} {'fwd ms':>8s} {'TF/s':>7s} {'%pk':>5s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
     for name, ci, co, k, res, ups in shapes:
         if a.only and a.only not in name:
             continue
         conv = torch.nn.Conv2d(ci, co, k, padding=k // 2).to(dev)
+        if res == 0:                                   # token rows: (B, 1, 276, C)
+            x = e.new(B, 1, 276, ci)
+            x.st.data.normal_()
+            out = e.new(B, 1, 276, co)
+            flops = 2.0 * B * 276 * co * ci
+            e.record = False
+            t_f = time_it(lambda: e.conv(x, conv, out=out), iters=a.iters)
+            print(f"{name:42s} {t_f:8.3f} {flops / t_f / 1e9:7.1f}")
+            continue
         x = e.new(B, res, res, ci)
         x.st.data.normal_()
         ro = res << ups
