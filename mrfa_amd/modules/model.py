@@ -27,6 +27,7 @@ class MRFA(nn.Module):
         train_params = _get(cfg, 'train_params')
         self.train_params = train_params
         prior = train_params['prior_model']
+        self.prior = prior
         if prior == 'fomm':
             self.encoder = KPDetector(**_get(cfg, 'fomm_kp_detector'))
             self.dense_motion = DenseMotionNetwork(**_get(cfg, 'dense_motion'))
@@ -43,8 +44,12 @@ class MRFA(nn.Module):
         self.down = AntiAliasInterpolation2d(3, 0.25)
 
     def forward(self, x, epoch=100, is_train=True):
-        kp_s = self.encoder(x['source'])
-        kp_d = self.encoder(x['driving'])
+        if self.training:
+            kp_s = self.encoder(x['source'])
+            kp_d = self.encoder(x['driving'])
+        else:
+            from ..train import encode_pair_eval
+            kp_s, kp_d = encode_pair_eval(self.encoder, x['source'], x['driving'])
         img_down = self.down(x['source'])
         dense_motion = self.dense_motion(x['source'], kp_d, kp_s, bg_param=None, dropout_flag=False, dropout_p=0)
         gen, warp_img, occlusion = self.decoder(kp_s['kp'], kp_d['kp'], dense_motion, img=img_down, img_full=x['source'])

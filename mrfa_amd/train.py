@@ -72,8 +72,9 @@ class HotPath(nn.Module):
     def encode_pair(self, source, driving):
         """(kp_source, kp_driving) = (encoder(source), encoder(driving)), reference model.py:185-186"""
         from . import engine
-        if not (self.concurrent_encoder and self.training and source.is_cuda and torch.is_grad_enabled()
-                and engine.prepare_packs(self.encoder)):
+        if not self.training:
+            return encode_pair_eval(self.encoder, source, driving)
+        if not (self.concurrent_encoder and source.is_cuda and torch.is_grad_enabled() and engine.prepare_packs(self.encoder)):
             return self.encoder(source), self.encoder(driving)
         main = torch.cuda.current_stream(source.device)
         if self._side is None or self._side.device != source.device:
@@ -101,6 +102,14 @@ class HotPath(nn.Module):
         dm = self.dense_motion(source, kp_d, kp_s)
         gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
         return gen
+
+
+def encode_pair_eval(encoder, source, driving):
+    """eval mode: BatchNorm uses its running statistics, every sample is independent, so the source and the driving frames go
+    through the keypoint encoder as ONE batch of 2B (half the launches, twice the rows per launch)"""
+    b = source.shape[0]
+    kp = encoder(torch.cat([source, driving], dim=0))
+    return {k: v[:b] for k, v in kp.items()}, {k: v[b:] for k, v in kp.items()}
 
 
 def l1_loss(gen: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:

@@ -200,3 +200,31 @@ def test_animator_source_cache_equals_full_forward():
         an.set_source(src)
         for f, r in zip(frames, ref):
             assert (an(f) - r).abs().max().item() <= 1e-4, graph
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_mtia_pipeline_vs_oracle(train):
+    """BASELINE config 2's wiring -- TokenPose_B (MTIA prior) -> DenseMotion -> RaftFlow refinement, 256^2, B=2 -- through
+    mrfa_amd.train.HotPath against the CPU oracle, eval (batched encoder pass) and train mode (batch statistics)."""
+    import bench
+    from mrfa_amd.train import VOX1, HotPath
+    b = 2
+    src, drv = cases.images("mtia/src", b, 256), cases.images("mtia/drv", b, 256)
+    model = HotPath(VOX1, prior="mtia")
+    P = {k: v.clone() for k, v in bench.init_weights(model).items()}
+    model.to(DEV).train(train)
+    with torch.no_grad():
+        gen = model(src.to(DEV), drv.to(DEV))
+        ogen, _, oks, okd, odm = O.mrfa_forward(src, drv, P, size=256, train=train, prior="mtia")
+        if not train:
+            ks, kd = model.encode_pair(src.to(DEV), drv.to(DEV))
+            _cmp(ks["kp"], oks["kp"].numpy(), 1e-4, 2e-5, "kp_s")
+            _cmp(kd["jacobian"], okd["jacobian"].numpy(), 1e-4, 2e-5, "jacobian_d")
+    # north_star's gate is the L1 (mean-abs) distance <= 1e-3; with B=2 batch statistics (8 values per channel at the 2x2
+    # hourglass level) isolated pixels amplify fp32 summation-order differences, hence the wider max bound in train mode
+    _cmp(gen, ogen.numpy(), 5e-3 if train else 1e-3, 1e-4, what="gen")
+    if train:
+        bufs = dict(model.named_buffers())
+        for n in ("encoder.pre_feature.bn1.running_mean", "encoder.pre_feature.stage3.3.fuse_layers.0.2.1.running_var"):
+            assert (bufs[n].cpu() - P[n]).abs().max().item() <= 1e-4 * max(1.0, P[n].abs().max().item()), n
+        assert int(bufs["encoder.pre_feature.bn1.num_batches_tracked"]) == 2          # source pass + driving pass

@@ -456,3 +456,36 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
         fake_step(d, od, 2)
         for (n, p), (_, q) in zip(a.named_parameters(), d.named_parameters()):
             assert (p - q).abs().max().item() <= 4e-7, n
+
+
+def test_baseline_config1_mrfa_mtia_prior_only_plumbing():
+    """BASELINE.json configs[0] / SURVEY 8(d)(1): the MRFA counterpart with the MTIA prior, prior_only=True, one 256x256 pair,
+    is_train=False, on CPU (kernels = their ABI specification): output tuple shapes incl. the (1,3,256,1792) visualisation
+    strip (6 prior-only levels + occlusion), finite L1 / PSNR, and agreement with the oracle's wiring."""
+    import copy
+    import bench
+    from mrfa_amd.modules import MRFA
+    from mrfa_amd.modules.util import convert_dict_to_attrit_dict
+    from mrfa_amd.train import VOX1
+    from mrfa_amd.utils.prng import det_uniform
+    from oracle import mrfa_oracle as O
+    cfg = copy.deepcopy(VOX1)
+    cfg["raft_flow"]["prior_only"] = True
+    cfg["train_params"].update(prior_model="mtia", bg_start=1000, num_epochs=100)
+    m = MRFA(convert_dict_to_attrit_dict(cfg))
+    P = bench.init_weights(m)
+    m.eval()
+    src, drv = det_uniform("c1/src", (1, 3, 256, 256), 0, 1), det_uniform("c1/drv", (1, 3, 256, 256), 0, 1)
+    with emulated_hip(), torch.no_grad():
+        gen, warp, losses, kp_s, kp_d = m({"source": src, "driving": drv}, is_train=False)
+    assert gen.shape == (1, 3, 256, 256) and warp.shape == (1, 3, 256, 1792) and kp_s.shape == kp_d.shape == (1, 10, 2)
+    assert losses == {} and torch.isfinite(gen).all() and torch.isfinite(warp).all()
+    l1 = (gen - drv).abs().mean().item()
+    psnr = 10 * np.log10(1.0 / ((gen - drv) ** 2).mean().item())
+    assert np.isfinite(l1) and np.isfinite(psnr) and 0 <= gen.min() and gen.max() <= 1
+    with torch.no_grad():
+        g2, w2, k_s, k_d, _ = O.mrfa_forward(src, drv, {k: v.clone() for k, v in P.items()}, size=256, prior_only=True, train=False,
+                                             prior="mtia")
+    assert (gen - g2).abs().max().item() <= 1e-3 and (gen - g2).abs().mean().item() <= 1e-4
+    assert (warp - w2).abs().max().item() <= 1e-3
+    assert (kp_s - k_s["kp"]).abs().max().item() <= 1e-5 and (kp_d - k_d["kp"]).abs().max().item() <= 1e-5
