@@ -11,6 +11,8 @@ No CPU path exists here: every op goes through libmrfa_hip.so (mrfa_amd.hip.lib(
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Callable, List, Optional, Sequence
 
@@ -35,6 +37,10 @@ DIRECT_PARAM_GRADS = False
 # into a hipGraph this becomes a parallel branch.  Correct (tests/test_graph_gpu.py passes with it) but measured SLOWER on
 # the benchmark step (97.0 vs 93.3 ms: the big kernels already fill the chip and then compete for L2), so it is off by default.
 WGRAD_STREAM = False
+# OFF by default: HRNet's three resolution branches side by side gain 2.6 % of the step without the pass-level concurrency
+# (141.9 -> 138.2 ms) and NESTED forks (branch streams forked from the side stream of HotPath.encode_pair) crash
+# hipStreamEndCapture on ROCm 7.2 -- the pass-level concurrency (-18 ms) is the one that is used
+BRANCH_STREAMS = os.environ.get("MRFA_BRANCH_STREAMS", "0") == "1"        # Ctx.lanes(): independent branches of a program as parallel branches of the captured hipGraph
 
 
 # ---- concurrent keypoint-encoder passes (mrfa_amd.train.HotPath.encode_pair): the pass issued on the side stream
@@ -540,13 +546,87 @@ class Ctx:
         self.nbt = {}                    # BatchNorm module -> forward passes in train mode during this program
         self.ext_grads = {}              # id(tensor) -> grad for module inputs / parameters touched by islands
         self.storages: List[Storage] = []            # forward activations whose gradients live in one zero arena
-        self.pool32 = ZeroPool(device, torch.float32, 32 << 20)     # 128 MiB chunks
-        self.pool64 = ZeroPool(device, torch.float64, 1 << 18)      # 2 MiB chunks
+        self._pools = {}                 # (stream, dtype) -> ZeroPool: a chunk is zero-filled on the stream that carves it up
+        self._home = hip.stream_ptr() if device.type == "cuda" else 0
 
     # -- plumbing
     @property
     def s(self):
         return hip.stream_ptr()
+
+    def _pool(self, dtype, big: int, small: int) -> "ZeroPool":
+        st = self.s
+        p = self._pools.get((st, dtype))
+        if p is None:
+            p = self._pools[(st, dtype)] = ZeroPool(self.dev, dtype, big if st == self._home else small)
+        return p
+
+    @property
+    def pool32(self) -> "ZeroPool":
+        return self._pool(torch.float32, 32 << 20, 2 << 20)         # 128 MiB chunks (8 MiB on branch streams)
+
+    @property
+    def pool64(self) -> "ZeroPool":
+        return self._pool(torch.float64, 1 << 18, 1 << 16)          # 2 MiB chunks (512 KiB on branch streams)
+
+    # -- parallel branches inside one program (HRNet's resolution branches): only while a hipGraph is being captured -- a
+    # captured graph owns static memory, whereas eager launches would hand blocks of the caching allocator from one stream
+    # to another without the allocator knowing
+    _lanes: dict = {}
+
+    def lanes(self, n: int):
+        """n side streams for branches of this program, or [] when branches must run in line (not capturing / CPU)"""
+        if self.dev.type != "cuda" or not BRANCH_STREAMS or not torch.cuda.is_current_stream_capturing():
+            return []
+        key = (self.dev, self.s)
+        have = Ctx._lanes.setdefault(key, [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=self.dev))
+        return have[:n]
+
+    def fork(self, streams):
+        """the branch streams start after everything issued so far; in backward the home stream waits for them here"""
+        if not streams:
+            return
+        home = torch.cuda.current_stream(self.dev)
+        for st in streams:
+            st.wait_stream(home)
+        if self.record:
+            def bwd():
+                cur = torch.cuda.current_stream(self.dev)
+                for st in streams:
+                    cur.wait_stream(st)
+            self.tape.append(bwd)
+
+    def join(self, streams):
+        """the home stream waits for the branches; in backward the branch streams start from here"""
+        if not streams:
+            return
+        home = torch.cuda.current_stream(self.dev)
+        for st in streams:
+            home.wait_stream(st)
+        if self.record:
+            def bwd():
+                cur = torch.cuda.current_stream(self.dev)
+                for st in streams:
+                    st.wait_stream(cur)
+            self.tape.append(bwd)
+
+    def branch(self, stream, fn):
+        """run fn() with `stream` current (None: in line); the backward closures it records run on the same stream"""
+        if stream is None:
+            return fn()
+        n0 = len(self.tape)
+        with torch.cuda.stream(stream):
+            out = fn()
+        for i in range(n0, len(self.tape)):
+            f = self.tape[i]
+
+            def on_stream(f=f):
+                with torch.cuda.stream(stream):
+                    f()
+            self.tape[i] = on_stream
+        return out
 
     def _chk(self, rc, what):
         if rc:

@@ -131,7 +131,7 @@ class GraphedTrainStep:
                  concurrent_encoder: Optional[bool] = None):
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
-            concurrent_encoder = getattr(model, "prior", "") == "mtia"
+            concurrent_encoder = getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_CONCURRENT_ENCODER", "1") == "1"
         if hasattr(model, "concurrent_encoder"):
             model.concurrent_encoder = bool(concurrent_encoder)
         self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the two graphs

@@ -165,9 +165,20 @@ class HighResolutionModule(nn.Module):
                 y = blk.run(e, y)
             return [y]
         x = list(x)
-        for i in range(self.num_branches):
+
+        def chain(i):
+            y = x[i]
             for blk in self.branches[i]:
-                x[i] = blk.run(e, x[i])
+                y = blk.run(e, y)
+            return y
+        # the resolution branches are independent chains of small latency-bound kernels: side by side on their own streams
+        # while a hipGraph is captured (Ctx.lanes), in line otherwise
+        lanes = e.lanes(self.num_branches - 1)
+        e.fork(lanes)
+        for i in range(1, self.num_branches):
+            x[i] = e.branch(lanes[i - 1] if lanes else None, lambda i=i: chain(i))
+        x[0] = chain(0)
+        e.join(lanes)
         out = []
         for i in range(len(self.fuse_layers)):
             # y = sum_j fuse[i][j](x[j]) in the reference's order j = 0, 1, ..; ReLU closes the sum (hr_base.py:278-289)
