@@ -332,9 +332,14 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __re
     if (dgamma) atomicAdd(dgamma + c, (float)red[C + c]);
 }
 
-static int pick_rows_per_block(long long rows, int chunks) {
-    // aim for ~2048 workgroups, at least 64 rows each
-    long long want = (2048 + chunks - 1) / chunks;
+static int pick_rows_per_block(long long rows, int chunks, int C) {
+    // Every workgroup ends with one fp64 atomic per channel into the same 2C addresses, and same-address atomics serialise in
+    // L2: 512 workgroups on a 4 MB tensor spent 9 of 15 us there (tools/bn_micro.py).  Total workgroups ~ one per 64 KB of
+    // tensor, between 256 (enough to stream a few MB) and 1024 (134 MB: 55 us, vs 76 us with 2048); at least 64 rows each.
+    long long target = rows * C * 4 / 65536;
+    if (target < 256) target = 256;
+    if (target > 1024) target = 1024;
+    long long want = (target + chunks - 1) / chunks;
     long long rpb = (rows + want - 1) / want;
     if (rpb < 64) rpb = 64;
     if (rpb > 4096) rpb = 4096;
@@ -346,7 +351,7 @@ static int pick_rows_per_block(long long rows, int chunks) {
 extern "C" int mrfa_bn_stats(void* stream, const float* x, int ldx, long long rows, int C, double* stats) {
     MRFA_CHECK_ARG(x && stats && rows > 0 && C > 0, "bn_stats: bad args");
     const int chunks = cdiv(C, CH);
-    const int rpb = pick_rows_per_block(rows, chunks);
+    const int rpb = pick_rows_per_block(rows, chunks, C);
     dim3 grid(chunks, cdiv(rows, rpb));
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C, stats, rpb);
     MRFA_CHECK_LAUNCH("bn_stats");
@@ -384,7 +389,7 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)) && !(p.dres && !p.res), "bn_act_bwd: residual excludes pool and blend");
     const long long rows = (long long)p.N * p.H * p.W;
     const int chunks = cdiv(p.C, CH);
-    const int rpb = pick_rows_per_block(rows, chunks);
+    const int rpb = pick_rows_per_block(rows, chunks, p.C);
     dim3 grid(chunks, cdiv(rows, rpb));
     const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.scale) &&
                      aligned16(p.shift) && (!p.mean || (aligned16(p.mean) && aligned16(p.invstd))) && (!p.gamma || aligned16(p.gamma)) &&

@@ -208,7 +208,7 @@ class GraphedTrainStep:
         """Self-check after capture.  Graph A is replayed several times at fixed weights and every replay's gradient is
         compared, per parameter group, with replay 0 and with an eager forward+backward at the same weights.  Identical
         inputs must give identical results up to atomic-order noise, so the allowed relative L2 distance of a group is
-        `band_mult` x the distance between two EAGER passes (the noise band, measured here: a randomly initialised model in
+        `band_mult` x the largest distance between three EAGER passes (the noise band, measured here: a randomly initialised model in
         train mode amplifies summation-order noise into 0.2 % of the decoder's gradient but into tens of percent of the
         keypoint encoder's after the first Adam steps) + `tol`/25; the best-conditioned group is therefore checked to a few
         percent, and a gradient that is zero or stale (distance >= 1) fails wherever the band is below 1/band_mult.  The
@@ -234,7 +234,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         e0, eloss = eager()
         e1, _ = eager()
-        band = dist(e1, e0)
+        e2, _ = eager()
+        band = [max(t) for t in zip(dist(e1, e0), dist(e2, e0), dist(e2, e1))]      # three samples of a heavy-tailed quantity
         allow = [band_mult * b + tol / 25.0 for b in band]
         best = min(range(len(segs)), key=lambda k: band[k])
         ref = ref_loss = None
