@@ -337,8 +337,39 @@ def g5_tokenpose():
     print("G5 TokenPose_B goldens:", len(out))
 
 
+# ----------------------------------------------------------------------------------------------- G6 callers of the path
+def _ref_function(path, name, extra_globals):
+    """compile ONE function of a reference script that cannot be imported as a module here (its other imports -- imageio,
+    skimage, lpips -- are absent) straight from the reference file; nothing of it is written anywhere"""
+    import ast
+    tree = ast.parse(open(path).read())
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = dict(extra_globals)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def g6_callers():
+    """normalize_kp (animate_ddp.py:17-37) and psnr (reconstruction.py:13-19) of the reference on fixed keypoint dicts"""
+    from scipy.spatial import ConvexHull
+    ref_norm = _ref_function(os.path.join(ref_import.REF_ROOT, "animate_ddp.py"), "normalize_kp", {"torch": torch, "np": np, "ConvexHull": ConvexHull})
+    ref_psnr = _ref_function(os.path.join(ref_import.REF_ROOT, "reconstruction.py"), "psnr", {"torch": torch})
+    out = {}
+    ks, kd, k0 = cases.keypoints("g6/ks", 2), cases.keypoints("g6/kd", 2), cases.keypoints("g6/k0", 2)
+    for adapt in (False, True):
+        for rel, relj in ((False, False), (True, False), (True, True)):
+            r = ref_norm({k: v.clone() for k, v in ks.items()}, {k: v.clone() for k, v in kd.items()}, {k: v.clone() for k, v in k0.items()},
+                         adapt_movement_scale=adapt, use_relative_movement=rel, use_relative_jacobian=relj)
+            tag = f"a{int(adapt)}_r{int(rel)}_j{int(relj)}"
+            out[f"norm_kp_{tag}"], out[f"norm_jac_{tag}"] = npy(r["kp"]), npy(r["jacobian"])
+    a, b = cases.images("g6/a", 2, 32), cases.images("g6/b", 2, 32)
+    out["psnr"] = np.array([float(ref_psnr(a, b))], np.float32)
+    np.savez_compressed(os.path.join(GOLD, "callers.npz"), **out)
+    print("G6 caller goldens:", len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers"]
     for w in which:
         print("==", w)
         globals()[w]()
