@@ -298,7 +298,7 @@ def main():
                         "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / nprof, 2),
                         "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the host cores are shared with N-1 busy ranks
             try:
                 cpu = cpu_baseline(B, prior=a.prior)
             except Exception as ex:               # the baseline must never take the GPU number down with it
