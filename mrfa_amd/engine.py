@@ -37,9 +37,10 @@ DIRECT_PARAM_GRADS = False
 # into a hipGraph this becomes a parallel branch.  Correct (tests/test_graph_gpu.py passes with it) but measured SLOWER on
 # the benchmark step (97.0 vs 93.3 ms: the big kernels already fill the chip and then compete for L2), so it is off by default.
 WGRAD_STREAM = False
-# OFF by default: HRNet's three resolution branches side by side gain 2.6 % of the step without the pass-level concurrency
-# (141.9 -> 138.2 ms) and NESTED forks (branch streams forked from the side stream of HotPath.encode_pair) crash
-# hipStreamEndCapture on ROCm 7.2 -- the pass-level concurrency (-18 ms) is the one that is used
+# OFF by default (MRFA_BRANCH_STREAMS=1 to try): measured on the training step, HRNet's three resolution branches side by side
+# gain 2.6 % without the pass-level concurrency (141.9 -> 138.2 ms) and nothing on top of it; RaftFlow's two structure
+# hourglasses beside the generator encoder gain nothing (122.9 vs 126.2 ms).  NESTED forks (branch streams forked from the side
+# stream of HotPath.encode_pair) crash hipStreamEndCapture on ROCm 7.2, so a side pass (Ctx.deferred) never forks.
 BRANCH_STREAMS = os.environ.get("MRFA_BRANCH_STREAMS", "0") == "1"        # Ctx.lanes(): independent branches of a program as parallel branches of the captured hipGraph
 
 
@@ -576,7 +577,7 @@ class Ctx:
 
     def lanes(self, n: int):
         """n side streams for branches of this program, or [] when branches must run in line (not capturing / CPU)"""
-        if self.dev.type != "cuda" or not BRANCH_STREAMS or not torch.cuda.is_current_stream_capturing():
+        if self.dev.type != "cuda" or not BRANCH_STREAMS or self.deferred is not None or not torch.cuda.is_current_stream_capturing():
             return []
         key = (self.dev, self.s)
         have = Ctx._lanes.setdefault(key, [])
