@@ -274,6 +274,22 @@ int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const float* out,
                        float* delta, int B, int n, int heads, int d, float scale, float* dqkv /*+=*/, int lddq);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K22: the reference's training losses (modules/model.py:26-141,219-254): VGG19 perceptual
+ * pyramid and the ImagePyramide of the generated image.  The VGG convolutions run on K1 (bias + ReLU in the epilogue).  */
+/* nn.MaxPool2d(2, 2) of torchvision's vgg19.features (model.py:88-105).  Backward: dx[first maximum of the window in
+ * (row, column) scan order] += dy, the index ATen's max_pool2d_with_indices records.  C % 4 == 0, 16-byte aligned views.  */
+int mrfa_maxpool2_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, float* y, int ldy);
+int mrfa_maxpool2_bwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, const float* dy, int lddy, float* dx /*+=*/, int lddx);
+/* out_sum[0] += coef * sum |x - y| (fp64): with coef = weight / numel one perceptual term
+ * weight * torch.abs(x_vgg[i] - y_vgg[i].detach()).mean() of model.py:226-227; backward dx += gscale[0] * coef * sign(x - y) (gscale: device scalar = upstream gradient, may be null = 1)  */
+int mrfa_l1_diff_fwd(void* stream, const float* x, int ldx, const float* y, int ldy, long long rows, int C, double coef, double* out_sum);
+int mrfa_l1_diff_bwd(void* stream, const float* x, int ldx, const float* y, int ldy, long long rows, int C, const float* gscale, float coef,
+                     float* dx /*+=*/, int lddx);
+/* gradient of mrfa_antialias_down (K18) with respect to its NCHW input image: dx += K^T dy                        */
+int mrfa_antialias_down_bwd(void* stream, const float* dy, int lddy, int N, int C, int H, int W, const float* kern, int k, int stride,
+                            float* dx_nchw /*+=*/);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K20: optimizer step of the data-parallel path on FLAT fp32 buffers (every parameter / gradient / Adam moment of a
  * parameter group in one allocation, 16-byte aligned slices).  Replaces torch.optim.Adam(betas=(0.5, 0.999)).step()
  * (reference train.py:21, 70) and nn.utils.clip_grad_norm_(.., norm_type=inf) (train.py:65-67); the 1/world of the

@@ -776,7 +776,8 @@ class Ctx:
                               "relu_bwd")
                 if res is not None:
                     self._chk(self.L.mrfa_copy_view(self.s, out.gptr, out.ld, out.rows, out.C, res.gptr, res.ld, 1.0, 1), "res_bwd")
-                self._conv_wgrad(x, cw, out, ups, pre, bias is not None)
+                if conv.weight.requires_grad:              # frozen weights (the VGG19 of the perceptual loss): data gradient only
+                    self._conv_wgrad(x, cw, out, ups, pre, bias is not None)
                 if need_dx:
                     self._conv_dgrad(x, cw, out, ups, pre)
             self.tape.append(bwd)
@@ -1116,15 +1117,25 @@ class Ctx:
             self.tape.append(bwd)
         return out
 
-    def antialias_down(self, img_nchw: torch.Tensor, kern: torch.Tensor, stride: int, out: Optional[View] = None) -> View:
-        """AntiAliasInterpolation2d on an NCHW image -> NHWC view (no gradient: inputs are images)."""
+    def antialias_down(self, img_nchw: torch.Tensor, kern: torch.Tensor, stride: int, out: Optional[View] = None,
+                       dimg: Optional[torch.Tensor] = None) -> View:
+        """AntiAliasInterpolation2d on an NCHW image -> NHWC view.  dimg: NCHW buffer that receives (+=) the image gradient
+        (the ImagePyramide of the GENERATED image); None = the input is data."""
         N, C_, H, W = img_nchw.shape
+        assert kern.device == img_nchw.device, f"anti-alias kernel on {kern.device}, image on {img_nchw.device}: move the module"
         img_nchw = img_nchw.contiguous().float()
         k = kern.shape[-1]
         kern2d = kern[0, 0].contiguous().float()
         out = out or self.new(N, H // stride, W // stride, C_)
         self._chk(self.L.mrfa_antialias_down(self.s, img_nchw.data_ptr(), N, C_, H, W, kern2d.data_ptr(), k, stride, out.ptr, out.ld),
                   "antialias_down")
+        if self.record and dimg is not None:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_antialias_down_bwd(self.s, out.gptr, out.ld, N, C_, H, W, kern2d.data_ptr(), k, stride, dimg.data_ptr()),
+                          "antialias_down_bwd")
+            self.tape.append(bwd)
         return out
 
     # -- MTIA prior (TokenPose_B): include/mrfa_hip.h K21 ------------------------------------------------------
@@ -1219,6 +1230,29 @@ class Ctx:
                                                     B, n, heads, d, scale, qkv.gptr, qkv.ld), "attention_bwd")
             self.tape.append(bwd)
         return out
+
+    # -- training losses: include/mrfa_hip.h K22 ---------------------------------------------------------------
+    def maxpool2(self, x: View, out: Optional[View] = None) -> View:
+        out = out or self.new(x.N, x.H // 2, x.W // 2, x.C)
+        self._chk(self.L.mrfa_maxpool2_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld), "maxpool2_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_maxpool2_bwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.gptr, out.ld, x.gptr, x.ld), "maxpool2_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def l1_diff(self, x: View, y: View, acc: torch.Tensor, coef: float, gscale: Optional[torch.Tensor] = None):
+        """acc (fp64 device scalar) += coef * sum|x - y|; backward dx += gscale * coef * sign(x - y) (y is a constant: the
+        detached VGG features of the real image, model.py:226)"""
+        assert (x.N, x.H, x.W, x.C) == (y.N, y.H, y.W, y.C)
+        self._chk(self.L.mrfa_l1_diff_fwd(self.s, x.ptr, x.ld, y.ptr, y.ld, x.rows, x.C, float(coef), acc.data_ptr()), "l1_diff_fwd")
+        if self.record:
+            def bwd():
+                self._chk(self.L.mrfa_l1_diff_bwd(self.s, x.ptr, x.ld, y.ptr, y.ld, x.rows, x.C, gscale.data_ptr() if gscale is not None else None,
+                                                  coef, x.gptr, x.ld), "l1_diff_bwd")
+            self.tape.append(bwd)
 
     # -- GEMMs for the correlation volume -----------------------------------------------------------------------
     def gemm_nt(self, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, M, Nn, K, alpha, nbatch, a_bs, b_bs, c_bs, accumulate=False):

@@ -133,6 +133,11 @@ _SIGNATURES = {
     "mrfa_gelu_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_attention_fwd": ([_V, _V, _I, _I, _I, _I, _I, _F, _V, _I, _V], C.c_int),
     "mrfa_attention_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _V, _I, _I, _I, _I, _F, _V, _I], C.c_int),
+    "mrfa_maxpool2_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
+    "mrfa_maxpool2_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _V, _I], C.c_int),
+    "mrfa_l1_diff_fwd": ([_V, _V, _I, _V, _I, _L, _I, C.c_double, _V], C.c_int),
+    "mrfa_l1_diff_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _F, _V, _I], C.c_int),
+    "mrfa_antialias_down_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
     "mrfa_adam_prepare": ([_V, _V, _I, C.c_double, C.c_double], C.c_int),
     "mrfa_grad_absmax": ([_V, _V, _L, _V, _I], C.c_int),
     "mrfa_adam_flat": ([_V, _V, _V, _V, _V, _L, _V, C.c_double, C.c_double, _F, _F, _I, _F], C.c_int),

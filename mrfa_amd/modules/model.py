@@ -1,8 +1,8 @@
 """MRFA model assembly (inference wiring).  reference: modules/model.py:145-216.
 
-Only the hot-path wiring is reproduced: encoder (FOMM KPDetector or MTIA TokenPose_B) -> dense_motion -> decoder (RaftFlow).  The training
-losses of the reference (VGG19 perceptual pyramid, equivariance, background) need torchvision + downloaded weights and
-are out of scope; bench.py trains with the surrogate L1 loss defined there."""
+encoder (FOMM KPDetector or MTIA TokenPose_B) -> dense_motion -> decoder (RaftFlow), and with is_train=True the generator losses
+of mrfa_amd/losses.py (VGG19 perceptual pyramid, equivariance).  The background predictor /
+loss (resnet18) is not built; bench.py's headline step uses the surrogate L1 loss SURVEY.md 8(d) defines."""
 from __future__ import annotations
 
 import torch
@@ -42,6 +42,10 @@ class MRFA(nn.Module):
             raise NotImplementedError("BGMotionPredictor (resnet18) is out of scope: SURVEY.md section 8(f) rank 2")
         self.decoder = RaftFlow(**_get(cfg, 'raft_flow'))
         self.down = AntiAliasInterpolation2d(3, 0.25)
+        self.losses = None
+        if 'loss_weights' in train_params and 'scales' in train_params:     # model.py:150-157: pyramid + VGG19 for the perceptual term
+            from ..losses import GeneratorFullLoss
+            self.losses = GeneratorFullLoss(train_params)
 
     def forward(self, x, epoch=100, is_train=True):
         if self.training:
@@ -57,6 +61,9 @@ class MRFA(nn.Module):
         loss_values = {}
         if not is_train:
             return gen, warp_img, loss_values, kp_s['kp'], kp_d['kp']
-        raise NotImplementedError(
-            "MRFA.forward(is_train=True): the reference's perceptual/equivariance losses need torchvision VGG19 weights "
-            "(out of scope); use mrfa_amd.train.surrogate_step or compute a loss on `gen` yourself")
+        if self.losses is None:
+            raise NotImplementedError("MRFA.forward(is_train=True) needs train_params['loss_weights'] / ['scales'] (model.py:148-157)")
+        # model.py:219-246: perceptual pyramid + equivariance (+ Jacobian); the VGG19 weights are whatever self.losses.perceptual.vgg
+        # holds (pretrained torchvision weights are not available offline: load the reference's Vgg19 state_dict into it)
+        loss_values = self.losses(self.encoder, x['driving'], gen, kp_d)
+        return gen, warp_img, loss_values, kp_s['kp'], kp_d['kp']

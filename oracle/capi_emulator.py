@@ -42,6 +42,39 @@ class Emulator:
     def __init__(self):
         self._err = b""
 
+    # ---------------------------------------------------------------- K22: training losses
+    def mrfa_maxpool2_fwd(self, stream, x, ldx, N, H, W, Cc, y, ldy):
+        v = F.max_pool2d(nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2), 2)
+        nhwc(y, N, H // 2, W // 2, ldy, Cc).copy_(v.permute(0, 2, 3, 1))
+        return 0
+
+    def mrfa_maxpool2_bwd(self, stream, x, ldx, N, H, W, Cc, dy, lddy, dx, lddx):
+        xx = nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        with torch.enable_grad():
+            out = F.max_pool2d(xx, 2)
+        (g,) = torch.autograd.grad(out, xx, nhwc(dy, N, H // 2, W // 2, lddy, Cc).permute(0, 3, 1, 2).contiguous())
+        nhwc(dx, N, H, W, lddx, Cc).add_(g.permute(0, 2, 3, 1))
+        return 0
+
+    def mrfa_l1_diff_fwd(self, stream, x, ldx, y, ldy, rows, Cc, coef, out_sum):
+        vec(out_sum, 1, torch.float64).add_(coef * (mat(x, rows, ldx, Cc) - mat(y, rows, ldy, Cc)).abs().double().sum())
+        return 0
+
+    def mrfa_l1_diff_bwd(self, stream, x, ldx, y, ldy, rows, Cc, gscale, coef, dx, lddx):
+        g = (float(vec(gscale, 1)[0]) if gscale else 1.0) * coef
+        mat(dx, rows, lddx, Cc).add_(g * torch.sign(mat(x, rows, ldx, Cc) - mat(y, rows, ldy, Cc)))
+        return 0
+
+    def mrfa_antialias_down_bwd(self, stream, dy, lddy, N, Cc, H, W, kern, k, stride, dx):
+        ker = _flat(kern, k * k).view(1, 1, k, k).expand(Cc, 1, k, k)
+        ka = k // 2
+        img = torch.zeros(N, Cc, H, W, requires_grad=True)
+        with torch.enable_grad():
+            v = F.conv2d(F.pad(img, (ka, ka, ka, ka)), ker, groups=Cc)[:, :, ::stride, ::stride]
+        (g,) = torch.autograd.grad(v, img, nhwc(dy, N, H // stride, W // stride, lddy, Cc).permute(0, 3, 1, 2).contiguous())
+        _flat(dx, N * Cc * H * W).view(N, Cc, H, W).add_(g)
+        return 0
+
     # ---------------------------------------------------------------- K21: MTIA prior (TokenPose_B)
     def mrfa_subsample_fwd(self, stream, x, ldx, N, H, W, Cc, stride, y, ldy):
         nhwc(y, N, H // stride, W // stride, ldy, Cc).copy_(nhwc(x, N, H, W, ldx, Cc)[:, ::stride, ::stride])

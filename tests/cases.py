@@ -88,3 +88,14 @@ def tokenpose_cfg(image_size: int = 256, depth: int = 12):
 def tokenpose_weights(sd_like: dict, tag: str) -> dict:
     """deterministic TokenPose_B weights (mrfa_amd.utils.prng.fill_tokenpose_state_dict)"""
     return fill_tokenpose_state_dict(sd_like, tag)
+
+
+def vgg_weights(sd_like: dict) -> dict:
+    """deterministic VGG19 weights for the loss tests (the pretrained ones do not exist offline): He-uniform convolutions with a
+    small positive bias so that ReLU keeps about half of every feature map alive through 16 layers; mean / std stay analytic"""
+    sd = fill_state_dict({k: v for k, v in sd_like.items() if k not in ("mean", "std")}, tag="vgg")
+    for k in list(sd):
+        if k.endswith(".bias"):
+            sd[k] = sd[k].abs() * 0.5
+    sd["mean"], sd["std"] = sd_like["mean"].detach().clone(), sd_like["std"].detach().clone()
+    return sd

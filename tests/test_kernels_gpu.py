@@ -875,3 +875,43 @@ def test_attention(B, n, heads, d):
         return side.done(out, lse, dqkv)
     ref, got = both(run)
     assert_close(ref, got, tol=2e-4, what="attention")
+
+
+# ---------------------------------------------------------------------------------------------- K22 (training losses)
+def test_maxpool2_with_ties():
+    """2x2 max-pool forward / backward; inputs are ReLU outputs quantised to 3 levels, so most windows tie and the gradient must
+    go to the first maximum in scan order (ATen's index)"""
+    def run(side):
+        N, H, W, Cc, ld = 2, 6, 8, 32, 36
+        x = torch.relu(torch.round(side.t("mp/x", (N * H * W, ld), -2, 2)))
+        y = side.garbage((N * (H // 2) * (W // 2), Cc))
+        side.call("mrfa_maxpool2_fwd", x.data_ptr(), ld, N, H, W, Cc, y.data_ptr(), Cc)
+        dy = side.t("mp/dy", (N * (H // 2) * (W // 2), Cc))
+        dx = side.t("mp/dx0", (N * H * W, ld))
+        side.call("mrfa_maxpool2_bwd", x.data_ptr(), ld, N, H, W, Cc, dy.data_ptr(), Cc, dx.data_ptr(), ld)
+        return side.done(y, dx[:, :Cc])
+    ref, got = both(run)
+    assert_close(ref, got, tol=0, what="maxpool2")
+
+
+def test_l1_diff_and_antialias_backward():
+    def run(side):
+        rows, Cc = 5000, 64
+        x, y = side.t("l1/x", (rows, Cc)), side.t("l1/y", (rows, Cc))
+        y[::7] = x[::7]                                             # exact zeros of the difference: sign(0) = 0
+        out = side.z((1,), torch.float64)
+        side.call("mrfa_l1_diff_fwd", x.data_ptr(), Cc, y.data_ptr(), Cc, rows, Cc, 0.125, out.data_ptr())
+        g = side.t("l1/g", (1,), 0.5, 1.5)
+        dx = side.t("l1/dx0", (rows, Cc))
+        side.call("mrfa_l1_diff_bwd", x.data_ptr(), Cc, y.data_ptr(), Cc, rows, Cc, g.data_ptr(), 0.25, dx.data_ptr(), Cc)
+        outs = [out.float(), dx]
+        for k, stride in ((5, 2), (13, 4), (29, 8)):
+            N, Cn, H, W = 2, 3, 32, 48
+            kern = side.t(f"aa/k{k}", (k, k), 0, 1)
+            dy = side.t(f"aa/dy{k}", (N * (H // stride) * (W // stride), 4))
+            dimg = side.t(f"aa/dx{k}", (N, Cn, H, W))
+            side.call("mrfa_antialias_down_bwd", dy.data_ptr(), 4, N, Cn, H, W, kern.data_ptr(), k, stride, dimg.data_ptr())
+            outs.append(dimg)
+        return side.done(*outs)
+    ref, got = both(run)
+    assert_close(ref, got, tol=2e-5, what="l1_diff / antialias_bwd")

@@ -1,0 +1,140 @@
+"""Generator training losses (reference modules/model.py:26-141,219-246) against
+tests/golden/losses.npz, recorded from the reference's OWN MRFA.forward(is_train=True) (tools/make_goldens.py:g7_losses):
+the oracle restatement, the product through the C-ABI emulator (CPU) and the product on the MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mrfa_amd.losses import GeneratorFullLoss, PerceptualLoss, Transform, Vgg19
+from oracle import losses_oracle as LO
+from tests import cases
+from tests.emu import emulated_hip
+
+SCALES = [1, 0.5, 0.25, 0.125]
+W_PERC = [10, 10, 10, 10, 10]
+TRAIN_PARAMS = dict(scales=SCALES, transform_params=dict(sigma_affine=0.05, sigma_tps=0.005, points_tps=5),
+                    loss_weights=dict(perceptual=W_PERC, equivariance=10, equivariance_jacobian=10))
+
+
+def _g(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "losses.npz")))
+
+
+def _vgg(dev="cpu"):
+    v = Vgg19()
+    v.load_state_dict(cases.vgg_weights(v.state_dict()))
+    return v.to(dev)
+
+
+def _transform(g, dev="cpu"):
+    t = Transform(1, sigma_affine=0.05, sigma_tps=0.005, points_tps=5)
+    t.theta = torch.from_numpy(g["theta"]).to(dev)
+    t.control_points = torch.from_numpy(g["control_points"]).to(dev)
+    t.control_params = torch.from_numpy(g["control_params"]).to(dev)
+    return t
+
+
+def test_vgg19_state_dict_is_the_references():
+    names = list(Vgg19().state_dict())
+    assert names[:4] == ["mean", "std", "slice1.0.weight", "slice1.0.bias"] and names[-1] == "slice5.28.bias" and len(names) == 28
+    assert [k for k in names if k.startswith("slice4.")] == [f"slice4.{i}.{p}" for i in (12, 14, 16, 19) for p in ("weight", "bias")]
+
+
+def test_oracle_vs_reference_goldens(golden_dir):
+    g = _g(golden_dir)
+    P = {k: v for k, v in cases.vgg_weights(Vgg19().state_dict()).items()}
+    gen, real = cases.images("g7/gen", 1, 256).requires_grad_(True), cases.images("g7/real", 1, 256)
+    val = LO.perceptual(gen, real, P, SCALES, W_PERC)
+    assert abs(val.item() - g["alone_perceptual"][0]) <= 1e-4 * g["alone_perceptual"][0]
+    val.backward()
+    assert np.abs(gen.grad[:, :, ::4, ::4].numpy() - g["alone_dgen_s4"]).max() <= 1e-4 * np.abs(g["alone_dgen_s4"]).max()
+    pyr = LO.image_pyramid(real, SCALES)
+    for s in SCALES:
+        assert np.abs(pyr[f"prediction_{s}"][:, :, ::2, ::2].numpy() - g[f"pyr_{s}_s2"]).max() <= 1e-5
+    th, cp, cq = (torch.from_numpy(g[k]) for k in ("theta", "control_points", "control_params"))
+    kq = cases.keypoints("g7/kq", 1)
+    assert np.abs(LO.warp_coordinates(kq["kp"], th, cp, cq).numpy() - g["warp_kp"]).max() <= 1e-6
+    assert np.abs(LO.warp_jacobian(kq["kp"], th, cp, cq).detach().numpy() - g["warp_jac"]).max() <= 1e-5
+    assert np.abs(LO.transform_frame(real, th, cp, cq)[:, :, ::4, ::4].numpy() - g["warp_frame_s4"]).max() <= 1e-5
+
+
+def _check_alone(g, dev):
+    gen, real = cases.images("g7/gen", 1, 256).to(dev).requires_grad_(True), cases.images("g7/real", 1, 256).to(dev)
+    loss = PerceptualLoss(SCALES, W_PERC, _vgg(dev)).to(dev)
+    val = loss(gen, real)
+    assert abs(val.item() - g["alone_perceptual"][0]) <= 2e-4 * g["alone_perceptual"][0], (val.item(), g["alone_perceptual"][0])
+    (val * 1.0).backward()
+    d = gen.grad.detach().cpu()
+    assert abs(d.norm().item() - g["alone_dgen_norm"][0]) <= 2e-3 * g["alone_dgen_norm"][0]
+    # sign(x - y), the ReLU masks and the max-pool argmax are discontinuous: summation-order differences flip isolated
+    # elements, so single pixels are compared at 2 % of the gradient's scale and the bulk through the mean error
+    err = np.abs(d[:, :, ::4, ::4].numpy() - g["alone_dgen_s4"])
+    assert err.max() <= 2e-2 * np.abs(g["alone_dgen_s4"]).max() and err.mean() <= 2e-4 * np.abs(g["alone_dgen_s4"]).max()
+    feats = _vgg(dev)(real)
+    for i, f in enumerate(feats):
+        assert abs(f.mean().item() - g[f"vgg_{i}_mean"][0]) <= 1e-4 * max(1.0, abs(g[f"vgg_{i}_mean"][0]))
+    t = _transform(g, dev)
+    kq = {k: v.to(dev) for k, v in cases.keypoints("g7/kq", 1).items()}
+    assert np.abs(t.warp_coordinates(kq["kp"]).cpu().numpy() - g["warp_kp"]).max() <= 1e-5
+    assert np.abs(t.jacobian(kq["kp"].clone().requires_grad_(True)).detach().cpu().numpy() - g["warp_jac"]).max() <= 1e-4
+    assert np.abs(t.transform_frame(real)[:, :, ::4, ::4].cpu().numpy() - g["warp_frame_s4"]).max() <= 1e-4
+
+
+def _check_full(g, golden_dir, dev):
+    """the reference's whole MRFA.forward(is_train=True): generator in front, three encoder passes, all loss terms, backward"""
+    from mrfa_amd.train import VOX1, HotPath
+    model = HotPath(VOX1, prior="fomm")
+    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+        mod.load_state_dict(cases.weights_for(mod.state_dict(), pfx))
+    model.to(dev).train(True)
+    src, drv = cases.images("g7/src", 1, 256).to(dev), cases.images("g7/drv", 1, 256).to(dev)
+    full = GeneratorFullLoss(TRAIN_PARAMS, _vgg(dev)).to(dev)
+    kp_s, kp_d = model.encoder(src), model.encoder(drv)
+    dm = model.dense_motion(src, kp_d, kp_s)
+    gen, _, _ = model.decoder(kp_s["kp"], kp_d["kp"], dm, img=model.down(src), img_full=src)
+    # train-mode BatchNorm over ONE sample (4 values per channel at the 2x2 hourglass level) is ill-conditioned: the fp32 reference
+    # itself is mean 8e-5 / max 8.5e-4 from an fp64 run of the same forward, the fp32 oracle mean 1.0e-4 / max 1.2e-3 from the reference
+    gerr = np.abs(gen.detach().cpu()[:, :, ::4, ::4].numpy() - g["gen_s4"])
+    assert gerr.mean() <= 5e-4 and gerr.max() <= 1e-2, (gerr.mean(), gerr.max())       # north_star's gate: L1 (mean) <= 1e-3
+    lv = full(model.encoder, drv, gen, kp_d, transform=_transform(g, dev))
+    assert abs(lv["perceptual"].item() - g["perceptual"][0]) <= 1e-3 * g["perceptual"][0], (lv["perceptual"].item(), g["perceptual"][0])
+    assert abs(lv["equivariance"].item() - g["equivariance"][0]) <= 1e-3 * g["equivariance"][0] + 1e-4
+    ej = lv["equivariance_jacobian"].detach().cpu().numpy()
+    assert np.abs(ej - g["equivariance_jacobian"]).max() <= 1e-3 * np.abs(g["equivariance_jacobian"]).max() + 1e-3
+    sum(v.mean() for v in lv.values()).backward()
+    names = json.load(open(os.path.join(golden_dir, "losses_param_names.json")))
+    params = dict(model.named_parameters())
+    ref = g["param_grad_norms"]
+    big = ref.max()
+    errs = []
+    for n, rn in zip(names, ref):
+        if n.startswith("vgg."):
+            continue
+        gn = float(params[n].grad.norm()) if params[n].grad is not None else 0.0
+        errs.append(abs(gn - rn) / max(rn, 1e-3 * big))
+    # B=1 batch statistics + the discontinuous perceptual gradient: per-parameter norms agree to ~1e-3 in the median; the worst few
+    # (convolutions in front of a 4-value BatchNorm) wander by several percent, as between the fp32 reference and its fp64 run
+    assert len(errs) > 300 and np.median(errs) <= 1e-2 and max(errs) <= 0.2, (np.median(errs), max(errs))
+
+
+def test_product_through_abi_emulator_alone(golden_dir):
+    with emulated_hip():
+        _check_alone(_g(golden_dir), "cpu")
+
+
+def test_product_through_abi_emulator_full_training_forward(golden_dir):
+    with emulated_hip():
+        _check_full(_g(golden_dir), golden_dir, "cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_alone(golden_dir):
+    _check_alone(_g(golden_dir), "cuda:0")
+
+
+@pytest.mark.gpu
+def test_gpu_full_training_forward(golden_dir):
+    _check_full(_g(golden_dir), golden_dir, "cuda:0")

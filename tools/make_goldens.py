@@ -368,8 +368,99 @@ def g6_callers():
     print("G6 caller goldens:", len(out))
 
 
+# ----------------------------------------------------------------------------------------------- G7 training losses
+def g7_losses():
+    """The reference's OWN MRFA.forward(is_train=True) (model.py:183-257: Vgg19 79-121, ImagePyramide, Transform, loss wiring)
+    on CPU, fomm prior, B=1, deterministic weights.  torchvision is absent: `models.vgg19` is bound to the published VGG19
+    architecture (oracle/losses_oracle.py) with deterministic weights, `.cuda()` is neutralised (model.py:155,157)."""
+    import modules.model as RM
+    from oracle import losses_oracle as LO
+    from mrfa_amd.train import VOX1
+
+    class _Features(torch.nn.Module):            # stands in for torchvision.models.vgg19(pretrained=True): only .features is used
+        def __init__(self):
+            super().__init__()
+            layers, cin = [], 3
+            for v in LO.VGG19_CFG:
+                if v == 'M':
+                    layers.append(torch.nn.MaxPool2d(2, 2))
+                else:
+                    layers += [torch.nn.Conv2d(cin, v, 3, padding=1), torch.nn.ReLU(inplace=True)]
+                    cin = v
+            self.features = torch.nn.Sequential(*layers)
+    RM.models.vgg19 = lambda pretrained=True: _Features()
+    old_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    made = []
+    old_init = RM.Transform.__init__
+
+    def rec_init(self, bs, **kw):
+        old_init(self, bs, **kw)
+        made.append(self)
+    RM.Transform.__init__ = rec_init
+    try:
+        cfg = RU.convert_dict_to_attrit_dict({
+            "fomm_kp_detector": cases.KP_DETECTOR_CFG, "dense_motion": cases.DENSE_MOTION_CFG, "raft_flow": cases.raft_cfg(256),
+            "train_params": dict(prior_model="fomm", num_epochs=100, bg_start=1000, scales=[1, 0.5, 0.25, 0.125], clip=10, lr=2.0e-4,
+                                 transform_params=dict(sigma_affine=0.05, sigma_tps=0.005, points_tps=5),
+                                 loss_weights=dict(perceptual=[10, 10, 10, 10, 10], equivariance=10, equivariance_jacobian=10))})
+        m = RM.MRFA(cfg)
+    finally:
+        torch.nn.Module.cuda = old_cuda
+    load(m.encoder, "encoder.")
+    load(m.dense_motion, "dense_motion.")
+    load(m.decoder, "decoder.")
+    vsd = cases.vgg_weights(m.vgg.state_dict())
+    m.vgg.load_state_dict(vsd)
+    m.train(True)
+    b = 1
+    x = {"source": cases.images("g7/src", b, 256), "driving": cases.images("g7/drv", b, 256)}
+    torch.manual_seed(1234)
+    gen, warp_img, lv, kp_s, kp_d = m(x, epoch=0, is_train=True)
+    total = sum(v.mean() for v in lv.values())
+    total.backward()
+    tr = made[-1]
+    out = {"perceptual": np.array([lv["perceptual"].item()], np.float32), "equivariance": np.array([lv["equivariance"].item()], np.float32),
+           "equivariance_jacobian": npy(lv["equivariance_jacobian"]), "gen_s4": npy(gen[:, :, ::4, ::4]),
+           "theta": npy(tr.theta), "control_points": npy(tr.control_points), "control_params": npy(tr.control_params),
+           "kp_d": npy(kp_d)}
+    names = [n for n, p in m.named_parameters() if p.grad is not None]
+    out["param_grad_norms"] = np.array([dict(m.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+    with open(os.path.join(GOLD, "losses_param_names.json"), "w") as f:
+        json.dump(names, f)
+    # stand-alone pieces on fixed inputs (so that the loss module can be checked without the generator in front of it)
+    g_in, r_in = cases.images("g7/gen", b, 256).requires_grad_(True), cases.images("g7/real", b, 256)
+    pg, pr = m.pyramid(g_in), m.pyramid(r_in)
+    val = 0
+    for sc in m.scales:
+        xv, yv = m.vgg(pg["prediction_" + str(sc)]), m.vgg(pr["prediction_" + str(sc)])
+        for i, w in enumerate(m.loss_weights["perceptual"]):
+            val = val + w * torch.abs(xv[i] - yv[i].detach()).mean()
+    val.backward()
+    out["alone_perceptual"] = np.array([val.item()], np.float32)
+    out["alone_dgen_s4"] = npy(g_in.grad[:, :, ::4, ::4])
+    out["alone_dgen_norm"] = np.array([g_in.grad.norm().item()], np.float32)
+    for sc in m.scales:
+        out[f"pyr_{sc}_s2"] = npy(pr["prediction_" + str(sc)][:, :, ::2, ::2])
+    feats = m.vgg(r_in)
+    for i, f in enumerate(feats):
+        out[f"vgg_{i}_mean"] = np.array([f.mean().item(), f.abs().max().item()], np.float32)
+    kq = cases.keypoints("g7/kq", b)
+    out["warp_kp"] = npy(tr.warp_coordinates(kq["kp"]))
+    out["warp_jac"] = npy(tr.jacobian(kq["kp"].clone().requires_grad_(True)))
+    out["warp_frame_s4"] = npy(tr.transform_frame(r_in)[:, :, ::4, ::4])
+    # oracle deltas
+    P = {k: v.clone() for k, v in vsd.items()}
+    o_val = LO.perceptual(g_in.detach(), r_in, P, m.scales, m.loss_weights["perceptual"])
+    print(f"   perceptual ref {val.item():.6f} oracle {o_val.item():.6f}")
+    delta("warp_coordinates", LO.warp_coordinates(kq["kp"], tr.theta, tr.control_points, tr.control_params), tr.warp_coordinates(kq["kp"]))
+    delta("transform_frame", LO.transform_frame(r_in, tr.theta, tr.control_points, tr.control_params), tr.transform_frame(r_in))
+    np.savez_compressed(os.path.join(GOLD, "losses.npz"), **out)
+    print("G7 loss goldens:", len(out), {k: float(v.mean()) for k, v in lv.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses"]
     for w in which:
         print("==", w)
         globals()[w]()
