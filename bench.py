@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE config: bs=8)")
     ap.add_argument("--prior", choices=["mtia", "fomm"], default="mtia",
                     help="keypoint prior: mtia = TokenPose_B (BASELINE config 2, `prior_model: mtia` of vox1.yaml), fomm = KPDetector")
+    ap.add_argument("--loss", choices=["surrogate", "reference"], default="surrogate",
+                    help="surrogate = mean|gen - driving| (SURVEY 8(d), the headline); reference = the reference's generator objective: VGG19 "
+                         "perceptual pyramid + equivariance terms (mrfa_amd/losses.py; VGG19 weights random: no checkpoint offline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel (RCCL) even with one rank")
@@ -147,7 +150,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    step = lambda: train_step(model, opt, src, drv, clip=clip)
+    loss_fn = None
+    if a.loss == "reference":
+        from mrfa_amd.losses import GeneratorFullLoss
+        from mrfa_amd.train import reference_loss
+        from mrfa_amd.utils.prng import fill_state_dict as _fill
+        full = GeneratorFullLoss(dict(scales=[1, 0.5, 0.25, 0.125], transform_params=dict(sigma_affine=0.05, sigma_tps=0.005, points_tps=5),
+                                      loss_weights=dict(perceptual=[10, 10, 10, 10, 10], equivariance=10, equivariance_jacobian=10)))
+        vsd = full.perceptual.vgg.state_dict()
+        vnew = _fill({k: v for k, v in vsd.items() if k not in ("mean", "std")}, tag="vgg")
+        vnew.update({k: (v.abs() * 0.5) for k, v in vnew.items() if k.endswith(".bias")})
+        vnew["mean"], vnew["std"] = vsd["mean"], vsd["std"]
+        full.perceptual.vgg.load_state_dict(vnew)
+        full.to(dev)
+        loss_fn = lambda m_, s_, d_: reference_loss(m_.module if hasattr(m_, "module") else m_, full, s_, d_)
+    step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
     launch = "eager"
     if use_graph:
         # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
@@ -157,7 +174,7 @@ def main():
         ok = 1
         try:
             gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange),
-                                     overlap_wgrad=a.wgrad_stream)
+                                     overlap_wgrad=a.wgrad_stream, loss_fn=loss_fn)
             try:
                 replay_noise = gstep.verify()         # replays must agree with each other and with eager passes, or the graph is not used
             except RuntimeError as ex:                # the noise band is a sampled, heavy-tailed quantity: a mis-ordered graph fails
@@ -179,7 +196,7 @@ def main():
             if world > 1:                         # (bucket views would unbind FlatAdam's flat .grad views)
                 model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                                   broadcast_buffers=False, gradient_as_bucket_view=not fused)
-                step = lambda: train_step(model, opt, src, drv, clip=clip)
+                step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
 
     for _ in range(a.warmup):
         loss = step()
@@ -205,10 +222,10 @@ def main():
         for prm in bare.parameters():
             prm.grad = None
         nprof = max(2, min(a.steps, 4))
-        train_step(bare, opt, src, drv, clip=clip)
+        train_step(bare, opt, src, drv, clip=clip, loss_fn=loss_fn)
         Ctx.profile = []
         for _ in range(nprof):
-            train_step(bare, opt, src, drv, clip=clip)
+            train_step(bare, opt, src, drv, clip=clip, loss_fn=loss_fn)
         torch.cuda.synchronize()
         prof, Ctx.profile = Ctx.profile, None
 
@@ -217,7 +234,7 @@ def main():
         # for the record (outside the timed region): the same step with every conv on the native fp32 matrix pipe
         try:
             hip.set_mfma_mode("f32")
-            g2 = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange))
+            g2 = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange), loss_fn=loss_fn)
             for _ in range(2):
                 g2(src, drv)
             barrier()
@@ -309,7 +326,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "vox1.yaml " + ("MTIA (TokenPose_B)" if a.prior == "mtia" else "FOMM KPDetector") +
                                    " prior + DenseMotion + RaftFlow refinement, 256x256, "
-                                   f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, surrogate L1 loss",
+                                   f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, " +
+                                   ("surrogate L1 loss" if a.loss == "surrogate" else
+                                    "the reference's generator losses (VGG19 perceptual pyramid on random-init weights + equivariance, 3 encoder passes)"),
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "sync_bn": bool(a.sync_bn), "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt,

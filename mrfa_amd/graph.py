@@ -128,8 +128,10 @@ class GraphedTrainStep:
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
                  clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False,
-                 concurrent_encoder: Optional[bool] = None):
+                 concurrent_encoder: Optional[bool] = None, loss_fn=None):
+        """loss_fn(model, source, driving) -> scalar loss; None = the surrogate mean|model(source, driving) - driving|"""
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
+        self.loss_fn = loss_fn
         if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
             concurrent_encoder = getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_CONCURRENT_ENCODER", "1") == "1"
         if hasattr(model, "concurrent_encoder"):
@@ -151,7 +153,7 @@ class GraphedTrainStep:
             engine.WGRAD_STREAM = overlap_wgrad
             try:
                 with engine.direct_param_grads():
-                    l1_loss(model(self.src, self.drv), self.drv).backward()
+                    self._loss()[0].backward()
                 self._join()
             finally:
                 engine.WGRAD_STREAM = False
@@ -169,13 +171,12 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_fb, stream=self.stream), engine.direct_param_grads():
                 self.flat.zero_()
                 self.packs.run()
-                gen = model(self.src, self.drv)
-                loss = l1_loss(gen, self.drv)
+                loss, gen = self._loss()
                 loss.backward()
                 self._join()
                 # detached handles: a static output that still referenced its autograd graph would keep the graph (and
                 # the parameters' AccumulateGrad nodes bound to the capture stream) alive for the life of this object
-                self.loss, self.gen = loss.detach(), gen.detach()
+                self.loss, self.gen = loss.detach(), (gen.detach() if gen is not None else None)
         finally:
             engine.CAPTURE_KEY = 0
             engine.WGRAD_STREAM = False
@@ -194,6 +195,12 @@ class GraphedTrainStep:
                     nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
                     nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
                 optimizer.step()
+
+    def _loss(self):
+        if self.loss_fn is not None:
+            return self.loss_fn(self.model, self.src, self.drv), None
+        gen = self.model(self.src, self.drv)
+        return l1_loss(gen, self.drv), gen
 
     def _join(self):
         if hasattr(self.model, "join"):
@@ -220,11 +227,18 @@ class GraphedTrainStep:
         def dist(a, b):
             return [float((a[lo:hi] - b[lo:hi]).norm() / (b[lo:hi].norm() + 1e-30)) for lo, hi in segs]
 
+        def reseed():
+            # a loss with random draws (the equivariance transform of the reference's objective): the same device-generator state
+            # before every eager pass and every replay, so that all of them see the same draw
+            if self.loss_fn is not None:
+                torch.cuda.manual_seed(20261002)
+
         def eager():
+            reseed()
             with torch.cuda.stream(self.stream):
                 self.flat.zero_()
                 with engine.direct_param_grads():
-                    loss = l1_loss(self.model(self.src, self.drv), self.drv)
+                    loss = self._loss()[0]
                     loss.backward()
                 self._join()
                 loss = float(loss.detach())
@@ -245,6 +259,7 @@ class GraphedTrainStep:
             for k in range(replays):
                 scratch.normal_()                       # unrelated device work between replays
                 float(scratch.sum())
+                reseed()
                 self.g_fb.replay()
                 torch.cuda.synchronize()
                 g, loss = self.flat.double().cpu(), float(self.loss)

@@ -162,14 +162,17 @@ class Transform:
     theta (B,2,3), control_points (1,P*P,2), control_params (B,1,P*P)); `generator` makes the draw reproducible in tests."""
 
     def __init__(self, bs, generator: Optional[torch.Generator] = None, device=None, **kwargs):
-        noise = torch.normal(mean=0, std=kwargs['sigma_affine'] * torch.ones([bs, 2, 3]), generator=generator)
-        self.theta = (noise + torch.eye(2, 3).view(1, 2, 3)).to(device)
+        # drawn on `device` (no host tensors: a hipGraph capture cannot copy from pageable host memory; the device generator is
+        # graph-safe), same distributions as the reference's CPU draws
+        # (torch.normal(mean, std_tensor) validates std with a host round trip, which a capture forbids: randn * sigma instead)
+        noise = torch.randn([bs, 2, 3], device=device, generator=generator) * kwargs['sigma_affine']
+        self.theta = noise + torch.eye(2, 3, device=device).view(1, 2, 3)
         self.bs = bs
         self.tps = ('sigma_tps' in kwargs) and ('points_tps' in kwargs)
         if self.tps:
             p = kwargs['points_tps']
-            self.control_points = make_coordinate_grid((p, p), noise).reshape(1, p * p, 2).to(device)
-            self.control_params = torch.normal(mean=0, std=kwargs['sigma_tps'] * torch.ones([bs, 1, p ** 2]), generator=generator).to(device)
+            self.control_points = make_coordinate_grid((p, p), noise).reshape(1, p * p, 2)
+            self.control_params = torch.randn([bs, 1, p ** 2], device=device, generator=generator) * kwargs['sigma_tps']
 
     def transform_frame(self, frame):
         h, w = frame.shape[2:]

@@ -96,12 +96,16 @@ class HotPath(nn.Module):
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
-    def forward(self, source, driving):
-        kp_s, kp_d = self.encode_pair(source, driving)
+    def decode(self, source, kp_s, kp_d):
+        """dense motion + refinement + generator for given keypoints (model.py:188-210)"""
         img_down = self.down(source)
         dm = self.dense_motion(source, kp_d, kp_s)
         gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
         return gen
+
+    def forward(self, source, driving):
+        kp_s, kp_d = self.encode_pair(source, driving)
+        return self.decode(source, kp_s, kp_d)
 
 
 def encode_pair_eval(encoder, source, driving):
@@ -125,6 +129,15 @@ def l1_loss(gen: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
     return d.mean()
 
 
+def reference_loss(model: HotPath, full_loss, source, driving) -> torch.Tensor:
+    """The reference's generator objective (train.py:60-63: sum of the .mean() of every entry of MRFA.forward's loss_values,
+    model.py:219-246): VGG19 perceptual pyramid + equivariance + equivariance-Jacobian; `full_loss` = mrfa_amd.losses.GeneratorFullLoss."""
+    kp_s, kp_d = model.encode_pair(source, driving)
+    gen = model.decode(source, kp_s, kp_d)
+    values = full_loss(model.encoder, driving, gen, kp_d)
+    return sum(v.mean() for v in values.values())
+
+
 def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False, fused=False, clip=10.0):
     """The reference's optimizer (train.py:21): Adam(lr, betas=(0.5, 0.999)) over three parameter groups.
 
@@ -140,7 +153,7 @@ def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False, fused=False, cli
                              {"params": m.dense_motion.parameters()}], lr=lr, betas=(0.5, 0.999), capturable=capturable)
 
 
-def train_step(model, optimizer, source, driving, clip=10.0):
+def train_step(model, optimizer, source, driving, clip=10.0, loss_fn=None):
     """one fwd + bwd + clip + Adam step; returns the (device) loss tensor, detached: a loss that still references its
     autograd graph would keep the parameters' AccumulateGrad nodes -- and the stream they were created on -- alive,
     which breaks a later hipGraph capture on another stream"""
@@ -149,8 +162,11 @@ def train_step(model, optimizer, source, driving, clip=10.0):
     wrapped = hasattr(model, "module")                 # DistributedDataParallel needs autograd's gradient hooks
     fused = getattr(optimizer, "fused_clip", False)
     with (engine.direct_param_grads() if (fused and not wrapped) else contextlib.nullcontext()):
-        gen = model(source, driving)
-        loss = l1_loss(gen, driving)
+        if loss_fn is None:
+            gen = model(source, driving)
+            loss = l1_loss(gen, driving)
+        else:
+            loss = loss_fn(model, source, driving)
         loss.backward()
     m = model.module if wrapped else model
     if hasattr(m, "join"):
