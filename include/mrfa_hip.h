@@ -71,7 +71,9 @@ int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
  *   1  fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate
- *      (fp32-accurate: the dropped cross terms are < 2^-23 of each product; 2.5 PF/s pipe / 6)                    */
+ *      (fp32-accurate: the dropped cross terms are < 2^-23 of each product; 2.5 PF/s pipe / 6)
+ *   2  the same kernels keeping only a1*b0 + a0*b1 + a0*b0 ("bf16x3"): product error ~2^-16 (a 16-17 bit significand, 32x
+ *      finer than TF32), 1.3x faster tiles; an opt-in mode, NOT the default                                         */
 int mrfa_set_mfma_mode(int mode);
 int mrfa_get_mfma_mode(void);
 /* (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) chosen by the most recent call on this thread (for roofline accounting) */

@@ -321,10 +321,11 @@ int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, i
 
 }  // namespace
 
-// 0: v_mfma_f32_32x32x2_f32 everywhere; 1: eligible launches (chunked K, 128 x 128 tile) run the bf16x6 split-operand kernel
+// 0: v_mfma_f32_32x32x2_f32 everywhere; 1: eligible launches (chunked K, 128-row tile) run the bf16x6 split-operand kernel;
+// 2: the same kernels keeping the three leading products only (bf16x3: 2^-16-class product error instead of 2^-24)
 static int g_mfma_mode = 0;
 extern "C" int mrfa_set_mfma_mode(int mode) {
-    if (mode != 0 && mode != 1) { mrfa_set_error("set_mfma_mode: unknown mode %d", mode); return 1; }
+    if (mode != 0 && mode != 1 && mode != 2) { mrfa_set_error("set_mfma_mode: unknown mode %d", mode); return 1; }
     g_mfma_mode = mode;
     return 0;
 }
@@ -368,7 +369,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     }
     // split-operand mode: the bf16x6 kernel only exists as a 128-wide tile and is ~1.5x faster than the fp32-MFMA tiles, which
     // outweighs the padding of 64 / 96 / 160 / 192-channel outputs to a multiple of 128
-    if (g_mfma_mode == 1 && !flat && p.Cout >= 32) BN = p.Cout <= 64 ? 64 : 128;
+    if (g_mfma_mode >= 1 && !flat && p.Cout >= 32) BN = p.Cout <= 64 ? 64 : 128;
     auto ntiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * cdiv(p.Cout, bn) * nb; };
     // Few output tiles (low-resolution hourglass / generator levels): every M-tile re-reads the whole weight tensor, so
     // keep the tile tall and split K across workgroups first; shrink BM only when K is too short to split.
@@ -418,7 +419,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
     if (!p.tile && BM == 128 && BN == 128 && !flat) w8 = true;      // 8 waves: 4 waves/SIMD hide the load/barrier phases (+4..13 %)
-    if (g_mfma_mode == 1 && BM == 128 && (BN == 128 || BN == 64) && !flat) {
+    if (g_mfma_mode >= 1 && BM == 128 && (BN == 128 || BN == 64) && !flat) {
         g_last_tile |= 4;                                            // bit 2: split-operand kernel
         rc = mrfa_conv_split_launch(st, p, KT, M, splitk, BN);
     } else if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, p, KT, M, splitk);

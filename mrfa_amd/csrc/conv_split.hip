@@ -46,7 +46,7 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
 
 // BN = 128: waves 2 x 2, each 64 x 64.  BN = 64 (layers with 64 output channels: half of a 128-wide tile would be padding):
 // waves 2 x 2, each 64 x 32 -- same loaders, the B operand simply has 64 rows.
-template <bool PRO, bool WS, int BN>
+template <bool PRO, bool WS, int BN, int NP = 6>
 __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split, const long long M,
                                                             const int tiles_n, const int total_tiles) {
     constexpr int TM = 2, TN = BN / 64;
@@ -205,26 +205,27 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     const int frag_half = lane >> 5;
     auto compute_slab = [&](int buf) {
         const unsigned char* base = smem + buf * SLAB;
+        constexpr int NPC = NP == 6 ? 3 : 2;               // pieces needed: all three, or the two leading ones
         bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * 64 + i * 32 + frag_row;
             const int off = row * 32 + (((frag_half ^ (row >> 3)) & 1) << 4);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[pc][i] = *reinterpret_cast<const bf16x8*>(base + pc * PLANE + off);
+            for (int pc = 0; pc < NPC; ++pc) a[pc][i] = *reinterpret_cast<const bf16x8*>(base + pc * PLANE + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * (TN * 32) + j * 32 + frag_row;
             const int off = row * 32 + (((frag_half ^ (row >> 3)) & 1) << 4);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + off);
+            for (int pc = 0; pc < NPC; ++pc) b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + off);
         }
         // six products, smallest first; the four accumulators interleave so no MFMA waits for its predecessor
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 6 - NP; t < 6; ++t)                    // NP = 3: a1*b0 + a0*b1 + a0*b0 (drops the three ~2^-16 terms)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -322,7 +323,12 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
     mrfa_conv_params q = p;
     q.splitk = splitk;
     if (p.in_scale && !p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
-#define SPLIT_LAUNCH(PRO_, WS_, BN_) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles)
+    const bool three = mrfa_get_mfma_mode() == 2;        // bf16x3
+#define SPLIT_LAUNCH(PRO_, WS_, BN_)                                                                                                          \
+    do {                                                                                                                                      \
+        if (three) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 3>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);     \
+        else hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 6>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);          \
+    } while (0)
     const bool pro = p.in_scale != nullptr, ws = p.w_split != nullptr;
     if (BN == 64) {
         if (pro && ws) SPLIT_LAUNCH(true, true, 64); else if (pro) SPLIT_LAUNCH(true, false, 64);

@@ -396,7 +396,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     if (flat && (BM == 96 || BN == 96)) { BM = BM == 96 ? 128 : BM; BN = BN == 96 ? 128 : BN; }
     // split-operand mode: the bf16x6 kernel is a 128 x 128 tile and ~1.6x faster than the fp32-MFMA tiles: prefer it over the
     // 64 / 96-wide tiles even at the cost of padding (eligibility: chunked K, Wout % 32 == 0, aligned dY)
-    const bool split_mode = mrfa_get_mfma_mode() == 1 && !flat && (p.Wout % 8) == 0 && (M % WBK) == 0 && !dy_scalar && p.Cout >= 32 && NTOT >= 32;
+    const bool split_mode = mrfa_get_mfma_mode() >= 1 && !flat && (p.Wout % 8) == 0 && (M % WBK) == 0 && !dy_scalar && p.Cout >= 32 && NTOT >= 32;
     if (split_mode) { BM = p.Cout <= 64 ? 64 : 128; BN = NTOT <= 64 ? 64 : 128; if (BM == 64 && BN == 64) BN = 128; }
     const int tiles_m = cdiv(p.Cout, BM), tiles_n = cdiv(NTOT, BN);
     const long long base = (long long)tiles_m * tiles_n * taps * nb;

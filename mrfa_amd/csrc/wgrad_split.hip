@@ -43,7 +43,7 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& p1, u32x4& 
 
 // BM x BN in {128 x 128, 64 x 128, 128 x 64}: waves 2 x 2, each (BM/2) x (BN/2); the 64-wide variants serve the layers with 64
 // output or input channels (half of a 128-wide tile would be padding); loader items beyond the tile width stay idle
-template <int BM, int BN>
+template <int BM, int BN, int NP = 6>
 __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
                                                              const int tiles_n, const int nsplit, const int inner, const int total_splits,
                                                              const int taps, const long long partial_stride) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 6 - NP; t < 6; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -270,7 +270,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
 
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
                             int total_splits, int taps, long long partial_stride, int BM, int BN) {
-    if (BM == 128 && BN == 128)
+    const bool three = mrfa_get_mfma_mode() == 2;        // bf16x3
+    if (three && BM == 128 && BN == 128)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 128, 3>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (three && BM == 64 && BN == 128)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<64, 128, 3>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (three && BM == 128 && BN == 64)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 64, 3>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (BM == 128 && BN == 128)
         hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 128>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
     else if (BM == 64 && BN == 128)
         hipLaunchKernelGGL((wgrad_bf16x6_kernel<64, 128>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);

@@ -177,7 +177,8 @@ def lib():
 #   "f32"     v_mfma_f32_32x32x2_f32 on fp32 operands
 #   "bf16x6"  fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate
 #             (fp32-accurate, csrc/conv_split.hip)
-MFMA_MODES = {"f32": 0, "bf16x6": 1}
+#   "bf16x3"  the same kernels with the three leading products only: ~1e-5 relative product error (opt-in)
+MFMA_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
 DEFAULT_MFMA = "bf16x6"
 
 
