@@ -282,6 +282,11 @@ int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const float* out,
  * (row, column) scan order] += dy, the index ATen's max_pool2d_with_indices records.  C % 4 == 0, 16-byte aligned views.  */
 int mrfa_maxpool2_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, float* y, int ldy);
 int mrfa_maxpool2_bwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, const float* dy, int lddy, float* dx /*+=*/, int lddx);
+/* nn.MaxPool2d(3, stride 2, padding 1) of the resnet18 stem of BGMotionPredictor (bg_motion_predictor.py:12; torchvision
+ * resnet.py maxpool): Ho = (H-1)/2+1, windows clipped to the image; backward scatters (atomically: windows overlap) to the first
+ * maximum in scan order                                                                                            */
+int mrfa_maxpool3s2_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, float* y, int ldy);
+int mrfa_maxpool3s2_bwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, const float* dy, int lddy, float* dx /*+=*/, int lddx);
 /* out_sum[0] += coef * sum |x - y| (fp64): with coef = weight / numel one perceptual term
  * weight * torch.abs(x_vgg[i] - y_vgg[i].detach()).mean() of model.py:226-227; backward dx += gscale[0] * coef * sign(x - y) (gscale: device scalar = upstream gradient, may be null = 1)  */
 int mrfa_l1_diff_fwd(void* stream, const float* x, int ldx, const float* y, int ldy, long long rows, int C, double coef, double* out_sum);

@@ -61,6 +61,63 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ldx, int H,
     }
 }
 
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of torchvision's resnet18 stem (BGMotionPredictor, bg_motion_predictor.py:12):
+// out (Ho = (H-1)/2+1) = max over the 3x3 window clipped to the image; backward: first maximum in (row, column) scan order
+__global__ void maxpool3s2_fwd_kernel(const float* __restrict__ x, int ldx, int H, int W, int Ho, int Wo, int C4, float* __restrict__ y, int ldy,
+                                      unsigned total4) {
+    GRID_STRIDE_U(i, total4) {
+        const unsigned opix = i / (unsigned)C4;
+        const unsigned c = (i - opix * (unsigned)C4) * 4u;
+        const int ox = (int)(opix % (unsigned)Wo);
+        const unsigned t = opix / (unsigned)Wo;
+        const int oy = (int)(t % (unsigned)Ho);
+        const unsigned n = t / (unsigned)Ho;
+        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        for (int a = 0; a < 3; ++a) {
+            const int iy = 2 * oy - 1 + a;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int b = 0; b < 3; ++b) {
+                const int ix = 2 * ox - 1 + b;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * ldx + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)opix * ldy + c) = m;
+    }
+}
+
+// windows overlap (stride 2 < kernel 3): the scatter into dx is atomic
+__global__ void maxpool3s2_bwd_kernel(const float* __restrict__ x, int ldx, int H, int W, int Ho, int Wo, int C4, const float* __restrict__ dy,
+                                      int lddy, float* __restrict__ dx, int lddx, unsigned total4) {
+    GRID_STRIDE_U(i, total4) {
+        const unsigned opix = i / (unsigned)C4;
+        const unsigned c = (i - opix * (unsigned)C4) * 4u;
+        const int ox = (int)(opix % (unsigned)Wo);
+        const unsigned t = opix / (unsigned)Wo;
+        const int oy = (int)(t % (unsigned)Ho);
+        const unsigned n = t / (unsigned)Ho;
+        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        int arg[4] = {-1, -1, -1, -1};
+        for (int a = 0; a < 3; ++a) {
+            const int iy = 2 * oy - 1 + a;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int b = 0; b < 3; ++b) {
+                const int ix = 2 * ox - 1 + b;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * ldx + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > m[k] || arg[k] < 0) { m[k] = v[k]; arg[k] = iy * W + ix; }
+            }
+        }
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)opix * lddy + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(dx + ((size_t)n * H * W + arg[k]) * lddx + c + k, d[k]);
+    }
+}
+
 // out[0] += coef * sum |x - y| (fp64)      /      dx += scale[0] * coef * sign(x - y)
 __global__ __launch_bounds__(256) void l1_diff_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy, int C4,
                                                          double* __restrict__ out, double coef, unsigned total4) {
@@ -151,6 +208,31 @@ extern "C" int mrfa_maxpool2_bwd(void* stream, const float* x, int ldx, int N, i
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, C / 4, dy, lddy, dx,
                        lddx, (unsigned)total4);
     MRFA_CHECK_LAUNCH("maxpool2_bwd");
+    return 0;
+}
+
+extern "C" int mrfa_maxpool3s2_fwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, float* y, int ldy) {
+    MRFA_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3s2_fwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && v4(x, ldx) && v4(y, ldy), "maxpool3s2_fwd: needs C %% 4 == 0 and 16-byte aligned views");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total4 = (long long)N * Ho * Wo * (C / 4);
+    MRFA_CHECK_ARG(total4 < (1ll << 31), "maxpool3s2_fwd: tensor too large");
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, Ho, Wo, C / 4, y,
+                       ldy, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("maxpool3s2_fwd");
+    return 0;
+}
+
+extern "C" int mrfa_maxpool3s2_bwd(void* stream, const float* x, int ldx, int N, int H, int W, int C, const float* dy, int lddy, float* dx,
+                                   int lddx) {
+    MRFA_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3s2_bwd: bad args");
+    MRFA_CHECK_ARG(C % 4 == 0 && v4(x, ldx) && v4(dy, lddy), "maxpool3s2_bwd: needs C %% 4 == 0 and 16-byte aligned views");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total4 = (long long)N * Ho * Wo * (C / 4);
+    MRFA_CHECK_ARG(total4 < (1ll << 31), "maxpool3s2_bwd: tensor too large");
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, H, W, Ho, Wo, C / 4, dy,
+                       lddy, dx, lddx, (unsigned)total4);
+    MRFA_CHECK_LAUNCH("maxpool3s2_bwd");
     return 0;
 }
 

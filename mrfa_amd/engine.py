@@ -1243,6 +1243,18 @@ class Ctx:
             self.tape.append(bwd)
         return out
 
+    def maxpool3s2(self, x: View, out: Optional[View] = None) -> View:
+        """nn.MaxPool2d(3, stride=2, padding=1)"""
+        out = out or self.new(x.N, (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C)
+        self._chk(self.L.mrfa_maxpool3s2_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld), "maxpool3s2_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                self._chk(self.L.mrfa_maxpool3s2_bwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.gptr, out.ld, x.gptr, x.ld), "maxpool3s2_bwd")
+            self.tape.append(bwd)
+        return out
+
     def l1_diff(self, x: View, y: View, acc: torch.Tensor, coef: float, gscale: Optional[torch.Tensor] = None):
         """acc (fp64 device scalar) += coef * sum|x - y|; backward dx += gscale * coef * sign(x - y) (y is a constant: the
         detached VGG features of the real image, model.py:226)"""

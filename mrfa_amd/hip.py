@@ -135,6 +135,8 @@ _SIGNATURES = {
     "mrfa_attention_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _V, _I, _I, _I, _I, _F, _V, _I], C.c_int),
     "mrfa_maxpool2_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
     "mrfa_maxpool2_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _V, _I], C.c_int),
+    "mrfa_maxpool3s2_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
+    "mrfa_maxpool3s2_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _V, _I], C.c_int),
     "mrfa_l1_diff_fwd": ([_V, _V, _I, _V, _I, _L, _I, C.c_double, _V], C.c_int),
     "mrfa_l1_diff_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _F, _V, _I], C.c_int),
     "mrfa_antialias_down_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),

@@ -11,7 +11,7 @@ backward is the data-gradient chain only.  Pretrained VGG19 weights (torchvision
 offline: `Vgg19(state_dict=...)` takes the `state_dict()` of the reference's Vgg19 module (same parameter names); without it
 the weights are a deterministic random initialisation and only the ARITHMETIC of the loss is comparable (tests use the same
 weights on both sides).  Transform and the equivariance terms act on (B,10,2) tensors and one image warp: torch device ops.
-BGMotionPredictor (resnet18) and its loss are not built: `bg_start` beyond the last epoch, as in vox1.yaml.
+The background term (model.py:248-253) uses mrfa_amd.modules.BGMotionPredictor (resnet18 on the engine).
 """
 from __future__ import annotations
 
@@ -215,7 +215,8 @@ class GeneratorFullLoss(nn.Module):
         self.perceptual = PerceptualLoss(self.scales, self.loss_weights['perceptual'], vgg) if sum(self.loss_weights['perceptual']) != 0 else None
 
     def forward(self, encoder: nn.Module, driving: torch.Tensor, generated: torch.Tensor, kp_driving: Dict[str, torch.Tensor],
-                transform: Optional[Transform] = None) -> Dict[str, torch.Tensor]:
+                transform: Optional[Transform] = None, bg_param: Optional[torch.Tensor] = None,
+                bg_param_reverse: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         out = {}
         if self.perceptual is not None:
             out['perceptual'] = self.perceptual(generated, driving)
@@ -232,4 +233,8 @@ class GeneratorFullLoss(nn.Module):
                 eye = torch.eye(2, device=value.device, dtype=value.dtype).view(1, 1, 2, 2)
                 # model.py:245 keeps the un-reduced |I - J| tensor; train.py:62 then takes .mean() of every loss value
                 out['equivariance_jacobian'] = w['equivariance_jacobian'] * torch.abs(eye - value)
+        if bg_param is not None:                                           # model.py:248-253: forward o reverse background motion = identity
+            value = torch.matmul(bg_param, bg_param_reverse)
+            eye = torch.eye(3, device=value.device, dtype=value.dtype).view(1, 3, 3)
+            out['bg'] = 10 * torch.abs(eye - value).mean()
         return out

@@ -6,8 +6,9 @@ from .kp_detector import KPDetector
 from .dense_motion import DenseMotionNetwork
 from .generator import OcclusionAwareGenerator
 from .raft import RaftFlow
+from .bg_motion_predictor import BGMotionPredictor
 from .model import MRFA
 
 __all__ = ["AntiAliasInterpolation2d", "AttributeDict", "ChannelBlock2d", "DownBlock2d", "Hourglass", "ResBlock2d",
            "SameBlock2d", "UpBlock2d", "convert_dict_to_attrit_dict", "KPDetector", "DenseMotionNetwork",
-           "OcclusionAwareGenerator", "RaftFlow", "MRFA"]
+           "OcclusionAwareGenerator", "RaftFlow", "MRFA", "BGMotionPredictor"]

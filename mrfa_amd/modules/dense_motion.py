@@ -28,14 +28,18 @@ class DenseMotionNetwork(nn.Module):
         if self.scale_factor != 1:
             self.down = AntiAliasInterpolation2d(num_channels, self.scale_factor)
 
-    def _program(self, e: Ctx, source_image, kd, ks, jd=None, js=None):
+    def _program(self, e: Ctx, source_image, kd, ks, jd=None, js=None, bg=None):
         src = self.down.run(e, source_image) if self.scale_factor != 1 else e.from_nchw(source_image)   # (B,h,w,3)
         b, h, w, c = src.N, src.H, src.W, src.C
         k1 = self.num_kp + 1
         var = self.kp_variance
         has_jac = jd is not None
 
-        def prep(kd_, ks_, jd_=None, js_=None):
+        has_bg = bg is not None
+
+        def prep(kd_, ks_, *rest):
+            jd_, js_ = (rest[0], rest[1]) if has_jac else (None, None)
+            bg_ = rest[-1] if has_bg else None
             # heat-map differences (dense_motion.py:36-46) and sparse motions (:48-76), NHWC-friendly layouts
             heat = kp2gaussian(kd_, (h, w), var) - kp2gaussian(ks_, (h, w), var)                   # (B,K,h,w)
             heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)                         # (B,K1,h,w)
@@ -50,9 +54,14 @@ class DenseMotionNetwork(nn.Module):
                 jac = torch.matmul(js_, inv)
                 z = torch.einsum("bkij,bkhwj->bkhwi", jac, z)
             d2s = z + ks_.view(b, -1, 1, 1, 2)
-            motions = torch.cat([ident.expand(b, 1, h, w, 2), d2s], dim=1)                         # (B,K1,h,w,2)
+            bg_grid = ident.expand(b, 1, h, w, 2)
+            if bg_ is not None:                                                                    # dense_motion.py:69-73
+                hom = torch.cat([bg_grid, torch.ones_like(bg_grid[..., :1])], dim=-1)
+                hom = torch.matmul(bg_.view(b, 1, 1, 1, 3, 3), hom.unsqueeze(-1)).squeeze(-1)
+                bg_grid = hom[..., :2] / hom[..., 2:3]
+            motions = torch.cat([bg_grid, d2s], dim=1)                                             # (B,K1,h,w,2)
             return [heat, motions.reshape(b * k1, h, w, 2)]
-        ins = [kd, ks] + ([jd, js] if has_jac else [])
+        ins = [kd, ks] + ([jd, js] if has_jac else []) + ([bg] if has_bg else [])
         heat, motions = e.island(prep, ins)
         deformed = e.grid_sample(src, motions.view(), 0, in_rep=k1, need_din=False)               # (B*K1,h,w,3)
 
@@ -82,14 +91,18 @@ class DenseMotionNetwork(nn.Module):
         return tuple(o.t for o in outs), tuple(o.add_grad for o in outs), tuple(in_grads)
 
     def forward(self, source_image, kp_driving, kp_source, bg_param=None, dropout_flag=False, dropout_p=0):
-        if bg_param is not None:
-            raise NotImplementedError("bg_param (BGMotionPredictor) is outside the hot path: SURVEY.md section 8(f) rank 2")
         if dropout_flag:
             raise NotImplementedError("dropout_softmax belongs to the TPSM prior (out of scope)")
         ins = [source_image, kp_driving['kp'], kp_source['kp']]
-        if 'jacobian' in kp_driving:
+        has_jac = 'jacobian' in kp_driving
+        if has_jac:
             ins += [kp_driving['jacobian'], kp_source['jacobian']]
-        outs = run_program(self, self._program, ins)
+        if bg_param is not None:
+            ins.append(bg_param)
+        prog = self._program
+        if bg_param is not None and not has_jac:
+            prog = lambda e, s_, kd_, ks_, bg_: self._program(e, s_, kd_, ks_, None, None, bg_)
+        outs = run_program(self, prog, ins)
         out_dict = {'sparse_deformed': outs[0], 'logit_mask': outs[1], 'mask': outs[2], 'deformation': outs[3]}
         if self.occlusion is not None:
             out_dict['occlusion'] = outs[4]

@@ -1,8 +1,9 @@
 """MRFA model assembly (inference wiring).  reference: modules/model.py:145-216.
 
 encoder (FOMM KPDetector or MTIA TokenPose_B) -> dense_motion -> decoder (RaftFlow), and with is_train=True the generator losses
-of mrfa_amd/losses.py (VGG19 perceptual pyramid, equivariance).  The background predictor /
-loss (resnet18) is not built; bench.py's headline step uses the surrogate L1 loss SURVEY.md 8(d) defines."""
+of mrfa_amd/losses.py (VGG19 perceptual pyramid, equivariance).  BGMotionPredictor (resnet18) and the
+background loss are wired in when train_params['bg_start'] < num_epochs (celebvhq.yaml); bench.py's headline step uses the surrogate
+L1 loss SURVEY.md 8(d) defines."""
 from __future__ import annotations
 
 import torch
@@ -38,8 +39,9 @@ class MRFA(nn.Module):
         else:
             raise NotImplementedError(f"prior_model={prior!r}: 'fomm' and 'mtia' are built natively; TPSM is out of scope (SURVEY.md section 8)")
         self.bg_start = train_params['bg_start']
-        if self.bg_start < train_params['num_epochs']:
-            raise NotImplementedError("BGMotionPredictor (resnet18) is out of scope: SURVEY.md section 8(f) rank 2")
+        if self.bg_start < train_params['num_epochs']:                     # model.py:174-176 (celebvhq.yaml: bg_start 0)
+            from .bg_motion_predictor import BGMotionPredictor
+            self.bg_predictor = BGMotionPredictor()
         self.decoder = RaftFlow(**_get(cfg, 'raft_flow'))
         self.down = AntiAliasInterpolation2d(3, 0.25)
         self.losses = None
@@ -55,7 +57,8 @@ class MRFA(nn.Module):
             from ..train import encode_pair_eval
             kp_s, kp_d = encode_pair_eval(self.encoder, x['source'], x['driving'])
         img_down = self.down(x['source'])
-        dense_motion = self.dense_motion(x['source'], kp_d, kp_s, bg_param=None, dropout_flag=False, dropout_p=0)
+        bg_param = self.bg_predictor(x['source'], x['driving']) if epoch >= self.bg_start else None        # model.py:189-192
+        dense_motion = self.dense_motion(x['source'], kp_d, kp_s, bg_param=bg_param, dropout_flag=False, dropout_p=0)
         gen, warp_img, occlusion = self.decoder(kp_s['kp'], kp_d['kp'], dense_motion, img=img_down, img_full=x['source'])
         warp_img = torch.cat([warp_img, occlusion.repeat(1, 3, 1, 1)], dim=3)
         loss_values = {}
@@ -65,5 +68,6 @@ class MRFA(nn.Module):
             raise NotImplementedError("MRFA.forward(is_train=True) needs train_params['loss_weights'] / ['scales'] (model.py:148-157)")
         # model.py:219-246: perceptual pyramid + equivariance (+ Jacobian); the VGG19 weights are whatever self.losses.perceptual.vgg
         # holds (pretrained torchvision weights are not available offline: load the reference's Vgg19 state_dict into it)
-        loss_values = self.losses(self.encoder, x['driving'], gen, kp_d)
+        bg_rev = self.bg_predictor(x['driving'], x['source']) if bg_param is not None else None
+        loss_values = self.losses(self.encoder, x['driving'], gen, kp_d, bg_param=bg_param, bg_param_reverse=bg_rev)
         return gen, warp_img, loss_values, kp_s['kp'], kp_d['kp']

@@ -56,6 +56,19 @@ class Emulator:
         nhwc(dx, N, H, W, lddx, Cc).add_(g.permute(0, 2, 3, 1))
         return 0
 
+    def mrfa_maxpool3s2_fwd(self, stream, x, ldx, N, H, W, Cc, y, ldy):
+        v = F.max_pool2d(nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2), 3, 2, 1)
+        nhwc(y, N, v.shape[2], v.shape[3], ldy, Cc).copy_(v.permute(0, 2, 3, 1))
+        return 0
+
+    def mrfa_maxpool3s2_bwd(self, stream, x, ldx, N, H, W, Cc, dy, lddy, dx, lddx):
+        xx = nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        with torch.enable_grad():
+            out = F.max_pool2d(xx, 3, 2, 1)
+        (g,) = torch.autograd.grad(out, xx, nhwc(dy, N, out.shape[2], out.shape[3], lddy, Cc).permute(0, 3, 1, 2).contiguous())
+        nhwc(dx, N, H, W, lddx, Cc).add_(g.permute(0, 2, 3, 1))
+        return 0
+
     def mrfa_l1_diff_fwd(self, stream, x, ldx, y, ldy, rows, Cc, coef, out_sum):
         vec(out_sum, 1, torch.float64).add_(coef * (mat(x, rows, ldx, Cc) - mat(y, rows, ldy, Cc)).abs().double().sum())
         return 0

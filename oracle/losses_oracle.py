@@ -20,7 +20,7 @@ from typing import Dict, List
 import torch
 import torch.nn.functional as F
 
-from .mrfa_oracle import antialias_down, coordinate_grid
+from .mrfa_oracle import antialias_down, batchnorm, coordinate_grid
 
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
 SLICE_ENDS = (2, 7, 12, 21, 30)                                    # model.py:91-100: features[0:2], [2:7], [7:12], [12:21], [21:30]
@@ -98,3 +98,45 @@ def equivariance(kp_d, transformed_kp, theta, control_points, control_params, w_
         value = torch.inverse(kp_d["jacobian"]) @ jt
         out["equivariance_jacobian"] = w_jacobian * torch.abs(torch.eye(2).view(1, 1, 2, 2).to(value) - value)
     return out
+
+
+# --------------------------------------------------------------------------------------------- background motion predictor
+def _rn_conv_bn(x, P, conv, bn, train, stride, relu, update=True):
+    w = P[conv + ".weight"].to(x.dtype)
+    y = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
+    y = batchnorm(y, P, bn, train, update_stats=train and update)
+    if train and update and (bn + ".num_batches_tracked") in P:
+        P[bn + ".num_batches_tracked"] += 1
+    return F.relu(y) if relu else y
+
+
+def resnet18_pooled(x, P, pfx, train):
+    """torchvision resnet18 up to the global average pool (resnet.py _forward_impl): 7x7/2 conv + BN + ReLU, 3x3/2 max-pool (pad 1),
+    layer1..4 = 2 BasicBlocks each (the first of layers 2-4 with stride 2 and a 1x1/2 conv + BN projection of the skip path)"""
+    y = _rn_conv_bn(x, P, pfx + "conv1", pfx + "bn1", train, 2, True)
+    y = F.max_pool2d(y, 3, 2, 1)
+    for layer in range(1, 5):
+        for blk in range(2):
+            b = f"{pfx}layer{layer}.{blk}."
+            stride = 2 if (layer > 1 and blk == 0) else 1
+            skip = y
+            if (b + "downsample.0.weight") in P:
+                skip = _rn_conv_bn(y, P, b + "downsample.0", b + "downsample.1", train, stride, False)
+            z = _rn_conv_bn(y, P, b + "conv1", b + "bn1", train, stride, True)
+            z = _rn_conv_bn(z, P, b + "conv2", b + "bn2", train, 1, False)
+            y = F.relu(z + skip)
+    return y.mean(dim=(2, 3))
+
+
+def bg_motion_predictor(source, driving, P, pfx="", train=False):
+    """BGMotionPredictor.forward, bg_motion_predictor.py:18-24 -> (B,3,3), third row [0 0 1]"""
+    feat = resnet18_pooled(torch.cat([source, driving], dim=1), P, pfx + "bg_encoder.", train)
+    pred = F.linear(feat, P[pfx + "bg_encoder.fc.weight"].to(feat.dtype), P[pfx + "bg_encoder.fc.bias"].to(feat.dtype))
+    b = source.shape[0]
+    return torch.cat([pred.view(b, 2, 3), torch.eye(3, dtype=feat.dtype)[2:3].expand(b, 1, 3)], dim=1)
+
+
+def bg_loss(bg_param, bg_param_reverse):
+    """model.py:248-253"""
+    value = bg_param @ bg_param_reverse
+    return 10 * torch.abs(torch.eye(3).view(1, 3, 3).to(value) - value).mean()

@@ -186,8 +186,9 @@ def kp_detector(x, P, pfx="", train=False, temperature=0.1, scale_factor=0.25):
 
 
 # --------------------------------------------------------------------------- DenseMotionNetwork
-def sparse_motions(kp_d: dict, kp_s: dict, h: int, w: int) -> torch.Tensor:
-    """(B,K+1,h,w,2): identity background + J_s J_d^-1 (z - kp_d) + kp_s.  dense_motion.py:48-76."""
+def sparse_motions(kp_d: dict, kp_s: dict, h: int, w: int, bg_param: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B,K+1,h,w,2): background (identity, or the affine bg_param applied in homogeneous coordinates, dense_motion.py:67-73)
+    + J_s J_d^-1 (z - kp_d) + kp_s.  dense_motion.py:48-76."""
     kd, ks = kp_d["kp"], kp_s["kp"]
     b, k = kd.shape[:2]
     ident = coordinate_grid(h, w, kd).view(1, 1, h, w, 2)
@@ -196,18 +197,23 @@ def sparse_motions(kp_d: dict, kp_s: dict, h: int, w: int) -> torch.Tensor:
         jac = torch.matmul(kp_s["jacobian"], torch.inverse(kp_d["jacobian"]))       # (B,K,2,2)
         z = torch.einsum("bkij,bkhwj->bkhwi", jac, z)
     d2s = z + ks.view(b, k, 1, 1, 2)
-    return torch.cat([ident.expand(b, 1, h, w, 2), d2s], dim=1)
+    bg = ident.expand(b, 1, h, w, 2)
+    if bg_param is not None:
+        hom = torch.cat([bg, torch.ones_like(bg[..., :1])], dim=-1).unsqueeze(-1)
+        hom = (bg_param.to(bg).view(b, 1, 1, 1, 3, 3) @ hom).squeeze(-1)
+        bg = hom[..., :2] / hom[..., 2:3]
+    return torch.cat([bg, d2s], dim=1)
 
 
-def dense_motion(source, kp_d: dict, kp_s: dict, P, pfx="", train=False, scale_factor=0.25, kp_variance=0.01):
-    """modules/dense_motion.py:104-146 (bg_param=None, dropout off)."""
+def dense_motion(source, kp_d: dict, kp_s: dict, P, pfx="", train=False, scale_factor=0.25, kp_variance=0.01, bg_param=None):
+    """modules/dense_motion.py:104-146 (dropout off)."""
     if scale_factor != 1:
         source = antialias_down(source, scale_factor, P.get(pfx + "down.weight"))
     b, c, h, w = source.shape
     k1 = kp_d["kp"].shape[1] + 1
     heat = gaussian_heatmap(kp_d["kp"], h, w, kp_variance) - gaussian_heatmap(kp_s["kp"], h, w, kp_variance)
     heat = torch.cat([torch.zeros(b, 1, h, w, dtype=heat.dtype, device=heat.device), heat], dim=1).unsqueeze(2)
-    motions = sparse_motions(kp_d, kp_s, h, w)                                   # (B,K1,h,w,2)
+    motions = sparse_motions(kp_d, kp_s, h, w, bg_param)                         # (B,K1,h,w,2)
     src_rep = source.unsqueeze(1).expand(b, k1, c, h, w).reshape(b * k1, c, h, w)
     deformed = sample_norm(src_rep, motions.reshape(b * k1, h, w, 2)).view(b, k1, c, h, w)
     inp = torch.cat([heat, deformed], dim=2).view(b, k1 * (c + 1), h, w)

@@ -99,3 +99,18 @@ def vgg_weights(sd_like: dict) -> dict:
             sd[k] = sd[k].abs() * 0.5
     sd["mean"], sd["std"] = sd_like["mean"].detach().clone(), sd_like["std"].detach().clone()
     return sd
+
+
+def bg_weights(sd_like: dict) -> dict:
+    """deterministic BGMotionPredictor (resnet18) weights: He-uniform convolutions, BatchNorm scales in [0.9, 1.1], perturbed running
+    statistics, and a small random fc around the identity transform (zero-initialised in the reference) so that the regressed
+    affine is a real one"""
+    sd = fill_state_dict(sd_like, tag="bg")
+    for name, t in sd_like.items():
+        if t.dim() == 1 and name.endswith(".weight"):
+            sd[name] = det_uniform(f"bg:{name}", tuple(t.shape), 0.9, 1.1)
+        elif name.endswith("fc.weight"):
+            sd[name] = sd[name] * 0.2
+        elif name.endswith("fc.bias"):
+            sd[name] = torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]) + sd[name] * 0.3
+    return sd

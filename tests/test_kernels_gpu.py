@@ -919,3 +919,18 @@ def test_l1_diff_and_antialias_backward():
         return side.done(*outs)
     ref, got = both(run)
     assert_close(ref, got, tol=2e-5, what="l1_diff / antialias_bwd")
+
+
+def test_maxpool3s2_with_ties():
+    def run(side):
+        N, H, W, Cc, ld = 2, 9, 12, 32, 36
+        x = torch.relu(torch.round(side.t("mp3/x", (N * H * W, ld), -2, 2)))
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = side.garbage((N * Ho * Wo, Cc))
+        side.call("mrfa_maxpool3s2_fwd", x.data_ptr(), ld, N, H, W, Cc, y.data_ptr(), Cc)
+        dy = side.t("mp3/dy", (N * Ho * Wo, Cc))
+        dx = side.t("mp3/dx0", (N * H * W, ld))
+        side.call("mrfa_maxpool3s2_bwd", x.data_ptr(), ld, N, H, W, Cc, dy.data_ptr(), Cc, dx.data_ptr(), ld)
+        return side.done(y, dx[:, :Cc])
+    ref, got = both(run)
+    assert_close(ref, got, tol=1e-6, what="maxpool3s2")

@@ -138,3 +138,37 @@ def test_gpu_alone(golden_dir):
 @pytest.mark.gpu
 def test_gpu_full_training_forward(golden_dir):
     _check_full(_g(golden_dir), golden_dir, "cuda:0")
+
+
+def test_mrfa_training_forward_with_background_predictor():
+    """celebvhq.yaml's setting (bg_start: 0): MRFA.forward(is_train=True) returns the reference's five-tuple with loss_values
+    {'perceptual', 'equivariance', 'equivariance_jacobian', 'bg'} (model.py:183-257), and one backward reaches the encoder, the
+    dense-motion network, the decoder AND the background predictor."""
+    import copy
+    from mrfa_amd.modules import MRFA
+    from mrfa_amd.modules.util import convert_dict_to_attrit_dict
+    from mrfa_amd.train import VOX1
+    cfg = copy.deepcopy(VOX1)
+    cfg["train_params"].update(prior_model="fomm", bg_start=0, num_epochs=100, **TRAIN_PARAMS)
+    m = MRFA(convert_dict_to_attrit_dict(cfg))
+    for pfx, mod in (("encoder.", m.encoder), ("dense_motion.", m.dense_motion), ("decoder.", m.decoder)):
+        mod.load_state_dict(cases.weights_for(mod.state_dict(), pfx))
+    m.bg_predictor.load_state_dict(cases.bg_weights(m.bg_predictor.state_dict()))
+    sd = m.bg_predictor.state_dict()
+    sd["bg_encoder.fc.weight"] = sd["bg_encoder.fc.weight"] * 0.02                 # a background transform close to the identity
+    sd["bg_encoder.fc.bias"] = torch.tensor([1.0, 0.0, 0.02, 0.0, 1.0, -0.03])
+    m.bg_predictor.load_state_dict(sd)
+    m.losses.perceptual.vgg.load_state_dict(cases.vgg_weights(m.losses.perceptual.vgg.state_dict()))
+    m.train(True)
+    x = {"source": cases.images("g7/src", 1, 256), "driving": cases.images("g7/drv", 1, 256)}
+    with emulated_hip():
+        gen, warp_img, lv, kp_s, kp_d = m(x, epoch=0, is_train=True)
+        assert set(lv) == {"perceptual", "equivariance", "equivariance_jacobian", "bg"}
+        assert gen.shape == (1, 3, 256, 256) and warp_img.shape == (1, 3, 256, 8 * 256) and kp_s.shape == (1, 10, 2)
+        total = sum(v.mean() for v in lv.values())
+        assert torch.isfinite(total)
+        total.backward()
+    for name in ("encoder.kp.weight", "dense_motion.mask.weight", "decoder.refine.conv2.weight", "bg_predictor.bg_encoder.conv1.weight",
+                 "bg_predictor.bg_encoder.fc.bias"):
+        gr = dict(m.named_parameters())[name].grad
+        assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().max()) > 0, name

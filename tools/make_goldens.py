@@ -459,8 +459,98 @@ def g7_losses():
     print("G7 loss goldens:", len(out), {k: float(v.mean()) for k, v in lv.items()})
 
 
+# ----------------------------------------------------------------------------------------------- G8 background motion
+def g8_background():
+    """The reference's BGMotionPredictor (bg_motion_predictor.py:5-24), DenseMotionNetwork with bg_param (dense_motion.py:67-73) and
+    the background loss (model.py:248-253).  torchvision is absent: `models.resnet18` is bound to the published resnet18
+    architecture restated below (the reference's class swaps its stem and fc as usual)."""
+    import modules.bg_motion_predictor as RB
+
+    class _Block(torch.nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(cout)
+            self.relu = torch.nn.ReLU(inplace=True)
+            self.conv2 = torch.nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+            self.bn2 = torch.nn.BatchNorm2d(cout)
+            self.downsample = None
+            if stride != 1 or cin != cout:
+                self.downsample = torch.nn.Sequential(torch.nn.Conv2d(cin, cout, 1, stride, bias=False), torch.nn.BatchNorm2d(cout))
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + idt)
+
+    class _ResNet18(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(64)
+            self.relu = torch.nn.ReLU(inplace=True)
+            self.maxpool = torch.nn.MaxPool2d(3, 2, 1)
+            cin = 64
+            for k, (c, st) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), start=1):
+                setattr(self, f"layer{k}", torch.nn.Sequential(_Block(cin, c, st), _Block(c, c, 1)))
+                cin = c
+            self.avgpool = torch.nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = torch.nn.Linear(512, 1000)
+
+        def forward(self, x):
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            return self.fc(torch.flatten(self.avgpool(x), 1))
+    RB.models.resnet18 = lambda pretrained=False: _ResNet18()
+    bg = RB.BGMotionPredictor()
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))
+    man["BGMotionPredictor"] = manifest(bg)
+    with open(os.path.join(GOLD, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0)
+    sd = cases.bg_weights(bg.state_dict())
+    out = {}
+    b = 2
+    src, drv = cases.images("g8/src", b, 256), cases.images("g8/drv", b, 256)
+    from oracle import losses_oracle as LO
+    for train in (False, True):
+        sfx = "train" if train else "eval"
+        bg.load_state_dict(sd)
+        bg.train(train)
+        bg.zero_grad()
+        fwd, rev = bg(src, drv), bg(drv, src)
+        value = torch.matmul(fwd, rev)
+        loss = 10 * torch.abs(torch.eye(3).view(1, 3, 3) - value).mean()
+        loss.backward()
+        out[f"bg_{sfx}"], out[f"bg_rev_{sfx}"], out[f"bg_loss_{sfx}"] = npy(fwd), npy(rev), np.array([loss.item()], np.float32)
+        out[f"param_grad_norms_{sfx}"] = np.array([p.grad.norm().item() for _, p in bg.named_parameters()], np.float32)
+        P = {k: v.clone() for k, v in sd.items()}
+        o = LO.bg_motion_predictor(src, drv, P, "", train)
+        delta(f"BGMotionPredictor {sfx}", o, fwd)
+        if train:
+            out["buf_bn1_running_var"] = npy(dict(bg.named_buffers())["bg_encoder.bn1.running_var"])
+    with open(os.path.join(GOLD, "bg_param_names.json"), "w") as f:
+        json.dump([n for n, _ in bg.named_parameters()], f)
+    # dense motion with a background transform
+    dmm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+    dsd = load(dmm, "dm")
+    kd, ks = cases.keypoints("g8/kd", b), cases.keypoints("g8/ks", b)
+    bgp = torch.from_numpy(out["bg_eval"])
+    dmm.eval()
+    with torch.no_grad():
+        r = dmm(src, kd, ks, bg_param=bgp)
+        sm = dmm.create_sparse_motions(torch.zeros(b, 3, 8, 8), kd, ks, bg_param=bgp)
+    out["dm_bg_deformation"], out["dm_bg_occlusion"], out["sparse_motions_bg"] = npy(r["deformation"]), npy(r["occlusion"]), npy(sm)
+    delta("sparse_motions(bg)", O.sparse_motions(kd, ks, 8, 8, bgp), sm)
+    with torch.no_grad():
+        od = O.dense_motion(src, kd, ks, {k: v.clone() for k, v in dsd.items()}, "", False, bg_param=bgp)
+    delta("DenseMotion(bg) deformation", od["deformation"], r["deformation"])
+    np.savez_compressed(os.path.join(GOLD, "background.npz"), **out)
+    print("G8 background goldens:", len(out), "bg_eval[0] =", out["bg_eval"][0].round(3).tolist())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background"]
     for w in which:
         print("==", w)
         globals()[w]()
