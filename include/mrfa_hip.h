@@ -73,7 +73,9 @@ int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
  *   1  fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate
  *      (fp32-accurate: the dropped cross terms are < 2^-23 of each product; 2.5 PF/s pipe / 6)
  *   2  the same kernels keeping only a1*b0 + a0*b1 + a0*b0 ("bf16x3"): product error ~2^-16 (a 16-17 bit significand, 32x
- *      finer than TF32), 1.3x faster tiles; an opt-in mode, NOT the default                                         */
+ *      finer than TF32), 1.3x faster tiles; an opt-in mode, NOT the default
+ *   3  plain bf16: operands rounded to nearest-even bf16, ONE product, fp32 accumulate and fp32 storage ("MFMA bf16 conv
+ *      tiles", BASELINE config 4); bf16-autocast accuracy (2^-9 operand error), opt-in                              */
 int mrfa_set_mfma_mode(int mode);
 int mrfa_get_mfma_mode(void);
 /* (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) chosen by the most recent call on this thread (for roofline accounting) */

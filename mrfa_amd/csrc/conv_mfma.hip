@@ -322,10 +322,11 @@ int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, i
 }  // namespace
 
 // 0: v_mfma_f32_32x32x2_f32 everywhere; 1: eligible launches (chunked K, 128-row tile) run the bf16x6 split-operand kernel;
-// 2: the same kernels keeping the three leading products only (bf16x3: 2^-16-class product error instead of 2^-24)
+// 2: the same kernels keeping the three leading products only (bf16x3: 2^-16-class product error instead of 2^-24);
+// 3: plain bf16 operands (round-to-nearest-even), one product: the arithmetic of a bf16 autocast (BASELINE config 4)
 static int g_mfma_mode = 0;
 extern "C" int mrfa_set_mfma_mode(int mode) {
-    if (mode != 0 && mode != 1 && mode != 2) { mrfa_set_error("set_mfma_mode: unknown mode %d", mode); return 1; }
+    if (mode < 0 || mode > 3) { mrfa_set_error("set_mfma_mode: unknown mode %d", mode); return 1; }
     g_mfma_mode = mode;
     return 0;
 }

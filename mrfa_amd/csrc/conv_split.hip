@@ -44,6 +44,16 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     }
 }
 
+// plain bf16 operands (NP = 1): round-to-nearest-even of the fp32 value, one product -- the arithmetic of a bf16 autocast
+__device__ __forceinline__ unsigned rne16(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void round1(const f32x4 v, u32x2& p1) {
+    p1[0] = rne16(v.x) | (rne16(v.y) << 16);
+    p1[1] = rne16(v.z) | (rne16(v.w) << 16);
+}
+
 // BN = 128: waves 2 x 2, each 64 x 64.  BN = 64 (layers with 64 output channels: half of a 128-wide tile would be padding):
 // waves 2 x 2, each 64 x 32 -- same loaders, the B operand simply has 64 rows.
 template <bool PRO, bool WS, int BN, int NP = 6>
@@ -173,15 +183,23 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             }
             v = a_inb[j] ? v : z;
             u32x2 p1, p2, p3;
-            split3(v, p1, p2, p3);
-            *reinterpret_cast<u32x2*>(base + 0 * PLANE + off) = p1;
-            *reinterpret_cast<u32x2*>(base + 1 * PLANE + off) = p2;
-            *reinterpret_cast<u32x2*>(base + 2 * PLANE + off) = p3;
-            if constexpr (!WS) {
-                split3(b_ok[j] ? rb[j][h] : z, p1, p2, p3);
+            if constexpr (NP == 1) {
+                round1(v, p1);
+                *reinterpret_cast<u32x2*>(base + 0 * PLANE + off) = p1;
+                static_assert(NP != 1 || !WS, "the pre-split weight pieces are truncations: plain bf16 rounds the fp32 weights itself");
+                round1(b_ok[j] ? rb[j][h] : z, p1);
                 *reinterpret_cast<u32x2*>(base + 3 * PLANE + off) = p1;
-                *reinterpret_cast<u32x2*>(base + 4 * PLANE + off) = p2;
-                *reinterpret_cast<u32x2*>(base + 5 * PLANE + off) = p3;
+            } else {
+                split3(v, p1, p2, p3);
+                *reinterpret_cast<u32x2*>(base + 0 * PLANE + off) = p1;
+                *reinterpret_cast<u32x2*>(base + 1 * PLANE + off) = p2;
+                *reinterpret_cast<u32x2*>(base + 2 * PLANE + off) = p3;
+                if constexpr (!WS) {
+                    split3(b_ok[j] ? rb[j][h] : z, p1, p2, p3);
+                    *reinterpret_cast<u32x2*>(base + 3 * PLANE + off) = p1;
+                    *reinterpret_cast<u32x2*>(base + 4 * PLANE + off) = p2;
+                    *reinterpret_cast<u32x2*>(base + 5 * PLANE + off) = p3;
+                }
             }
         }
         if constexpr (WS) {
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     const int frag_half = lane >> 5;
     auto compute_slab = [&](int buf) {
         const unsigned char* base = smem + buf * SLAB;
-        constexpr int NPC = NP == 6 ? 3 : 2;               // pieces needed: all three, or the two leading ones
+        constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);      // pieces needed: all three, the two leading ones, or one
         bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -324,9 +342,11 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
     q.splitk = splitk;
     if (p.in_scale && !p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
     const bool three = mrfa_get_mfma_mode() == 2;        // bf16x3
+    const bool one = mrfa_get_mfma_mode() == 3;          // plain bf16
 #define SPLIT_LAUNCH(PRO_, WS_, BN_)                                                                                                          \
     do {                                                                                                                                      \
-        if (three) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 3>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);     \
+        if (one) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, false, BN_, 1>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);    \
+        else if (three) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 3>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);     \
         else hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 6>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);          \
     } while (0)
     const bool pro = p.in_scale != nullptr, ws = p.w_split != nullptr;

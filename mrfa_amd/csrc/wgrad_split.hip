@@ -43,6 +43,11 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& p1, u32x4& 
 
 // BM x BN in {128 x 128, 64 x 128, 128 x 64}: waves 2 x 2, each (BM/2) x (BN/2); the 64-wide variants serve the layers with 64
 // output or input channels (half of a 128-wide tile would be padding); loader items beyond the tile width stay idle
+__device__ __forceinline__ unsigned rne16(float x) {          // plain bf16 (NP = 1): round to nearest even
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
 template <int BM, int BN, int NP = 6>
 __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_params p, const long long M, const long long k_per_split,
                                                              const int tiles_n, const int nsplit, const int inner, const int total_splits,
@@ -175,11 +180,17 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             u32x4 p1, p2, p3;
-            split3x8(v[q], p1, p2, p3);
             unsigned char* d = base + (col + q) * ROWB;
-            *reinterpret_cast<u32x4*>(d + 0 * PLANE) = p1;
-            *reinterpret_cast<u32x4*>(d + 1 * PLANE) = p2;
-            *reinterpret_cast<u32x4*>(d + 2 * PLANE) = p3;
+            if constexpr (NP == 1) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) p1[h] = rne16(v[q][2 * h]) | (rne16(v[q][2 * h + 1]) << 16);
+                *reinterpret_cast<u32x4*>(d + 0 * PLANE) = p1;
+            } else {
+                split3x8(v[q], p1, p2, p3);
+                *reinterpret_cast<u32x4*>(d + 0 * PLANE) = p1;
+                *reinterpret_cast<u32x4*>(d + 1 * PLANE) = p2;
+                *reinterpret_cast<u32x4*>(d + 2 * PLANE) = p3;
+            }
         }
     };
 
@@ -194,16 +205,17 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     const int fi = lane & 31, fh = lane >> 5;
     auto compute_slab = [&](int sl) {
         const unsigned char* base = smem + sl * SLAB + fh * 16;
+        constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
         bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < NPC; ++pc)
                 a[pc][i] = *reinterpret_cast<const bf16x8*>(base + pc * PLANE + (wm * (TM * 32) + i * 32 + fi) * ROWB);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < NPC; ++pc)
                 b[pc][j] = *reinterpret_cast<const bf16x8*>(base + (3 + pc) * PLANE + (wn * (TN * 32) + j * 32 + fi) * ROWB);
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -271,7 +283,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
                             int total_splits, int taps, long long partial_stride, int BM, int BN) {
     const bool three = mrfa_get_mfma_mode() == 2;        // bf16x3
-    if (three && BM == 128 && BN == 128)
+    const bool one = mrfa_get_mfma_mode() == 3;          // plain bf16
+    if (one && BM == 128 && BN == 128)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 128, 1>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (one && BM == 64 && BN == 128)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<64, 128, 1>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (one && BM == 128 && BN == 64)
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 64, 1>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
+    else if (three && BM == 128 && BN == 128)
         hipLaunchKernelGGL((wgrad_bf16x6_kernel<128, 128, 3>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);
     else if (three && BM == 64 && BN == 128)
         hipLaunchKernelGGL((wgrad_bf16x6_kernel<64, 128, 3>), grid, dim3(NT), 0, st, p, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride);

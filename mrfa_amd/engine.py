@@ -539,7 +539,7 @@ class Ctx:
         self.record = record
         self.tape: List[Callable[[], None]] = []
         self.L = hip.lib()
-        self.split = self.L.mrfa_get_mfma_mode() >= 1        # bf16x6 kernels: also hand over pre-split weights
+        self.split = self.L.mrfa_get_mfma_mode() in (1, 2)   # bf16x6 / bf16x3 kernels: also hand over pre-split weights
         self.in_backward = False
         self.deferred = SIDE_PASS            # not None: this program runs on the side stream next to another pass of its module
         self.touched_convs: List[ConvW] = []

@@ -194,6 +194,8 @@ class GraphedTrainStep:
                 if clip:
                     nn.utils.clip_grad_norm_(model.encoder.parameters(), max_norm=clip, norm_type=math.inf)
                     nn.utils.clip_grad_norm_(model.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
+                    if getattr(model, "bg_predictor", None) is not None:
+                        nn.utils.clip_grad_norm_(model.bg_predictor.parameters(), max_norm=clip, norm_type=math.inf)
                 optimizer.step()
 
     def _loss(self):
@@ -211,7 +213,7 @@ class GraphedTrainStep:
         very different conditioning) or, without FlatAdam, the whole buffer"""
         return list(self.opt.segments) if self.fused else [(0, self.flat.numel())]
 
-    def verify(self, replays: int = 3, tol: float = 0.5, band_mult: float = 4.0) -> float:
+    def verify(self, replays: int = 3, tol: float = 0.5, band_mult: float = 4.0, loss_tol: float = 1e-4) -> float:
         """Self-check after capture.  Graph A is replayed several times at fixed weights and every replay's gradient is
         compared, per parameter group, with replay 0 and with an eager forward+backward at the same weights.  Identical
         inputs must give identical results up to atomic-order noise, so the allowed relative L2 distance of a group is
@@ -219,7 +221,7 @@ class GraphedTrainStep:
         train mode amplifies summation-order noise into 0.2 % of the decoder's gradient but into tens of percent of the
         keypoint encoder's after the first Adam steps) + `tol`/25; the best-conditioned group is therefore checked to a few
         percent, and a gradient that is zero or stale (distance >= 1) fails wherever the band is below 1/band_mult.  The
-        loss must agree to 1e-4.  Returns the worst distance seen in the best-conditioned group.  A replay that depends on
+        loss must agree to `loss_tol` (1e-4; plain-bf16 arithmetic amplifies summation-order noise to ~1e-3).  Returns the worst distance seen in the best-conditioned group.  A replay that depends on
         what ran before it means a node of the graph is not ordered (see "kernel nodes only" above)."""
         saved = [b.detach().clone() for b in self.model.buffers()]
         segs = self._segments()
@@ -263,7 +265,7 @@ class GraphedTrainStep:
                 self.g_fb.replay()
                 torch.cuda.synchronize()
                 g, loss = self.flat.double().cpu(), float(self.loss)
-                if abs(loss - eloss) > 1e-4 * max(1.0, abs(eloss)):
+                if abs(loss - eloss) > loss_tol * max(1.0, abs(eloss)):
                     raise RuntimeError(f"hipGraph replay {k}: loss {loss} differs from the eager pass {eloss}")
                 checks = [("the eager pass", dist(g, e0))]
                 if ref is None:

@@ -180,7 +180,8 @@ def lib():
 #   "bf16x6"  fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate
 #             (fp32-accurate, csrc/conv_split.hip)
 #   "bf16x3"  the same kernels with the three leading products only: ~1e-5 relative product error (opt-in)
-MFMA_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
+#   "bf16"    operands rounded to bf16, one product (a bf16 autocast's arithmetic; fp32 accumulate / storage): BASELINE config 4
+MFMA_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}
 DEFAULT_MFMA = "bf16x6"
 
 

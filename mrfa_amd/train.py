@@ -45,11 +45,16 @@ class HotPath(nn.Module):
     """encoder -> dense_motion -> decoder wiring of MRFA.forward (modules/model.py:185-210), attribute names as in the
     reference so checkpoints and train.py's parameter groups line up."""
 
-    def __init__(self, cfg=VOX1, prior: str = "fomm"):
+    def __init__(self, cfg=VOX1, prior: str = "fomm", background: bool = False):
         """prior: 'fomm' = KPDetector (hourglass + soft-argmax), 'mtia' = TokenPose_B (HRNet + token transformer; the
-        `prior_model` both reference YAMLs select, model.py:170-172)"""
+        `prior_model` both reference YAMLs select, model.py:170-172); background: BGMotionPredictor feeding bg_param to the dense
+        motion network (celebvhq.yaml `bg_start: 0`, model.py:174-176,189-192)"""
         super().__init__()
         self.prior = prior
+        self.bg_predictor = None
+        if background:
+            from .modules.bg_motion_predictor import BGMotionPredictor
+            self.bg_predictor = BGMotionPredictor()
         if prior == "fomm":
             self.encoder = KPDetector(**cfg["fomm_kp_detector"])
         elif prior == "mtia":
@@ -96,16 +101,17 @@ class HotPath(nn.Module):
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
-    def decode(self, source, kp_s, kp_d):
+    def decode(self, source, kp_s, kp_d, bg_param=None):
         """dense motion + refinement + generator for given keypoints (model.py:188-210)"""
         img_down = self.down(source)
-        dm = self.dense_motion(source, kp_d, kp_s)
+        dm = self.dense_motion(source, kp_d, kp_s, bg_param=bg_param)
         gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
         return gen
 
     def forward(self, source, driving):
         kp_s, kp_d = self.encode_pair(source, driving)
-        return self.decode(source, kp_s, kp_d)
+        bg_param = self.bg_predictor(source, driving) if self.bg_predictor is not None else None
+        return self.decode(source, kp_s, kp_d, bg_param)
 
 
 def encode_pair_eval(encoder, source, driving):
@@ -133,8 +139,10 @@ def reference_loss(model: HotPath, full_loss, source, driving) -> torch.Tensor:
     """The reference's generator objective (train.py:60-63: sum of the .mean() of every entry of MRFA.forward's loss_values,
     model.py:219-246): VGG19 perceptual pyramid + equivariance + equivariance-Jacobian; `full_loss` = mrfa_amd.losses.GeneratorFullLoss."""
     kp_s, kp_d = model.encode_pair(source, driving)
-    gen = model.decode(source, kp_s, kp_d)
-    values = full_loss(model.encoder, driving, gen, kp_d)
+    bg = model.bg_predictor(source, driving) if model.bg_predictor is not None else None
+    gen = model.decode(source, kp_s, kp_d, bg)
+    bg_rev = model.bg_predictor(driving, source) if bg is not None else None
+    values = full_loss(model.encoder, driving, gen, kp_d, bg_param=bg, bg_param_reverse=bg_rev)
     return sum(v.mean() for v in values.values())
 
 
@@ -145,12 +153,18 @@ def make_optimizer(model: HotPath, lr=2.0e-4, capturable=False, fused=False, cli
     fused=True   mrfa_amd.optim.FlatAdam: parameters, gradients and moments re-homed into flat HBM buffers, inf-norm
                  clipping of the encoder / dense_motion groups (train.py:65-67) + Adam as 6 HIP launches."""
     m = model.module if hasattr(model, "module") else model
+    bg = getattr(m, "bg_predictor", None)           # train.py:23-25,68-72: its own Adam in the reference (same lr / betas), clipped too
     if fused:
         from .optim import FlatAdam
-        return FlatAdam([{"params": list(m.encoder.parameters()), "clip": clip}, {"params": list(m.decoder.parameters())},
-                         {"params": list(m.dense_motion.parameters()), "clip": clip}], lr=lr, betas=(0.5, 0.999))
-    return torch.optim.Adam([{"params": m.encoder.parameters()}, {"params": m.decoder.parameters()},
-                             {"params": m.dense_motion.parameters()}], lr=lr, betas=(0.5, 0.999), capturable=capturable)
+        groups = [{"params": list(m.encoder.parameters()), "clip": clip}, {"params": list(m.decoder.parameters())},
+                  {"params": list(m.dense_motion.parameters()), "clip": clip}]
+        if bg is not None:
+            groups.append({"params": list(bg.parameters()), "clip": clip})
+        return FlatAdam(groups, lr=lr, betas=(0.5, 0.999))
+    groups = [{"params": m.encoder.parameters()}, {"params": m.decoder.parameters()}, {"params": m.dense_motion.parameters()}]
+    if bg is not None:
+        groups.append({"params": bg.parameters()})
+    return torch.optim.Adam(groups, lr=lr, betas=(0.5, 0.999), capturable=capturable)
 
 
 def train_step(model, optimizer, source, driving, clip=10.0, loss_fn=None):
@@ -174,6 +188,8 @@ def train_step(model, optimizer, source, driving, clip=10.0, loss_fn=None):
     if clip and not fused:
         nn.utils.clip_grad_norm_(m.encoder.parameters(), max_norm=clip, norm_type=math.inf)
         nn.utils.clip_grad_norm_(m.dense_motion.parameters(), max_norm=clip, norm_type=math.inf)
+        if getattr(m, "bg_predictor", None) is not None:
+            nn.utils.clip_grad_norm_(m.bg_predictor.parameters(), max_norm=clip, norm_type=math.inf)
     optimizer.step()
     return loss.detach()
 

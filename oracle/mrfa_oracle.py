@@ -431,7 +431,11 @@ def mrfa_forward(source, driving, P, size=256, prior_only=False, train=False, pr
         kp_s = kp_detector(source, P, "encoder.", train)
         kp_d = kp_detector(driving, P, "encoder.", train)
     img_down = antialias_down(source, 0.25)
-    dm = dense_motion(source, kp_d, kp_s, P, "dense_motion.", train)
+    bg_param = None
+    if any(k.startswith("bg_predictor.") for k in P):              # celebvhq.yaml bg_start 0: model.py:189-192
+        from .losses_oracle import bg_motion_predictor
+        bg_param = bg_motion_predictor(source, driving, P, "bg_predictor.", train)
+    dm = dense_motion(source, kp_d, kp_s, P, "dense_motion.", train, bg_param=bg_param)
     gen, warp_img, occ = raft_flow(kp_s["kp"], kp_d["kp"], dm, img_down, source, P, "decoder.",
                                    size=size, prior_only=prior_only, train=train)
     warp_vis = torch.cat([warp_img, occ.repeat(1, 3, 1, 1)], dim=3)

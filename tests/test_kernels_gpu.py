@@ -219,7 +219,7 @@ def test_split_operand_mode_is_fp32_accurate():
     xd, wd = x.reshape(-1, Cin).to(side.dev).contiguous(), w.to(side.dev)
     wp = pack(side, wd, 0)
     errs = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         y = side.garbage((N * H * W, Cout))
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = xd.data_ptr(), Cin, H, W, 0, N, Cin
@@ -242,6 +242,10 @@ def test_split_operand_mode_is_fp32_accurate():
     # between fp32 (6e-8) and TF32 (5e-4); documented, not fp32-accurate
     assert errs[2][0] <= 1e-4 * scale and errs[2][1] <= 1e-5 * scale, (errs, scale)
     assert errs[2][1] >= 4.0 * errs[1][1], "bf16x3 unexpectedly as accurate as bf16x6: is it running the 6-product kernel?"
+    # mode 3 (plain bf16 operands, round-to-nearest-even, one product): 2^-9 operand error, unbiased -> rms error ~ 2^-9 / sqrt(K)-ish
+    # of the output scale; the bound also catches truncation instead of rounding (a one-sided 2^-8 error: ~3x this rms)
+    assert errs[3][1] <= 2e-3 * scale and errs[3][0] <= 2e-2 * scale, (errs, scale)
+    assert errs[3][1] >= 10.0 * errs[2][1]
 
 
 def test_gemm_nt_batched():

@@ -228,3 +228,56 @@ def test_mtia_pipeline_vs_oracle(train):
         for n in ("encoder.pre_feature.bn1.running_mean", "encoder.pre_feature.stage3.3.fuse_layers.0.2.1.running_var"):
             assert (bufs[n].cpu() - P[n]).abs().max().item() <= 1e-4 * max(1.0, P[n].abs().max().item()), n
         assert int(bufs["encoder.pre_feature.bn1.num_batches_tracked"]) == 2          # source pass + driving pass
+
+
+def test_celebvhq_wiring_vs_oracle():
+    """celebvhq.yaml's wiring (bg_start 0): MTIA prior + BGMotionPredictor -> bg_param -> DenseMotion -> RaftFlow, eval mode, B=2,
+    through HotPath(background=True) against the oracle"""
+    import bench
+    from mrfa_amd.train import VOX1, HotPath
+    b = 2
+    src, drv = cases.images("cv/src", b, 256), cases.images("cv/drv", b, 256)
+    model = HotPath(VOX1, prior="mtia", background=True)
+    P = {k: v.clone() for k, v in bench.init_weights(model).items()}
+    model.to(DEV).eval()
+    with torch.no_grad():
+        gen = model(src.to(DEV), drv.to(DEV))
+        ogen, _, _, _, odm = O.mrfa_forward(src, drv, P, size=256, train=False, prior="mtia")
+        bgp = model.bg_predictor(src.to(DEV), drv.to(DEV))
+    assert (bgp[:, 2].cpu() - torch.tensor([0.0, 0.0, 1.0])).abs().max() == 0 and (bgp[:, :2].cpu() - torch.eye(3)[:2]).abs().max() > 1e-3
+    _cmp(gen, ogen.numpy(), what="gen (celebvhq wiring)")
+
+
+@pytest.mark.parametrize("mode,max_tol,mean_tol", [("bf16x3", 3e-3, 2e-4), ("bf16", 0.25, 2e-2)])
+def test_reduced_precision_matrix_modes_stay_inside_their_tolerance(mode, max_tol, mean_tol):
+    """The two OPT-IN matrix modes against the fp32 oracle (KPDetector -> DenseMotion -> RaftFlow, 256^2, B=2, eval):
+    bf16x3 (three split products): measured max 8e-4 / mean 5e-5 -- inside north_star's L1 <= 1e-3;
+    bf16 (BASELINE config 4, "MFMA bf16 conv tiles": operands rounded to bf16, fp32 accumulate): measured max 6e-2 / mean 3.4e-3 --
+    SURVEY.md 8(c) measured L1 1.4e-2 (max 0.21) for the reference under torch's own bf16 autocast and proposes L1 <= 2e-2."""
+    b, size = 2, 256
+    src, drv = cases.images("acc/src", b, size), cases.images("acc/drv", b, size)
+    kp = KPDetector(**cases.KP_DETECTOR_CFG)
+    dm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+    rf = RaftFlow(**cases.raft_cfg(size))
+    sds = {}
+    for n, m in (("kp", kp), ("dm", dm), ("rf", rf)):
+        sds[n] = cases.weights_for(m.state_dict(), n)
+        m.load_state_dict(sds[n])
+        m.to(DEV).eval()
+    img = torch.nn.functional.avg_pool2d(src, 4)
+    prev = hip.mfma_mode()
+    hip.set_mfma_mode(mode)
+    try:
+        with torch.no_grad():
+            ks, kd = kp(src.to(DEV)), kp(drv.to(DEV))
+            d = dm(src.to(DEV), kd, ks)
+            out, _, _ = rf(ks["kp"], kd["kp"], d, img.to(DEV), src.to(DEV))
+            torch.cuda.synchronize()
+    finally:
+        hip.set_mfma_mode(prev)
+    with torch.no_grad():
+        P = {"encoder." + k: v for k, v in sds["kp"].items()}
+        oks, okd = O.kp_detector(src, P, "encoder."), O.kp_detector(drv, P, "encoder.")
+        od = O.dense_motion(src, okd, oks, {"dm." + k: v for k, v in sds["dm"].items()}, "dm.")
+        oout, _, _ = O.raft_flow(oks["kp"], okd["kp"], od, img, src, {"rf." + k: v for k, v in sds["rf"].items()}, "rf.", size=size)
+    _cmp(out, oout.numpy(), max_tol, mean_tol, what=f"out ({mode})")

@@ -28,7 +28,7 @@ with torch.no_grad():
     od = O.dense_motion(src, okd, oks, {"dm." + k: v for k, v in sds["dm"].items()}, "dm.")
     img = torch.nn.functional.avg_pool2d(src, 4)
     oout, owarp, _ = O.raft_flow(oks["kp"], okd["kp"], od, img, src, {"rf." + k: v for k, v in sds["rf"].items()}, "rf.", size=size)
-    for mode in ("f32", "bf16x6", "bf16x3"):
+    for mode in ("f32", "bf16x6", "bf16x3", "bf16"):
         hip.set_mfma_mode(mode)
         ks, kd = kp(src.to(DEV)), kp(drv.to(DEV))
         d = dm(src.to(DEV), kd, ks)
