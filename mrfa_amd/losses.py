@@ -216,7 +216,8 @@ class GeneratorFullLoss(nn.Module):
 
     def forward(self, encoder: nn.Module, driving: torch.Tensor, generated: torch.Tensor, kp_driving: Dict[str, torch.Tensor],
                 transform: Optional[Transform] = None, bg_param: Optional[torch.Tensor] = None,
-                bg_param_reverse: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                bg_param_reverse: Optional[torch.Tensor] = None, transformed_kp: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """transformed_kp: the encoder's output on transform.transform_frame(driving) when the caller already ran that pass"""
         out = {}
         if self.perceptual is not None:
             out['perceptual'] = self.perceptual(generated, driving)
@@ -224,7 +225,8 @@ class GeneratorFullLoss(nn.Module):
         if w['equivariance'] != 0:
             if transform is None:
                 transform = Transform(driving.shape[0], device=driving.device, **self.train_params['transform_params'])
-            transformed_kp = encoder(transform.transform_frame(driving))
+            if transformed_kp is None:
+                transformed_kp = encoder(transform.transform_frame(driving))
             value = torch.abs(kp_driving['kp'] - transform.warp_coordinates(transformed_kp['kp'])).mean()
             out['equivariance'] = w['equivariance'] * value
             if w['equivariance_jacobian'] != 0:

@@ -72,34 +72,48 @@ class HotPath(nn.Module):
         # average); side by side they take 39 ms instead of 58 ms (tools/graph_two_encoders.py).  Same results as the
         # sequential order: see engine.SIDE_PASS.  mrfa_amd.graph.GraphedTrainStep switches it on for the MTIA prior.
         self.concurrent_encoder = False
-        self._side = None
+        object.__setattr__(self, "_sides", [])
+
+    def encode_many(self, frames):
+        """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234), in the reference's order as far as
+        the BatchNorm running statistics are concerned; on a GPU in training mode with `concurrent_encoder`, frame 0 runs on the
+        current stream and every further frame on its own side stream"""
+        from . import engine
+        first = frames[0]
+        if not (self.training and self.concurrent_encoder and first.is_cuda and torch.is_grad_enabled() and len(frames) > 1
+                and engine.prepare_packs(self.encoder)):
+            return [self.encoder(f) for f in frames]
+        main = torch.cuda.current_stream(first.device)
+        sides = self._sides
+        while len(sides) < len(frames) - 1:
+            sides.append(torch.cuda.Stream(device=first.device))
+        outs, deferred = [None] * len(frames), []
+        for i, f in enumerate(frames[1:], start=1):
+            side = sides[i - 1]
+            side.wait_stream(main)
+            with torch.cuda.stream(side), engine.side_pass() as d:
+                f.record_stream(side)
+                outs[i] = self.encoder(f)
+            deferred.append(d)
+        outs[0] = self.encoder(first)
+        for i in range(1, len(frames)):
+            main.wait_stream(sides[i - 1])
+            for t in outs[i].values():
+                t.record_stream(main)
+            engine.apply_deferred_bn(deferred[i - 1])   # running-statistics updates in frame order, after frame 0's
+        return outs
 
     def encode_pair(self, source, driving):
         """(kp_source, kp_driving) = (encoder(source), encoder(driving)), reference model.py:185-186"""
-        from . import engine
         if not self.training:
             return encode_pair_eval(self.encoder, source, driving)
-        if not (self.concurrent_encoder and source.is_cuda and torch.is_grad_enabled() and engine.prepare_packs(self.encoder)):
-            return self.encoder(source), self.encoder(driving)
-        main = torch.cuda.current_stream(source.device)
-        if self._side is None or self._side.device != source.device:
-            object.__setattr__(self, "_side", torch.cuda.Stream(device=source.device))
-        side = self._side
-        side.wait_stream(main)
-        with torch.cuda.stream(side), engine.side_pass() as deferred:
-            driving.record_stream(side)
-            kp_d = self.encoder(driving)
-        kp_s = self.encoder(source)
-        main.wait_stream(side)
-        for t in kp_d.values():
-            t.record_stream(main)
-        engine.apply_deferred_bn(deferred)          # the driving pass's running-statistics update, after the source pass's
+        kp_s, kp_d = self.encode_many([source, driving])
         return kp_s, kp_d
 
     def join(self):
         """after backward(): the side stream's backward kernels are ordered before whatever the caller issues next"""
-        if self._side is not None:
-            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+        for st in self._sides:
+            torch.cuda.current_stream(st.device).wait_stream(st)
 
     def decode(self, source, kp_s, kp_d, bg_param=None):
         """dense motion + refinement + generator for given keypoints (model.py:188-210)"""
@@ -138,11 +152,19 @@ def l1_loss(gen: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
 def reference_loss(model: HotPath, full_loss, source, driving) -> torch.Tensor:
     """The reference's generator objective (train.py:60-63: sum of the .mean() of every entry of MRFA.forward's loss_values,
     model.py:219-246): VGG19 perceptual pyramid + equivariance + equivariance-Jacobian; `full_loss` = mrfa_amd.losses.GeneratorFullLoss."""
-    kp_s, kp_d = model.encode_pair(source, driving)
+    transform = transformed_kp = None
+    if full_loss.loss_weights['equivariance'] != 0:
+        # the third encoder pass (model.py:232-234) depends on the driving frame only: issued together with the first two
+        from .losses import Transform
+        transform = Transform(driving.shape[0], device=driving.device, **full_loss.train_params['transform_params'])
+        kp_s, kp_d, transformed_kp = model.encode_many([source, driving, transform.transform_frame(driving)])
+    else:
+        kp_s, kp_d = model.encode_pair(source, driving)
     bg = model.bg_predictor(source, driving) if model.bg_predictor is not None else None
     gen = model.decode(source, kp_s, kp_d, bg)
     bg_rev = model.bg_predictor(driving, source) if bg is not None else None
-    values = full_loss(model.encoder, driving, gen, kp_d, bg_param=bg, bg_param_reverse=bg_rev)
+    values = full_loss(model.encoder, driving, gen, kp_d, transform=transform, transformed_kp=transformed_kp, bg_param=bg,
+                       bg_param_reverse=bg_rev)
     return sum(v.mean() for v in values.values())
 
 

@@ -195,7 +195,7 @@ def test_concurrent_encoder_passes_equal_sequential():
     l0, g0, b0 = run(False)
     l1, g1, b1 = run(False)
     l2, g2, b2 = run(True)
-    assert model._side is not None, "the concurrent path did not run"
+    assert len(model._sides) == 1, "the concurrent path did not run"
     assert abs(l2 - l0) <= 1e-5 * max(1.0, abs(l0))
     for grp in ("encoder.", "dense_motion.", "decoder."):
         names = [n for n in g0 if n.startswith(grp)]
