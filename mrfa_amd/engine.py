@@ -1402,6 +1402,13 @@ class _ProgramFn(torch.autograd.Function):
     @staticmethod
     def backward(actx, *gouts):
         ectx = actx.ectx
+        if ectx.deferred is not None and ectx.dev.type == "cuda":
+            # side pass: the incoming gradients were allocated on the main stream; tell the caching allocator that this stream reads
+            # them (eager launches only matter: a captured graph owns static memory)
+            cur = torch.cuda.current_stream(ectx.dev)
+            for g in gouts:
+                if g is not None and g.is_cuda:
+                    g.record_stream(cur)
         for seed, g in zip(actx.seeders, gouts):
             if g is not None and seed is not None:
                 seed(g)
