@@ -13,18 +13,11 @@ from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step  # noqa: E4
 from mrfa_amd.utils.prng import fill_state_dict  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+prior = sys.argv[2] if len(sys.argv) > 2 else "mtia"
 dev = torch.device("cuda", 0)
-model = HotPath(VOX1)
-for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
-    sd = fill_state_dict(mod.state_dict(), tag=pfx)
-    for k in list(sd):
-        if k.endswith("jacobian.weight"):
-            sd[k] = sd[k] * 0.05
-        if k.endswith("jacobian.bias"):
-            sd[k] = torch.tensor([1.0, 0.0, 0.0, 1.0]) + sd[k] * 0.5
-        if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
-            sd[k] = sd[k] * 0.3
-    mod.load_state_dict(sd)
+import bench  # noqa: E402
+model = HotPath(VOX1, prior=prior)
+bench.init_weights(model)
 model.to(dev).train()
 opt = make_optimizer(model, fused=True)
 g = torch.Generator(device=dev).manual_seed(0)
