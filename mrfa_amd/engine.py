@@ -37,6 +37,9 @@ DIRECT_PARAM_GRADS = False
 # into a hipGraph this becomes a parallel branch.  Correct (tests/test_graph_gpu.py passes with it) but measured SLOWER on
 # the benchmark step (97.0 vs 93.3 ms: the big kernels already fill the chip and then compete for L2), so it is off by default.
 WGRAD_STREAM = False
+# gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
+# zero arena (one fill instead of hundreds of tiny ones)
+FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "4")) << 20) // 4
 # OFF by default (MRFA_BRANCH_STREAMS=1 to try): measured on the training step, HRNet's three resolution branches side by side
 # gain 2.6 % without the pass-level concurrency (141.9 -> 138.2 ms) and nothing on top of it; RaftFlow's two structure
 # hourglasses beside the generator encoder gain nothing (122.9 vs 126.2 ms).  NESTED forks (branch streams forked from the side
@@ -134,7 +137,7 @@ def _r4(c: int) -> int:
 # ------------------------------------------------------------------------------------------------- storage / views
 class Storage:
     """[rows, ld] fp32 buffer + lazily allocated gradient buffer of the same geometry."""
-    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit")
+    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh")
 
     def __init__(self, data: torch.Tensor):
         assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
@@ -144,10 +147,18 @@ class Storage:
         # True: the gradient buffer has exactly one writer that overwrites all of it (a raw conv output whose only consumer
         # is its BatchNorm): allocated uninitialised, outside the zero arena
         self.grad_noinit = False
+        # True: `grad` is allocated but NOT yet initialised and nobody has written it (big gradient buffers are not zero-filled up
+        # front).  The first writer either overwrites all of it (Ctx._claim: conv data-gradients, BatchNorm backward) or, touching
+        # it through grad_buf() / View.gptr like every other op, gets it zero-filled first.  A producer that finds its output still
+        # fresh knows that no consumer sent a gradient (View.has_grad is False) and skips its backward.
+        self.fresh = False
 
     def grad_buf(self) -> torch.Tensor:
         if self.grad is None:
             self.grad = torch.zeros_like(self.data)
+        elif self.fresh:
+            self.grad.zero_()
+            self.fresh = False
         return self.grad
 
 
@@ -180,7 +191,7 @@ class View:
 
     @property
     def has_grad(self) -> bool:
-        return self.st.grad is not None
+        return self.st.grad is not None and not self.st.fresh
 
     def slice(self, c0: int, c1: int) -> "View":
         assert 0 <= c0 < c1 <= self.C
@@ -700,6 +711,16 @@ class Ctx:
     def f64z(self, n):
         return self.pool64.take(n)
 
+    @staticmethod
+    def _claim(v: View) -> bool:
+        """True: the caller is the first writer of v's gradient buffer and covers all of it -- it must then OVERWRITE (no zero fill
+        happened, nothing may be read).  Views with padding columns or a channel offset never qualify."""
+        st = v.st
+        if st.grad is not None and st.fresh and v.coff == 0 and v.C == st.ld:
+            st.fresh = False
+            return True
+        return False
+
     # -- convolution ------------------------------------------------------------------------------------------
     def conv(self, x: View, conv: torch.nn.Conv2d, out: Optional[View] = None, *, relu=False, ups=False, pre=None,
              stats: Optional[torch.Tensor] = None, res: Optional[View] = None, need_dx=True, use_bias=True) -> View:
@@ -827,10 +848,11 @@ class Ctx:
         through the pre-activation BN+ReLU by the caller-registered closure (see prebn)."""
         Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
         direct = (not ups) and pre is None
+        first = direct and self._claim(x)             # first writer of x.grad covering all of it: overwrite, no zero fill needed
         if direct and cw.fewin and out.ld % 4 == 0 and out.coff % 4 == 0:
             # few input channels: the data gradient is a few-output conv over dY
             self._chk(self.L.mrfa_conv_fewout_fwd(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewin_dgrad_pack().data_ptr(),
-                                                  None, x.gptr, x.ld, cw.Cin, cw.R, cw.R - 1 - cw.pad, 1), "conv_fewout(dgrad)")
+                                                  None, x.gptr, x.ld, cw.Cin, cw.R, cw.R - 1 - cw.pad, 0 if first else 1), "conv_fewout(dgrad)")
             return
         tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
         p = hip.ConvParams()
@@ -862,7 +884,7 @@ class Ctx:
         p.Cout, p.Hout, p.Wout = cw.Cin, Hv, Wv
         p.R, p.S, p.pad = cw.R, cw.S, cw.R - 1 - cw.pad
         p.alpha, p.nbatch = 1.0, 1
-        p.accumulate = 1 if direct else 0
+        p.accumulate = 1 if (direct and not first) else 0
         self._launch_conv(p, "dgrad", cw.Cout)
         if direct:
             return
@@ -969,8 +991,8 @@ class Ctx:
         if res is not None:
             q.res, q.ldr, q.dres, q.lddr = res.ptr, res.ld, res.gptr, res.ld
         q.red = red.data_ptr()
+        q.dx_overwrite = int(self._claim(dx_view))         # before .gptr, which would zero-fill a fresh buffer
         q.dx, q.lddx = dx_view.gptr, dx_view.ld
-        q.dx_overwrite = int(dx_view.st.grad_noinit)
         q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
         q.train = int(train)
         q.phase = 1
@@ -1338,8 +1360,9 @@ class Ctx:
         # one zero arena for the gradients of every forward activation (single memset instead of ~500 fills)
         self.in_backward = True
         for st in self.storages:
-            if st.grad is None and st.grad_noinit:
+            if st.grad is None and (st.grad_noinit or st.data.numel() >= FRESH_MIN_ELEMS):
                 st.grad = torch.empty_like(st.data)
+                st.fresh = True
         todo = [st for st in self.storages if st.grad is None]
         total = sum(st.data.numel() for st in todo)
         if total:

@@ -10,12 +10,15 @@ from mrfa_amd.train import VOX1, HotPath, l1_loss
 from mrfa_amd.utils.prng import det_uniform
 orig = engine.Ctx.run_backward
 def patched(self):
-    noinit = sum(st.data.numel() for st in self.storages if st.grad is None and st.grad_noinit)
-    zero = sum(st.data.numel() for st in self.storages if st.grad is None and not st.grad_noinit)
-    big = sorted((st.data.numel() for st in self.storages if st.grad is None and not st.grad_noinit), reverse=True)[:5]
-    print(f"program: zero-filled {zero*4/2**20:8.1f} MiB in {sum(1 for st in self.storages if st.grad is None and not st.grad_noinit)} storages, "
-          f"uninitialised {noinit*4/2**20:8.1f} MiB; biggest zeroed: {[round(b*4/2**20) for b in big]} MiB")
-    return orig(self)
+    todo = [st for st in self.storages if st.grad is None]
+    lazy = [st for st in todo if st.grad_noinit or st.data.numel() >= engine.FRESH_MIN_ELEMS]
+    arena = [st for st in todo if st not in lazy]
+    r = orig(self)
+    untouched = [st for st in lazy if st.fresh]                   # never written: dead branches, skipped by their producers
+    print(f"program: {len(todo)} gradient buffers, {sum(st.data.numel() for st in todo) * 4 / 2**20:.0f} MiB; zero arena {len(arena)} buffers "
+          f"{sum(st.data.numel() for st in arena) * 4 / 2**20:.0f} MiB; allocated uninitialised {len(lazy)} buffers "
+          f"{sum(st.data.numel() for st in lazy) * 4 / 2**20:.0f} MiB, of which never written {sum(st.data.numel() for st in untouched) * 4 / 2**20:.0f} MiB")
+    return r
 engine.Ctx.run_backward = patched
 dev = torch.device("cuda", 0)
 model = HotPath(VOX1, prior="mtia"); bench.init_weights(model); model.to(dev).train(True)
