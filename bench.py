@@ -333,7 +333,7 @@ def main():
                     with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
                         tj = json.load(tf)
                         if split:
-                            tj = tj["split_operand"]["conv_bf16x6_kernel"]
+                            tj = tj.get("split_operand_mtia_lazy_gradients", tj["split_operand"])["conv_bf16x6_kernel"]
                         traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 4)
                 except Exception:
                     pass
