@@ -245,7 +245,7 @@ def main():
         prof, Ctx.profile = Ctx.profile, None
 
     alt = alt3 = None
-    if launch == "hipGraph" and hip.mfma_mode() == "bf16x6" and not a.no_forward:
+    if launch == "hipGraph" and hip.mfma_mode() == "bf16x6" and not a.no_forward and world == 1:      # N=1 only: a failed re-capture on ONE rank would leave the others in the all-reduce
         # for the record (outside the timed region): the same step in the opt-in 3-product mode (~1e-5 product error)
         try:
             hip.set_mfma_mode("bf16x3")
@@ -266,7 +266,7 @@ def main():
             print(f"[bench] bf16x3 comparison run failed: {ex!r}", file=sys.stderr)
         finally:
             hip.set_mfma_mode("bf16x6")
-    if launch == "hipGraph" and hip.mfma_mode() == "bf16x6" and not a.no_forward:
+    if launch == "hipGraph" and hip.mfma_mode() == "bf16x6" and not a.no_forward and world == 1:      # N=1 only: a failed re-capture on ONE rank would leave the others in the all-reduce
         # for the record (outside the timed region): the same step with every conv on the native fp32 matrix pipe
         try:
             hip.set_mfma_mode("f32")
