@@ -209,3 +209,44 @@ def test_concurrent_encoder_passes_equal_sequential():
             assert (b2[n] - b0[n]).abs().max().item() <= 1e-5 + 1e-5 * b0[n].abs().max().item(), n
         else:
             assert torch.equal(b2[n], b0[n]), n
+
+
+def test_encode_many_three_passes_keep_the_sequential_batchnorm_order():
+    """three TokenPose_B passes side by side (source, driving, the equivariance pass of the reference's objective): outputs and the
+    BatchNorm running statistics / batch counters equal those of three sequential passes (momentum updates applied in frame order)"""
+    import bench
+    from mrfa_amd.train import VOX1, HotPath
+    model = HotPath(VOX1, prior="mtia")
+    bench.init_weights(model)
+    model.to(DEV).train(True)
+    frames = [_pairs(2, f"g/em{k}")[0] for k in range(3)]
+    saved = [b.clone() for b in model.buffers()]
+
+    def run(concurrent):
+        for b, sv in zip(model.buffers(), saved):
+            b.copy_(sv)
+        model.concurrent_encoder = concurrent
+        outs = model.encode_many(frames)
+        loss = sum(o["kp"].sum() + o["jacobian"].sum() for o in outs)
+        for p in model.encoder.parameters():
+            p.grad = None
+        loss.backward()
+        model.join()
+        torch.cuda.synchronize()
+        return [o["kp"].detach().clone() for o in outs], {n: b.clone() for n, b in model.encoder.named_buffers()}, \
+            {n: p.grad.double().clone() for n, p in model.encoder.named_parameters() if p.grad is not None}
+
+    run(False)                                              # builds the packs: a first pass never forks
+    k0, b0, g0 = run(False)
+    k1, b1, g1 = run(True)
+    assert len(model._sides) == 2
+    for a, b in zip(k0, k1):
+        assert (a - b).abs().max().item() <= 1e-5
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert (b1[n] - b0[n]).abs().max().item() <= 1e-5 + 1e-5 * b0[n].abs().max().item(), n
+        else:
+            assert int(b1[n]) == int(b0[n]) == 3, n         # three forward passes counted
+    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0) ** 0.5
+    den = sum(float(g0[n].pow(2).sum()) for n in g0) ** 0.5
+    assert num / den <= 0.05, num / den
