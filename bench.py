@@ -1,16 +1,20 @@
 #!/usr/bin/env python
 """bench.py -- headline metric of BASELINE.json: 256x256 (source, driving) pairs/s, forward+backward(+clip+Adam), fp32,
-vox1.yaml shapes with the FOMM prior and RAFT refinement, B=8 per GPU, synthetic inputs resident in HBM.
+BASELINE.json configs[1] = vox1.yaml shapes with the MTIA prior (TokenPose_B; `--prior fomm` = KPDetector) and RAFT refinement,
+B=8 per GPU, synthetic inputs resident in HBM.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --size 512 --batch 4 --inference          # BASELINE.json configs[4]: 512x512 inference-only generator path
 
 Rank 0 prints ONE JSON line.  A step = pack + forward + backward + (flat RCCL all-reduce, N > 1) + clip + Adam, replayed
 as hipGraphs (mrfa_amd/graph.py; `--no-graph` launches every kernel eagerly, with DistributedDataParallel for N > 1).
-`roofline` is measured live with HIP events around every launch of the dominant kernel (the 128x128-tile, 8-wave fp32
-MFMA implicit-GEMM convolution, forward + data-gradient launches): inside the timed region for eager launches, and on
-the same step re-issued eagerly right after the timed region when it was a graph replay (events cannot be recorded
-inside a replayed graph; the kernels, shapes and stream are identical).
+`roofline` is measured live with HIP events around every launch of the dominant kernel (the 128x128 implicit-GEMM convolution
+tile, forward + data-gradient launches: `conv_bf16x6_kernel` on the bf16 matrix pipe with exactly split fp32 operands by default,
+`conv_mfma_kernel<128,128,...>` on the native fp32 matrix pipe with `--mfma f32`): inside the timed region for eager launches,
+and on the same step re-issued eagerly right after the timed region when it was a graph replay (events cannot be recorded
+inside a replayed graph; the kernels, shapes and stream are identical).  `roofline.traffic` is NOT measured in this run: it is
+read from the committed PMC passes of the same command (profiles/README.md) and labelled `traffic_source`.
 `cpu_baseline` times the CPU oracle (the reference restated, oracle/mrfa_oracle.py) on a bounded sample on rank 0."""
 import argparse
 import json
@@ -341,6 +345,7 @@ def main():
                 peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
                 roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
+                        "traffic_source": "profiles/r1_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run",
                         "peak_is": (f"bf16 dense MFMA peak 2500 / {nprod} split products (fp32-equivalent FLOPs)" if split
                                     else "fp32 dense MFMA peak"),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -40,6 +40,10 @@ WGRAD_STREAM = False
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones)
 FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "4")) << 20) // 4
+# debug switch (MRFA_FRESH_NAN=1; tests set it together with FRESH_MIN_ELEMS = 0): every lazily initialised gradient buffer starts
+# as NaN instead of whatever the allocator hands out, so a kernel that READS a buffer no writer has covered -- or a first writer that
+# does not cover all of it -- shows up as a non-finite gradient instead of passing by luck
+FRESH_NAN = os.environ.get("MRFA_FRESH_NAN", "0") == "1"
 # OFF by default (MRFA_BRANCH_STREAMS=1 to try): measured on the training step, HRNet's three resolution branches side by side
 # gain 2.6 % without the pass-level concurrency (141.9 -> 138.2 ms) and nothing on top of it; RaftFlow's two structure
 # hourglasses beside the generator encoder gain nothing (122.9 vs 126.2 ms).  NESTED forks (branch streams forked from the side
@@ -1362,6 +1366,8 @@ class Ctx:
         for st in self.storages:
             if st.grad is None and (st.grad_noinit or st.data.numel() >= FRESH_MIN_ELEMS):
                 st.grad = torch.empty_like(st.data)
+                if FRESH_NAN:
+                    st.grad.fill_(float("nan"))
                 st.fresh = True
         todo = [st for st in self.storages if st.grad is None]
         total = sum(st.data.numel() for st in todo)

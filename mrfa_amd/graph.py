@@ -35,7 +35,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from . import engine
+from . import engine, graph_replay_safe
 
 
 def l1_loss(gen, driving):
@@ -95,20 +95,43 @@ class GraphedForward:
         self.out = None
         self.recapture()
 
-    def recapture(self):
+    def recapture(self, check: bool = True):
+        graph_replay_safe("GraphedForward")
         m = self.model
         was_training = m.training
         m.eval()
         try:
             with torch.no_grad():
-                m(self.src, self.drv)                   # packs weights / builds gather tables outside the graph
+                eager = m(self.src, self.drv)           # packs weights / builds gather tables outside the graph
+                eager = tuple(t.clone() for t in eager) if isinstance(eager, (tuple, list)) else eager.clone()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self.out = m(self.src, self.drv)
             self.graph = g
+            if check:
+                self._self_check(eager)
         finally:
             m.train(was_training)
+
+    def _self_check(self, eager, replays: int = 3, tol: float = 1e-4):
+        """the first AND later replays against the eager output at the same inputs (a mis-ordered memcpy / memset node shows from
+        the second replay on): inference has no batch statistics and no split-K over the outputs checked here, so the only
+        differences are fp32 summation order (<= 1e-5 measured); `tol` is absolute on outputs in [0, 1]"""
+        outs = self.out if isinstance(self.out, (tuple, list)) else (self.out,)
+        refs = eager if isinstance(eager, (tuple, list)) else (eager,)
+        scratch = torch.empty(1 << 20, device=self.src.device)
+        for k in range(replays):
+            scratch.normal_()                           # unrelated device work between replays
+            self.graph.replay()
+            torch.cuda.synchronize()
+            for i, (o, r) in enumerate(zip(outs, refs)):
+                if not torch.is_tensor(o):
+                    continue
+                d = float((o - r).abs().max())
+                if not d <= tol * max(1.0, float(r.abs().max())):
+                    raise RuntimeError(f"GraphedForward: replay {k} differs from the eager forward (output {i}: max |diff| {d:.3e}); "
+                                       f"the captured graph is not trustworthy (see mrfa_amd/graph.py, MEMCPY / MEMSET NODES)")
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor):
         if source.data_ptr() != self.src.data_ptr():
@@ -130,6 +153,7 @@ class GraphedTrainStep:
                  clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False,
                  concurrent_encoder: Optional[bool] = None, loss_fn=None):
         """loss_fn(model, source, driving) -> scalar loss; None = the surrogate mean|model(source, driving) - driving|"""
+        graph_replay_safe("GraphedTrainStep")
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         self.loss_fn = loss_fn
         if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
@@ -225,6 +249,8 @@ class GraphedTrainStep:
         what ran before it means a node of the graph is not ordered (see "kernel nodes only" above)."""
         saved = [b.detach().clone() for b in self.model.buffers()]
         segs = self._segments()
+        dev = self.flat.device
+        rng_state = torch.cuda.get_rng_state(dev) if self.loss_fn is not None else None      # reseed() below must not leak out
 
         def dist(a, b):
             return [float((a[lo:hi] - b[lo:hi]).norm() / (b[lo:hi].norm() + 1e-30)) for lo, hi in segs]
@@ -280,6 +306,8 @@ class GraphedTrainStep:
                                            f"the allowed {allow} (eager noise band {band})")
             for b, sv in zip(self.model.buffers(), saved):
                 b.copy_(sv)
+        if rng_state is not None:
+            torch.cuda.set_rng_state(rng_state, dev)      # every rank / run continues from ITS generator state, not from the fixed seed
         return worst
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:

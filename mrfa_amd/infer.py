@@ -41,13 +41,22 @@ class Animator:
         if not self.use_graph:
             return self._frame(driving)
         if self._g is None:                                   # capture the per-frame program once per source
+            from . import graph_replay_safe
+            graph_replay_safe("Animator(graph=True)")
             self._drv = driving.clone()
-            self._frame(self._drv)                            # packs / tables outside the graph
+            eager = self._frame(self._drv).clone()            # packs / tables outside the graph
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._out = self._frame(self._drv)
             self._g = g
+            for k in range(3):                                # first AND later replays against the eager frame (mrfa_amd/graph.py)
+                g.replay()
+                torch.cuda.synchronize()
+                d = float((self._out - eager).abs().max())
+                if not d <= 1e-4:
+                    self._g = None
+                    raise RuntimeError(f"Animator: hipGraph replay {k} differs from the eager frame (max |diff| {d:.3e})")
         self._drv.copy_(driving)
         self._g.replay()
         return self._out

@@ -27,6 +27,22 @@ class MRFA(nn.Module):
         self.cfg = cfg
         train_params = _get(cfg, 'train_params')
         self.train_params = train_params
+        # model.py:150-157: `pyramid` (and `vgg` when the perceptual weights are not all zero) are TOP-LEVEL sub-modules of the
+        # reference's MRFA, registered before the networks: its checkpoints hold `pyramid.downs.*.weight` and `vgg.*`, and demo.py /
+        # Logger.load_cpk load them with strict=True.  The loss container that uses them (mrfa_amd.losses.GeneratorFullLoss) is
+        # therefore NOT a registered child: it only borrows the two modules registered here.
+        object.__setattr__(self, 'losses', None)
+        if 'loss_weights' in train_params and 'scales' in train_params:
+            from ..losses import GeneratorFullLoss, ImagePyramide
+            full = GeneratorFullLoss(train_params)
+            self.scales = train_params['scales']
+            self.loss_weights = train_params['loss_weights']
+            if full.perceptual is not None:
+                self.pyramid = full.perceptual.pyramid
+                self.vgg = full.perceptual.vgg
+            else:
+                self.pyramid = ImagePyramide(self.scales, 3)
+            object.__setattr__(self, 'losses', full)
         prior = train_params['prior_model']
         self.prior = prior
         if prior == 'fomm':
@@ -44,10 +60,6 @@ class MRFA(nn.Module):
             self.bg_predictor = BGMotionPredictor()
         self.decoder = RaftFlow(**_get(cfg, 'raft_flow'))
         self.down = AntiAliasInterpolation2d(3, 0.25)
-        self.losses = None
-        if 'loss_weights' in train_params and 'scales' in train_params:     # model.py:150-157: pyramid + VGG19 for the perceptual term
-            from ..losses import GeneratorFullLoss
-            self.losses = GeneratorFullLoss(train_params)
 
     def forward(self, x, epoch=100, is_train=True):
         if self.training:

@@ -218,20 +218,56 @@ def train_step(model, optimizer, source, driving, clip=10.0, loss_fn=None):
 
 def save_checkpoint(path: str, model, optimizer, epoch: int):
     """The reference's checkpoint file (logger.py:50-58, train.py:94): {'model': state_dict with DDP's 'module.' prefix,
-    'optimizer': optimizer.state_dict(), 'epoch': int} -- readable by the reference's Logger.load_cpk and by load_checkpoint."""
+    'optimizer': optimizer.state_dict(), 'epoch': int} -- readable by the reference's Logger.load_cpk and by load_checkpoint.
+    `model` = mrfa_amd.modules.MRFA gives the reference MRFA's exact key set (`pyramid.*`, `vgg.*`, `encoder.*`, ...: pinned by
+    tests/golden/state_dict_manifest.json['MRFA']); a HotPath writes the networks only (no loss modules: the reference's strict
+    loader then reports the missing `pyramid.*` / `vgg.*` keys, as it would for any file without them)."""
     m = model.module if hasattr(model, "module") else model
     sd = {"module." + k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     torch.save({"model": sd, "optimizer": optimizer.state_dict(), "epoch": int(epoch)}, path)
 
 
-def load_checkpoint(path: str, model, optimizer=None) -> int:
+# keys a checkpoint may hold that a model without the loss modules has no slot for (reference model.py:154-157), and vice versa
+_LOSS_PREFIXES = ("pyramid.", "vgg.")
+
+
+def load_checkpoint(path: str, model, optimizer=None, strict: bool = True) -> int:
     """Logger.load_cpk (logger.py:60-66) for either side's files: accepts keys with or without the 'module.' prefix and an
-    optimizer state written by torch.optim.Adam or by FlatAdam; returns the epoch to resume from."""
+    optimizer state written by torch.optim.Adam or by FlatAdam; returns the epoch to resume from.
+
+    strict=True (the reference's behaviour): every key of the model must be in the file and every key of the file must have a slot in
+    the model, otherwise RuntimeError naming the keys -- with ONE documented exception in each direction: the loss modules'
+    `pyramid.*` / `vgg.*` entries are ignored when the model has no such modules (a HotPath loading a full MRFA checkpoint), and are
+    reported in the warning log, never silently, when the file lacks them (a HotPath checkpoint loaded into an MRFA: the VGG19 then
+    keeps whatever weights it had).  strict=False: train.py:27-32's fine-tuning load (missing / unexpected keys are returned by
+    torch and logged)."""
+    import logging
+    log = logging.getLogger("mrfa_amd")
     cpk = torch.load(path, map_location="cpu")
     m = model.module if hasattr(model, "module") else model
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in cpk["model"].items()}
     own = m.state_dict()
-    m.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=set(own) <= set(sd))
+    has_loss_modules = any(k.startswith(_LOSS_PREFIXES) for k in own)
+    if not has_loss_modules:
+        dropped = sorted(k for k in sd if k.startswith(_LOSS_PREFIXES))
+        if dropped:
+            log.warning("load_checkpoint: %d loss-module entries of %s have no slot in %s and are not loaded (%s ...)", len(dropped), path,
+                        type(m).__name__, dropped[0])
+        sd = {k: v for k, v in sd.items() if not k.startswith(_LOSS_PREFIXES)}
+    missing = sorted(k for k in own if k not in sd)
+    unexpected = sorted(k for k in sd if k not in own)
+    loss_missing = [k for k in missing if k.startswith(_LOSS_PREFIXES)]
+    if loss_missing and len(loss_missing) == len(missing) and not unexpected:
+        log.warning("load_checkpoint: %s holds no `pyramid.*` / `vgg.*` entries (%d keys): the perceptual-loss modules keep their current "
+                    "weights", path, len(loss_missing))
+        m.load_state_dict(sd, strict=False)
+    elif strict and (missing or unexpected):
+        raise RuntimeError(f"load_checkpoint({path}): missing keys {missing[:8]}{' ...' if len(missing) > 8 else ''} ({len(missing)}), "
+                           f"unexpected keys {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''} ({len(unexpected)})")
+    else:
+        res = m.load_state_dict(sd, strict=False)
+        if res.missing_keys or res.unexpected_keys:
+            log.warning("load_checkpoint(strict=False): %d missing, %d unexpected keys", len(res.missing_keys), len(res.unexpected_keys))
     if optimizer is not None and "optimizer" in cpk:
         optimizer.load_state_dict(cpk["optimizer"])
     return int(cpk.get("epoch", 0))

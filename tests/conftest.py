@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=[False, True], ids=["fresh-default", "fresh-all-nan"])
+def fresh_mode(request, monkeypatch):
+    """the lazily initialised gradient buffers (engine.Storage.fresh).  Second leg: EVERY activation-gradient buffer is
+    lazy (threshold 0 instead of 4 MiB) and starts as NaN, so an uncovered element or a read-before-write cannot pass."""
+    if request.param:
+        from mrfa_amd import engine
+        monkeypatch.setattr(engine, "FRESH_MIN_ELEMS", 0)
+        monkeypatch.setattr(engine, "FRESH_NAN", True)
+    return request.param

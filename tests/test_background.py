@@ -89,7 +89,7 @@ def _check_dense_motion(g, dev):
 
 
 @pytest.mark.parametrize("train", [False, True])
-def test_product_through_abi_emulator(golden_dir, train):
+def test_product_through_abi_emulator(golden_dir, train, fresh_mode):
     with emulated_hip():
         _check(_g(golden_dir), golden_dir, "cpu", train)
 
@@ -101,6 +101,6 @@ def test_dense_motion_with_background_through_abi_emulator(golden_dir):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("train", [False, True])
-def test_gpu(golden_dir, train):
+def test_gpu(golden_dir, train, fresh_mode):
     _check(_g(golden_dir), golden_dir, "cuda:0", train)
     _check_dense_motion(_g(golden_dir), "cuda:0")

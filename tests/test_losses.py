@@ -125,7 +125,7 @@ def test_product_through_abi_emulator_alone(golden_dir):
         _check_alone(_g(golden_dir), "cpu")
 
 
-def test_product_through_abi_emulator_full_training_forward(golden_dir):
+def test_product_through_abi_emulator_full_training_forward(golden_dir, fresh_mode):
     with emulated_hip():
         _check_full(_g(golden_dir), golden_dir, "cpu")
 
@@ -136,7 +136,7 @@ def test_gpu_alone(golden_dir):
 
 
 @pytest.mark.gpu
-def test_gpu_full_training_forward(golden_dir):
+def test_gpu_full_training_forward(golden_dir, fresh_mode):
     _check_full(_g(golden_dir), golden_dir, "cuda:0")
 
 

@@ -82,7 +82,7 @@ def test_raft_flow_vs_reference_goldens(golden_dir, size, b, stride, prior_only)
         _cmp(o.mean(dim=(2, 3)), g[f"out_mean_{sfx}"], 1e-4, 1e-4, what=f"out mean {sfx}")
 
 
-def test_raft_flow_gradients_vs_reference_goldens(golden_dir):
+def test_raft_flow_gradients_vs_reference_goldens(golden_dir, fresh_mode):
     g = _g(golden_dir, "grads_64.npz")
     names = json.load(open(os.path.join(golden_dir, "grads_64_param_names.json")))
     size, b = 64, 2

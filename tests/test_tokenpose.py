@@ -90,7 +90,7 @@ def test_sine_position_code_is_the_reference_buffer():
 
 
 @pytest.mark.parametrize("train", [False, True])
-def test_host_logic_through_abi_emulator(golden_dir, train):
+def test_host_logic_through_abi_emulator(golden_dir, train, fresh_mode):
     """the product nn.Module (engine program, tape, islands) with every kernel replaced by its CPU specification"""
     g, names = _g(golden_dir)
     sfx = "train" if train else "eval"
@@ -111,7 +111,7 @@ def test_host_logic_through_abi_emulator(golden_dir, train):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["bf16x6", "f32"])
 @pytest.mark.parametrize("train", [False, True])
-def test_gpu_vs_reference_goldens(golden_dir, train, mode):
+def test_gpu_vs_reference_goldens(golden_dir, train, mode, fresh_mode):
     from mrfa_amd import hip
     g, names = _g(golden_dir)
     sfx = "train" if train else "eval"

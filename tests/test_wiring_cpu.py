@@ -142,7 +142,7 @@ def test_raft_flow_through_emulator(golden_dir, prior_only):
 
 
 @pytest.mark.parametrize("direct", [False, True])
-def test_raft_flow_backward_through_emulator(golden_dir, direct):
+def test_raft_flow_backward_through_emulator(golden_dir, direct, fresh_mode):
     """the hand-written backward tape (every op's gradient wiring) against the reference's autograd gradients.
     direct=True: engine.direct_param_grads() -- the backward kernels accumulate straight into pre-bound .grad tensors
     (the flat gradient buffer of the hipGraph step) and autograd is handed None for the parameters."""
@@ -169,8 +169,10 @@ def test_raft_flow_backward_through_emulator(golden_dir, direct):
         assert not direct or fg.bound()
     assert abs(loss.item() - float(g["loss"][0])) < 1e-6
     for n, t in zip(("kp_s", "kp_d", "deformation", "occlusion"), leaves):
+        assert torch.isfinite(t.grad).all(), n
         assert np.abs(t.grad.numpy() - g[f"grad_{n}"]).max() < 1e-4, n
     P = dict(rf.named_parameters())
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in P.values())
     norms = np.array([0.0 if P[n].grad is None else P[n].grad.norm().item() for n in names], np.float32)
     ref = g["param_grad_norms"]
     assert np.abs(norms - ref).max() <= 1e-4 + 1e-3 * np.abs(ref).max()
@@ -489,3 +491,97 @@ def test_baseline_config1_mrfa_mtia_prior_only_plumbing():
     assert (gen - g2).abs().max().item() <= 1e-3 and (gen - g2).abs().mean().item() <= 1e-4
     assert (warp - w2).abs().max().item() <= 1e-3
     assert (kp_s - k_s["kp"]).abs().max().item() <= 1e-5 and (kp_d - k_d["kp"]).abs().max().item() <= 1e-5
+
+
+# the reference's train_params blocks (config/vox1.yaml:66-101; celebvhq.yaml differs in bg_start only)
+_YAML_TRAIN = dict(prior_model="mtia", num_epochs=100, num_repeats=150, epoch_milestones=[60, 90], lr=2.0e-4, batch_size=80,
+                   scales=[1, 0.5, 0.25, 0.125], clip_grad=True, clip=10, bg_start=1000, checkpoint_freq=100,
+                   transform_params=dict(sigma_affine=0.05, sigma_tps=0.005, points_tps=5),
+                   loss_weights=dict(perceptual=[10, 10, 10, 10, 10], equivariance=10, equivariance_jacobian=10))
+
+
+def _mrfa(**train_overrides):
+    import copy
+    from mrfa_amd.modules import MRFA
+    from mrfa_amd.modules.util import convert_dict_to_attrit_dict
+    from mrfa_amd.train import VOX1
+    cfg = copy.deepcopy(VOX1)
+    cfg["train_params"] = dict(_YAML_TRAIN, **train_overrides)
+    return MRFA(convert_dict_to_attrit_dict(cfg))
+
+
+@pytest.mark.parametrize("name,over", [("MRFA_vox1", {}), ("MRFA_celebvhq", {"bg_start": 0}), ("MRFA_vox1_fomm", {"prior_model": "fomm"})])
+def test_whole_mrfa_state_dict_equals_the_reference_mrfa(golden_dir, name, over):
+    """The checkpoint key set of the reference's OWN MRFA built from its YAML files (tools/make_goldens.py:g9_mrfa_manifest): same
+    names, shapes, dtypes AND order -- `pyramid.*` / `vgg.*` at the top level (model.py:154-157), `encoder.*`, `dense_motion.*`,
+    [`bg_predictor.*`,] `decoder.*`, `down.weight`.  demo.py:36-38 and Logger.load_cpk load such files with strict=True."""
+    man = json.load(open(os.path.join(golden_dir, "state_dict_manifest.json")))
+    assert manifest_of(_mrfa(**over)) == man[name]
+
+
+def test_mrfa_checkpoint_roundtrip_is_strict_and_keeps_the_loss_modules(tmp_path, caplog):
+    """a reference MRFA checkpoint's VGG19 / pyramid weights must land in the perceptual loss (not be dropped), files we
+    write must carry them under the reference's names, and key mismatches must be reported, not filtered away."""
+    import logging
+    from mrfa_amd.train import HotPath, load_checkpoint, save_checkpoint
+    from mrfa_amd.utils.prng import fill_state_dict
+    a = _mrfa(prior_model="fomm")
+    a.load_state_dict(fill_state_dict(a.state_dict(), "ckm"))
+    opt = torch.optim.Adam([{"params": a.encoder.parameters()}, {"params": a.decoder.parameters()}, {"params": a.dense_motion.parameters()}])
+    f = str(tmp_path / "00000007-checkpoint.pth")
+    save_checkpoint(f, a, opt, epoch=7)
+    raw = torch.load(f)["model"]
+    assert "module.vgg.slice1.0.weight" in raw and "module.pyramid.downs.0-5.weight" in raw and not any("losses." in k for k in raw)
+    b = _mrfa(prior_model="fomm")
+    assert load_checkpoint(f, b) == 7
+    # the SAME tensor object serves the perceptual loss: what the checkpoint carried is what the loss will use
+    assert b.losses.perceptual.vgg is b.vgg and b.losses.perceptual.pyramid is b.pyramid
+    for k, v in a.state_dict().items():
+        assert torch.equal(b.state_dict()[k], v), k
+    # a network-only model takes the same file, says what it leaves out ...
+    h = HotPath(prior="fomm")
+    with caplog.at_level(logging.WARNING, logger="mrfa_amd"):
+        assert load_checkpoint(f, h) == 7
+    assert any("loss-module entries" in r.message for r in caplog.records)
+    assert torch.equal(h.decoder.refine.conv1.weight, a.decoder.refine.conv1.weight)
+    # ... and anything else that does not line up raises instead of being filtered
+    bad = dict(torch.load(f))
+    bad["model"] = {k: v for k, v in bad["model"].items() if "refine.conv1" not in k}
+    bad["model"]["module.decoder.not_a_layer.weight"] = torch.zeros(1)
+    f2 = str(tmp_path / "bad.pth")
+    torch.save(bad, f2)
+    with pytest.raises(RuntimeError, match="missing keys.*refine.conv1.*unexpected keys.*not_a_layer"):
+        load_checkpoint(f2, _mrfa(prior_model="fomm"))
+    with caplog.at_level(logging.WARNING, logger="mrfa_amd"):
+        load_checkpoint(f2, _mrfa(prior_model="fomm"), strict=False)          # train.py:27-32's fine-tuning load
+
+
+def test_graph_capture_refuses_a_late_import(tmp_path):
+    """replays are only trustworthy when DEBUG_CLR_GRAPH_PACKET_CAPTURE was 0 at HIP start-up.  A process that
+    touched the device first gets a warning at import and a RuntimeError at capture time (not silently wrong replays)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, types, warnings
+os.environ.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+import torch
+torch.cuda.is_initialized = lambda: True          # stands for 'the host application already used the GPU'
+sys.path.insert(0, sys.argv[1])
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    import mrfa_amd
+assert mrfa_amd.GRAPH_REPLAY_UNSAFE and any("hipGraph capture" in str(x.message) for x in w), [str(x.message) for x in w]
+try:
+    mrfa_amd.graph_replay_safe("probe")
+except RuntimeError as e:
+    assert "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in str(e)
+else:
+    raise SystemExit("graph_replay_safe did not raise")
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    # the normal order (import mrfa_amd before any device call, or the flag exported as 0) stays silent
+    code2 = "import sys; sys.path.insert(0, sys.argv[1]); import mrfa_amd; assert not mrfa_amd.GRAPH_REPLAY_UNSAFE; mrfa_amd.graph_replay_safe(); print('ok')"
+    r = subprocess.run([sys.executable, "-c", code2, ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -549,8 +549,75 @@ def g8_background():
     print("G8 background goldens:", len(out), "bg_eval[0] =", out["bg_eval"][0].round(3).tolist())
 
 
+# ----------------------------------------------------------------------------------------------- G9 whole-MRFA key layout
+def g9_mrfa_manifest():
+    """state_dict manifests of the reference's OWN MRFA (model.py:145-181) built from its two YAML files: vox1.yaml (MTIA prior, no
+    background predictor) and celebvhq.yaml (bg_start 0 -> BGMotionPredictor), plus the FOMM-prior variant of vox1.  These pin the
+    checkpoint key set demo.py / Logger.load_cpk load with strict=True (`pyramid.*`, `vgg.*` at the top level, then the networks).
+    torchvision is absent: vgg19 / resnet18 are bound to the published architectures as in g7 / g8 (shapes and names only matter)."""
+    import copy
+    import yaml
+    import modules.model as RM
+    import modules.bg_motion_predictor as RB
+    from oracle import losses_oracle as LO
+
+    class _Features(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            layers, cin = [], 3
+            for v in LO.VGG19_CFG:
+                if v == 'M':
+                    layers.append(torch.nn.MaxPool2d(2, 2))
+                else:
+                    layers += [torch.nn.Conv2d(cin, v, 3, padding=1), torch.nn.ReLU(inplace=True)]
+                    cin = v
+            self.features = torch.nn.Sequential(*layers)
+
+    class _Block(torch.nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(cout)
+            self.conv2 = torch.nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+            self.bn2 = torch.nn.BatchNorm2d(cout)
+            self.downsample = None
+            if stride != 1 or cin != cout:
+                self.downsample = torch.nn.Sequential(torch.nn.Conv2d(cin, cout, 1, stride, bias=False), torch.nn.BatchNorm2d(cout))
+
+    class _ResNet18(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(64)
+            cin = 64
+            for k, (c, st) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), start=1):
+                setattr(self, f"layer{k}", torch.nn.Sequential(_Block(cin, c, st), _Block(c, c, 1)))
+                cin = c
+            self.fc = torch.nn.Linear(512, 1000)
+    RM.models.vgg19 = lambda pretrained=True: _Features()
+    RB.models.resnet18 = lambda pretrained=False: _ResNet18()
+    RM.BGMotionPredictor = RB.BGMotionPredictor
+    old_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))
+    try:
+        for name, yml, prior in (("MRFA_vox1", "vox1.yaml", None), ("MRFA_celebvhq", "celebvhq.yaml", None), ("MRFA_vox1_fomm", "vox1.yaml", "fomm")):
+            cfg = yaml.safe_load(open(os.path.join(ref_import.REF_ROOT, "config", yml)))
+            if prior:
+                cfg = copy.deepcopy(cfg)
+                cfg["train_params"]["prior_model"] = prior
+            m = RM.MRFA(RU.convert_dict_to_attrit_dict(cfg))
+            man[name] = manifest(m)
+            print(f"   {name}: {len(man[name])} entries, first {man[name][0][0]}, has bg_predictor {hasattr(m, 'bg_predictor')}")
+    finally:
+        torch.nn.Module.cuda = old_cuda
+    with open(os.path.join(GOLD, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0)
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest"]
     for w in which:
         print("==", w)
         globals()[w]()
