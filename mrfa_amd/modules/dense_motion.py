@@ -107,3 +107,12 @@ class DenseMotionNetwork(nn.Module):
         if self.occlusion is not None:
             out_dict['occlusion'] = outs[4]
         return out_dict
+
+
+class TPSDenseMotionNetwork(nn.Module):
+    """Name kept importable for `from .dense_motion import DenseMotionNetwork, TPSDenseMotionNetwork` (reference modules/model.py:20);
+    the TPSM prior's dense-motion network (dense_motion.py:150-312) is out of scope (SURVEY.md section 2 #9)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("TPSDenseMotionNetwork (prior_model: tpsm) is out of scope of the MI355X hot path")

@@ -62,3 +62,12 @@ class KPDetector(nn.Module):
         if self.estimate_jacobian:
             out['jacobian'] = outs[1]
         return out
+
+
+class TPSKPDetector(nn.Module):
+    """Name kept importable for `from .kp_detector import KPDetector, TPSKPDetector` (reference modules/model.py:19).  The TPSM prior
+    (kp_detector.py:136-158: resnet18 + thin-plate splines) is in no BASELINE config and out of scope (SURVEY.md section 2 #9)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("TPSKPDetector (prior_model: tpsm) is out of scope of the MI355X hot path: use prior_model mtia or fomm")

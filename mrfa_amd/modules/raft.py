@@ -12,7 +12,49 @@ from torch import nn
 
 from ..engine import Ctx, View, run_program
 from .generator import OcclusionAwareGenerator
-from .util import Hourglass, coords_grid_nhwc, kp2gaussian
+from .util import _FN, Hourglass, batch_bilinear_sampler, bilinear_sampler, coords_grid, coords_grid_nhwc, kp2gaussian  # noqa: F401
+
+
+class CorrBlock:
+    """2-level correlation pyramid + (2r+1)^2-window bilinear lookup.  reference: modules/raft.py:12-48 (same constructor and call):
+    corr (B*h1*w1, 1, H, W) = one source map per query pixel; __call__(coords (B,2,h1,w1), pixel (x,y) on the H x W map) ->
+    (B, num_levels*(2r+1)^2, h1, w1), channel = lvl*(2r+1)^2 + a*(2r+1) + b sampled at (x/2^lvl + a - r, y/2^lvl + b - r).
+    Runs mrfa_corr_lookup_fwd/bwd (K11/K13) on the rows of the volume in place; differentiable w.r.t. corr and coords."""
+
+    def __init__(self, corr, num_levels=2, radius=3):
+        if num_levels != 2:
+            raise NotImplementedError("CorrBlock: the lookup kernel holds the reference's two pyramid levels (raft.py:238)")
+        assert corr.dim() == 4 and corr.shape[1] == 1 and corr.shape[2] % 2 == 0 and corr.shape[3] % 2 == 0
+        self.num_levels, self.radius = num_levels, radius
+        self.corr = corr
+
+    def __call__(self, coords):
+        corr, r = self.corr, self.radius
+        BQ, _, H, W = corr.shape
+        B, _, h1, w1 = coords.shape
+        assert B * h1 * w1 == BQ, "CorrBlock: one source map per query pixel"
+
+        def program(e: Ctx, corr_, coords_):
+            vol0 = corr_.contiguous().float().view(BQ, H * W)
+            vol1 = torch.empty((BQ, (H // 2) * (W // 2)), dtype=torch.float32, device=vol0.device)
+            e._chk(e.L.mrfa_avgpool2_fwd(e.s, vol0.data_ptr(), 1, BQ, H, W, 1, vol1.data_ptr(), 1), "corr pyramid level 1")
+            cv = e.wrap_nhwc(coords_.float().permute(0, 2, 3, 1).contiguous())
+            d = {}
+
+            def dvols():
+                if not d:
+                    d[0], d[1] = torch.zeros_like(vol0), torch.zeros_like(vol1)
+                return d[0], d[1]
+            o = e.corr_lookup(vol0, vol1, dvols, H, W, cv, radius=r)
+
+            def dcorr():
+                if not d:
+                    return None
+                e._chk(e.L.mrfa_unpool2_acc(e.s, d[1].data_ptr(), 1, BQ, H // 2, W // 2, 1, d[0].data_ptr(), 1, 0.25), "corr pyramid bwd")
+                return d[0].view(BQ, 1, H, W)
+            return (e.to_nchw(o),), (lambda g: e.seed_grad_nchw(o, g),), \
+                (dcorr, (lambda: cv.st.grad.view(B, h1, w1, 2).permute(0, 3, 1, 2) if cv.has_grad else None))
+        return run_program(_FN, program, [corr, coords])[0]
 
 
 class BasicMotionEncoder(nn.Module):
@@ -37,6 +79,17 @@ class BasicMotionEncoder(nn.Module):
         e.conv(corflo, self.conv, out=out.slice(0, 126), relu=True)
         e.copy(flow, out=out.slice(126, 128))
 
+    def forward(self, delta_flow, corr):
+        """(B,2,r,r), (B,98,r,r) -> (B,128,r,r) = [conv(126) | delta_flow].  reference: modules/raft.py:60-68"""
+        def program(e: Ctx, flow_, corr_):
+            fv = e.from_nchw(flow_)
+            cv = e.from_nchw(corr_, out=e.new(corr_.shape[0], corr_.shape[2], corr_.shape[3], corr_.shape[1], pad32=True))
+            out = e.new(fv.N, fv.H, fv.W, 128)
+            self.run(e, fv, cv, out)
+            return (e.to_nchw(out),), (lambda g: e.seed_grad_nchw(out, g),), \
+                ((lambda: e.grad_to_nchw(fv) if fv.has_grad else None), (lambda: e.grad_to_nchw(cv) if cv.has_grad else None))
+        return run_program(self, program, [delta_flow, corr])[0]
+
 
 class RefineFlow(nn.Module):
     """The stateless update operator (NOT a GRU).  reference: modules/raft.py:70-88"""
@@ -58,6 +111,19 @@ class RefineFlow(nn.Module):
         h2 = e.conv(inp, self.convo1, relu=True)
         e.conv(h2, self.convo2, out=d.slice(2, 3))
         return d
+
+    def forward(self, m_f, warp_f):
+        """(B,128,r,r) motion features, (B,192,r,r) context -> (out (B,3,r,r) = [d_flow(2) | d_occlusion(1)], inp (B,256,r,r)).
+        reference: modules/raft.py:80-88"""
+        def program(e: Ctx, mf_, wf_):
+            inp = e.new(mf_.shape[0], mf_.shape[2], mf_.shape[3], 256)
+            mv = e.from_nchw(mf_, out=inp.slice(0, 128))
+            wv = e.from_nchw(wf_)
+            d = self.run(e, inp, wv)
+            return (e.to_nchw(d), e.to_nchw(inp)), ((lambda g: e.seed_grad_nchw(d, g)), (lambda g: e.seed_grad_nchw(inp, g))), \
+                ((lambda: e.grad_to_nchw(mv) if mv.has_grad else None), (lambda: e.grad_to_nchw(wv) if wv.has_grad else None))
+        out, inp = run_program(self, program, [m_f, warp_f])
+        return out, inp
 
 
 class _CorrVolume:

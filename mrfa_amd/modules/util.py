@@ -40,8 +40,12 @@ def convert_dict_to_attrit_dict(d):
 
 # ------------------------------------------------------------------------------------------------ small torch helpers
 # (used by the tiny "glue" islands that run as torch device ops on (B,10,2)-sized tensors)
-def make_coordinate_grid(spatial_size, like: torch.Tensor) -> torch.Tensor:
-    """(h,w,2) grid over [-1,1]^2, last dim (x,y).  reference: modules/util.py:90-108"""
+def make_coordinate_grid(spatial_size, type=None, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(h,w,2) grid over [-1,1]^2, last dim (x,y).  reference: modules/util.py:90-108.  The reference's second argument is a
+    tensor-type STRING (`type=frame.type()`, model.py:37,45); a tensor to take dtype / device from is accepted as well."""
+    like = type if like is None else like
+    if not torch.is_tensor(like):
+        like = torch.empty(0).type(like) if like is not None else torch.empty(0)
     h, w = spatial_size
     xs = 2.0 * (torch.arange(w, dtype=like.dtype, device=like.device) / (w - 1)) - 1.0
     ys = 2.0 * (torch.arange(h, dtype=like.dtype, device=like.device) / (h - 1)) - 1.0
@@ -60,6 +64,48 @@ def kp2gaussian(kp: torch.Tensor, spatial_size, kp_variance: float) -> torch.Ten
     g = make_coordinate_grid((h, w), kp).view(1, 1, h, w, 2)
     d = g - kp.view(kp.shape[0], kp.shape[1], 1, 1, 2)
     return torch.exp(-0.5 * (d * d).sum(-1) / kp_variance)
+
+
+# ------------------------------------------------------------------------------------------------ reference helper surface
+class _Stateless(nn.Module):
+    """parameter-free owner for functional programs (run_program wants a module for its train flag and parameter list)"""
+
+
+_FN = _Stateless()
+
+
+def coords_grid(batch, ht, wd, device="cpu"):
+    """(batch,2,ht,wd) fp32 pixel-index grid, channel 0 = x, channel 1 = y.  reference: modules/util.py:53-56"""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+    return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+
+
+def bilinear_sampler(img, coords, mode='bilinear', mask=False):
+    """grid_sample in PIXEL coordinates (align_corners=True, zeros outside): img (N,C,H,W), coords (N,h,w,2) as (x,y) ->
+    (N,C,h,w) [, in-bounds mask (N,h,w,1)].  reference: modules/util.py:26-38 (same arguments; `mode` is ignored there too).
+    Runs mrfa_grid_sample_fwd/bwd mode 1 (K10), differentiable w.r.t. img and coords."""
+    assert img.dim() == 4 and coords.dim() == 4 and coords.shape[-1] == 2 and coords.shape[0] == img.shape[0]
+    N, C, H, W = img.shape
+    h, w = coords.shape[1], coords.shape[2]
+
+    def program(e: Ctx, img_, coords_):
+        f = e.from_nchw(img_)
+        # the kernel samples at (output pixel index + flow): hand it coords - index grid (exact in fp32 for |index| < 2^24)
+        flow = e.wrap_nhwc((coords_.float() - coords_grid_nhwc(h, w, coords_.float())).contiguous())
+        o = e.grid_sample(f, flow, 1)
+        return (e.to_nchw(o),), (lambda g: e.seed_grad_nchw(o, g),), \
+            ((lambda: e.grad_to_nchw(f) if f.has_grad else None), (lambda: flow.st.grad.view(N, h, w, 2) if flow.has_grad else None))
+    out = run_program(_FN, program, [img, coords])[0]
+    if mask:
+        xg, yg = (2 * coords[..., 0:1] / (W - 1) - 1), (2 * coords[..., 1:2] / (H - 1) - 1)
+        return out, ((xg > -1) & (yg > -1) & (xg < 1) & (yg < 1)).float()
+    return out
+
+
+def batch_bilinear_sampler(img, coords, mode='bilinear', mask=False, h=256, w=256, mini_batch=4):
+    """reference: modules/util.py:40-51 -- the same sampling issued in mini-batches of `mini_batch` x h x w one-channel maps to
+    bound torch's temporaries; the kernel has none, so this is bilinear_sampler (identical results)."""
+    return bilinear_sampler(img, coords, mode=mode, mask=mask)
 
 
 # ------------------------------------------------------------------------------------------------ blocks
