@@ -114,10 +114,11 @@ class GraphedForward:
         finally:
             m.train(was_training)
 
-    def _self_check(self, eager, replays: int = 3, tol: float = 1e-4):
+    def _self_check(self, eager, replays: int = 3, tol: float = 5e-3, mean_tol: float = 2e-5):
         """the first AND later replays against the eager output at the same inputs (a mis-ordered memcpy / memset node shows from
-        the second replay on): inference has no batch statistics and no split-K over the outputs checked here, so the only
-        differences are fp32 summation order (<= 1e-5 measured); `tol` is absolute on outputs in [0, 1]"""
+        the second replay on).  Inference has no batch statistics; the only legitimate differences are fp32 summation order
+        (split-K atomics): ~1e-6 typically, ~1e-4 on single border pixels of sharply warped frames, whereas a mis-ordered graph is
+        wrong everywhere -- so the mean is gated tightly (`mean_tol`) and the max loosely (`tol`), relative to max |output|"""
         outs = self.out if isinstance(self.out, (tuple, list)) else (self.out,)
         refs = eager if isinstance(eager, (tuple, list)) else (eager,)
         scratch = torch.empty(1 << 20, device=self.src.device)
@@ -128,10 +129,11 @@ class GraphedForward:
             for i, (o, r) in enumerate(zip(outs, refs)):
                 if not torch.is_tensor(o):
                     continue
-                d = float((o - r).abs().max())
-                if not d <= tol * max(1.0, float(r.abs().max())):
-                    raise RuntimeError(f"GraphedForward: replay {k} differs from the eager forward (output {i}: max |diff| {d:.3e}); "
-                                       f"the captured graph is not trustworthy (see mrfa_amd/graph.py, MEMCPY / MEMSET NODES)")
+                diff = (o - r).abs()
+                d, dm, sc = float(diff.max()), float(diff.mean()), max(1.0, float(r.abs().max()))
+                if not (d <= tol * sc and dm <= mean_tol * sc):
+                    raise RuntimeError(f"GraphedForward: replay {k} differs from the eager forward (output {i}: max |diff| {d:.3e}, mean "
+                                       f"{dm:.3e}); the captured graph is not trustworthy (see mrfa_amd/graph.py, MEMCPY / MEMSET NODES)")
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor):
         if source.data_ptr() != self.src.data_ptr():
