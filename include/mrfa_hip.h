@@ -299,6 +299,64 @@ int mrfa_antialias_down_bwd(void* stream, const float* dy, int lddy, int N, int 
                             float* dx_nchw /*+=*/);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * K14-K17: the prior-motion stage's small dense ops, csrc/prior.hip.
+ *
+ * K15  kp2gaussian (reference modules/util.py:59-87) on the [-1,1]^2 grid of make_coordinate_grid (util.py:90-108), written into
+ *      an NHWC view (channel k of out row (b,y,x)):  out = exp(-0.5 |g(y,x) - kp[b,k]|^2 / variance) [+ pos[k,y,x]]
+ *      (pos = RaftFlow.pos_embedding (1,K,H,W), raft.py:177-178; may be null).  Backward: dkp (B,K,2) += , dpos (K,H,W) += .   */
+int mrfa_kp_gaussian_fwd(void* stream, const float* kp, const float* pos, int B, int K, int H, int W, float variance, float* out, int ldo);
+int mrfa_kp_gaussian_bwd(void* stream, const float* kp, int B, int K, int H, int W, float variance, const float* dout, int lddo,
+                         float* dkp /*+=, may be null*/, float* dpos /*+=, may be null*/);
+
+/* K15+K16+K10: DenseMotionNetwork.create_heatmap_representations / create_sparse_motions / create_deformed_source_image and the
+ * channel interleave of its hourglass input (reference modules/dense_motion.py:36-46, 48-76, 78-85, 117-119) in ONE kernel.
+ *   motion_0(g) = g, or from_homogeneous(bg[b] (g,1)) with a background affine (dense_motion.py:69-73);
+ *   motion_k(g) = js[b,k] inv(jd[b,k]) (g - kd[b,k]) + ks[b,k]   (k = 1..K; closed-form 2x2 inverse; jd = js = null: identity Jacobians);
+ *   heat_0 = 0, heat_k = exp(-|g - kd|^2 / 2 var) - exp(-|g - ks|^2 / 2 var);
+ *   warp_k = grid_sample(src[b], motion_k), bilinear, zeros padding, align_corners=False (dense_motion.py:83).
+ * Outputs: motions (B*(K+1), H, W, 2) rows with leading dimension ldm; inp (B,H,W) rows of ldi floats, channels
+ * [k (C+1)] = heat_k, [k (C+1) + 1 + c] = warp_k[c]  (= the reference's (B, (K+1)(C+1), H, W) hourglass input in NHWC);
+ * sparse (B, K+1, C, H, W) dense = the returned `sparse_deformed` (may be null).
+ * Backward reads dinp (same geometry as inp, lddi), dmotions (gradient of `motions` from K17, same ldm; may be null), dsparse
+ * (may be null) and adds into dkd, dks (B,K,2), djd, djs (B,K,4), dbg (B,9) (each may be null); the source image gets no
+ * gradient (it is the network input).                                                                            */
+typedef struct mrfa_prior_params {
+    const float *kd, *ks, *jd, *js, *bg;
+    const float* src; int lds;
+    int B, K, H, W, C;
+    float inv_var;                       /* 1 / kp_variance */
+    float* motions; int ldm;
+    float* inp; int ldi;
+    float* sparse;
+    /* backward only */
+    const float* dinp; int lddi;
+    const float* dmotions;
+    const float* dsparse;
+    float *dkd, *dks, *djd, *djs, *dbg;
+} mrfa_prior_params;
+int mrfa_prior_motion_fwd(void* stream, const mrfa_prior_params* p);
+int mrfa_prior_motion_bwd(void* stream, const mrfa_prior_params* p);
+
+/* K14+K17: mask = softmax over the K1 = K+1 motions of logit (B,H,W,K1 NHWC, ldl); deformation (B,H,W,2) = sum_k mask_k motion_k
+ * (reference modules/dense_motion.py:129-136); also exports mask and the logits as NCHW (B,K1,H,W) (the returned `mask`,
+ * `logit_mask`).  Backward: dlogit (NHWC view, lddl) += softmax backward of (ddeformation . motion_k + dmask_k) + dlogit_nchw,
+ * dmotions (same geometry as motions) += mask_k ddeformation.  ddeformation / dmask / dlogit_nchw / dmotions may be null.   */
+int mrfa_softmax_combine_fwd(void* stream, const float* logit, int ldl, const float* motions, int ldm, int B, int H, int W, int K1,
+                             float* deformation, float* mask_nchw, float* logit_nchw);
+int mrfa_softmax_combine_bwd(void* stream, const float* motions, int ldm, int B, int H, int W, int K1, const float* mask_nchw,
+                             const float* ddeformation, const float* dmask_nchw, const float* dlogit_nchw, float* dlogit /*+=*/, int lddl,
+                             float* dmotions /*+=*/);
+
+/* K14: KPDetector head (reference modules/kp_detector.py:90-120): heat = softmax over the H*W positions of logits[b,:,:,k] / T,
+ * kp[b,k] = sum heat * grid, jac[b,k,:] = sum heat * jm[b,:,:,0..3] (jm: the 4 Jacobian maps, NHWC, may be null).  stat (B,K,2)
+ * receives (max, 1/sum) for the backward, which recomputes heat:  dlogits (NHWC view, lddl) +=, djm (lddj) += .           */
+int mrfa_kp_head_fwd(void* stream, const float* logits, int ldl, const float* jm, int ldj, int B, int H, int W, int K, float temperature,
+                     float* kp, float* jac, float* stat);
+int mrfa_kp_head_bwd(void* stream, const float* logits, int ldl, const float* jm, int ldj, int B, int H, int W, int K, float temperature,
+                     const float* kp, const float* jac, const float* stat, const float* dkp, const float* djac, float* dlogits /*+=*/,
+                     int lddl, float* djm /*+=*/, int lddj);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K20: optimizer step of the data-parallel path on FLAT fp32 buffers (every parameter / gradient / Adam moment of a
  * parameter group in one allocation, 16-byte aligned slices).  Replaces torch.optim.Adam(betas=(0.5, 0.999)).step()
  * (reference train.py:21, 70) and nn.utils.clip_grad_norm_(.., norm_type=inf) (train.py:65-67); the 1/world of the

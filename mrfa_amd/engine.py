@@ -1088,6 +1088,123 @@ class Ctx:
             self.tape.append(bwd)
         return out
 
+    # -- prior-motion stage: K14-K17 (csrc/prior.hip) -----------------------------------------------------------------
+    def _ext_acc(self, x: torch.Tensor) -> torch.Tensor:
+        """zero-initialised fp32 accumulator for the gradient of a module input / parameter that a kernel adds into (delivered
+        by the program's in_grads / _ProgramFn.backward exactly like the gradients torch islands compute)"""
+        k = id(x)
+        g = self.ext_grads.get(k)
+        if g is None:
+            g = self.ext_grads[k] = torch.zeros(x.shape, dtype=torch.float32, device=x.device)
+        elif not g.is_contiguous():
+            g = self.ext_grads[k] = g.contiguous()
+        return g
+
+    @staticmethod
+    def _cf(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if t is None else t.detach().contiguous().float()
+
+    def kp_gaussian(self, kp: torch.Tensor, variance: float, out: View, pos: Optional[torch.Tensor] = None) -> View:
+        """out[b,y,x,k] = exp(-|grid(y,x) - kp[b,k]|^2 / (2 variance)) [+ pos[0,k,y,x]]   (util.py:59-87, raft.py:177-178)"""
+        kc, pc = self._cf(kp), self._cf(pos)
+        B, K = kc.shape[0], kc.shape[1]
+        assert out.C == K and out.N == B
+        self._chk(self.L.mrfa_kp_gaussian_fwd(self.s, kc.data_ptr(), pc.data_ptr() if pc is not None else None, B, K, out.H, out.W,
+                                              float(variance), out.ptr, out.ld), "kp_gaussian_fwd")
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                dk = self._ext_acc(kp)
+                dp = self._ext_acc(pos) if pos is not None else None
+                self._chk(self.L.mrfa_kp_gaussian_bwd(self.s, kc.data_ptr(), B, K, out.H, out.W, float(variance), out.gptr, out.ld,
+                                                      dk.data_ptr(), dp.data_ptr() if dp is not None else None), "kp_gaussian_bwd")
+            self.tape.append(bwd)
+        return out
+
+    def prior_motion(self, src: View, kd, ks, jd, js, bg, variance: float):
+        """DenseMotionNetwork's heat-map differences, sparse motions and the K+1 warps of the 1/4-scale source in one launch
+        (dense_motion.py:36-85, 117-119) -> (motions View (B*K1,h,w,2), hourglass input View (B,h,w,K1*(C+1)), sparse_deformed IslandOut)"""
+        B, H, W, Cc = src.N, src.H, src.W, src.C
+        K = kd.shape[1]
+        K1 = K + 1
+        t = [self._cf(x) for x in (kd, ks, jd, js, bg)]
+        motions = self.new(B * K1, H, W, 2)
+        inp = self.new(B, H, W, K1 * (Cc + 1), pad32=True)
+        sparse = IslandOut(torch.empty((B, K1, Cc, H, W), dtype=torch.float32, device=self.dev))
+        p = hip.PriorParams()
+        p.kd, p.ks = t[0].data_ptr(), t[1].data_ptr()
+        p.jd, p.js = (t[2].data_ptr(), t[3].data_ptr()) if t[2] is not None else (None, None)
+        p.bg = t[4].data_ptr() if t[4] is not None else None
+        p.src, p.lds, p.B, p.K, p.H, p.W, p.C, p.inv_var = src.ptr, src.ld, B, K, H, W, Cc, 1.0 / float(variance)
+        p.motions, p.ldm, p.inp, p.ldi, p.sparse = motions.ptr, motions.ld, inp.ptr, inp.ld, sparse.t.data_ptr()
+        self._chk(self.L.mrfa_prior_motion_fwd(self.s, C.byref(p)), "prior_motion_fwd")
+        if self.record:
+            def bwd():
+                ds = sparse.total_grad()
+                if not (inp.has_grad or motions.has_grad or ds is not None):
+                    return
+                q = hip.PriorParams()
+                C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
+                q.dinp, q.lddi = inp.gptr, inp.ld                      # (zero-filled on first touch when no consumer wrote it)
+                q.dmotions = motions.gptr if motions.has_grad else None
+                dsc = ds.contiguous().float() if ds is not None else None
+                q.dsparse = dsc.data_ptr() if dsc is not None else None
+                q.dkd, q.dks = self._ext_acc(kd).data_ptr(), self._ext_acc(ks).data_ptr()
+                if jd is not None:
+                    q.djd, q.djs = self._ext_acc(jd).data_ptr(), self._ext_acc(js).data_ptr()
+                if bg is not None:
+                    q.dbg = self._ext_acc(bg).data_ptr()
+                self._chk(self.L.mrfa_prior_motion_bwd(self.s, C.byref(q)), "prior_motion_bwd")
+            self.tape.append(bwd)
+        return motions, inp, sparse
+
+    def softmax_combine(self, logit: View, motions: View):
+        """mask = softmax_k(logit), deformation = sum_k mask_k motion_k (dense_motion.py:129-136) -> IslandOuts deformation (B,h,w,2),
+        mask (B,K1,h,w), logit_mask (B,K1,h,w)"""
+        B, H, W, K1 = logit.N, logit.H, logit.W, logit.C
+        assert motions.N == B * K1 and motions.C == 2
+        mk = lambda *shp: IslandOut(torch.empty(shp, dtype=torch.float32, device=self.dev))
+        deform, mask, lg = mk(B, H, W, 2), mk(B, K1, H, W), mk(B, K1, H, W)
+        self._chk(self.L.mrfa_softmax_combine_fwd(self.s, logit.ptr, logit.ld, motions.ptr, motions.ld, B, H, W, K1, deform.t.data_ptr(),
+                                                  mask.t.data_ptr(), lg.t.data_ptr()), "softmax_combine_fwd")
+        if self.record:
+            def bwd():
+                g = [self._cf(o.total_grad()) for o in (deform, mask, lg)]
+                if all(x is None for x in g):
+                    return
+                ptr = lambda x: x.data_ptr() if x is not None else None
+                self._chk(self.L.mrfa_softmax_combine_bwd(self.s, motions.ptr, motions.ld, B, H, W, K1, mask.t.data_ptr(), ptr(g[0]), ptr(g[1]),
+                                                          ptr(g[2]), logit.gptr, logit.ld, motions.gptr if g[0] is not None else None),
+                          "softmax_combine_bwd")
+            self.tape.append(bwd)
+        return deform, mask, lg
+
+    def kp_head(self, logits: View, jm: Optional[View], temperature: float):
+        """spatial softmax at temperature T + soft-argmax (+ heat-map-weighted Jacobian pooling), kp_detector.py:90-120 ->
+        IslandOuts kp (B,K,2) [, jacobian (B,K,2,2)]"""
+        B, H, W, K = logits.N, logits.H, logits.W, logits.C
+        kp = IslandOut(torch.empty((B, K, 2), dtype=torch.float32, device=self.dev))
+        jac = IslandOut(torch.empty((B, K, 2, 2), dtype=torch.float32, device=self.dev)) if jm is not None else None
+        stat = torch.empty((B, K, 2), dtype=torch.float32, device=self.dev)
+        self._chk(self.L.mrfa_kp_head_fwd(self.s, logits.ptr, logits.ld, jm.ptr if jm is not None else None, jm.ld if jm is not None else 0,
+                                          B, H, W, K, float(temperature), kp.t.data_ptr(), jac.t.data_ptr() if jac is not None else None,
+                                          stat.data_ptr()), "kp_head_fwd")
+        if self.record:
+            def bwd():
+                dk = self._cf(kp.total_grad())
+                dj = self._cf(jac.total_grad()) if jac is not None else None
+                if dk is None and dj is None:
+                    return
+                self._chk(self.L.mrfa_kp_head_bwd(self.s, logits.ptr, logits.ld, jm.ptr if jm is not None else None,
+                                                  jm.ld if jm is not None else 0, B, H, W, K, float(temperature), kp.t.data_ptr(),
+                                                  jac.t.data_ptr() if jac is not None else None, stat.data_ptr(),
+                                                  dk.data_ptr() if dk is not None else None, dj.data_ptr() if dj is not None else None,
+                                                  logits.gptr, logits.ld, jm.gptr if (jm is not None and dj is not None) else None,
+                                                  jm.ld if jm is not None else 0), "kp_head_bwd")
+            self.tape.append(bwd)
+        return kp, jac
+
     # -- elementwise ------------------------------------------------------------------------------------------
     def copy(self, x: View, out: Optional[View] = None, mul: float = 1.0, acc: bool = False) -> View:
         """out (=|+=) mul * x"""

@@ -85,6 +85,21 @@ class BnBwdParams(C.Structure):
     ]
 
 
+class PriorParams(C.Structure):
+    _fields_ = [
+        ("kd", C.c_void_p), ("ks", C.c_void_p), ("jd", C.c_void_p), ("js", C.c_void_p), ("bg", C.c_void_p),
+        ("src", C.c_void_p), ("lds", C.c_int),
+        ("B", C.c_int), ("K", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+        ("inv_var", C.c_float),
+        ("motions", C.c_void_p), ("ldm", C.c_int),
+        ("inp", C.c_void_p), ("ldi", C.c_int),
+        ("sparse", C.c_void_p),
+        ("dinp", C.c_void_p), ("lddi", C.c_int),
+        ("dmotions", C.c_void_p), ("dsparse", C.c_void_p),
+        ("dkd", C.c_void_p), ("dks", C.c_void_p), ("djd", C.c_void_p), ("djs", C.c_void_p), ("dbg", C.c_void_p),
+    ]
+
+
 _V, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
 _SIGNATURES = {
@@ -140,6 +155,14 @@ _SIGNATURES = {
     "mrfa_l1_diff_fwd": ([_V, _V, _I, _V, _I, _L, _I, C.c_double, _V], C.c_int),
     "mrfa_l1_diff_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _F, _V, _I], C.c_int),
     "mrfa_antialias_down_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
+    "mrfa_kp_gaussian_fwd": ([_V, _V, _V, _I, _I, _I, _I, _F, _V, _I], C.c_int),
+    "mrfa_kp_gaussian_bwd": ([_V, _V, _I, _I, _I, _I, _F, _V, _I, _V, _V], C.c_int),
+    "mrfa_prior_motion_fwd": ([_V, C.POINTER(PriorParams)], C.c_int),
+    "mrfa_prior_motion_bwd": ([_V, C.POINTER(PriorParams)], C.c_int),
+    "mrfa_softmax_combine_fwd": ([_V, _V, _I, _V, _I, _I, _I, _I, _I, _V, _V, _V], C.c_int),
+    "mrfa_softmax_combine_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V], C.c_int),
+    "mrfa_kp_head_fwd": ([_V, _V, _I, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V], C.c_int),
+    "mrfa_kp_head_bwd": ([_V, _V, _I, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V, _V, _V, _I, _V, _I], C.c_int),
     "mrfa_adam_prepare": ([_V, _V, _I, C.c_double, C.c_double], C.c_int),
     "mrfa_grad_absmax": ([_V, _V, _L, _V, _I], C.c_int),
     "mrfa_adam_flat": ([_V, _V, _V, _V, _V, _L, _V, C.c_double, C.c_double, _F, _F, _I, _F], C.c_int),

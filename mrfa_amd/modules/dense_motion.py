@@ -33,59 +33,19 @@ class DenseMotionNetwork(nn.Module):
         b, h, w, c = src.N, src.H, src.W, src.C
         k1 = self.num_kp + 1
         var = self.kp_variance
-        has_jac = jd is not None
-
-        has_bg = bg is not None
-
-        def prep(kd_, ks_, *rest):
-            jd_, js_ = (rest[0], rest[1]) if has_jac else (None, None)
-            bg_ = rest[-1] if has_bg else None
-            # heat-map differences (dense_motion.py:36-46) and sparse motions (:48-76), NHWC-friendly layouts
-            heat = kp2gaussian(kd_, (h, w), var) - kp2gaussian(ks_, (h, w), var)                   # (B,K,h,w)
-            heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)                         # (B,K1,h,w)
-            ident = make_coordinate_grid((h, w), kd_).view(1, 1, h, w, 2)
-            z = ident - kd_.view(b, -1, 1, 1, 2)
-            if jd_ is not None:
-                # closed-form 2x2 inverse (reference: torch.inverse, dense_motion.py:54): no solver library call, so the
-                # island stays free of host synchronisation and can be captured in a hipGraph
-                a, b_, c_, d = jd_[..., 0, 0], jd_[..., 0, 1], jd_[..., 1, 0], jd_[..., 1, 1]
-                det = a * d - b_ * c_
-                inv = torch.stack([torch.stack([d, -b_], dim=-1), torch.stack([-c_, a], dim=-1)], dim=-2) / det[..., None, None]
-                jac = torch.matmul(js_, inv)
-                z = torch.einsum("bkij,bkhwj->bkhwi", jac, z)
-            d2s = z + ks_.view(b, -1, 1, 1, 2)
-            bg_grid = ident.expand(b, 1, h, w, 2)
-            if bg_ is not None:                                                                    # dense_motion.py:69-73
-                hom = torch.cat([bg_grid, torch.ones_like(bg_grid[..., :1])], dim=-1)
-                hom = torch.matmul(bg_.view(b, 1, 1, 1, 3, 3), hom.unsqueeze(-1)).squeeze(-1)
-                bg_grid = hom[..., :2] / hom[..., 2:3]
-            motions = torch.cat([bg_grid, d2s], dim=1)                                             # (B,K1,h,w,2)
-            return [heat, motions.reshape(b * k1, h, w, 2)]
-        ins = [kd, ks] + ([jd, js] if has_jac else []) + ([bg] if has_bg else [])
-        heat, motions = e.island(prep, ins)
-        deformed = e.grid_sample(src, motions.view(), 0, in_rep=k1, need_din=False)               # (B*K1,h,w,3)
-
-        def assemble(heat_, deformed_):
-            d = deformed_.reshape(b, k1, h, w, c).permute(0, 2, 3, 1, 4)                            # (B,h,w,K1,c)
-            return [torch.cat([heat_.permute(0, 2, 3, 1).unsqueeze(-1), d], dim=-1).reshape(b, h, w, k1 * (c + 1))]
-        (inp,) = e.island(assemble, [heat, deformed])
-        pred = self.hourglass.run(e, inp.view())
+        # K15 + K16 + K10 in one launch (csrc/prior.hip): heat-map differences (dense_motion.py:36-46), the K+1 sparse motions with the
+        # closed-form 2x2 inverse and the optional background affine (:48-76), the K+1 warps of the 1/4-scale source (:78-85), written
+        # straight into the interleaved hourglass input [heat_k | warp_k(3)] (:117-119)
+        ins = [kd, ks] + ([jd, js] if jd is not None else []) + ([bg] if bg is not None else [])
+        motions, inp, sparse_deformed = e.prior_motion(src, kd, ks, jd, js, bg, var)
+        pred = self.hourglass.run(e, inp)
         logit = e.conv(pred, self.mask)                                                              # (B,h,w,K1)
         occ = e.conv(pred, self.occlusion) if self.occlusion is not None else None
-
-        def combine(logit_, motions_):
-            mask = F.softmax(logit_, dim=-1)                                                         # (B,h,w,K1)
-            m = motions_.reshape(b, k1, h, w, 2).permute(0, 2, 3, 1, 4)                              # (B,h,w,K1,2)
-            deformation = (m * mask.unsqueeze(-1)).sum(dim=3)                                        # (B,h,w,2)
-            return [deformation, mask.permute(0, 3, 1, 2), logit_.permute(0, 3, 1, 2)]
-        deformation, mask, logit_nchw = e.island(combine, [logit, motions])
-
-        def export_deformed(d_):
-            return [d_.reshape(b, k1, h, w, c).permute(0, 1, 4, 2, 3)]
-        (sparse_deformed,) = e.island(export_deformed, [deformed])
+        # K14 + K17: softmax over the K+1 motions, mask-weighted deformation, NCHW exports of mask / logits (dense_motion.py:129-136)
+        deformation, mask, logit_nchw = e.softmax_combine(logit, motions)
         outs = [sparse_deformed, logit_nchw, mask, deformation]
         if occ is not None:
-            (occ_out,) = e.island(lambda o: [o.permute(0, 3, 1, 2)], [occ])
+            (occ_out,) = e.island(lambda o: [o.permute(0, 3, 1, 2)], [occ])                          # (B,h,w,1) -> (B,1,h,w): a view
             outs.append(occ_out)
         in_grads = [None] + [(lambda t=t: e.ext_grads.get(id(t))) for t in ins]
         return tuple(o.t for o in outs), tuple(o.add_grad for o in outs), tuple(in_grads)

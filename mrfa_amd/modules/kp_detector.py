@@ -37,23 +37,10 @@ class KPDetector(nn.Module):
         xs = self.down.run(e, x) if self.scale_factor != 1 else e.from_nchw(x)
         fmap = self.predictor.run(e, xs, need_dx=False)
         logits = e.conv(fmap, self.kp)                                     # (B,58,58,K) NHWC
-        views = [logits]
-        if self.estimate_jacobian:
-            views.append(e.conv(fmap, self.jacobian))                      # (B,58,58,4)
-        temp = self.temperature
-
-        def glue(lg, jm=None):
-            # spatial softmax + soft-argmax (+ Jacobian pooling): kp_detector.py:90-120
-            b, hh, ww, k = lg.shape
-            heat = F.softmax(lg.reshape(b, hh * ww, k) / temp, dim=1)                    # (B,HW,K)
-            grid = make_coordinate_grid((hh, ww), lg).reshape(1, hh * ww, 2)
-            kp = torch.einsum("bpk,bpc->bkc", heat, grid.expand(b, -1, -1))
-            outs = [kp]
-            if jm is not None:
-                jac = torch.einsum("bpk,bpj->bkj", heat, jm.reshape(b, hh * ww, 4)).reshape(b, k, 2, 2)
-                outs.append(jac)
-            return outs
-        outs = e.island(glue, views)
+        jm = e.conv(fmap, self.jacobian) if self.estimate_jacobian else None       # (B,58,58,4)
+        # K14 (csrc/prior.hip): spatial softmax at temperature T + soft-argmax + heat-map-weighted Jacobian pooling, kp_detector.py:90-120
+        kp, jac = e.kp_head(logits, jm, self.temperature)
+        outs = [kp] + ([jac] if jac is not None else [])
         return tuple(o.t for o in outs), tuple(o.add_grad for o in outs), (None,)
 
     def forward(self, x):

@@ -214,12 +214,19 @@ class RaftFlow(nn.Module):
             cache = {"imgf": imgf, "feature": gen.run_encode(e, imgf), "shape": tuple(img_full.shape)}
             if not self.prior_only:
                 h, w = img.shape[2], img.shape[3]
-                (in_s,) = e.island(lambda ks_, pos_, img_: [torch.cat([(kp2gaussian(ks_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1),
-                                                                        img_.permute(0, 2, 3, 1)], dim=-1)], [kp_s, self.pos_embedding, img])
-                k_s = e.conv(self.kp_img.run(e, in_s.view()), self.kp_img_head)
+                in_s = self._source_input(e, kp_s, img, h, w)
+                k_s = e.conv(self.kp_img.run(e, in_s), self.kp_img_head)
                 cache["k_s"], cache["k_pool"] = k_s, e.avgpool2(k_s)
             e.flush_forward()
         return cache
+
+    def _source_input(self, e: Ctx, kp_s, img, h, w) -> View:
+        """[heat-maps(kp_s) + pos_embedding (K) | 1/4-scale source image (3)] as one NHWC buffer (raft.py:177,179)"""
+        K = kp_s.shape[1]
+        in_s = e.new(kp_s.shape[0], h, w, K + img.shape[1])
+        e.kp_gaussian(kp_s, 0.1, in_s.slice(0, K), pos=self.pos_embedding)
+        e.from_nchw(img, out=in_s.slice(K, K + img.shape[1]))
+        return in_s
 
     def _program(self, e: Ctx, kp_s, kp_d, deformation, occlusion, img, img_full, cache=None):
         gen = self.generator
@@ -257,19 +264,16 @@ class RaftFlow(nn.Module):
         # ---- structure encoders + correlation volumes (raft.py:177-185)
         pos = self.pos_embedding
 
-        def heatmaps(ks_, kd_, pos_, img_):
-            hs = (kp2gaussian(ks_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)
-            hd = (kp2gaussian(kd_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)
-            return [torch.cat([hs, img_.permute(0, 2, 3, 1)], dim=-1), hd]
+        # K15 (csrc/prior.hip): Gaussian heat-maps of the keypoints + pos_embedding, written as NHWC (raft.py:177-178)
+        in_d = e.kp_gaussian(kp_d, 0.1, e.new(b, h, w, kp_d.shape[1]), pos=pos)
         if cache is not None:
-            (in_d,) = e.island(lambda kd_, pos_: [(kp2gaussian(kd_, (h, w), 0.1) + pos_).permute(0, 2, 3, 1)], [kp_d, pos])
             k_s, k_pool = cache["k_s"], cache["k_pool"]
         else:
-            in_s, in_d = e.island(heatmaps, [kp_s, kp_d, pos, img])
-            k_s = e.conv(self.kp_img.run(e, in_s.view()), self.kp_img_head)    # (B,h,w,dim)
+            in_s = self._source_input(e, kp_s, img, h, w)
+            k_s = e.conv(self.kp_img.run(e, in_s), self.kp_img_head)            # (B,h,w,dim)
             k_pool = e.avgpool2(k_s)
         in_grads = ((lambda: e.ext_grads.get(id(kp_s))), (lambda: e.ext_grads.get(id(kp_d)))) + in_grads[2:]
-        fe_d = self.kp.run(e, in_d.view())
+        fe_d = self.kp.run(e, in_d)
         q_d = e.conv(fe_d, self.kp_head)
         base = self.basic_res_index
         q_levels = {base: q_d}

@@ -42,6 +42,171 @@ class Emulator:
     def __init__(self):
         self._err = b""
 
+    # ---------------------------------------------------------------- K14-K17: prior-motion stage (csrc/prior.hip)
+    @staticmethod
+    def _grid(H, W):
+        xs = 2.0 * (torch.arange(W, dtype=torch.float32) / (W - 1)) - 1.0
+        ys = 2.0 * (torch.arange(H, dtype=torch.float32) / (H - 1)) - 1.0
+        return torch.stack([xs.view(1, W).expand(H, W), ys.view(H, 1).expand(H, W)], dim=-1)          # (H,W,2) as (x,y)
+
+    def _gauss(self, kp, H, W, variance):
+        d = self._grid(H, W).view(1, 1, H, W, 2) - kp.view(kp.shape[0], kp.shape[1], 1, 1, 2)
+        return torch.exp(-0.5 * (d * d).sum(-1) / variance)                                           # (B,K,H,W)
+
+    def mrfa_kp_gaussian_fwd(self, stream, kp, pos, B, K, H, W, variance, out, ldo):
+        g = self._gauss(_flat(kp, B * K * 2).view(B, K, 2), H, W, variance)
+        if pos:
+            g = g + _flat(pos, K * H * W).view(1, K, H, W)
+        nhwc(out, B, H, W, ldo, K).copy_(g.permute(0, 2, 3, 1))
+        return 0
+
+    def mrfa_kp_gaussian_bwd(self, stream, kp, B, K, H, W, variance, dout, lddo, dkp, dpos):
+        k = _flat(kp, B * K * 2).view(B, K, 2).clone().requires_grad_(True)
+        with torch.enable_grad():
+            g = self._gauss(k, H, W, variance)
+        d = nhwc(dout, B, H, W, lddo, K).permute(0, 3, 1, 2).contiguous()
+        if dkp:
+            (gk,) = torch.autograd.grad(g, k, d)
+            _flat(dkp, B * K * 2).view(B, K, 2).add_(gk)
+        if dpos:
+            _flat(dpos, K * H * W).view(K, H, W).add_(d.sum(0))
+        return 0
+
+    def _prior(self, p, kd, ks, jd, js, bg):
+        """-> heat (B,K1,H,W), motions (B,K1,H,W,2), warp (B,K1,C,H,W) exactly as dense_motion.py:36-85 computes them"""
+        B, K, H, W, Cc = p.B, p.K, p.H, p.W, p.C
+        var = 1.0 / p.inv_var
+        heat = self._gauss(kd, H, W, var) - self._gauss(ks, H, W, var)
+        heat = torch.cat([torch.zeros_like(heat[:, :1]), heat], dim=1)
+        ident = self._grid(H, W).view(1, 1, H, W, 2)
+        z = ident - kd.view(B, K, 1, 1, 2)
+        if jd is not None:
+            a, b_, c_, d = jd[..., 0], jd[..., 1], jd[..., 2], jd[..., 3]
+            det = a * d - b_ * c_
+            inv = torch.stack([torch.stack([d, -b_], -1), torch.stack([-c_, a], -1)], -2) / det[..., None, None]
+            jac = torch.matmul(js.view(B, K, 2, 2), inv)
+            z = torch.einsum("bkij,bkhwj->bkhwi", jac, z)
+        d2s = z + ks.view(B, K, 1, 1, 2)
+        bgg = ident.expand(B, 1, H, W, 2)
+        if bg is not None:
+            hom = torch.cat([bgg, torch.ones_like(bgg[..., :1])], -1)
+            hom = torch.matmul(bg.view(B, 1, 1, 1, 3, 3), hom.unsqueeze(-1)).squeeze(-1)
+            bgg = hom[..., :2] / hom[..., 2:3]
+        motions = torch.cat([bgg, d2s], dim=1)
+        src = nhwc(p.src, B, H, W, p.lds, Cc).permute(0, 3, 1, 2)
+        rep = src.unsqueeze(1).expand(B, K + 1, Cc, H, W).reshape(B * (K + 1), Cc, H, W)
+        warp = F.grid_sample(rep, motions.reshape(B * (K + 1), H, W, 2), mode="bilinear", padding_mode="zeros", align_corners=False)
+        return heat, motions, warp.view(B, K + 1, Cc, H, W)
+
+    def _prior_inputs(self, p, grad=False):
+        B, K = p.B, p.K
+        f = lambda ptr, n, shp: (_flat(ptr, n).view(*shp).clone().requires_grad_(grad) if ptr else None)
+        return (f(p.kd, B * K * 2, (B, K, 2)), f(p.ks, B * K * 2, (B, K, 2)), f(p.jd, B * K * 4, (B, K, 4)), f(p.js, B * K * 4, (B, K, 4)),
+                f(p.bg, B * 9, (B, 9)))
+
+    def mrfa_prior_motion_fwd(self, stream, pref):
+        p = _obj(pref)
+        B, K, H, W, Cc = p.B, p.K, p.H, p.W, p.C
+        K1 = K + 1
+        heat, motions, warp = self._prior(p, *self._prior_inputs(p))
+        nhwc(p.motions, B * K1, H, W, p.ldm, 2).copy_(motions.reshape(B * K1, H, W, 2))
+        inp = nhwc(p.inp, B, H, W, p.ldi, K1 * (Cc + 1))
+        inter = torch.cat([heat.unsqueeze(2), warp], dim=2)                                           # (B,K1,C+1,H,W)
+        inp.copy_(inter.reshape(B, K1 * (Cc + 1), H, W).permute(0, 2, 3, 1))
+        if p.sparse:
+            _flat(p.sparse, B * K1 * Cc * H * W).view(B, K1, Cc, H, W).copy_(warp)
+        return 0
+
+    def mrfa_prior_motion_bwd(self, stream, pref):
+        p = _obj(pref)
+        B, K, H, W, Cc = p.B, p.K, p.H, p.W, p.C
+        K1 = K + 1
+        ins = self._prior_inputs(p, grad=True)
+        with torch.enable_grad():
+            heat, motions, warp = self._prior(p, *ins)
+        dinp = nhwc(p.dinp, B, H, W, p.lddi, K1 * (Cc + 1)).permute(0, 3, 1, 2).reshape(B, K1, Cc + 1, H, W)
+        dwarp = dinp[:, :, 1:].clone()
+        if p.dsparse:
+            dwarp = dwarp + _flat(p.dsparse, B * K1 * Cc * H * W).view(B, K1, Cc, H, W)
+        outs, grads = [heat, warp], [dinp[:, :, 0].contiguous(), dwarp]
+        if p.dmotions:
+            outs.append(motions)
+            grads.append(nhwc(p.dmotions, B * K1, H, W, p.ldm, 2).reshape(B, K1, H, W, 2).clone())
+        live = [t for t in ins if t is not None]
+        g = torch.autograd.grad(outs, live, grads, allow_unused=True)
+        it = iter(g)
+        for t, dst, n in zip(ins, (p.dkd, p.dks, p.djd, p.djs, p.dbg), (B * K * 2, B * K * 2, B * K * 4, B * K * 4, B * 9)):
+            if t is None:
+                continue
+            gt = next(it)
+            if dst and gt is not None:
+                _flat(dst, n).add_(gt.reshape(-1))
+        return 0
+
+    def mrfa_softmax_combine_fwd(self, stream, logit, ldl, motions, ldm, B, H, W, K1, deformation, mask, logit_nchw):
+        l = nhwc(logit, B, H, W, ldl, K1)
+        m = F.softmax(l, dim=-1)
+        mo = nhwc(motions, B * K1, H, W, ldm, 2).reshape(B, K1, H, W, 2).permute(0, 2, 3, 1, 4)
+        _flat(deformation, B * H * W * 2).view(B, H, W, 2).copy_((mo * m.unsqueeze(-1)).sum(3))
+        _flat(mask, B * K1 * H * W).view(B, K1, H, W).copy_(m.permute(0, 3, 1, 2))
+        _flat(logit_nchw, B * K1 * H * W).view(B, K1, H, W).copy_(l.permute(0, 3, 1, 2))
+        return 0
+
+    def mrfa_softmax_combine_bwd(self, stream, motions, ldm, B, H, W, K1, mask, ddeformation, dmask, dlogit_nchw, dlogit, lddl, dmotions):
+        m = _flat(mask, B * K1 * H * W).view(B, K1, H, W).permute(0, 2, 3, 1)                        # (B,H,W,K1)
+        mo = nhwc(motions, B * K1, H, W, ldm, 2).reshape(B, K1, H, W, 2).permute(0, 2, 3, 1, 4)
+        dd = _flat(ddeformation, B * H * W * 2).view(B, H, W, 2) if ddeformation else torch.zeros(B, H, W, 2)
+        dm = (mo * dd.unsqueeze(3)).sum(-1)
+        if dmask:
+            dm = dm + _flat(dmask, B * K1 * H * W).view(B, K1, H, W).permute(0, 2, 3, 1)
+        dl = m * (dm - (m * dm).sum(-1, keepdim=True))
+        if dlogit_nchw:
+            dl = dl + _flat(dlogit_nchw, B * K1 * H * W).view(B, K1, H, W).permute(0, 2, 3, 1)
+        nhwc(dlogit, B, H, W, lddl, K1).add_(dl)
+        if dmotions:
+            nhwc(dmotions, B * K1, H, W, ldm, 2).add_((m.unsqueeze(-1) * dd.unsqueeze(3)).permute(0, 3, 1, 2, 4).reshape(B * K1, H, W, 2))
+        return 0
+
+    def _kp_head(self, lg, jm, temperature):
+        B, H, W, K = lg.shape
+        heat = F.softmax(lg.reshape(B, H * W, K) / temperature, dim=1)
+        kp = torch.einsum("bpk,pc->bkc", heat, self._grid(H, W).reshape(H * W, 2))
+        jac = torch.einsum("bpk,bpj->bkj", heat, jm.reshape(B, H * W, 4)) if jm is not None else None
+        return kp, jac, heat
+
+    def mrfa_kp_head_fwd(self, stream, logits, ldl, jm, ldj, B, H, W, K, temperature, kp, jac, stat):
+        lg = nhwc(logits, B, H, W, ldl, K)
+        j = nhwc(jm, B, H, W, ldj, 4) if jm else None
+        k, ja, _ = self._kp_head(lg, j, temperature)
+        _flat(kp, B * K * 2).view(B, K, 2).copy_(k)
+        if jm:
+            _flat(jac, B * K * 4).view(B, K, 4).copy_(ja)
+        s = lg.reshape(B, H * W, K) / temperature
+        mx = s.max(dim=1).values
+        st = _flat(stat, B * K * 2).view(B, K, 2)
+        st[..., 0] = mx
+        st[..., 1] = 1.0 / torch.exp(s - mx.unsqueeze(1)).sum(1)
+        return 0
+
+    def mrfa_kp_head_bwd(self, stream, logits, ldl, jm, ldj, B, H, W, K, temperature, kp, jac, stat, dkp, djac, dlogits, lddl, djm, lddj):
+        lg = nhwc(logits, B, H, W, ldl, K).clone().requires_grad_(True)
+        j = nhwc(jm, B, H, W, ldj, 4).clone().requires_grad_(True) if jm else None
+        with torch.enable_grad():
+            k, ja, _ = self._kp_head(lg, j, temperature)
+        outs, grads = [], []
+        if dkp:
+            outs.append(k); grads.append(_flat(dkp, B * K * 2).view(B, K, 2).clone())
+        if jm and djac:
+            outs.append(ja); grads.append(_flat(djac, B * K * 4).view(B, K, 4).clone())
+        if not outs:
+            return 0
+        ins = [lg] + ([j] if (jm and djac) else [])
+        g = torch.autograd.grad(outs, ins, grads, allow_unused=True)
+        nhwc(dlogits, B, H, W, lddl, K).add_(g[0])
+        if jm and djac and djm and g[1] is not None:
+            nhwc(djm, B, H, W, lddj, 4).add_(g[1])
+        return 0
+
     # ---------------------------------------------------------------- K22: training losses
     def mrfa_maxpool2_fwd(self, stream, x, ldx, N, H, W, Cc, y, ldy):
         v = F.max_pool2d(nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2), 2)

@@ -938,3 +938,100 @@ def test_maxpool3s2_with_ties():
         return side.done(y, dx[:, :Cc])
     ref, got = both(run)
     assert_close(ref, got, tol=1e-6, what="maxpool3s2")
+
+
+# ---------------------------------------------------------------------------------------------- K14-K17 (prior-motion stage)
+@pytest.mark.parametrize("with_pos", [False, True])
+def test_kp_gaussian(with_pos):
+    B, K, H, W, ld, var = 3, 10, 12, 9, 16, 0.1
+
+    def run(side):
+        kp = side.t("pg/kp", (B, K, 2), -0.9, 0.9)
+        pos = side.t("pg/pos", (1, K, H, W), -0.1, 0.1) if with_pos else None
+        out = side.garbage((B * H * W, ld))
+        side.call("mrfa_kp_gaussian_fwd", kp.data_ptr(), pos.data_ptr() if with_pos else None, B, K, H, W, var, out.data_ptr(), ld)
+        dout = side.t("pg/dout", (B * H * W, ld))
+        dkp, dpos = side.t("pg/dkp0", (B, K, 2)), side.t("pg/dpos0", (K, H, W))          # += semantics: non-zero start
+        side.call("mrfa_kp_gaussian_bwd", kp.data_ptr(), B, K, H, W, var, dout.data_ptr(), ld, dkp.data_ptr(),
+                  dpos.data_ptr() if with_pos else None)
+        return side.done(out[:, :K], dkp, dpos)
+    a, b = both(run)
+    assert_close(a, b, what="kp_gaussian")
+
+
+@pytest.mark.parametrize("jac,bg", [(True, False), (False, False), (True, True)])
+def test_prior_motion(jac, bg):
+    """dense_motion.py:36-85 in one kernel: motions, interleaved hourglass input, sparse_deformed; backward into kd / ks / jd / js / bg"""
+    B, K, H, W, Cc, var = 2, 10, 16, 16, 3, 0.01
+    K1 = K + 1
+    lds, ldm, ldi = 4, 4, 64
+
+    def run(side):
+        P = hip.PriorParams()
+        kd, ks = side.t("pm/kd", (B, K, 2), -0.8, 0.8), side.t("pm/ks", (B, K, 2), -0.8, 0.8)
+        eye = torch.tensor([1.0, 0.0, 0.0, 1.0], device=side.dev)
+        jd, js = eye + 0.2 * side.t("pm/jd", (B, K, 4)), eye + 0.2 * side.t("pm/js", (B, K, 4))
+        bgm = torch.tensor([1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0], device=side.dev) + 0.1 * side.t("pm/bg", (B, 9))
+        src = side.t("pm/src", (B * H * W, lds), 0, 1)
+        motions, inp = side.garbage((B * K1 * H * W, ldm)), side.z((B * H * W, ldi))
+        sparse = side.garbage((B, K1, Cc, H, W))
+        P.kd, P.ks = kd.data_ptr(), ks.data_ptr()
+        if jac:
+            P.jd, P.js = jd.data_ptr(), js.data_ptr()
+        if bg:
+            P.bg = bgm.data_ptr()
+        P.src, P.lds, P.B, P.K, P.H, P.W, P.C, P.inv_var = src.data_ptr(), lds, B, K, H, W, Cc, 1.0 / var
+        P.motions, P.ldm, P.inp, P.ldi, P.sparse = motions.data_ptr(), ldm, inp.data_ptr(), ldi, sparse.data_ptr()
+        side.call("mrfa_prior_motion_fwd", C.byref(P))
+        dinp, dmot, dsp = side.t("pm/dinp", (B * H * W, ldi)), side.t("pm/dmot", (B * K1 * H * W, ldm)), side.t("pm/dsp", (B, K1, Cc, H, W))
+        grads = [side.t(f"pm/g{i}", shp) for i, shp in enumerate([(B, K, 2), (B, K, 2), (B, K, 4), (B, K, 4), (B, 9)])]
+        P.dinp, P.lddi, P.dmotions, P.dsparse = dinp.data_ptr(), ldi, dmot.data_ptr(), dsp.data_ptr()
+        P.dkd, P.dks = grads[0].data_ptr(), grads[1].data_ptr()
+        if jac:
+            P.djd, P.djs = grads[2].data_ptr(), grads[3].data_ptr()
+        if bg:
+            P.dbg = grads[4].data_ptr()
+        side.call("mrfa_prior_motion_bwd", C.byref(P))
+        return side.done(motions[:, :2], inp[:, :K1 * (Cc + 1)], sparse, *grads)
+    a, b = both(run)
+    assert_close(a[:3], b[:3], tol=1e-5, what="prior_motion fwd")
+    assert_close(a[3:], b[3:], tol=5e-4, what="prior_motion bwd")          # sums over 256 pixels of kinked bilinear gradients
+
+
+def test_softmax_combine():
+    B, H, W, K1, ldl, ldm = 2, 9, 7, 11, 12, 4
+
+    def run(side):
+        logit = side.t("sc/l", (B * H * W, ldl), -3, 3)
+        mot = side.t("sc/m", (B * K1 * H * W, ldm))
+        deform, mask, lg = side.garbage((B, H, W, 2)), side.garbage((B, K1, H, W)), side.garbage((B, K1, H, W))
+        side.call("mrfa_softmax_combine_fwd", logit.data_ptr(), ldl, mot.data_ptr(), ldm, B, H, W, K1, deform.data_ptr(), mask.data_ptr(),
+                  lg.data_ptr())
+        dd, dmk, dlg = side.t("sc/dd", (B, H, W, 2)), side.t("sc/dmk", (B, K1, H, W)), side.t("sc/dlg", (B, K1, H, W))
+        dlogit, dmot = side.t("sc/dl0", (B * H * W, ldl)), side.t("sc/dm0", (B * K1 * H * W, ldm))
+        side.call("mrfa_softmax_combine_bwd", mot.data_ptr(), ldm, B, H, W, K1, mask.data_ptr(), dd.data_ptr(), dmk.data_ptr(), dlg.data_ptr(),
+                  dlogit.data_ptr(), ldl, dmot.data_ptr())
+        return side.done(deform, mask, lg, dlogit[:, :K1], dmot[:, :2])
+    a, b = both(run)
+    assert_close(a, b, tol=1e-5, what="softmax_combine")
+
+
+@pytest.mark.parametrize("jac", [True, False])
+def test_kp_head(jac):
+    """kp_detector.py:90-120 at the reference's geometry: 58 x 58 logits, K = 10, temperature 0.1"""
+    B, H, W, K, ldl, ldj, T = 2, 58, 58, 10, 12, 4, 0.1
+
+    def run(side):
+        lg = side.t("kh/l", (B * H * W, ldl), -1, 1)
+        jm = side.t("kh/j", (B * H * W, ldj))
+        kp, ja, st = side.garbage((B, K, 2)), side.garbage((B, K, 4)), side.garbage((B, K, 2))
+        side.call("mrfa_kp_head_fwd", lg.data_ptr(), ldl, jm.data_ptr() if jac else None, ldj, B, H, W, K, T, kp.data_ptr(),
+                  ja.data_ptr() if jac else None, st.data_ptr())
+        dkp, dja = side.t("kh/dk", (B, K, 2)), side.t("kh/dj", (B, K, 4))
+        dl, djm = side.t("kh/dl0", (B * H * W, ldl)), side.t("kh/djm0", (B * H * W, ldj))
+        side.call("mrfa_kp_head_bwd", lg.data_ptr(), ldl, jm.data_ptr() if jac else None, ldj, B, H, W, K, T, kp.data_ptr(),
+                  ja.data_ptr() if jac else None, st.data_ptr(), dkp.data_ptr(), dja.data_ptr() if jac else None, dl.data_ptr(), ldl,
+                  djm.data_ptr() if jac else None, ldj)
+        return side.done(kp, ja if jac else kp, dl[:, :K], djm if jac else dl[:, :K])
+    a, b = both(run)
+    assert_close(a, b, tol=2e-5, what="kp_head")
