@@ -1140,10 +1140,13 @@ class Ctx:
         p.motions, p.ldm, p.inp, p.ldi, p.sparse = motions.ptr, motions.ld, inp.ptr, inp.ld, sparse.t.data_ptr()
         self._chk(self.L.mrfa_prior_motion_fwd(self.s, C.byref(p)), "prior_motion_fwd")
         if self.record:
+            keep = (src, t)            # `p` holds raw pointers only: the source image and the input copies must outlive the forward
+
             def bwd():
                 ds = sparse.total_grad()
                 if not (inp.has_grad or motions.has_grad or ds is not None):
                     return
+                assert keep[0].st.data is not None
                 q = hip.PriorParams()
                 C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
                 q.dinp, q.lddi = inp.gptr, inp.ld                      # (zero-filled on first touch when no consumer wrote it)
