@@ -95,12 +95,135 @@ def cpu_baseline(batch: int, max_seconds: float = 25.0, prior: str = "mtia", bac
             "sample": f"{n} x (B=1 fwd+bwd, train-mode BN, L1 loss) of the CPU oracle in {dt:.1f}s"}
 
 
+def run_inference(a):
+    """BASELINE.json configs[4]: vox1 512x512 inference-only generator path (RaftFlow forward: generator encode, 16 384^2 correlation
+    volume, 6-level refinement, deformed-feature warps, decode), bs=4, one MI355X -- the HBM-bound grid_sample stress.  One JSON line:
+    value = pairs/s of the hipGraph-replayed forward; roofline = the six-level feature-warp set (grid_sample_fwd, the kernel SURVEY 8(d)
+    names for this config) in algorithmic GB/s against the 8 TB/s HBM peak, each launch timed with HIP events on the launch stream."""
+    import copy
+    from mrfa_amd import hip
+    from mrfa_amd.engine import Ctx
+    from mrfa_amd.graph import GraphedForward
+    from mrfa_amd.modules import RaftFlow
+    from mrfa_amd.train import VOX1
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--inference: replicas only (no collective exists on the inference path); run one process per GPU"
+    hip.lib()
+    if a.mfma:
+        hip.set_mfma_mode(a.mfma)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, size = a.batch, a.size
+    h = size // 4
+    cfg = copy.deepcopy(VOX1["raft_flow"])
+    cfg["size"] = size
+    rf = RaftFlow(**cfg)
+    sd = fill_state_dict(rf.state_dict(), tag="decoder.")
+    for k in list(sd):
+        if k.endswith(("refine.conv2.weight", "refine.convo2.weight")):
+            sd[k] = sd[k] * 0.3
+    rf.load_state_dict(sd)
+    rf.to(dev).eval()
+    img_full = det_uniform("c5/img", (B, 3, size, size), 0, 1).to(dev)
+    img = torch.nn.functional.avg_pool2d(img_full, 4)
+    kp_s, kp_d = det_uniform("c5/ks", (B, 10, 2), -0.8, 0.8).to(dev), det_uniform("c5/kd", (B, 10, 2), -0.8, 0.8).to(dev)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, h), indexing="ij")
+    deform = (torch.stack([xs, ys], dim=-1)[None].expand(B, h, h, 2) + det_uniform("c5/d", (B, h, h, 2), -0.1, 0.1)).contiguous().to(dev)
+    dm = {"deformation": deform, "occlusion": det_uniform("c5/o", (B, 1, h, h), -2, 2).to(dev)}
+
+    class _Fwd(torch.nn.Module):                      # GraphedForward wants model(source, driving): close over the fixed prior inputs
+        def __init__(self):
+            super().__init__()
+            self.rf = rf
+
+        def forward(self, full, quarter):
+            return self.rf(kp_s, kp_d, dm, quarter, full)[0]
+    m = _Fwd().eval()
+    launch = "eager"
+    with torch.no_grad():
+        step = lambda: m(img_full, img)
+        if not a.no_graph:
+            gf = GraphedForward(m, img_full, img)     # raises if the capture cannot be trusted (no silent eager fallback)
+            step = lambda: gf(gf.src, gf.drv)         # the graph's own static inputs: no per-step copy
+            launch = "hipGraph"
+        for _ in range(a.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ms = 1e3 * dt / a.steps
+    scale = (size / 256.0) ** 2
+    gflop = (scale * (362.73 - 8.59) + 8.59 * scale * scale) * B          # SURVEY 8(d): conv FLOPs x (size/256)^2, correlation GEMM x (size/256)^4
+    roof = None
+    if not a.no_roofline:
+        ectx = Ctx(dev, train=False, record=False)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        tot_b = tot_ms = 0.0
+        n = 0
+        levels = []
+        for C_, r in ((512, size // 32), (512, size // 16), (512, size // 8), (256, size // 4), (128, size // 2), (64, size)):
+            f = ectx.new(B, r, r, C_)
+            f.st.data.normal_()
+            grid = ectx.new(B, r, r, 2)
+            grid.st.data.uniform_(-3, 3)
+            o = ectx.new(B, r, r, C_)
+            for _ in range(3):
+                ectx.grid_sample(f, grid, 1, out=o)
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(20):
+                ectx.grid_sample(f, grid, 1, out=o)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / 20
+            byt = 4.0 * B * (2 * C_ * r * r + 2 * r * r)                    # SURVEY 8(d): read C*H*W, write C*H*W, read the (x,y) grid
+            tot_b, tot_ms, n = tot_b + byt, tot_ms + t, n + 1
+            levels.append({"C": C_, "res": r, "us": round(t * 1e3, 1), "GBps": round(byt / t / 1e6, 0)})
+        ach = tot_b / tot_ms / 1e6
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                "kernel": "grid_sample_fwd (one six-level deformed-feature warp set, flow-in-pixels sampling; the forward runs three sets + the image warp)",
+                "algorithmic_GB_per_set": round(tot_b / 1e9, 3), "ms_per_set": round(tot_ms, 4), "launches_per_set": n, "levels": levels,
+                "whole_forward_algorithmic_tflops": round(gflop / ms, 2),
+                "whole_forward_frac_of_fp32_mfma_peak": round(gflop / ms / PEAK_FP32_MFMA_TFLOPS, 4)}
+    cpu = None
+    if not a.no_cpu_baseline:
+        try:
+            from oracle import mrfa_oracle as O
+            torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+            P = {k: v.detach().cpu().clone() for k, v in rf.state_dict().items()}
+            t1 = time.time()
+            with torch.no_grad():
+                O.raft_flow(kp_s[:1].cpu(), kp_d[:1].cpu(), {k: v[:1].cpu() for k, v in dm.items()}, img[:1].cpu(), img_full[:1].cpu(), P, "",
+                            size=size, train=False)
+            cdt = time.time() - t1
+            cpu = {"value": 1.0 / cdt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"1 x (B=1 RaftFlow forward at {size}x{size}) of the CPU oracle in {cdt:.1f}s"}
+        except Exception as ex:
+            cpu = {"error": repr(ex)}
+    line = {"metric": f"frames/sec ({size}x{size} source+driving pair) inference, generator path", "value": round(B * a.steps / dt, 3), "unit": "pairs/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": ("bf16" if hip.mfma_mode() == "bf16" else "f32"), "data": "synthetic",
+            "config": {"workload": f"vox1.yaml RaftFlow generator path (encode + correlation + 6-level refinement + warps + decode), {size}x{size}, "
+                                   f"bs={B}, inference only (eval-mode BN, no autograd)", "global_batch": B, "parallelism": "dp1",
+                       "launch": launch, "mfma": hip.mfma_mode(), "out_finite": bool(torch.isfinite(out).all()),
+                       "memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+            "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE config: bs=8)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (BASELINE configs[1]: bs=8; with --inference: 4)")
+    ap.add_argument("--size", type=int, default=256, help="image size; 512 only with --inference (BASELINE configs[4])")
+    ap.add_argument("--inference", action="store_true",
+                    help="BASELINE configs[4]: inference-only generator path (RaftFlow forward) at --size, bs=--batch; roofline = the HBM-bound "
+                         "grid_sample feature-warp set")
     ap.add_argument("--prior", choices=["mtia", "fomm"], default="mtia",
                     help="keypoint prior: mtia = TokenPose_B (BASELINE config 2, `prior_model: mtia` of vox1.yaml), fomm = KPDetector")
     ap.add_argument("--background", action="store_true",
@@ -122,6 +245,12 @@ def main():
     ap.add_argument("--wgrad-stream", action="store_true", help="graph mode: weight-gradient kernels as a parallel graph branch (measured slower)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of the flat K20 optimizer kernels")
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 4 if a.inference else 8
+    if a.inference:
+        return run_inference(a)
+    if a.size != 256:
+        ap.error("--size other than 256 is the inference configuration: add --inference")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -367,7 +496,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if hip.mfma_mode() == "bf16" else "f32"),
             "data": "synthetic",
-            "config": {"workload": "vox1.yaml " + ("MTIA (TokenPose_B)" if a.prior == "mtia" else "FOMM KPDetector") +
+            "config": {"workload": ("celebvhq.yaml (bg_start 0: BGMotionPredictor -> bg_param), " if a.background else "vox1.yaml ") +
+                                   ("MTIA (TokenPose_B)" if a.prior == "mtia" else "FOMM KPDetector") +
                                    " prior + DenseMotion + RaftFlow refinement, 256x256, "
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, " +
                                    ("surrogate L1 loss" if a.loss == "surrogate" else

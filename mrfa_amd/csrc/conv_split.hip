@@ -157,11 +157,20 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
                 rb[j][1] = *reinterpret_cast<const f32x4*>(src + 16);
             }
         }
-        if (++l_c == KC) {
-            l_c = 0;
-            l_w += p.w_tap;
-            l_ws += p.w_tap;
-            if (++l_s == p.S) { l_s = 0; ++l_r; }
+        // K order: the R*S taps of one 32-channel chunk are consecutive k-tiles (channel-chunk-major).  The shifted re-reads of
+        // a chunk by the next tap then hit the XCD's L2 while it still holds that chunk: with tap-major order the working set of
+        // the 32 workgroups of an XCD between two visits of a row was the whole Cin depth of ~34 image rows (> the 4 MB L2).
+        // Measured on the pre-split micro-benchmark (tools/ubench/split_gemm.hip): +7 % at Cout = 128, +2 % at 256.
+        l_w += p.w_tap;
+        l_ws += p.w_tap;
+        if (++l_s == p.S) {
+            l_s = 0;
+            if (++l_r == p.R) {
+                l_r = 0;
+                ++l_c;
+                l_w -= (size_t)p.R * p.S * p.w_tap;
+                l_ws -= (size_t)p.R * p.S * p.w_tap;
+            }
         }
     };
 
@@ -254,8 +263,9 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     const int kt_begin = blockIdx.z * kt_per_split;
     const int kt_end = min(KT, kt_begin + kt_per_split);
     {
-        const int tap0 = kt_begin / KC;
-        l_c = kt_begin - tap0 * KC;
+        const int T = p.R * p.S;
+        l_c = kt_begin / T;
+        const int tap0 = kt_begin - l_c * T;
         l_r = tap0 / p.S;
         l_s = tap0 - l_r * p.S;
         l_w = w + (size_t)tap0 * p.w_tap;

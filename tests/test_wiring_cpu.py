@@ -585,3 +585,11 @@ print("ok")
     code2 = "import sys; sys.path.insert(0, sys.argv[1]); import mrfa_amd; assert not mrfa_amd.GRAPH_REPLAY_UNSAFE; mrfa_amd.graph_replay_safe(); print('ok')"
     r = subprocess.run([sys.executable, "-c", code2, ROOT], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("train,b", [(False, 2), (True, 4)])
+def test_prior_stage_gradients_through_emulator(golden_dir, train, b, fresh_mode):
+    """KPDetector / DenseMotionNetwork backward (K14-K17 specifications + tape wiring) against the reference's autograd gradients"""
+    from tests.grad_checks import check_prior_stage_gradients
+    with emulated_hip():
+        check_prior_stage_gradients(golden_dir, train, b, "cpu")

@@ -657,8 +657,113 @@ def g10_helpers():
     print("G10 helper goldens:", {k: v.shape for k, v in out.items()})
 
 
+# ----------------------------------------------------------------------------------------------- G11 prior-stage + chained gradients
+def _grad_record(out, tag, mods, samples):
+    """per-parameter gradient norms of `mods` = [(prefix, module)] and a few whole gradient tensors"""
+    names, norms = [], []
+    for pfx, m in mods:
+        for n, p in m.named_parameters():
+            names.append(pfx + n)
+            norms.append(0.0 if p.grad is None else p.grad.norm().item())
+    out[f"{tag}_pgrad_norms"] = np.array(norms, np.float32)
+    allp = {pfx + n: p for pfx, m in mods for n, p in m.named_parameters()}
+    for n in samples:
+        out[f"{tag}_pgrad_{n}"] = npy(allp[n].grad)
+    return names
+
+
+def g11_prior_grads():
+    """VERDICT r1 'weak' item 1: backward goldens from the reference's autograd for KPDetector (kp_detector.py:102-133) and
+    DenseMotionNetwork (dense_motion.py:104-146) alone, and for the chained KPDetector -> DenseMotionNetwork -> RaftFlow pipeline at
+    256 x 256 (model.py:185-210 with is_train wiring, loss = mean|out - driving|), eval-mode BatchNorm at B=2 and train-mode at B=4.
+    The fp64 oracle's gradient norms are stored next to the reference's so that a test can see how far fp32 itself is from the truth."""
+    out, names = {}, {}
+    for train, b in ((False, 2), (True, 4)):
+        sfx = "train" if train else "eval"
+        # ---- KPDetector
+        kpm = KPDetector(**cases.KP_DETECTOR_CFG)
+        sd = load(kpm, "kp")
+        kpm.train(train)
+        x = cases.images(f"g11/x_{sfx}", b, 256)
+        r = kpm(x)
+        loss = (r["kp"] * det_uniform("g11/wkp", (b, 10, 2), -1, 1)).sum() + (r["jacobian"] * det_uniform("g11/wjac", (b, 10, 2, 2), -1, 1)).sum()
+        loss.backward()
+        out[f"kp_{sfx}_loss"] = np.array([loss.item()], np.float32)
+        names[f"kp_{sfx}"] = _grad_record(out, f"kp_{sfx}", [("", kpm)], ["kp.weight", "jacobian.bias", "predictor.decoder.up_blocks.4.conv.weight",
+                                                                         "predictor.encoder.down_blocks.0.norm.weight"])
+        P = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        r64 = O.kp_detector(x.double(), P, "", train)
+        ((r64["kp"] * det_uniform("g11/wkp", (b, 10, 2), -1, 1).double()).sum() + (r64["jacobian"] * det_uniform("g11/wjac", (b, 10, 2, 2), -1, 1).double()).sum()).backward()
+        out[f"kp_{sfx}_pgrad_norms_fp64"] = np.array([0.0 if P[n].grad is None else P[n].grad.norm().item() for n in names[f"kp_{sfx}"]], np.float32)
+        # ---- DenseMotionNetwork
+        dmm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+        sdd = load(dmm, "dm")
+        dmm.train(train)
+        kd, ks = cases.keypoints(f"g11/kd_{sfx}", b), cases.keypoints(f"g11/ks_{sfx}", b)
+        for d in (kd, ks):
+            for t in d.values():
+                t.requires_grad_(True)
+        r = dmm(x, kd, ks)
+        loss = ((r["deformation"] * det_uniform("g11/wdef", (b, 64, 64, 2), -1, 1)).sum() + (r["occlusion"] * det_uniform("g11/wocc", (b, 1, 64, 64), -1, 1)).sum()
+                + (r["mask"] * det_uniform("g11/wmask", (b, 11, 64, 64), -1, 1)).sum()) / 64.0
+        loss.backward()
+        out[f"dm_{sfx}_loss"] = np.array([loss.item()], np.float32)
+        for nm, d in (("kd", kd), ("ks", ks)):
+            out[f"dm_{sfx}_grad_{nm}_kp"], out[f"dm_{sfx}_grad_{nm}_jac"] = npy(d["kp"].grad), npy(d["jacobian"].grad)
+        names[f"dm_{sfx}"] = _grad_record(out, f"dm_{sfx}", [("", dmm)], ["mask.weight", "occlusion.bias", "hourglass.encoder.down_blocks.0.conv.weight",
+                                                                         "hourglass.decoder.up_blocks.4.norm.bias"])
+        P = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sdd.items()}
+        kd64 = {k: v.detach().double().requires_grad_(True) for k, v in kd.items()}
+        ks64 = {k: v.detach().double().requires_grad_(True) for k, v in ks.items()}
+        r64 = O.dense_motion(x.double(), kd64, ks64, P, "", train)
+        (((r64["deformation"] * det_uniform("g11/wdef", (b, 64, 64, 2), -1, 1).double()).sum() + (r64["occlusion"] * det_uniform("g11/wocc", (b, 1, 64, 64), -1, 1).double()).sum()
+          + (r64["mask"] * det_uniform("g11/wmask", (b, 11, 64, 64), -1, 1).double()).sum()) / 64.0).backward()
+        for nm, d in (("kd", kd64), ("ks", ks64)):
+            out[f"dm_{sfx}_grad_{nm}_kp_fp64"], out[f"dm_{sfx}_grad_{nm}_jac_fp64"] = npy(d["kp"].grad), npy(d["jacobian"].grad)
+        out[f"dm_{sfx}_pgrad_norms_fp64"] = np.array([0.0 if P[n].grad is None else P[n].grad.norm().item() for n in names[f"dm_{sfx}"]], np.float32)
+        for nm in ("kd", "ks"):
+            for short in ("kp", "jac"):
+                a_, t_ = out[f"dm_{sfx}_grad_{nm}_{short}"], out[f"dm_{sfx}_grad_{nm}_{short}_fp64"]
+                print(f"   DenseMotion {sfx} d{nm}.{short}: reference-vs-fp64 max {np.abs(a_ - t_).max():.2e} of {np.abs(t_).max():.2e}")
+        # ---- chained pipeline, 256 x 256
+        kpm = KPDetector(**cases.KP_DETECTOR_CFG)
+        dmm = DenseMotionNetwork(**cases.DENSE_MOTION_CFG)
+        rf = RaftFlow(**cases.raft_cfg(256))
+        sds = {"encoder.": load(kpm, "kp"), "dense_motion.": load(dmm, "dm"), "decoder.": load(rf, "rf")}
+        for m in (kpm, dmm, rf):
+            m.train(train)
+        src, drv = cases.images(f"g11/src_{sfx}", b, 256), cases.images(f"g11/drv_{sfx}", b, 256)
+        down = RU.AntiAliasInterpolation2d(3, 0.25)
+        k_s, k_d = kpm(src), kpm(drv)
+        dmo = dmm(src, k_d, k_s)
+        gen, _, _ = rf(k_s["kp"], k_d["kp"], dmo, img=down(src), img_full=src)
+        loss = (gen - drv).abs().mean()
+        loss.backward()
+        out[f"chain_{sfx}_loss"] = np.array([loss.item()], np.float32)
+        out[f"chain_{sfx}_gen_s4"] = npy(gen[:, :, ::4, ::4])
+        names[f"chain_{sfx}"] = _grad_record(out, f"chain_{sfx}", [("encoder.", kpm), ("dense_motion.", dmm), ("decoder.", rf)],
+                                              ["encoder.kp.weight", "encoder.jacobian.weight", "dense_motion.mask.weight", "decoder.refine.conv2.weight",
+                                               "decoder.to_context.0.weight", "decoder.generator.final.weight", "decoder.pos_embedding"])
+        # the same pipeline through the oracle in fp64: the truth the fp32 reference itself is measured against
+        P = {}
+        for pfx, sd_ in sds.items():
+            P.update({pfx + k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd_.items()})
+        g64, _, _, _, _ = O.mrfa_forward(src.double(), drv.double(), P, size=256, train=train, prior="fomm")
+        l64 = (g64 - drv.double()).abs().mean()
+        l64.backward()
+        truth = np.array([0.0 if (n not in P or P[n].grad is None) else P[n].grad.norm().item() for n in names[f"chain_{sfx}"]], np.float64)
+        out[f"chain_{sfx}_pgrad_norms_fp64"] = truth.astype(np.float32)
+        refn = out[f"chain_{sfx}_pgrad_norms"].astype(np.float64)
+        rel = np.abs(refn - truth) / np.maximum(truth, 1e-3 * truth.max())
+        print(f"   chain {sfx}: loss ref {loss.item():.6f} fp64 oracle {l64.item():.6f}; reference-vs-fp64 gradient norms: median {np.median(rel):.2e} max {rel.max():.2e}")
+    with open(os.path.join(GOLD, "prior_grads_param_names.json"), "w") as f:
+        json.dump(names, f)
+    np.savez_compressed(os.path.join(GOLD, "prior_grads.npz"), **out)
+    print("G11 prior / chained gradient goldens:", len(out), {k: float(v[0]) for k, v in out.items() if k.endswith("_loss")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest", "g10_helpers"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest", "g10_helpers", "g11_prior_grads"]
     for w in which:
         print("==", w)
         globals()[w]()
