@@ -16,6 +16,14 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
                             int total_splits, int taps, long long partial_stride, int BM, int BN);
 
+// conv_small.hip: one wave per 16..32-row output tile, operands straight from L1/L2 into v_mfma_f32_16x16x4_f32 (small problems)
+bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M);
+int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M);
+
+// wgrad_small.hip: one wave per 32 x 32 weight block of one tap over a pixel range (small problems)
+bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M);
+int mrfa_wgrad_small_launch(hipStream_t st, const mrfa_wgrad_params& p, long long M);
+
 #define MRFA_CHECK_ARG(cond, ...)                      \
     do {                                               \
         if (!(cond)) {                                 \

@@ -17,6 +17,7 @@
 // Reference call sites replaced: every F.conv2d on the hot path (see include/mrfa_hip.h) and the all-pairs
 // correlation einsum (modules/raft.py:185).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -356,6 +357,12 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     const int KT = (Ktot + BK - 1) / BK;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
 
+    // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
+    static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    if (small_on && mrfa_conv_small_eligible(p, M)) {
+        g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
+        return mrfa_conv_small_launch(st, p, M);
+    }
     // ---- tile selection: largest BN whose padding waste is small, then BM by how many workgroups result
     int BN = 128;
     {

@@ -1,0 +1,215 @@
+// Small-problem implicit-GEMM convolution: ONE WAVE per output tile, operands straight from L1/L2 into MFMA registers.
+//
+// The MTIA prior (HRNet-W32 stages + the token transformer's nn.Linear layers) issues ~600 convolutions per pass with 0.1-0.6 GFLOP
+// each: 32->32 @64^2, 64->64 @32^2, 128->128 @16^2 3x3 convolutions and 192<->576 linears over 2 208 token rows.  On the LDS-tiled
+// 64..128-row workgroup tiles of conv_mfma.hip / conv_split.hip they ran at 10-25 TF/s (20-57 us each; profiles/r2_encoder_convs.log):
+// too few workgroups to fill 256 CUs, a barrier and an exposed global-load round trip per 32-deep k-step, split-K init / epilogue
+// launches around 6-step k-loops, and 50-75 % padding of 128-wide tiles for 32..64 output channels.
+//
+// Here a wave64 owns a (16 TMW) x (16 TNW) output tile built from v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles, 4 accumulator
+// registers per 16x16 tile).  A and B fragments of that MFMA are ONE float per lane (lane l: row l & 15, k = l >> 4), so a lane
+// loads float4 = k 4q..4q+3 of its row (q = l >> 4) for a 16-deep k-chunk and feeds components x, y, z, w to four successive MFMAs
+// (A and B use the same k permutation, as in conv_mfma.hip).  No LDS, no barrier, no split-K: latency is hidden by a 4-chunk
+// register prefetch ring and by 1 000+ independent waves per launch; the 64-byte row segments of a chunk are adjacent in the NHWC
+// row, so successive chunks hit the lines the previous ones brought into L1.  Output tiles of 16 x 16 ... 32 x 32 per wave put
+// 256-1 024 waves on a 0.6 GFLOP layer where the 128-row tiles had 64-256 workgroups.
+//
+// Same arguments, packed-weight layout ([tap][Cout up to a multiple of 128][Cin], pack mode 0 / 2) and epilogue semantics as the
+// chunked path of mrfa_conv2d_nhwc (bias, output affine, residual, ReLU, accumulate, per-channel sum / sum-of-squares for
+// train-mode BatchNorm): mrfa_conv2d_nhwc dispatches here (mrfa_conv_small_launch) when the shape qualifies.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int DEPTH = 4;        // k16 chunks in flight per wave
+
+template <int TMW, int TNW>
+__global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int wave_tiles_m) {
+    constexpr int WM = 16 * TMW, WN = 16 * TNW;
+    __shared__ float sred[4][2][WN];                  // per-wave column sums for the BatchNorm statistics
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tile_n = blockIdx.x % tiles_n;
+    const long long wt_m = (long long)(blockIdx.x / tiles_n) * 4 + wave;          // this wave's row tile
+    const bool wave_on = wt_m < wave_tiles_m;
+    const long long m0 = wt_m * WM;
+    const int n0 = tile_n * WN;
+    const int HWo = p.Hout * p.Wout;
+    const int KC = p.Cin >> 4;                        // k16 chunks per tap
+    const int T = p.R * p.S;
+    const int nq = T * KC;
+
+    int a_oy[TMW], a_ox[TMW];
+    long long a_img[TMW];
+    bool a_ok[TMW];
+#pragma unroll
+    for (int a = 0; a < TMW; ++a) {
+        const long long m = m0 + a * 16 + li;
+        a_ok[a] = wave_on && m < M;
+        const long long mm = a_ok[a] ? m : 0;
+        const int n_img = (int)(mm / HWo);
+        const int rem = (int)(mm - (long long)n_img * HWo);
+        a_oy[a] = rem / p.Wout;
+        a_ox[a] = rem - a_oy[a] * p.Wout;
+        a_img[a] = (long long)n_img * p.Hin * p.Win;
+    }
+    // B rows: packed weights are zero-padded to a multiple of 128 rows, so every row n0 + b*16 + li < w_rows is readable
+    const float* wrow[TNW];
+#pragma unroll
+    for (int b = 0; b < TNW; ++b) {
+        int n = n0 + b * 16 + li;
+        if (n >= p.w_rows) n = p.w_rows - 1;          // (its products land in columns >= Cout, which are never stored)
+        wrow[b] = p.w + (size_t)n * p.w_ld + kq * 4;
+    }
+
+    f32x4v ra[DEPTH][TMW], rb[DEPTH][TNW];
+    // loader state: tap (l_r, l_s), chunk l_c; per-tap A row pointers (null = outside the image)
+    int l_r = 0, l_s = 0, l_c = 0;
+    const float* arow[TMW];
+    const float* l_w_off = nullptr;                   // tap offset into the packed weights, as a pointer difference base
+    size_t w_tap_off = 0;
+    auto set_tap = [&]() {
+        const int dr = l_r - p.pad, ds = l_s - p.pad;
+#pragma unroll
+        for (int a = 0; a < TMW; ++a) {
+            const int iy = a_oy[a] + dr, ix = a_ox[a] + ds;
+            const bool inb = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            arow[a] = inb ? p.x + (size_t)(a_img[a] + (long long)iy * p.Win + ix) * p.ldx + kq * 4 : nullptr;
+        }
+    };
+    set_tap();
+    auto load_chunk = [&](int slot) {
+        const int c0 = l_c * 16;
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+            ra[slot][a] = arow[a] ? *reinterpret_cast<const f32x4v*>(arow[a] + c0) : f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < TNW; ++b) rb[slot][b] = *reinterpret_cast<const f32x4v*>(wrow[b] + w_tap_off + c0);
+        if (++l_c == KC) {
+            l_c = 0;
+            w_tap_off += p.w_tap;
+            if (++l_s == p.S) { l_s = 0; ++l_r; }
+            set_tap();
+        }
+    };
+    (void)l_w_off;
+
+    f32x4v acc[TMW][TNW];
+#pragma unroll
+    for (int a = 0; a < TMW; ++a)
+#pragma unroll
+        for (int b = 0; b < TNW; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TMW; ++a)
+#pragma unroll
+                for (int b = 0; b < TNW; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][a][j], rb[slot][b][j], acc[a][b], 0, 0, 0);
+    };
+
+    if (wave_on) {
+        // register ring of DEPTH chunks: chunk q lives in slot q % DEPTH; the loop is unrolled by DEPTH so every index is static
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (s < nq) load_chunk(s);
+        for (int q0 = 0; q0 < nq; q0 += DEPTH) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                const int q = q0 + s;
+                if (q + DEPTH - 1 < nq) load_chunk((s + DEPTH - 1) % DEPTH);
+                if (q < nq) compute(s);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
+    float s1[TNW], s2[TNW];
+#pragma unroll
+    for (int b = 0; b < TNW; ++b) {
+        const int c = n0 + b * 16 + li;
+        const bool c_ok = wave_on && c < p.Cout;
+        float bias = 0.f, osc = 1.f, osh = 0.f;
+        if (c_ok) {
+            if (p.bias) bias = p.bias[c];
+            if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+        }
+        s1[b] = 0.f; s2[b] = 0.f;
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = m0 + a * 16 + kq * 4 + r;
+                if (c_ok && m < M) {
+                    float v = acc[a][b][r] * p.alpha + bias;
+                    v = v * osc + osh;
+                    float* dst = p.y + (size_t)m * p.ldy + c;
+                    if (p.res) v += p.res[(size_t)m * p.ldr + c];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                    s1[b] += v;
+                    s2[b] += v * v;
+                }
+            }
+    }
+    if (p.stats) {
+        // column sums: over the 4 row groups of a wave (lanes li, li+16, li+32, li+48), then over the 4 waves through LDS: one
+        // fp64 atomic per column per workgroup
+#pragma unroll
+        for (int b = 0; b < TNW; ++b) {
+            s1[b] += __shfl_xor(s1[b], 16, 64); s1[b] += __shfl_xor(s1[b], 32, 64);
+            s2[b] += __shfl_xor(s2[b], 16, 64); s2[b] += __shfl_xor(s2[b], 32, 64);
+            if (kq == 0) { sred[wave][0][b * 16 + li] = s1[b]; sred[wave][1][b * 16 + li] = s2[b]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * WN) {
+            const int which = threadIdx.x / WN, col = threadIdx.x % WN;
+            const int c = n0 + col;
+            if (c < p.Cout) {
+                const double v = (double)sred[0][which][col] + (double)sred[1][which][col] + (double)sred[2][which][col] + (double)sred[3][which][col];
+                atomicAdd(p.stats + which * p.Cout + c, v);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 1: the shape runs here.  Chunked (non-flat) layout, no fused upsample / pre-activation prologue / batched GEMM, channels in
+// multiples of 16, and a problem small enough that the 128-row workgroup tiles cannot fill the chip.
+bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
+    if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.tile || p.splitk > 1) return false;
+    if ((p.Cin & 15) || (p.ldx & 3) || (p.w_ld & 3)) return false;
+    if (!aligned16(p.x) || !aligned16(p.w)) return false;
+    const long long ktot = (long long)p.R * p.S * p.Cin;
+    // what the big tiles do well stays there: long K with >= 256 row tiles of 128, or wide outputs at large M
+    const long long big_tiles = ((M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout > 640 || ktot > 1152) return false;
+    if (big_tiles >= 512 && p.Cout > 64) return false;
+    if (M > 65536) return false;
+    return true;
+}
+
+int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M) {
+    // wave tile: the largest of 32x32 / 16x32 / 16x16 that still yields >= ~1 000 waves (4 per SIMD-pair of the chip)
+    const int ncols = (p.Cout + 15) / 16 * 16;
+    auto waves = [&](int wm, int wn) { return ((M + wm - 1) / wm) * ((ncols + wn - 1) / wn); };
+    int tm = 2, tn = 2;
+    if (waves(32, 32) < 1024) { tm = 1; tn = 2; }
+    if (tm == 1 && waves(16, 32) < 1024) { tn = 1; }
+    if (ncols % 32 != 0 && tn == 2 && ncols < 32) tn = 1;
+    const int WM = 16 * tm, WN = 16 * tn;
+    const int tiles_n = (ncols + WN - 1) / WN;
+    const int wave_tiles_m = (int)((M + WM - 1) / WM);
+    const long long blocks = (long long)((wave_tiles_m + 3) / 4) * tiles_n;
+    dim3 grid((unsigned)blocks);
+    if (tm == 2 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<2, 2>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<1, 2>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+    else hipLaunchKernelGGL((conv_small_kernel<1, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+    MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(small)");
+    return 0;
+}

@@ -15,6 +15,7 @@
 // Replaces the weight/bias-gradient half of aten::convolution_backward for every F.conv2d on the hot path
 // (call sites listed in include/mrfa_hip.h) and d(k_s) of the correlation einsum (modules/raft.py:185).
 #include "common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -373,6 +374,9 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     const long long M = (long long)p.N * p.Hout * p.Wout;
     MRFA_CHECK_ARG(M < (1ll << 31) - 64, "wgrad: too many pixels");
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    // small problems (the MTIA prior's layers): one wave per 32 x 32 weight block, no LDS staging, in-workgroup reduction (wgrad_small.hip)
+    static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    if (small_on && mrfa_wgrad_small_eligible(p, M)) return mrfa_wgrad_small_launch(st, p, M);
     const int taps = flat ? 1 : p.R * p.S;
     const int NTOT = flat ? p.kflat : p.Cin;
     // tile selection: (BM over Cout) x (BN over Cin or taps*Cin)

@@ -1,0 +1,162 @@
+// Small-problem weight gradient: dW[tap][co][ci] += alpha * sum_m dY[m][co] * X[m + tap][ci] for the MTIA prior's 0.1-0.6 GFLOP
+// layers (32->32 @64^2, 64->64 @32^2, 128->128 @16^2 3x3 convolutions, 192<->576 linears over 2 208 token rows), which ran at
+// 3-20 TF/s (28-57 us each) on the 64..128-wide LDS tiles of wgrad_mfma.hip / wgrad_split.hip: an output of 32 x 32 ... 128 x 128
+// weights per tap pads a 128 x 128 tile by 4-16x, and the pixel axis (the GEMM's K) had to be split across workgroups and reduced
+// by a second kernel.
+//
+// Here ONE WAVE owns a 32 (co) x 32 (ci) block of one tap over a range of pixels, with v_mfma_f32_16x16x4_f32 (exact fp32).  Both
+// operands are pixel-major ([m][channel]), i.e. the GEMM's K axis is the slow one -- so a lane loads float2 = channels 2i, 2i+1 of
+// pixel m (16 lanes x 8 B = one 128-byte line per pixel row; lane group q = lane >> 4 takes pixel m0 + 4j + q for MFMA j) and uses
+// component t as the A (or B) operand of MFMA tile t: tile (t, u) then holds rows co0 + 2 i_a + t and columns ci0 + 2 i_b + u --
+// a strided channel set per tile, which costs nothing (only the final store knows).  No LDS staging, no barrier in the loop.
+// The four waves of a workgroup take four consecutive pixel ranges of the same block and add their 32 x 32 partials in LDS, so one
+// workgroup issues 1 024 global atomics; the number of pixel ranges is chosen for ~2 000 waves per launch.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_params p, const long long M, const int chunks_per_wave, const int nblk_ci,
+                                                         const int nblk, const int pow2_w /* log2(Wout) or -1 */, const int pow2_hw) {
+    __shared__ float sacc[32][33];
+    __shared__ float sbias[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    // blockIdx.x = (range group g, tap, block): the 4 waves of a workgroup = pixel ranges 4g .. 4g+3 of the same (tap, block)
+    const int T = p.R * p.S;
+    const int blk = blockIdx.x % nblk;
+    const int tap = (blockIdx.x / nblk) % T;
+    const int g = blockIdx.x / (nblk * T);
+    const int co0 = (blk / nblk_ci) * 32, ci0 = (blk % nblk_ci) * 32;
+    const int dr = tap / p.S - p.pad, ds = tap % p.S - p.pad;
+    const long long range = (long long)(4 * g + wave) * chunks_per_wave * 16;
+    const int HWo = p.Hout * p.Wout;
+    const bool spatial = T > 1 || p.Hin != p.Hout || p.Win != p.Wout;
+
+    for (int i = threadIdx.x; i < 32 * 33; i += 256) (&sacc[0][0])[i] = 0.f;
+    if (threadIdx.x < 32) sbias[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+    const float* dyp = p.dy + co0 + 2 * li;
+    const float* xp = p.x + ci0 + 2 * li;
+
+    auto load = [&](long long m0c, f32x2v (&a)[4], f32x2v (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long m = m0c + 4 * j + kq;
+            const bool ok = m < M;
+            a[j] = ok ? *reinterpret_cast<const f32x2v*>(dyp + (size_t)m * p.ldy) : f32x2v{0.f, 0.f};
+            bool xok = ok;
+            long long xrow = m;
+            if (spatial && ok) {
+                int img, oy, ox;
+                if (pow2_w >= 0) {
+                    img = (int)(m >> pow2_hw);
+                    const int rem = (int)(m & ((1 << pow2_hw) - 1));
+                    oy = rem >> pow2_w;
+                    ox = rem & ((1 << pow2_w) - 1);
+                } else {
+                    img = (int)(m / HWo);
+                    const int rem = (int)(m - (long long)img * HWo);
+                    oy = rem / p.Wout;
+                    ox = rem - oy * p.Wout;
+                }
+                const int iy = oy + dr, ix = ox + ds;
+                xok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                xrow = ((long long)img * p.Hin + iy) * p.Win + ix;
+            }
+            b[j] = xok ? *reinterpret_cast<const f32x2v*>(xp + (size_t)xrow * p.ldx) : f32x2v{0.f, 0.f};
+        }
+    };
+    auto compute = [&](const f32x2v (&a)[4], const f32x2v (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][t], b[j][u], acc[t][u], 0, 0, 0);
+            bsum[0] += a[j][0];
+            bsum[1] += a[j][1];
+        }
+    };
+
+    // two-deep register pipeline over this wave's 16-pixel chunks
+    f32x2v a0[4], b0[4], a1[4], b1[4];
+    int nc = 0;
+    if (range < M) {
+        const long long left = (M - range + 15) / 16;
+        nc = left < chunks_per_wave ? (int)left : chunks_per_wave;
+    }
+    if (nc > 0) load(range, a0, b0);
+    for (int c = 0; c < nc; c += 2) {
+        if (c + 1 < nc) load(range + (long long)(c + 1) * 16, a1, b1);
+        compute(a0, b0);
+        if (c + 1 < nc) {
+            if (c + 2 < nc) load(range + (long long)(c + 2) * 16, a0, b0);
+            compute(a1, b1);
+        }
+    }
+    // C/D layout: column = lane & 15 (B row index i_b -> ci), row = (lane >> 4) * 4 + r (A row index i_a -> co)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&sacc[2 * (kq * 4 + r) + t][2 * li + u], acc[t][u][r]);
+    if (p.dbias && tap == 0 && ci0 == 0) {
+        // column sums of dY over this wave's pixels: lane (li, kq) summed channels 2 li + {0, 1} of its pixels
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = bsum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) atomicAdd(&sbias[2 * li + t], v);
+        }
+    }
+    __syncthreads();
+    float* dw = p.dw + ((size_t)tap * p.Cout + co0) * p.Cin + ci0;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int r = i >> 5, c = i & 31;
+        if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * sacc[r][c]);
+    }
+    if (p.dbias && tap == 0 && ci0 == 0 && threadIdx.x < 32 && co0 + threadIdx.x < p.Cout) atomicAdd(p.dbias + co0 + threadIdx.x, sbias[threadIdx.x]);
+}
+
+}  // namespace
+
+bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M) {
+    if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.ksplit > 0) return false;
+    if ((p.Cin & 31) || (p.Cout & 31) || (p.ldx & 1) || (p.ldy & 1)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.x) & 7) || (reinterpret_cast<uintptr_t>(p.dy) & 7)) return false;
+    if (M > 65536 || p.Cout > 640 || p.Cin > 640) return false;
+    // what the 128-wide tiles do well stays there: >= 128 x 128 weights per tap over many pixels
+    if (p.Cout >= 128 && p.Cin >= 128 && M > 4096) return false;
+    return true;
+}
+
+int mrfa_wgrad_small_launch(hipStream_t st, const mrfa_wgrad_params& p, long long M) {
+    const int T = p.R * p.S;
+    const int nblk_ci = p.Cin / 32, nblk = (p.Cout / 32) * nblk_ci;
+    const long long chunks = (M + 15) / 16;
+    long long groups = (2048 + (long long)nblk * T * 4 - 1) / ((long long)nblk * T * 4);      // workgroups (of 4 ranges) per block
+    const long long max_groups = (chunks + 15) / 16;                                           // >= 4 chunks per wave
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1) groups = 1;
+    const int chunks_per_wave = (int)((chunks + groups * 4 - 1) / (groups * 4));
+    groups = (chunks + (long long)chunks_per_wave * 4 - 1) / ((long long)chunks_per_wave * 4);
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    int pw = lg2(p.Wout), ph = lg2(p.Hout);
+    if (ph < 0) pw = -1;
+    dim3 grid((unsigned)(groups * T * nblk));
+    hipLaunchKernelGGL(wgrad_small_kernel, grid, dim3(256), 0, st, p, M, chunks_per_wave, nblk_ci, nblk, pw, pw >= 0 ? pw + ph : 0);
+    MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc(small)");
+    return 0;
+}

@@ -21,11 +21,22 @@ def _pg(golden_dir):
     return _g(golden_dir, "prior_grads.npz"), json.load(open(os.path.join(golden_dir, "prior_grads_param_names.json")))
 
 
-def _ref_noise(g, tag):
+def _ref_noise(g, tag, names=None):
     """3 x the relative distance of the fp32 reference's gradient norms from the fp64 oracle's (the same computation in double): a
-    kernel cannot be held closer to the reference than the reference is to the truth (train-mode BatchNorm amplifies rounding)"""
+    kernel cannot be held closer to the reference than the reference is to the truth (train-mode BatchNorm amplifies rounding: the
+    reference's own keypoint-encoder gradients are median 4e-3 / max 1.9e-2 from fp64 in the chained train-mode case, 2e-4 in eval
+    mode).  The distance is a random sample per parameter, so the allowance of a parameter is the LARGEST distance within its
+    sub-network (`encoder.` / `dense_motion.` / `decoder.`; one group for a stand-alone module): the conditioning is a property of
+    the sub-network, not of one tensor."""
     ref, truth = g[f"{tag}_pgrad_norms"].astype(np.float64), g[f"{tag}_pgrad_norms_fp64"].astype(np.float64)
-    return 3.0 * np.abs(ref - truth) / np.maximum(ref, 1e-3 * ref.max())
+    rel = np.abs(ref - truth) / np.maximum(ref, 1e-3 * ref.max())
+    if names is None or not any(n.startswith(("encoder.", "dense_motion.", "decoder.")) for n in names[tag]):
+        return np.full_like(rel, 3.0 * rel.max())
+    out = np.zeros_like(rel)
+    for grp in ("encoder.", "dense_motion.", "decoder."):
+        idx = [i for i, n in enumerate(names[tag]) if n.startswith(grp)]
+        out[idx] = 3.0 * rel[idx].max()
+    return out
 
 
 def _check_pgrads(mods, g, names, tag, rel_tol, extra=None):
@@ -108,5 +119,5 @@ def check_chained_pipeline_gradients(golden_dir, train, b, DEV):
     gerr = np.abs(gen.detach().cpu()[:, :, ::4, ::4].numpy() - g[f"chain_{sfx}_gen_s4"])
     assert gerr.mean() <= 1e-4 and gerr.max() <= 5e-3, (gerr.mean(), gerr.max())
     mods = [("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)]
-    rel = _check_pgrads(mods, g, names, f"chain_{sfx}", 1e-3, extra=_ref_noise(g, f"chain_{sfx}"))
+    rel = _check_pgrads(mods, g, names, f"chain_{sfx}", 1e-3, extra=_ref_noise(g, f"chain_{sfx}", names))
     print(f"chained {sfx}: per-parameter gradient-norm error vs reference: median {np.median(rel):.2e}, max {rel.max():.2e}")

@@ -167,6 +167,14 @@ CONV_CASES = {
     "splitk4_relu_stats": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True),
     "splitk_auto_small": dict(N=1, H=2, W=2, Cin=512, Cout=512, splitk=0, stats=True, relu=False),
     "splitk3_accumulate": dict(N=1, H=4, W=4, Cin=128, Cout=64, splitk=3, acc=True, relu=False, bias=False),
+    # conv_small.hip (one wave per 16..32-row tile, no LDS): the MTIA prior's shapes, every epilogue option, ragged M / Cout
+    "small_hr32_stats": dict(N=2, H=16, W=16, Cin=32, Cout=32, stats=True, relu=False, bias=False),
+    "small_hr64_res": dict(N=2, H=8, W=8, Cin=64, Cout=64, res=True, relu=True),
+    "small_hr128_acc": dict(N=1, H=16, W=16, Cin=128, Cout=128, acc=True, alpha=0.5, relu=False, bias=False),
+    "small_linear_192_576": dict(N=2, H=1, W=276, Cin=192, Cout=576, R=1, pad=0, res=True, relu=False),
+    "small_linear_576_192_affine": dict(N=1, H=1, W=276, Cin=576, Cout=192, R=1, pad=0, oaff=True),
+    "small_ragged": dict(N=1, H=7, W=9, Cin=48, Cout=40, stats=True),
+    "small_wide_m": dict(N=8, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False),
 }
 
 
@@ -351,7 +359,12 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
                                  dict(N=2, H=32, W=32, Cin=192, Cout=128), dict(N=2, H=32, W=32, Cin=128, Cout=96),
                                  dict(N=2, H=32, W=32, Cin=160, Cout=126, pro=True), dict(N=1, H=32, W=64, Cin=64, Cout=128, ups=1),
                                  dict(N=4, H=64, W=64, Cin=98, Cout=128, R=1, pad=0, ksplit=40, ws=True),
-                                 dict(N=2, H=64, W=64, Cin=2, Cout=128, R=7, pad=3, ksplit=32, ws=True)])
+                                 dict(N=2, H=64, W=64, Cin=2, Cout=128, R=7, pad=3, ksplit=32, ws=True),
+                                 # wgrad_small.hip: one wave per 32 x 32 weight block of one tap (the MTIA prior's shapes)
+                                 dict(N=2, H=16, W=16, Cin=32, Cout=32), dict(N=4, H=32, W=32, Cin=64, Cout=64),
+                                 dict(N=2, H=16, W=16, Cin=128, Cout=128), dict(N=2, H=1, W=276, Cin=192, Cout=576, R=1, pad=0),
+                                 dict(N=1, H=1, W=276, Cin=576, Cout=192, R=1, pad=0), dict(N=3, H=12, W=20, Cin=64, Cout=32),
+                                 dict(N=1, H=5, W=7, Cin=32, Cout=96)])
 def test_wgrad(cfg):
     tag = "wgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
     ref, got = both(lambda s: wgrad_case(s, tag=tag, **cfg))
