@@ -65,36 +65,44 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     }
 
     f32x4v ra[DEPTH][TMW], rb[DEPTH][TNW];
-    // loader state: tap (l_r, l_s), chunk l_c; per-tap A row pointers (null = outside the image)
-    int l_r = 0, l_s = 0, l_c = 0;
+    // loader state: tap (l_r, l_s), chunk l_c; per-tap A row pointers.  BRANCH-FREE: a row outside the image reads a valid address
+    // (its image's pixel 0) and is zeroed by a select -- a load inside a divergent branch makes hipcc wait vmcnt(0) at the join, i.e.
+    // for the newest prefetch instead of the oldest (measured: 20 us per layer instead of 8).  Past the last chunk the loader keeps
+    // re-reading the last one (never consumed), so the k-loop needs no tail conditions either.
+    int l_r = 0, l_s = 0, l_c = 0, l_q = 0;
     const float* arow[TMW];
-    const float* l_w_off = nullptr;                   // tap offset into the packed weights, as a pointer difference base
+    bool ainb[TMW];
     size_t w_tap_off = 0;
     auto set_tap = [&]() {
         const int dr = l_r - p.pad, ds = l_s - p.pad;
 #pragma unroll
         for (int a = 0; a < TMW; ++a) {
             const int iy = a_oy[a] + dr, ix = a_ox[a] + ds;
-            const bool inb = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            arow[a] = inb ? p.x + (size_t)(a_img[a] + (long long)iy * p.Win + ix) * p.ldx + kq * 4 : nullptr;
+            ainb[a] = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const long long pix = ainb[a] ? a_img[a] + (long long)iy * p.Win + ix : a_img[a];
+            arow[a] = p.x + (size_t)pix * p.ldx + kq * 4;
         }
     };
     set_tap();
     auto load_chunk = [&](int slot) {
         const int c0 = l_c * 16;
 #pragma unroll
-        for (int a = 0; a < TMW; ++a)
-            ra[slot][a] = arow[a] ? *reinterpret_cast<const f32x4v*>(arow[a] + c0) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < TMW; ++a) {
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(arow[a] + c0);
+            ra[slot][a] = ainb[a] ? v : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int b = 0; b < TNW; ++b) rb[slot][b] = *reinterpret_cast<const f32x4v*>(wrow[b] + w_tap_off + c0);
-        if (++l_c == KC) {
-            l_c = 0;
-            w_tap_off += p.w_tap;
-            if (++l_s == p.S) { l_s = 0; ++l_r; }
-            set_tap();
+        if (l_q + 1 < nq) {                          // (uniform) advance; at the end: stay on the last chunk
+            ++l_q;
+            if (++l_c == KC) {
+                l_c = 0;
+                w_tap_off += p.w_tap;
+                if (++l_s == p.S) { l_s = 0; ++l_r; }
+                set_tap();
+            }
         }
     };
-    (void)l_w_off;
 
     f32x4v acc[TMW][TNW];
 #pragma unroll
@@ -111,18 +119,15 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][a][j], rb[slot][b][j], acc[a][b], 0, 0, 0);
     };
 
-    if (wave_on) {
-        // register ring of DEPTH chunks: chunk q lives in slot q % DEPTH; the loop is unrolled by DEPTH so every index is static
+    // register ring of DEPTH chunks: chunk q lives in slot q % DEPTH; the loop is unrolled by DEPTH so every index is static.
+    // (waves past the last row tile run the loop on clamped addresses and store nothing: no divergent control flow around the loads)
 #pragma unroll
-        for (int s = 0; s < DEPTH - 1; ++s)
-            if (s < nq) load_chunk(s);
-        for (int q0 = 0; q0 < nq; q0 += DEPTH) {
+    for (int s = 0; s < DEPTH - 1; ++s) load_chunk(s);
+    for (int q0 = 0; q0 < nq; q0 += DEPTH) {
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) {
-                const int q = q0 + s;
-                if (q + DEPTH - 1 < nq) load_chunk((s + DEPTH - 1) % DEPTH);
-                if (q < nq) compute(s);
-            }
+        for (int s = 0; s < DEPTH; ++s) {
+            load_chunk((s + DEPTH - 1) % DEPTH);
+            if (q0 + s < nq) compute(s);
         }
     }
 
@@ -191,6 +196,8 @@ bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
     if (p.Cout > 640 || ktot > 1152) return false;
     if (big_tiles >= 512 && p.Cout > 64) return false;
     if (M > 65536) return false;
+    // ~1.3 GFLOP at most: beyond that the LDS-tiled 128-row tiles (operand reuse across 4-8 waves, bf16 pipe) are the faster kernels
+    if (2.0 * (double)M * p.Cout * (double)ktot > 1.3e9) return false;
     return true;
 }
 

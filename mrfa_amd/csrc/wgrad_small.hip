@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     const int g = blockIdx.x / (nblk * T);
     const int co0 = (blk / nblk_ci) * 32, ci0 = (blk % nblk_ci) * 32;
     const int dr = tap / p.S - p.pad, ds = tap % p.S - p.pad;
-    const long long range = (long long)(4 * g + wave) * chunks_per_wave * 16;
+    const int Mi = (int)M;                                  // (eligibility: M <= 65536) 32-bit pixel arithmetic: 64-bit division is a branchy routine
+    const int range = (4 * g + wave) * chunks_per_wave * 16;
     const int HWo = p.Hout * p.Wout;
     const bool spatial = T > 1 || p.Hin != p.Hout || p.Win != p.Wout;
 
@@ -48,32 +49,38 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     const float* dyp = p.dy + co0 + 2 * li;
     const float* xp = p.x + ci0 + 2 * li;
 
-    auto load = [&](long long m0c, f32x2v (&a)[4], f32x2v (&b)[4]) {
+    // BRANCH-FREE loads (a load inside a divergent branch makes hipcc wait vmcnt(0) at the join, which serialises the prefetch):
+    // pixels past the end / taps outside the image read a valid row (the last pixel / the pixel itself) and are zeroed by a select
+    auto load = [&](int m0c, f32x2v (&a)[4], f32x2v (&b)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long long m = m0c + 4 * j + kq;
-            const bool ok = m < M;
-            a[j] = ok ? *reinterpret_cast<const f32x2v*>(dyp + (size_t)m * p.ldy) : f32x2v{0.f, 0.f};
+            const int mraw = m0c + 4 * j + kq;
+            const bool ok = mraw < Mi;
+            const int m = ok ? mraw : Mi - 1;
+            const f32x2v av = *reinterpret_cast<const f32x2v*>(dyp + (size_t)m * p.ldy);
+            a[j] = ok ? av : f32x2v{0.f, 0.f};
             bool xok = ok;
-            long long xrow = m;
-            if (spatial && ok) {
+            int xrow = m;
+            if (spatial) {
                 int img, oy, ox;
                 if (pow2_w >= 0) {
-                    img = (int)(m >> pow2_hw);
-                    const int rem = (int)(m & ((1 << pow2_hw) - 1));
+                    img = m >> pow2_hw;
+                    const int rem = m & ((1 << pow2_hw) - 1);
                     oy = rem >> pow2_w;
                     ox = rem & ((1 << pow2_w) - 1);
                 } else {
-                    img = (int)(m / HWo);
-                    const int rem = (int)(m - (long long)img * HWo);
+                    img = m / HWo;
+                    const int rem = m - img * HWo;
                     oy = rem / p.Wout;
                     ox = rem - oy * p.Wout;
                 }
                 const int iy = oy + dr, ix = ox + ds;
-                xok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                xrow = ((long long)img * p.Hin + iy) * p.Win + ix;
+                const bool inb = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                xok = ok && inb;
+                xrow = inb ? (img * p.Hin + iy) * p.Win + ix : img * p.Hin * p.Win;
             }
-            b[j] = xok ? *reinterpret_cast<const f32x2v*>(xp + (size_t)xrow * p.ldx) : f32x2v{0.f, 0.f};
+            const f32x2v bv = *reinterpret_cast<const f32x2v*>(xp + (size_t)xrow * p.ldx);
+            b[j] = xok ? bv : f32x2v{0.f, 0.f};
         }
     };
     auto compute = [&](const f32x2v (&a)[4], const f32x2v (&b)[4]) {
@@ -91,18 +98,17 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     // two-deep register pipeline over this wave's 16-pixel chunks
     f32x2v a0[4], b0[4], a1[4], b1[4];
     int nc = 0;
-    if (range < M) {
-        const long long left = (M - range + 15) / 16;
-        nc = left < chunks_per_wave ? (int)left : chunks_per_wave;
+    if (range < Mi) {
+        const int left = (Mi - range + 15) / 16;
+        nc = left < chunks_per_wave ? left : chunks_per_wave;
     }
-    if (nc > 0) load(range, a0, b0);
+    // (loads past this wave's range are clamped by `load` itself and never consumed: the loop carries no load conditions)
+    load(range, a0, b0);
     for (int c = 0; c < nc; c += 2) {
-        if (c + 1 < nc) load(range + (long long)(c + 1) * 16, a1, b1);
+        load(range + (c + 1) * 16, a1, b1);
         compute(a0, b0);
-        if (c + 1 < nc) {
-            if (c + 2 < nc) load(range + (long long)(c + 2) * 16, a0, b0);
-            compute(a1, b1);
-        }
+        load(range + (c + 2) * 16, a0, b0);
+        if (c + 1 < nc) compute(a1, b1);
     }
     // C/D layout: column = lane & 15 (B row index i_b -> ci), row = (lane >> 4) * 4 + r (A row index i_a -> co)
 #pragma unroll
@@ -139,6 +145,7 @@ bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M) {
     if (M > 65536 || p.Cout > 640 || p.Cin > 640) return false;
     // what the 128-wide tiles do well stays there: >= 128 x 128 weights per tap over many pixels
     if (p.Cout >= 128 && p.Cin >= 128 && M > 4096) return false;
+    if (2.0 * (double)M * p.Cout * (double)p.Cin * p.R * p.S > 1.3e9) return false;
     return true;
 }
 
