@@ -67,6 +67,12 @@ typedef struct {
     long long w_piece;     /*   bf16 elements between consecutive pieces.  Used by the split-operand kernel when present.     */
 } mrfa_conv_params;
 
+/* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize): MRFA_STATS_SLOTS
+ * consecutive blocks of 2*C doubles ([sum | sum of squares] per channel), zero-initialised by the caller.  A producing workgroup adds
+ * into block (workgroup index % MRFA_STATS_SLOTS) and mrfa_bn_finalize sums the blocks: device-scope atomics on ONE address are
+ * performed at the memory side at ~20-40 ns each (the per-XCD L2s are not coherent), so 256-512 workgroups adding into the same
+ * 2*C words cost 5-21 us per launch on the MTIA prior's 0.6-GFLOP layers (tools/ubench/small_kernels.cpp) -- more than the layer. */
+#define MRFA_STATS_SLOTS 32
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)

@@ -264,8 +264,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && c_ok) {
-                atomicAdd(p.stats + c, (double)s1);
-                atomicAdd(p.stats + p.Cout + c, (double)s2);
+                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                atomicAdd(st + c, (double)s1);
+                atomicAdd(st + p.Cout + c, (double)s2);
             }
         }
     }
@@ -298,8 +299,9 @@ __global__ void splitk_epilogue_kernel(float* y, int ldy, long long rows, int C,
         s2 += v * v;
     }
     if (stats) {
-        atomicAdd(stats + c, (double)s1);
-        atomicAdd(stats + C + c, (double)s2);
+        double* st = stats + (size_t)(blockIdx.y % MRFA_STATS_SLOTS) * 2 * C;
+        atomicAdd(st + c, (double)s1);
+        atomicAdd(st + C + c, (double)s2);
     }
 }
 

@@ -9,7 +9,7 @@
 // Here a wave64 owns a (16 TMW) x (16 TNW) output tile built from v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles, 4 accumulator
 // registers per 16x16 tile).  A and B fragments of that MFMA are ONE float per lane (lane l: row l & 15, k = l >> 4), so a lane
 // loads float4 = k 4q..4q+3 of its row (q = l >> 4) for a 16-deep k-chunk and feeds components x, y, z, w to four successive MFMAs
-// (A and B use the same k permutation, as in conv_mfma.hip).  No LDS, no barrier, no split-K: latency is hidden by a 4-chunk
+// (A and B use the same k permutation, as in conv_mfma.hip).  No LDS, no barrier, no split-K: latency is hidden by an 8-chunk
 // register prefetch ring and by 1 000+ independent waves per launch; the 64-byte row segments of a chunk are adjacent in the NHWC
 // row, so successive chunks hit the lines the previous ones brought into L1.  Output tiles of 16 x 16 ... 32 x 32 per wave put
 // 256-1 024 waves on a 0.6 GFLOP layer where the 128-row tiles had 64-256 workgroups.
@@ -23,9 +23,10 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int DEPTH = 4;        // k16 chunks in flight per wave
 
-template <int TMW, int TNW>
+// DEPTH = k16 chunks in flight per wave: 4 for short K (a 12-chunk linear would mostly prefetch past its end), 8 for K >= 512 (the loop is
+// load-latency bound at one wave per SIMD: ~1.5 us per round trip under load)
+template <int TMW, int TNW, int DEPTH>
 __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int wave_tiles_m) {
     constexpr int WM = 16 * TMW, WN = 16 * TNW;
     __shared__ float sred[4][2][WN];                  // per-wave column sums for the BatchNorm statistics
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
             const int c = n0 + col;
             if (c < p.Cout) {
                 const double v = (double)sred[0][which][col] + (double)sred[1][which][col] + (double)sred[2][which][col] + (double)sred[3][which][col];
-                atomicAdd(p.stats + which * p.Cout + c, v);
+                atomicAdd(p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout + which * p.Cout + c, v);
             }
         }
     }
@@ -214,9 +215,16 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
     const int wave_tiles_m = (int)((M + WM - 1) / WM);
     const long long blocks = (long long)((wave_tiles_m + 3) / 4) * tiles_n;
     dim3 grid((unsigned)blocks);
-    if (tm == 2 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<2, 2>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
-    else if (tm == 1 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<1, 2>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
-    else hipLaunchKernelGGL((conv_small_kernel<1, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+    const bool deep = (long long)p.R * p.S * p.Cin >= 512;
+#define SMALL_LAUNCH(TM_, TN_)                                                                                                   \
+    do {                                                                                                                         \
+        if (deep) hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 8>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);      \
+        else hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 4>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);           \
+    } while (0)
+    if (tm == 2 && tn == 2) SMALL_LAUNCH(2, 2);
+    else if (tm == 1 && tn == 2) SMALL_LAUNCH(1, 2);
+    else SMALL_LAUNCH(1, 1);
+#undef SMALL_LAUNCH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(small)");
     return 0;
 }

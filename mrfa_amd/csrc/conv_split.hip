@@ -332,8 +332,9 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && c_ok) {
-                atomicAdd(p.stats + c, (double)s1);
-                atomicAdd(p.stats + p.Cout + c, (double)s2);
+                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                atomicAdd(st + c, (double)s1);
+                atomicAdd(st + p.Cout + c, (double)s2);
             }
         }
     }

@@ -32,8 +32,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     if (wave == 0 && c < C) {
         double a = 0.0, b = 0.0;
         for (int w = 0; w < NW; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
-        atomicAdd(stats + c, a);
-        atomicAdd(stats + C + c, b);
+        double* st = stats + (size_t)((blockIdx.y + blockIdx.x) % MRFA_STATS_SLOTS) * 2 * C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+        atomicAdd(st + c, a);
+        atomicAdd(st + C + c, b);
     }
 }
 
@@ -45,8 +46,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long c
     if (c >= C) return;
     float mean, invstd;
     if (train) {
-        const double m = stats[c] / (double)count;
-        double var = stats[C + c] / (double)count - m * m;
+        double t1 = 0.0, t2 = 0.0;
+        for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += stats[(size_t)s * 2 * C + c]; t2 += stats[(size_t)s * 2 * C + C + c]; }
+        const double m = t1 / (double)count;
+        double var = t2 / (double)count - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));

@@ -20,7 +20,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_params p, const long long M, const int chunks_per_wave, const int nblk_ci,
                                                          const int nblk, const int pow2_w /* log2(Wout) or -1 */, const int pow2_hw) {
-    __shared__ float sacc[32][33];
+    __shared__ float sacc[4][32][33];                 // one 32 x 32 partial per wave (plain stores: LDS float atomics cost 11 us here)
     __shared__ float sbias[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -31,12 +31,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     const int g = blockIdx.x / (nblk * T);
     const int co0 = (blk / nblk_ci) * 32, ci0 = (blk % nblk_ci) * 32;
     const int dr = tap / p.S - p.pad, ds = tap % p.S - p.pad;
-    const int Mi = (int)M;                                  // (eligibility: M <= 65536) 32-bit pixel arithmetic: 64-bit division is a branchy routine
+    const int Mi = (int)M;                                 // (eligibility: M <= 65536) 32-bit pixel arithmetic: 64-bit division is a branchy routine
     const int range = (4 * g + wave) * chunks_per_wave * 16;
     const int HWo = p.Hout * p.Wout;
     const bool spatial = T > 1 || p.Hin != p.Hout || p.Win != p.Wout;
 
-    for (int i = threadIdx.x; i < 32 * 33; i += 256) (&sacc[0][0])[i] = 0.f;
     if (threadIdx.x < 32) sbias[threadIdx.x] = 0.f;
     __syncthreads();
 
@@ -95,20 +94,22 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
         }
     };
 
-    // two-deep register pipeline over this wave's 16-pixel chunks
-    f32x2v a0[4], b0[4], a1[4], b1[4];
+    // four-deep register ring over this wave's 16-pixel chunks (measured: with one chunk in flight the loop was load-latency bound,
+    // ~1 us per round trip under load); loads past this wave's range are clamped by `load` itself and never consumed
+    f32x2v ra[4][4], rb[4][4];
     int nc = 0;
     if (range < Mi) {
         const int left = (Mi - range + 15) / 16;
         nc = left < chunks_per_wave ? left : chunks_per_wave;
     }
-    // (loads past this wave's range are clamped by `load` itself and never consumed: the loop carries no load conditions)
-    load(range, a0, b0);
-    for (int c = 0; c < nc; c += 2) {
-        load(range + (c + 1) * 16, a1, b1);
-        compute(a0, b0);
-        load(range + (c + 2) * 16, a0, b0);
-        if (c + 1 < nc) compute(a1, b1);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) load(range + s * 16, ra[s], rb[s]);
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load(range + (c0 + s + 3) * 16, ra[(s + 3) & 3], rb[(s + 3) & 3]);
+            if (c0 + s < nc) compute(ra[s], rb[s]);
+        }
     }
     // C/D layout: column = lane & 15 (B row index i_b -> ci), row = (lane >> 4) * 4 + r (A row index i_a -> co)
 #pragma unroll
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&sacc[2 * (kq * 4 + r) + t][2 * li + u], acc[t][u][r]);
+            for (int r = 0; r < 4; ++r) sacc[wave][2 * (kq * 4 + r) + t][2 * li + u] = acc[t][u][r];
     if (p.dbias && tap == 0 && ci0 == 0) {
         // column sums of dY over this wave's pixels: lane (li, kq) summed channels 2 li + {0, 1} of its pixels
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     float* dw = p.dw + ((size_t)tap * p.Cout + co0) * p.Cin + ci0;
     for (int i = threadIdx.x; i < 32 * 32; i += 256) {
         const int r = i >> 5, c = i & 31;
-        if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * sacc[r][c]);
+        if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * (sacc[0][r][c] + sacc[1][r][c] + sacc[2][r][c] + sacc[3][r][c]));
     }
     if (p.dbias && tap == 0 && ci0 == 0 && threadIdx.x < 32 && co0 + threadIdx.x < p.Cout) atomicAdd(p.dbias + co0 + threadIdx.x, sbias[threadIdx.x]);
 }

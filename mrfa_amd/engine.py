@@ -583,7 +583,7 @@ class Ctx:
 
     @property
     def pool64(self) -> "ZeroPool":
-        return self._pool(torch.float64, 1 << 18, 1 << 16)          # 2 MiB chunks (512 KiB on branch streams)
+        return self._pool(torch.float64, 1 << 21, 1 << 19)          # 16 MiB chunks (4 MiB on branch streams): [STATS_SLOTS][2C] per BatchNorm
 
     # -- parallel branches inside one program (HRNet's resolution branches): only while a hipGraph is being captured -- a
     # captured graph owns static memory, whereas eager launches would hand blocks of the caching allocator from one stream
@@ -945,7 +945,7 @@ class Ctx:
         self.nbt = {}
 
     def bn_stats_buf(self, bn):
-        return self.f64z(2 * bn.num_features) if self.train else None
+        return self.f64z(hip.STATS_SLOTS * 2 * bn.num_features) if self.train else None
 
     def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None,
                sole_consumer: bool = False, res: Optional[View] = None) -> View:
@@ -1019,7 +1019,7 @@ class Ctx:
         """Pre-activation BN+ReLU folded into the next conv's prologue (ResBlock2d / ChannelBlock2d).  Returns the `pre`
         triple for conv(); must be called BEFORE that conv so the tape order is right (its closure runs AFTER the conv's)."""
         if self.train and stats is None:
-            stats = self.f64z(2 * x.C)
+            stats = self.f64z(hip.STATS_SLOTS * 2 * x.C)
             self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
         scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
         stash = {}
@@ -1290,7 +1290,7 @@ class Ctx:
         not accumulate them (the stride-2 convolutions, which are sub-sampled after the conv)"""
         if not self.train:
             return None
-        stats = self.f64z(2 * bn.num_features)
+        stats = self.f64z(hip.STATS_SLOTS * 2 * bn.num_features)
         self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
         return stats
 

@@ -204,6 +204,7 @@ def lib():
 #             (fp32-accurate, csrc/conv_split.hip)
 #   "bf16x3"  the same kernels with the three leading products only: ~1e-5 relative product error (opt-in)
 #   "bf16"    operands rounded to bf16, one product (a bf16 autocast's arithmetic; fp32 accumulate / storage): BASELINE config 4
+STATS_SLOTS = 32       # MRFA_STATS_SLOTS of include/mrfa_hip.h: BatchNorm statistics buffers are [STATS_SLOTS][2C] doubles
 MFMA_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}
 DEFAULT_MFMA = "bf16x6"
 

@@ -15,6 +15,9 @@ import torch
 import torch.nn.functional as F
 
 
+STATS_SLOTS = 32        # MRFA_STATS_SLOTS (include/mrfa_hip.h)
+
+
 def _flat(ptr: int, n: int, dtype=torch.float32) -> torch.Tensor:
     ct = {torch.float32: C.c_float, torch.float64: C.c_double, torch.int32: C.c_int}[dtype]
     return torch.frombuffer((ct * n).from_address(ptr), dtype=dtype)
@@ -515,7 +518,9 @@ class Emulator:
                          invstd_out):
         g, b = vec(gamma, Cc), vec(beta, Cc)
         if train:
-            st = vec(stats, 2 * Cc, torch.float64)
+            # [MRFA_STATS_SLOTS][2C]: the kernels spread their atomics over the slots (mrfa_hip.h); this specification's producers write
+            # slot 0 only, the consumer sums all of them
+            st = vec(stats, STATS_SLOTS * 2 * Cc, torch.float64).view(STATS_SLOTS, 2 * Cc).sum(0)
             m = st[:Cc] / count
             var = (st[Cc:] / count - m * m).clamp_min(0)
             mean = m.float()

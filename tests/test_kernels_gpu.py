@@ -132,12 +132,12 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         rt = side.t(f"{tag}/res", (N * Ho * Wo, Cout + 4))
         keep.append(rt)
         p.res, p.ldr = rt.data_ptr(), Cout + 4
-    st = side.z((2 * Cout,), torch.float64)
+    st = side.z((hip.STATS_SLOTS, 2 * Cout), torch.float64)          # [MRFA_STATS_SLOTS][2C], summed by the consumer
     if stats:
         p.stats = st.data_ptr()
     p.alpha, p.accumulate, p.nbatch, p.splitk, p.tile = alpha, int(acc), 1, splitk, tile
     side.call("mrfa_conv2d_nhwc", C.byref(p))
-    return side.done(y[:, :Cout], st)
+    return side.done(y[:, :Cout], st.sum(0))
 
 
 CONV_CASES = {
@@ -473,7 +473,7 @@ def test_bn_forward_backward(Cc, ld, N):
         rm, rv = side.t("bn/rm", (Cc,)), side.t("bn/rv", (Cc,), 0.5, 1.5)
         outs = []
         for train in (1, 0):
-            st = side.z((2 * Cc,), torch.float64)
+            st = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
             side.call("mrfa_bn_stats", x.data_ptr(), ld, N * H * W, Cc, st.data_ptr())
             sc, sh, mean, inv = (side.z((Cc,)) for _ in range(4))
             side.call("mrfa_bn_finalize", st.data_ptr(), N * H * W, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
@@ -602,12 +602,12 @@ def test_layout_and_elementwise():
         bias = side.t("el/bias", (Cc,))
         for act in (0, 1, 2):
             o = side.garbage((rows, Cc))
-            st = side.z((2 * Cc,), torch.float64)
+            st = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
             side.call("mrfa_bias_act", d.data_ptr(), 48, rows, Cc, bias.data_ptr(), act, o.data_ptr(), Cc, st.data_ptr())
             g = side.t("el/g", (rows, Cc))
             dx = side.t("el/dx0", (rows, Cc))
             side.call("mrfa_act_bwd", o.data_ptr(), Cc, g.data_ptr(), Cc, rows, Cc, act, dx.data_ptr(), Cc, 1)
-            outs += [o, st, dx]
+            outs += [o, st.view(hip.STATS_SLOTS, 2 * Cc).sum(0), dx]
         a, b2, occ = side.t("el/a", (rows, Cc)), side.t("el/b2", (rows, Cc)), side.t("el/occ", (rows, 1), 0, 1)
         yb = side.garbage((rows, Cc))
         side.call("mrfa_blend_fwd", a.data_ptr(), Cc, b2.data_ptr(), Cc, occ.data_ptr(), 1, rows, Cc, yb.data_ptr(), Cc)
@@ -785,7 +785,7 @@ def test_bn_residual(Cc, ld):
         res = side.t("bnr/res", (rows, ld))
         gamma, beta = side.t("bnr/g", (Cc,), 0.5, 1.5), side.t("bnr/b", (Cc,))
         rm, rv = side.t("bnr/rm", (Cc,)), side.t("bnr/rv", (Cc,), 0.5, 1.5)
-        st = side.z((2 * Cc,), torch.float64)
+        st = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
         side.call("mrfa_bn_stats", x.data_ptr(), ld, rows, Cc, st.data_ptr())
         sc, sh, mean, inv = (side.z((Cc,)) for _ in range(4))
         side.call("mrfa_bn_finalize", st.data_ptr(), rows, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, Cc, 1,

@@ -115,7 +115,7 @@ def main():
         byt = 4.0 * (2 * B * res * res * cch + 2 * B * res * res)
         print(f"grid_sample C={cch} @{res}: {t:.3f} ms  {byt/t/1e6:.0f} GB/s")
         bn = torch.nn.BatchNorm2d(cch).to(dev)
-        st = e.f64z(2 * cch)
+        st = e.f64z(hip.STATS_SLOTS * 2 * cch)
         t = time_it(lambda: e.L.mrfa_bn_stats(e.s, f.ptr, f.ld, f.rows, cch, st.data_ptr()))
         print(f"bn_stats    C={cch} @{res}: {t:.3f} ms  {4.0*B*res*res*cch/t/1e6:.0f} GB/s")
         t = time_it(lambda: e.bn_act(f, bn, st, relu=True, out=o))

@@ -1,0 +1,71 @@
+// True per-launch time of mrfa_conv2d_nhwc / mrfa_conv2d_wgrad_nhwc on the MTIA prior's small shapes: 200 back-to-back launches from C++
+// (no Python launch overhead), HIP events.  Links libmrfa_hip.so.
+//   hipcc --offload-arch=gfx950 -O2 -Iinclude tools/ubench/small_kernels.cpp -Lmrfa_amd/_lib -lmrfa_hip -Wl,-rpath,'$ORIGIN/../../../mrfa_amd/_lib' -o tools/ubench/bin/small_kernels
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "mrfa_hip.h"
+
+static float* dalloc(size_t n, float v) {
+    float* p;
+    hipMalloc(&p, n * 4);
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = v * (float)((i * 2654435761u) % 1000) / 1000.f - v * 0.5f;
+    hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice);
+    return p;
+}
+
+int main() {
+    struct Shape { const char* name; int N, H, W, Cin, Cout, R; };
+    const Shape shapes[] = {{"hr 32->32 3x3 @64", 8, 64, 64, 32, 32, 3}, {"hr 64->64 3x3 @32", 8, 32, 32, 64, 64, 3},
+                            {"hr 128->128 3x3 @16", 8, 16, 16, 128, 128, 3}, {"vit 192->576 1x1 tokens", 8, 1, 276, 192, 576, 1},
+                            {"vit 576->192 1x1 tokens", 8, 1, 276, 576, 192, 1}, {"vit 192->192 1x1 tokens", 8, 1, 276, 192, 192, 1},
+                            {"hr 64->256 1x1 @64", 8, 64, 64, 64, 256, 1},
+                            {"gen 128->64 3x3 @256", 8, 256, 256, 128, 64, 3}, {"gen 256->128 3x3 @128", 8, 128, 128, 256, 128, 3},
+                            {"gen 512->512 3x3 @32", 8, 32, 32, 512, 512, 3}, {"hg 256->512 3x3 @8", 8, 8, 8, 256, 512, 3}};
+    mrfa_set_mfma_mode(getenv("MFMA") ? atoi(getenv("MFMA")) : 1);      // the product's default: bf16x6 on the 128-row tiles
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 200;
+    printf("%-28s %10s %8s | %10s %8s\n", "shape", "conv us", "TF/s", "wgrad us", "TF/s");
+    for (const Shape& s : shapes) {
+        const long long M = (long long)s.N * s.H * s.W;
+        const int T = s.R * s.R, cop = (s.Cout + 127) / 128 * 128;
+        float* x = dalloc(M * s.Cin, 1.f);
+        float* w = dalloc((size_t)T * cop * s.Cin, 0.2f);
+        float* y = dalloc(M * s.Cout, 1.f);
+        float* dw = dalloc((size_t)T * s.Cout * s.Cin, 0.f);
+        double* stats; hipMalloc(&stats, MRFA_STATS_SLOTS * 2 * s.Cout * 8); hipMemset(stats, 0, MRFA_STATS_SLOTS * 2 * s.Cout * 8);
+        mrfa_conv_params p;
+        memset(&p, 0, sizeof(p));
+        p.x = x; p.ldx = s.Cin; p.Hin = s.H; p.Win = s.W; p.N = s.N; p.Cin = s.Cin;
+        p.w = w; p.w_ld = s.Cin; p.w_tap = (long long)cop * s.Cin; p.w_rows = cop;
+        p.y = y; p.ldy = s.Cout; p.Cout = s.Cout; p.Hout = s.H; p.Wout = s.W; p.R = s.R; p.S = s.R; p.pad = s.R / 2;
+        p.alpha = 1.f; p.nbatch = 1; p.stats = getenv("NOSTATS") ? nullptr : stats;
+        mrfa_wgrad_params q;
+        memset(&q, 0, sizeof(q));
+        q.x = x; q.ldx = s.Cin; q.Hin = s.H; q.Win = s.W; q.N = s.N; q.Cin = s.Cin;
+        q.dy = y; q.ldy = s.Cout; q.Cout = s.Cout; q.Hout = s.H; q.Wout = s.W; q.R = s.R; q.S = s.R; q.pad = s.R / 2;
+        q.dw = dw; q.alpha = 1.f; q.nbatch = 1;
+        float ms[2];
+        for (int which = 0; which < 2; ++which) {
+            for (int i = 0; i < 5; ++i) { if (which == 0) mrfa_conv2d_nhwc(nullptr, &p); else mrfa_conv2d_wgrad_nhwc(nullptr, &q); }
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int i = 0; i < iters; ++i) {
+                int rc = which == 0 ? mrfa_conv2d_nhwc(nullptr, &p) : mrfa_conv2d_wgrad_nhwc(nullptr, &q);
+                if (rc) { printf("error: %s\n", mrfa_last_error()); return 1; }
+            }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms[which], e0, e1);
+        }
+        const double fl = 2.0 * M * s.Cout * (double)s.Cin * T;
+        printf("%-28s %10.2f %8.1f | %10.2f %8.1f\n", s.name, 1e3 * ms[0] / iters, fl / (ms[0] / iters) / 1e9, 1e3 * ms[1] / iters,
+               fl / (ms[1] / iters) / 1e9);
+        hipFree(x); hipFree(w); hipFree(y); hipFree(dw); hipFree(stats);
+    }
+    return 0;
+}
