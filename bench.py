@@ -461,20 +461,24 @@ def main():
             if sel:
                 fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
                 achieved = fl / (ms * 1e-3) / 1e12
-                traffic = None
+                traffic, tsrc = None, None
                 try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-                    with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
-                        tj = json.load(tf)
-                        if split:
-                            tj = tj.get("split_operand_mtia_lazy_gradients", tj["split_operand"])["conv_bf16x6_kernel"]
-                        traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 4)
+                    if split:                         # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
+                        tsrc = "profiles/r2_traffic.json"
+                        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as tf:
+                            tj = json.load(tf)["kernels"]["conv_bf16x6_kernel<false, true, 128, 6>"]
+                    else:
+                        tsrc = "profiles/r1_traffic.json"
+                        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
+                            tj = json.load(tf)
+                    traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 4)
                 except Exception:
-                    pass
+                    tsrc = None
                 # bf16x6: six bf16 MFMA products per fp32 multiply-add -> ceiling = bf16 dense peak / 6, in fp32-equivalent FLOPs
                 peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
                 roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
-                        "traffic_source": "profiles/r1_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run",
+                        "traffic_source": (f"{tsrc}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run" if tsrc else None),
                         "peak_is": (f"bf16 dense MFMA peak 2500 / {nprod} split products (fp32-equivalent FLOPs)" if split
                                     else "fp32 dense MFMA peak"),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
