@@ -8,9 +8,17 @@ data-dependent control flow, no host synchronisation), so a whole step is captur
 private memory pool) and replayed with one launch per step:
 
   graph A   zero the flat gradient buffer, re-pack the weights, forward, loss, backward (every kernel of mrfa_hip.h)
-  (eager)   N > 1 only: ONE RCCL all-reduce of the flat gradient buffer (all parameters, ~60 M floats) -- the only
-            exchange step of the data-parallel path; it is 2 ms of a 135 ms step on xGMI, so it is not overlapped
   graph B   inf-norm clipping of the encoder / dense_motion gradients + Adam (reference train.py:21-25, 58-70)
+With N > 1 ranks the exchange of the data-parallel path -- the only collective on it -- is ONE RCCL all-reduce of the flat gradient
+buffer between graph A and graph B (457 MB; ~2.6 ms of a 113 ms step at N=8 by RCCL's bus bandwidth, not overlapped).  Opt-in
+(`overlap_exchange=True` / MRFA_OVERLAP_EXCHANGE=1, see GraphedTrainStep.__init__ for why it is not the default): graph A is cut where
+the backward reaches the keypoint encoder (mrfa_amd.train.SplitBackward), and the exchange is issued between the pieces:
+  graph A1  ... forward, loss, backward of the decoder / dense motion (/ background) networks
+  (eager)   async RCCL all-reduce of their gradient ranges of the flat buffer (408 of 457 MB with the MTIA prior), on RCCL's stream
+  graph A2  the encoder's backward (~30 ms), which hides that all-reduce
+  (eager)   all-reduce of the encoder's range (49 MB), wait for both
+  graph B   1/N, clipping, Adam
+(the reference overlaps through DistributedDataParallel's buckets, train.py:45-48; here the flat buffer has two buckets in backward order)
 
 `GraphedForward` is the inference counterpart (one graph, weights packed once outside it).
 
@@ -77,9 +85,26 @@ class FlatGradients:
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.total
         return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
 
-    def all_reduce(self):
-        """sum over ranks (the mean's 1/world is applied by the caller: GraphedTrainStep folds it into graph B)"""
-        torch.distributed.all_reduce(self.flat)
+    def ranges_of(self, params):
+        """merged [lo, hi) element ranges of the flat buffer that hold the gradients of `params`"""
+        want = {id(p) for p in params}
+        out, off = [], 0
+        for p in self.params:
+            n = (p.numel() + 3) // 4 * 4
+            if id(p) in want:
+                if out and out[-1][1] == off:
+                    out[-1][1] = off + n
+                else:
+                    out.append([off, off + n])
+            off += n
+        return [tuple(r) for r in out]
+
+    def all_reduce(self, ranges=None, async_op: bool = False):
+        """sum over ranks (the mean's 1/world is applied by the caller: GraphedTrainStep folds it into graph B), of the whole buffer
+        or of the given element ranges (contiguous views: in place); async_op=True returns the work handles"""
+        views = [self.flat] if ranges is None else [self.flat[lo:hi] for lo, hi in ranges if hi > lo]
+        handles = [torch.distributed.all_reduce(v, async_op=async_op) for v in views]
+        return handles if async_op else None
 
 
 class GraphedForward:
@@ -153,8 +178,14 @@ class GraphedTrainStep:
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
                  clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False,
-                 concurrent_encoder: Optional[bool] = None, loss_fn=None):
-        """loss_fn(model, source, driving) -> scalar loss; None = the surrogate mean|model(source, driving) - driving|"""
+                 concurrent_encoder: Optional[bool] = None, loss_fn=None, overlap_exchange: Optional[bool] = None):
+        """loss_fn(model, source, driving) -> scalar loss; None = the surrogate mean|model(source, driving) - driving|.
+        overlap_exchange: cut graph A at the encoder boundary and overlap the all-reduce with the encoder's backward (surrogate-loss step
+        of a HotPath only).  OPT-IN (argument or MRFA_OVERLAP_EXCHANGE=1): measured on one MI355X with a one-rank RCCL group, cutting the
+        graph costs nothing (111.7 vs 112.3 ms) and the two all-reduces issued serially cost nothing (112.6), but the 408 MB all-reduce
+        launched beside graph A2 costs +4.5 ms (116.1) although it moves no data -- and no multi-GPU box was available to show that the
+        overlap wins against that at N > 1, where the serial all-reduce is ~2.6 ms at N=8 (2 % of the step).  Default: ONE all-reduce."""
+        from .train import SplitBackward, exchange_ranges
         graph_replay_safe("GraphedTrainStep")
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         self.loss_fn = loss_fn
@@ -162,7 +193,11 @@ class GraphedTrainStep:
             concurrent_encoder = getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_CONCURRENT_ENCODER", "1") == "1"
         if hasattr(model, "concurrent_encoder"):
             model.concurrent_encoder = bool(concurrent_encoder)
-        self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the two graphs
+        self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the graphs
+        if overlap_exchange is None:
+            env = os.environ.get("MRFA_OVERLAP_EXCHANGE", "0")     # "force": cut the graph even without an exchange (timing the cut alone)
+            overlap_exchange = env == "force" or (self.exchange and env == "1")
+        self.split = SplitBackward(model) if (overlap_exchange and SplitBackward.supported(model, loss_fn)) else None
         self.src, self.drv = source.clone(), driving.clone()
         self.fused = getattr(optimizer, "fused_clip", False)      # mrfa_amd.optim.FlatAdam: owns the flat buffers
         self.grads = optimizer.grads if self.fused else FlatGradients(model.parameters())
@@ -179,13 +214,14 @@ class GraphedTrainStep:
             engine.WGRAD_STREAM = overlap_wgrad
             try:
                 with engine.direct_param_grads():
-                    self._loss()[0].backward()
-                self._join()
+                    self._head()
+                    self._tail()
             finally:
                 engine.WGRAD_STREAM = False
             for b, sv in zip(model.buffers(), saved):
                 b.copy_(sv)
             self.grads.bind()
+        self.head_ranges, self.tail_ranges = exchange_ranges(self.grads, model) if self.split is not None else (None, None)
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize()
         self.packs = engine.PackPlan(model)                           # every layout the warm pass packed, in one launch
@@ -197,12 +233,18 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_fb, stream=self.stream), engine.direct_param_grads():
                 self.flat.zero_()
                 self.packs.run()
-                loss, gen = self._loss()
-                loss.backward()
-                self._join()
+                loss, gen = self._head()
+                if self.split is None:
+                    self._tail()
                 # detached handles: a static output that still referenced its autograd graph would keep the graph (and
                 # the parameters' AccumulateGrad nodes bound to the capture stream) alive for the life of this object
                 self.loss, self.gen = loss.detach(), (gen.detach() if gen is not None else None)
+            del loss, gen
+            self.g_tail = None
+            if self.split is not None:                                # graph A2: the encoder's backward, from the keypoint gradients of A1
+                self.g_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_tail, pool=self.g_fb.pool(), stream=self.stream), engine.direct_param_grads():
+                    self._tail()
         finally:
             engine.CAPTURE_KEY = 0
             engine.WGRAD_STREAM = False
@@ -233,6 +275,25 @@ class GraphedTrainStep:
     def _join(self):
         if hasattr(self.model, "join"):
             self.model.join()
+
+    def _head(self):
+        """forward + loss + backward: all of it, or (overlapped exchange) down to the keypoint encoder's outputs"""
+        if self.split is not None:
+            return self.split.head(self.src, self.drv)
+        loss, gen = self._loss()
+        loss.backward()
+        return loss, gen
+
+    def _tail(self):
+        if self.split is not None:
+            self.split.tail()                                         # encoder backward + join of the side streams
+        else:
+            self._join()
+
+    def _replay_fwd_bwd(self):
+        self.g_fb.replay()
+        if self.g_tail is not None:
+            self.g_tail.replay()
 
     def _segments(self):
         """flat-buffer segments to compare separately: the optimizer's parameter groups (encoder / decoder / dense_motion have
@@ -268,9 +329,8 @@ class GraphedTrainStep:
             with torch.cuda.stream(self.stream):
                 self.flat.zero_()
                 with engine.direct_param_grads():
-                    loss = self._loss()[0]
-                    loss.backward()
-                self._join()
+                    loss = self._head()[0]
+                    self._tail()
                 loss = float(loss.detach())
             torch.cuda.synchronize()
             return self.flat.double().cpu(), loss
@@ -290,7 +350,7 @@ class GraphedTrainStep:
                 scratch.normal_()                       # unrelated device work between replays
                 float(scratch.sum())
                 reseed()
-                self.g_fb.replay()
+                self._replay_fwd_bwd()
                 torch.cuda.synchronize()
                 g, loss = self.flat.double().cpu(), float(self.loss)
                 if abs(loss - eloss) > loss_tol * max(1.0, abs(eloss)):
@@ -320,7 +380,15 @@ class GraphedTrainStep:
         if self.fused:
             self.opt.sync_lr()                                        # an LR scheduler may have edited param_groups
         self.g_fb.replay()
-        if self.exchange:
+        if self.g_tail is not None:
+            # RCCL's stream waits for A1 (the work is enqueued behind the current stream), A2 runs beside it on the current stream
+            handles = self.grads.all_reduce(self.head_ranges, async_op=True) if self.exchange else []
+            self.g_tail.replay()
+            if self.exchange:
+                handles += self.grads.all_reduce(self.tail_ranges, async_op=True)
+            for h in handles:
+                h.wait()
+        elif self.exchange:
             self.grads.all_reduce()
         self.g_opt.replay()
         # the replay changed the weights behind autograd's back: bump the version counters, on which the engine's

@@ -216,6 +216,90 @@ def train_step(model, optimizer, source, driving, clip=10.0, loss_fn=None):
     return loss.detach()
 
 
+class SplitBackward:
+    """The step's forward + backward cut at the keypoint encoder's outputs, so that the data-parallel gradient exchange can start
+    while the encoder's backward still runs (the reference gets the same overlap from DistributedDataParallel's buckets,
+    train.py:45-48): `head()` = encoder forward, dense motion + decoder forward, loss, backward down to d(loss)/d(keypoints) --
+    after it the decoder / dense-motion / background gradients (408 of the 457 MB of the MTIA configuration) are final;
+    `tail()` = the encoder's backward (both passes; ~30 ms of the 113 ms step) from those keypoint gradients.  Same arithmetic as
+    one backward() call: autograd would run exactly these nodes in this order."""
+
+    def __init__(self, model, loss_fn=None):
+        assert self.supported(model, loss_fn)
+        self.model = model
+        self.cut = self.det = None
+
+    @staticmethod
+    def supported(model, loss_fn=None) -> bool:
+        """the surrogate-loss step of a HotPath; the reference objective (third encoder pass, equivariance terms on the keypoints
+        themselves) keeps the single backward and the un-overlapped exchange"""
+        return loss_fn is None and all(hasattr(model, a) for a in ("encode_pair", "decode", "encoder"))
+
+    def head(self, source, driving):
+        m = self.model
+        kp_s, kp_d = m.encode_pair(source, driving)
+        self.cut, self.det = [], []
+
+        def leaves(kp):
+            out = {}
+            for k, v in kp.items():
+                if torch.is_tensor(v) and v.requires_grad:
+                    w = v.detach().requires_grad_(True)
+                    self.cut.append(v)
+                    self.det.append(w)
+                    out[k] = w
+                else:
+                    out[k] = v
+            return out
+        kp_s, kp_d = leaves(kp_s), leaves(kp_d)
+        bg = m.bg_predictor(source, driving) if getattr(m, "bg_predictor", None) is not None else None
+        gen = m.decode(source, kp_s, kp_d, bg)
+        loss = l1_loss(gen, driving)
+        loss.backward()
+        return loss, gen
+
+    def tail(self):
+        pairs = [(c, d.grad) for c, d in zip(self.cut, self.det) if d.grad is not None]
+        self.cut = self.det = None
+        if pairs:
+            torch.autograd.backward([c for c, _ in pairs], [g for _, g in pairs])
+        if hasattr(self.model, "join"):
+            self.model.join()
+
+
+def exchange_ranges(grads, model):
+    """(head, tail) element ranges of the flat gradient buffer `grads` (mrfa_amd.graph.FlatGradients): tail = the keypoint encoder's
+    parameters, head = everything else (final after SplitBackward.head())"""
+    enc = {id(p) for p in model.encoder.parameters()}
+    return (grads.ranges_of([p for p in grads.params if id(p) not in enc]), grads.ranges_of([p for p in grads.params if id(p) in enc]))
+
+
+def train_step_overlapped(model, optimizer, source, driving, world: int = 1):
+    """train_step's data-parallel form WITHOUT DistributedDataParallel, as mrfa_amd.graph.GraphedTrainStep schedules it (this is the
+    same schedule launched eagerly; it runs on CPU / gloo through the ABI emulator in tests/):
+        head -> async all-reduce of the non-encoder gradient ranges -> tail (encoder backward) -> all-reduce of the encoder range
+        -> wait -> 1/world + clip + Adam (FlatAdam).
+    `model` is the bare HotPath, `optimizer` a FlatAdam (make_optimizer(fused=True))."""
+    from . import engine
+    assert getattr(optimizer, "fused_clip", False) and not hasattr(model, "module")
+    grads = optimizer.grads
+    if not grads.bound():
+        grads.bind()
+    grads.flat.zero_()
+    head_r, tail_r = exchange_ranges(grads, model)
+    sb = SplitBackward(model)
+    with engine.direct_param_grads():
+        loss, _ = sb.head(source, driving)
+        handles = grads.all_reduce(head_r, async_op=True) if world > 1 else []
+        sb.tail()
+        handles += grads.all_reduce(tail_r, async_op=True) if world > 1 else []
+    for h in handles:
+        h.wait()
+    optimizer.grad_scale = 1.0 / world
+    optimizer.step()
+    return loss.detach()
+
+
 def save_checkpoint(path: str, model, optimizer, epoch: int):
     """The reference's checkpoint file (logger.py:50-58, train.py:94): {'model': state_dict with DDP's 'module.' prefix,
     'optimizer': optimizer.state_dict(), 'epoch': int} -- readable by the reference's Logger.load_cpk and by load_checkpoint.

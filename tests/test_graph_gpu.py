@@ -250,3 +250,52 @@ def test_encode_many_three_passes_keep_the_sequential_batchnorm_order():
     num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0) ** 0.5
     den = sum(float(g0[n].pow(2).sum()) for n in g0) ** 0.5
     assert num / den <= 0.05, num / den
+
+
+def test_overlapped_exchange_graph_step_equals_the_single_graph_step():
+    """Data-parallel schedule of GraphedTrainStep (graph A cut at the keypoint encoder, async RCCL all-reduce of the decoder /
+    dense-motion gradient ranges beside the encoder's backward graph, encoder range after it) on a ONE-rank RCCL group, MTIA prior
+    with the side-stream encoder pass: verify() accepts the two-graph replay against eager passes, the gradient ranges cover the flat
+    buffer exactly once, and three steps give the losses / weights of the un-split, exchange-free graph step within the
+    run-to-run band of that step itself."""
+    import os
+    import bench
+    import torch.distributed as dist
+    from mrfa_amd.graph import GraphedTrainStep
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(36000 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        src, drv = _pairs(2, "g/ovl")
+
+        def run(exchange):
+            torch.manual_seed(0)
+            model = HotPath(VOX1, prior="mtia")
+            bench.init_weights(model)
+            model.to(DEV).train(True)
+            opt = make_optimizer(model, fused=True)
+            train_step(model, opt, src, drv)                 # optimizer state exists before capture
+            step = GraphedTrainStep(model, opt, src, drv, world=1, exchange=exchange, overlap_exchange=exchange)
+            step.verify()
+            losses = [float(step(src, drv)) for _ in range(3)]
+            torch.cuda.synchronize()
+            return step, losses, opt.flat_w.clone()
+        s1, l1, w1 = run(True)
+        assert s1.split is not None and s1.g_tail is not None and len(s1.model._sides) == 1
+        covered = sorted(s1.head_ranges + s1.tail_ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == s1.grads.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        n_enc = sum((p.numel() + 3) // 4 * 4 for p in s1.model.encoder.parameters() if p.requires_grad)
+        assert sum(hi - lo for lo, hi in s1.tail_ranges) == n_enc
+        s0, l0, w0 = run(False)
+        assert s0.split is None
+        s0b, l0b, w0b = run(False)
+        band = float((w0b - w0).abs().mean())                # two runs of the same step: atomic-order noise through 4 Adam steps
+        # (the eager first step already differs run to run: random-init weights in train mode amplify atomic-order noise)
+        assert max(abs(a - b) for a, b in zip(l1, l0)) <= 3 * max(abs(a - b) for a, b in zip(l0b, l0)) + 2e-3, (l1, l0, l0b)
+        assert float((w1 - w0).abs().mean()) <= 3 * band + 1e-6, (float((w1 - w0).abs().mean()), band)
+    finally:
+        if own_group:
+            dist.destroy_process_group()

@@ -333,6 +333,65 @@ def test_flat_gradient_exchange_world2_matches_single_process(tmp_path):
         assert torch.allclose(got[n], p.grad, atol=1e-5, rtol=1e-4), n
 
 
+OVERLAP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+torch.set_num_threads(4)
+from tests.emu import emulated_hip
+from tests import cases
+from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step_overlapped
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+with emulated_hip():
+    model = HotPath(VOX1, prior="fomm")
+    for mod, tag in ((model.encoder, "kp"), (model.dense_motion, "dm"), (model.decoder, "rf")):
+        mod.load_state_dict(cases.weights_for(mod.state_dict(), tag))
+    model.eval()                                     # running statistics: 2 ranks x 1 sample == 1 process x 2 samples exactly
+    opt = make_optimizer(model, fused=True)
+    src, drv = cases.images("ovl/src", 2, 256)[rank:rank + 1], cases.images("ovl/drv", 2, 256)[rank:rank + 1]
+    loss = train_step_overlapped(model, opt, src, drv, world=world)
+    torch.save({"grad_sum": opt.grads.flat.clone(), "w": opt.flat_w.clone(), "loss": float(loss)}, out + f".{rank}")
+dist.destroy_process_group()
+"""
+
+
+def test_overlapped_exchange_world2_matches_single_process(tmp_path):
+    """The hipGraph step's data-parallel schedule (mrfa_amd/graph.py: backward cut at the keypoint encoder, async all-reduce of the
+    decoder / dense-motion gradient ranges beside the encoder's backward, encoder range after it, 1/world folded into FlatAdam), issued
+    eagerly by train.train_step_overlapped on 2 gloo ranks x 1 sample through the emulated ABI: summed gradients / 2 and the weights after
+    the step equal a 1-process step on the 2-sample batch, both ranks end with identical weights, and the split backward equals the
+    single backward() of train_step."""
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step, train_step_overlapped
+    script = tmp_path / "worker.py"
+    script.write_text(OVERLAP_WORKER)
+    out = str(tmp_path / "res.pt")
+    port = str(35500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["grad_sum"], r1["grad_sum"]) and torch.equal(r0["w"], r1["w"])       # replicas stay replicas
+
+    def single(step):
+        with emulated_hip():
+            model = HotPath(VOX1, prior="fomm")
+            for mod, tag in ((model.encoder, "kp"), (model.dense_motion, "dm"), (model.decoder, "rf")):
+                mod.load_state_dict(cases.weights_for(mod.state_dict(), tag))
+            model.eval()
+            opt = make_optimizer(model, fused=True)
+            loss = step(model, opt, cases.images("ovl/src", 2, 256), cases.images("ovl/drv", 2, 256))
+            return opt.grads.flat.clone(), opt.flat_w.clone(), float(loss)
+    g1, w1, l1 = single(lambda m, o, s, d: train_step_overlapped(m, o, s, d, world=1))
+    g2, w2, l2 = single(lambda m, o, s, d: train_step(m, o, s, d))
+    assert abs(l1 - l2) <= 1e-7 and abs(0.5 * (r0["loss"] + r1["loss"]) - l1) <= 1e-6
+    sc = float(g1.abs().max())
+    assert float((g1 - g2).abs().max()) <= 1e-6 * sc                       # split backward == one backward
+    assert float((0.5 * r0["grad_sum"] - g1).abs().max()) <= 2e-5 * sc     # mean over ranks == gradient of the global batch
+    # Adam's first step moves every weight by ~lr * sign(g): equal except where |g| is at the noise level
+    assert float((r0["w"] - w1).abs().mean()) <= 2e-6 and float((w1 - w2).abs().max()) <= 4.1e-4
+
+
 def test_flat_adam_matches_torch_adam_and_clip():
     """mrfa_amd.optim.FlatAdam (flat buffers + K20 entry points, emulated here) against torch.optim.Adam(betas=(0.5, 0.999))
     + clip_grad_norm_(norm_type=inf) as the reference's train.py:21,65-70 uses them: same weights after every step, with

@@ -30,7 +30,9 @@ int main() {
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 200;
     printf("%-28s %10s %8s | %10s %8s\n", "shape", "conv us", "TF/s", "wgrad us", "TF/s");
-    for (const Shape& s : shapes) {
+    const int nmul = getenv("NMUL") ? atoi(getenv("NMUL")) : 1;          // batch multiplier (how the kernels scale with rows)
+    for (Shape s : shapes) {
+        s.N *= nmul;
         const long long M = (long long)s.N * s.H * s.W;
         const int T = s.R * s.R, cop = (s.Cout + 127) / 128 * 128;
         float* x = dalloc(M * s.Cin, 1.f);
@@ -65,6 +67,26 @@ int main() {
         const double fl = 2.0 * M * s.Cout * (double)s.Cin * T;
         printf("%-28s %10.2f %8.1f | %10.2f %8.1f\n", s.name, 1e3 * ms[0] / iters, fl / (ms[0] / iters) / 1e9, 1e3 * ms[1] / iters,
                fl / (ms[1] / iters) / 1e9);
+        if (getenv("BN") && s.Cin == s.Cout) {                  // BatchNorm apply / two-phase backward on the same activation
+            float *sc = dalloc(s.Cout, 1.f), *sh = dalloc(s.Cout, 1.f), *dx = dalloc(M * s.Cout, 0.f), *dg = dalloc(s.Cout, 0.f), *db = dalloc(s.Cout, 0.f);
+            double* red; hipMalloc(&red, 2 * s.Cout * 8); hipMemset(red, 0, 2 * s.Cout * 8);
+            mrfa_bnact_params a; memset(&a, 0, sizeof(a));
+            a.x = x; a.ldx = s.Cin; a.N = s.N; a.H = s.H; a.W = s.W; a.C = s.Cin; a.scale = sc; a.shift = sh; a.relu = 1; a.y = y; a.ldy = s.Cout;
+            mrfa_bnbwd_params b; memset(&b, 0, sizeof(b));
+            b.x = x; b.ldx = s.Cin; b.N = s.N; b.H = s.H; b.W = s.W; b.C = s.Cin; b.scale = sc; b.shift = sh; b.relu = 1; b.mean = sh; b.invstd = sc;
+            b.gamma = sc; b.dy = y; b.lddy = s.Cout; b.red = red; b.dx = dx; b.lddx = s.Cin; b.dgamma = dg; b.dbeta = db; b.train = 1; b.dx_overwrite = 1;
+            float t[3];
+            for (int which = 0; which < 3; ++which) {
+                b.phase = which == 1 ? 1 : 2;
+                for (int i = 0; i < iters + 5; ++i) {
+                    if (i == 5) { hipDeviceSynchronize(); hipEventRecord(e0); }
+                    if (which == 0) mrfa_bn_act_fwd(nullptr, &a); else mrfa_bn_act_bwd(nullptr, &b);
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&t[which], e0, e1);
+            }
+            printf("    bn_act fwd %.2f us, bwd phase 1 %.2f us, phase 2 %.2f us\n", 1e3 * t[0] / iters, 1e3 * t[1] / iters, 1e3 * t[2] / iters);
+            hipFree(sc); hipFree(sh); hipFree(dx); hipFree(dg); hipFree(db); hipFree(red);
+        }
         hipFree(x); hipFree(w); hipFree(y); hipFree(dw); hipFree(stats);
     }
     return 0;
