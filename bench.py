@@ -239,6 +239,8 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (reference train.py:43) instead of per-GPU statistics")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (DDP for N>1) instead of replaying hipGraphs")
     ap.add_argument("--force-exchange", action="store_true", help="graph mode: initialise RCCL and run the flat gradient all-reduce even with one rank")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="graph mode, N > 1: cut graph A at the keypoint encoder and overlap the all-reduce of the other gradients with its backward (opt-in, see mrfa_amd/graph.py)")
     ap.add_argument("--mfma", choices=["f32", "bf16x6", "bf16x3", "bf16"], default=None,
                     help="matrix pipe of the 128x128 conv tiles: native fp32 MFMA, or exactly split fp32 operands on the bf16 pipe "
                          "(fp32-accurate; default: MRFA_MFMA or the library default)")
@@ -321,6 +323,7 @@ def main():
         ok = 1
         try:
             gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange),
+                                     overlap_exchange=(True if a.overlap_exchange else None),
                                      overlap_wgrad=a.wgrad_stream, loss_fn=loss_fn)
             ltol = 5e-3 if hip.mfma_mode() == "bf16" else 1e-4
             try:

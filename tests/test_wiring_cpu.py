@@ -234,6 +234,72 @@ def test_sync_batchnorm_world2_matches_big_batch(tmp_path):
         assert torch.allclose(got["grads"][n], p.grad, atol=2e-5, rtol=1e-4), n
 
 
+SYNCBN_HRNET_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+torch.set_num_threads(2)
+from tests.emu import emulated_hip
+from tests.test_wiring_cpu import small_hrnet
+from mrfa_amd.utils.prng import det_uniform
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+with emulated_hip():
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(small_hrnet())       # reference train.py:43
+    m.train(True)
+    y = m(det_uniform("sbh/x", (4, 3, 32, 32))[rank * 2:(rank + 1) * 2])
+    (y * det_uniform("sbh/w", (4, 32, 8, 8))[rank * 2:(rank + 1) * 2]).sum().div(4.0).mul(world).backward()
+    for p in m.parameters():
+        dist.all_reduce(p.grad)
+        p.grad.div_(world)
+    if rank == 0:
+        torch.save({"grads": {n: p.grad for n, p in m.named_parameters()}, "y": y.detach(), "bufs": {n: b.clone() for n, b in m.named_buffers()}}, out)
+dist.destroy_process_group()
+"""
+
+
+def small_hrnet():
+    """the MTIA prior's HRNet trunk with one module and one block per branch (every BatchNorm call pattern of the encoder: conv-epilogue
+    statistics, the separate statistics pass behind stride-2 convolutions, residual-closing BatchNorm, 1x1 fuse layers)"""
+    from mrfa_amd.modules.transformer.hr_base import HRNET_base
+    from mrfa_amd.utils.prng import fill_state_dict
+    cfg = {"MODEL": {"EXTRA": {"PRETRAINED_LAYERS": [],
+                               "STAGE2": dict(NUM_MODULES=1, NUM_BRANCHES=2, BLOCK="BASIC", NUM_BLOCKS=[1, 1], NUM_CHANNELS=[32, 64], FUSE_METHOD="SUM"),
+                               "STAGE3": dict(NUM_MODULES=1, NUM_BRANCHES=3, BLOCK="BASIC", NUM_BLOCKS=[1, 1, 1], NUM_CHANNELS=[32, 64, 128],
+                                              FUSE_METHOD="SUM")}}}
+    m = HRNET_base(cfg)
+    m.load_state_dict(fill_state_dict(m.state_dict(), "sbh"))
+    return m
+
+
+def test_sync_batchnorm_hrnet_world2_matches_big_batch(tmp_path):
+    """SyncBatchNorm through the MTIA encoder's BatchNorm call patterns (transformer/hr_base.py): 2 gloo ranks x 2 samples == 1 process
+    x 4 samples for the output, every running statistic / batch counter and every gradient."""
+    from mrfa_amd.utils.prng import det_uniform
+    script = tmp_path / "worker.py"
+    script.write_text(SYNCBN_HRNET_WORKER)
+    out = tmp_path / "res.pt"
+    port = str(37500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = torch.load(out)
+    with emulated_hip():
+        m = small_hrnet()
+        m.train(True)
+        y = m(det_uniform("sbh/x", (4, 3, 32, 32)))
+        (y * det_uniform("sbh/w", (4, 32, 8, 8))).sum().div(4.0).backward()
+    assert (got["y"] - y.detach()[:2]).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    for n, b in m.named_buffers():
+        if b.dtype.is_floating_point:
+            assert (got["bufs"][n] - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), n
+        else:
+            assert int(got["bufs"][n]) == int(b) == 1, n
+    for n, p in m.named_parameters():
+        sc = max(p.grad.abs().max().item(), 1e-6)
+        assert (got["grads"][n] - p.grad).abs().max().item() <= 2e-3 * sc + 1e-6, (n, (got["grads"][n] - p.grad).abs().max().item(), sc)
+
+
 DDP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
