@@ -67,7 +67,7 @@ typedef struct {
     long long w_piece;     /*   bf16 elements between consecutive pieces.  Used by the split-operand kernel when present.     */
 } mrfa_conv_params;
 
-/* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize): MRFA_STATS_SLOTS
+/* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS
  * consecutive blocks of 2*C doubles ([sum | sum of squares] per channel), zero-initialised by the caller.  A producing workgroup adds
  * into block (workgroup index % MRFA_STATS_SLOTS) and mrfa_bn_finalize sums the blocks: device-scope atomics on ONE address are
  * performed at the memory side at ~20-40 ns each (the per-XCD L2s are not coherent), so 256-512 workgroups adding into the same
@@ -186,7 +186,8 @@ typedef struct {
     const float* blend_a; int lda; const float* occ; int ldo;
     float* dblend_a; int ldda;                   /* += dy*occ                                                    */
     float* docc; int lddo;                       /* += sum_c dy*(a - act)                                        */
-    double* red;                                 /* [2C] zeroed: sum(dz), sum(dz*xhat)                           */
+    double* red;                                 /* [MRFA_STATS_SLOTS][2C] zeroed: sum(dz), sum(dz*xhat); phase 1 adds
+                                                    into block (workgroup % MRFA_STATS_SLOTS), phase 2 sums the blocks */
     float* dx; int lddx;                         /* += BN input gradient                                         */
     float* dgamma; float* dbeta;                 /* += (phase 2)                                                 */
     int train;                                   /* 0: eval-mode BN (no batch-statistics terms)                  */

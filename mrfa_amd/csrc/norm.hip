@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params
 }
 
 // ---------------------------------------------------------------------------------------------- backward
+// how many of the MRFA_STATS_SLOTS blocks of `red` a launch with `row_blocks` workgroups per channel chunk spreads its phase-1 atomics
+// over (both phases run the same grid): summing 32 blocks costs phase 2 ~1 us, which only pays when >= 64 workgroups would otherwise
+// queue on one address (measured: 32 ch @ 64^2 x 8: phase 1 10.7 -> 6.2 us; 128 ch @ 16^2 x 8 with 32 workgroups: nothing to gain)
+__device__ __forceinline__ int red_slots(unsigned row_blocks) {
+    return row_blocks >= 64 ? MRFA_STATS_SLOTS : (row_blocks >= 16 ? 8 : 1);
+}
+
 // u = x*scale+shift ; a = relu(u) ; out = pool(a) or blend(A, a, occ).  PHASE 1: per-channel sum(du), sum(du*xhat),
 // plus dA / docc of the blend.  PHASE 2: dx += gamma*invstd*(du - mean(du) - xhat*mean(du*xhat)) (train) or du*scale.
 template <int PHASE>
@@ -122,8 +129,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
         if (p.mean) { mean = p.mean[c]; invstd = p.invstd[c]; }
         if (PHASE == 2 && p.train) {
             const double cnt = (double)rows;
-            k1 = (float)(p.red[c] / cnt);
-            k2 = (float)(p.red[p.C + c] / cnt);
+            double t1 = 0.0, t2 = 0.0;
+            for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += p.red[(size_t)s * 2 * p.C + c]; t2 += p.red[(size_t)s * 2 * p.C + p.C + c]; }
+            k1 = (float)(t1 / cnt);
+            k2 = (float)(t2 / cnt);
             gi = p.gamma[c] * invstd;
         }
     }
@@ -183,8 +192,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
         if (wave == 0 && c_ok) {
             double a = 0.0, b = 0.0;
             for (int w = 0; w < NW; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
-            atomicAdd(p.red + c, a);
-            atomicAdd(p.red + p.C + c, b);
+            double* rd = p.red + (size_t)((blockIdx.y + blockIdx.x) % red_slots(gridDim.y)) * 2 * p.C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+            atomicAdd(rd + c, a);
+            atomicAdd(rd + p.C + c, b);
         }
     }
 }
@@ -197,11 +207,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
 template <int PHASE>
 __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
     __shared__ float red[2][16][CH];
+    __shared__ double redsum[2][CH];                         // phase 2: the MRFA_STATS_SLOTS partial sums of phase 1, added up once per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cg = lane & 15, rsub = lane >> 4;
     const int slot = wave * 4 + rsub;                       // 16 row slots per workgroup
     const int c = blockIdx.x * CH + cg * 4;
     const bool c_ok = c < p.C;                              // C % 4 == 0: all four channels valid together
+    if (PHASE == 2 && (p.train || p.dbeta || p.dgamma)) {
+        // thread (channel, quarter) adds every 4th of the used slots; the 4 quarters of a channel are lanes 4k..4k+3 of one wave
+        const int nslots = red_slots(gridDim.y);
+        const int q = threadIdx.x & 3, col = (threadIdx.x >> 2) & 63;
+        const int cc = blockIdx.x * CH + col;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            double t = 0.0;
+            if (cc < p.C) {
+                for (int s = q; s < nslots; s += 4) t += p.red[(size_t)s * 2 * p.C + which * p.C + cc];
+            }
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            if (q == 0) redsum[which][col] = t;
+        }
+        __syncthreads();
+    }
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
     const int Wo = p.W / 2, Ho = p.H / 2;
@@ -218,16 +246,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                k1[k] = (float)(p.red[c + k] / cnt);
-                k2[k] = (float)(p.red[p.C + c + k] / cnt);
+                k1[k] = (float)(redsum[0][cg * 4 + k] / cnt);
+                k2[k] = (float)(redsum[1][cg * 4 + k] / cnt);
                 gi[k] = g[k] * invstd[k];
             }
         }
         if (PHASE == 2 && blockIdx.y == 0 && slot == 0) {   // parameter gradients, once per channel
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (p.dbeta) atomicAdd(p.dbeta + c + k, (float)p.red[c + k]);         // atomic: see unpack_multi_kernel
-                if (p.dgamma) atomicAdd(p.dgamma + c + k, (float)p.red[p.C + c + k]);
+                if (p.dbeta) atomicAdd(p.dbeta + c + k, (float)redsum[0][cg * 4 + k]);         // atomic: see unpack_multi_kernel
+                if (p.dgamma) atomicAdd(p.dgamma + c + k, (float)redsum[1][cg * 4 + k]);
             }
         }
     }
@@ -320,8 +348,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
         if (threadIdx.x < CH && cc < p.C) {
             double a = 0.0, b = 0.0;
             for (int w = 0; w < 16; ++w) { a += red[0][w][threadIdx.x]; b += red[1][w][threadIdx.x]; }
-            atomicAdd(p.red + cc, a);
-            atomicAdd(p.red + p.C + cc, b);
+            double* rd = p.red + (size_t)((blockIdx.y + blockIdx.x) % red_slots(gridDim.y)) * 2 * p.C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+            atomicAdd(rd + cc, a);
+            atomicAdd(rd + p.C + cc, b);
         }
     }
 }
@@ -331,8 +360,10 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __re
     // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (dbeta) atomicAdd(dbeta + c, (float)red[c]);
-    if (dgamma) atomicAdd(dgamma + c, (float)red[C + c]);
+    double t1 = 0.0, t2 = 0.0;
+    for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += red[(size_t)s * 2 * C + c]; t2 += red[(size_t)s * 2 * C + C + c]; }
+    if (dbeta) atomicAdd(dbeta + c, (float)t1);
+    if (dgamma) atomicAdd(dgamma + c, (float)t2);
 }
 
 static int pick_rows_per_block(long long rows, int chunks, int C) {

@@ -982,7 +982,7 @@ class Ctx:
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
         dg, db = bg.acc(self.pool32)
-        red = self.f64z(2 * x.C)
+        red = self.f64z(hip.STATS_SLOTS * 2 * x.C)          # slotted like the statistics buffers (MRFA_STATS_SLOTS)
         q = hip.BnBwdParams()
         q.x, q.ldx, q.N, q.H, q.W, q.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
         q.scale, q.shift, q.relu, q.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
@@ -1005,10 +1005,12 @@ class Ctx:
         if world > 1:
             # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums
             Cn = x.C
-            db.add_(red[:Cn].float())
-            dg.add_(red[Cn:].float())
-            red_g = red.clone()
-            torch.distributed.all_reduce(red_g)
+            local = red.view(hip.STATS_SLOTS, 2 * Cn).sum(0)
+            db.add_(local[:Cn].float())
+            dg.add_(local[Cn:].float())
+            red_g = torch.zeros_like(red)
+            red_g[:2 * Cn] = local
+            torch.distributed.all_reduce(red_g[:2 * Cn])
             red_g.div_(world)                                # kernel divides by the LOCAL row count
             q.red = red_g.data_ptr()
             q.dgamma = q.dbeta = None

@@ -590,11 +590,12 @@ class Emulator:
         mean = vec(p.mean, Cc) if p.mean else torch.zeros(Cc)
         invstd = vec(p.invstd, Cc) if p.invstd else torch.zeros(Cc)
         xhat = (x - mean) * invstd
-        red = vec(p.red, 2 * Cc, torch.float64)
+        slots = vec(p.red, STATS_SLOTS * 2 * Cc, torch.float64).view(STATS_SLOTS, 2 * Cc)   # slotted like the statistics buffers
         if p.phase == 1:
-            red[:Cc] += du.reshape(-1, Cc).double().sum(0)
-            red[Cc:] += (du * xhat).reshape(-1, Cc).double().sum(0)
+            slots[1, :Cc] += du.reshape(-1, Cc).double().sum(0)          # any slot: phase 2 sums them all
+            slots[1, Cc:] += (du * xhat).reshape(-1, Cc).double().sum(0)
             return 0
+        red = slots.sum(0)
         rows = p.N * p.H * p.W
         if p.train:
             k1 = (red[:Cc] / rows).float()

@@ -494,7 +494,7 @@ def test_bn_forward_backward(Cc, ld, N):
                 dx = side.t("bn/dx0", (N * H * W, Cc))
                 da, docc = side.z((N * Ho * Wo, Cc)), side.z((N * Ho * Wo, 1))
                 dg, dbt = side.z((Cc,)), side.z((Cc,))
-                red = side.z((2 * Cc,), torch.float64)
+                red = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
                 q = hip.BnBwdParams()
                 q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), ld, N, H, W, Cc
                 q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), 1, pool
@@ -802,7 +802,7 @@ def test_bn_residual(Cc, ld):
             dy = side.t("bnr/dy", (rows, ld))
             dx, dres = side.t("bnr/dx0", (rows, ld)), side.t("bnr/dr0", (rows, ld))
             dg, dbt = side.z((Cc,)), side.z((Cc,))
-            red = side.z((2 * Cc,), torch.float64)
+            red = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
             q = hip.BnBwdParams()
             q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), ld, N, H, W, Cc
             q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), relu, 0

@@ -12,7 +12,7 @@ for (N, H, W, Cc) in ((8, 64, 64, 32), (8, 32, 32, 64), (8, 16, 16, 128), (8, 64
     rows = N * H * W
     x = torch.randn(rows, Cc, device=dev); dy = torch.randn(rows, Cc, device=dev); dx = torch.zeros(rows, Cc, device=dev)
     sc, sh, mean, inv, gamma = (torch.rand(Cc, device=dev) + 0.5 for _ in range(5))
-    red = torch.zeros(2 * Cc, dtype=torch.float64, device=dev); dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    red = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=dev); dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
     st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=dev)      # MRFA_STATS_SLOTS blocks
     q = hip.BnBwdParams()
     q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), Cc, N, H, W, Cc

@@ -69,7 +69,7 @@ int main() {
                fl / (ms[1] / iters) / 1e9);
         if (getenv("BN") && s.Cin == s.Cout) {                  // BatchNorm apply / two-phase backward on the same activation
             float *sc = dalloc(s.Cout, 1.f), *sh = dalloc(s.Cout, 1.f), *dx = dalloc(M * s.Cout, 0.f), *dg = dalloc(s.Cout, 0.f), *db = dalloc(s.Cout, 0.f);
-            double* red; hipMalloc(&red, 2 * s.Cout * 8); hipMemset(red, 0, 2 * s.Cout * 8);
+            double* red; hipMalloc(&red, MRFA_STATS_SLOTS * 2 * s.Cout * 8); hipMemset(red, 0, MRFA_STATS_SLOTS * 2 * s.Cout * 8);
             mrfa_bnact_params a; memset(&a, 0, sizeof(a));
             a.x = x; a.ldx = s.Cin; a.N = s.N; a.H = s.H; a.W = s.W; a.C = s.Cin; a.scale = sc; a.shift = sh; a.relu = 1; a.y = y; a.ldy = s.Cout;
             mrfa_bnbwd_params b; memset(&b, 0, sizeof(b));
