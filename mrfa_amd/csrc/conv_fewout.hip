@@ -22,7 +22,7 @@ template <int COUT>
 __global__ __launch_bounds__(256) void conv_fewout_fwd_kernel(const float* __restrict__ x, int ldx, int H, int W, int Cin,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ y, int ldy, int Ho, int Wo, int R, int pad,
-                                                             int accumulate, int tiles_x, int tiles_y) {
+                                                             int accumulate, int tiles_x, int tiles_y, int cper) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HT = FT + R - 1;                       // halo tile edge
     const int tid = threadIdx.x;
@@ -36,8 +36,13 @@ __global__ __launch_bounds__(256) void conv_fewout_fwd_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
     const float* xin = x + (size_t)n * H * W * ldx;
+    // gridDim.y > 1: the channel chunks are split over blockIdx.y and the partial sums meet in y through atomics (y holds the bias /
+    // the running sum already).  Low-resolution levels have 8-32 tiles, and one workgroup walking all Cin x R x R taps alone is a
+    // 180-220 us chain of dependent LDS / scalar loads whatever the image size (measured per level of the refinement pyramid).
+    const int cbeg = blockIdx.y * cper;
+    const int cend = min(Cin, cbeg + cper);
 
-    for (int c0 = 0; c0 < Cin; c0 += FCC) {
+    for (int c0 = cbeg; c0 < cend; c0 += FCC) {
         __syncthreads();
         // stage the halo tile: HT*HT pixels x 4 float4
         for (int i = tid; i < HT * HT * 4; i += 256) {
@@ -71,12 +76,26 @@ __global__ __launch_bounds__(256) void conv_fewout_fwd_kernel(const float* __res
     const int oy = ty0 + ty, ox = tx0 + tx;
     if (oy < Ho && ox < Wo) {
         float* d = y + ((size_t)(n * Ho + oy) * Wo + ox) * ldy;
+        if (gridDim.y > 1) {
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) {
-            float v = acc[co] + (bias ? bias[co] : 0.f);
-            d[co] = accumulate ? d[co] + v : v;
+            for (int co = 0; co < COUT; ++co) atomicAdd(d + co, acc[co] + ((bias && blockIdx.y == 0 && accumulate) ? bias[co] : 0.f));
+        } else {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float v = acc[co] + (bias ? bias[co] : 0.f);
+                d[co] = accumulate ? d[co] + v : v;
+            }
         }
     }
+}
+
+// y[p][co] = bias[co] (or 0): initialises the output of a channel-split forward launch
+__global__ void fewout_init_kernel(float* __restrict__ y, int ldy, long long pixels, int Cout, const float* __restrict__ bias) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= pixels * Cout) return;
+    const long long pix = i / Cout;
+    const int co = (int)(i - pix * Cout);
+    y[(size_t)pix * ldy + co] = bias ? bias[co] : 0.f;
 }
 
 // dW[co][tap][ci] += sum_p dY[p][co] * X[p + tap - pad][ci]
@@ -98,7 +117,10 @@ __global__ __launch_bounds__(256) void conv_fewout_wgrad_kernel(const float* __r
     const int tap = active ? tid / groups : 0, g4 = active ? tid - (tid / groups) * groups : 0;
     const int r = tap / R, s = tap - r * R;
 
-    for (int c0 = 0; c0 < Cin; c0 += cc) {
+    // blockIdx.y = channel chunk: every workgroup stages its tiles for ONE chunk (the tile was re-staged per chunk anyway), so a
+    // low-resolution level with 8 tiles runs Cin / cc times as many workgroups instead of 8 long ones
+    {
+        const int c0 = blockIdx.y * cc;
         f32x4 acc[COUT];
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -172,10 +194,23 @@ extern "C" int mrfa_conv_fewout_fwd(void* stream, const float* x, int ldx, int N
     const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
     const int HT = FT + R - 1;
     const size_t lds = (size_t)HT * HT * FPS * sizeof(float);
-    dim3 grid((unsigned)(N * tiles_x * tiles_y));
     hipStream_t st = (hipStream_t)stream;
+    const int ntiles = N * tiles_x * tiles_y;
+    const int chunks = cdiv(Cin, FCC);
+    int csplit = 1;
+    if (ntiles < 256 && chunks > 1) {
+        csplit = cdiv(512, ntiles);
+        if (csplit > chunks) csplit = chunks;
+    }
+    const int cper = cdiv(chunks, csplit) * FCC;
+    csplit = cdiv(Cin, cper);
+    if (csplit > 1 && !accumulate) {
+        const long long tot = (long long)N * Ho * Wo * Cout;
+        hipLaunchKernelGGL(fewout_init_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, y, ldy, (long long)N * Ho * Wo, Cout, bias);
+    }
+    dim3 grid((unsigned)ntiles, (unsigned)csplit);
 #define FWD(co) hipLaunchKernelGGL((conv_fewout_fwd_kernel<co>), grid, dim3(256), lds, st, x, ldx, H, W, Cin, w, bias, y, ldy, Ho, Wo, R, pad, \
-                                   accumulate, tiles_x, tiles_y)
+                                   accumulate, tiles_x, tiles_y, cper)
     switch (Cout) { case 1: FWD(1); break; case 2: FWD(2); break; case 3: FWD(3); break; default: FWD(4); break; }
 #undef FWD
     MRFA_CHECK_LAUNCH("conv_fewout_fwd");
@@ -194,12 +229,14 @@ extern "C" int mrfa_conv_fewout_wgrad(void* stream, const float* x, int ldx, int
     int cc = 4;                                   // largest chunk with T * cc/4 <= 256 work items, <= 64 channels
     const int HT = FT + R - 1;
     auto lds_of = [&](int c) { return ((size_t)HT * HT * (c + 4) + 256 * 4) * sizeof(float); };
-    while (cc * 2 <= 64 && T * (cc * 2 / 4) <= 256 && cc * 2 <= ((Cin + 3) / 4 * 4) && lds_of(cc * 2) <= 64 * 1024) cc *= 2;
+    // few tiles (low-resolution levels): 16-channel chunks, i.e. more workgroups with shorter chains
+    const int cc_max = ntiles < 64 ? 16 : 64;
+    while (cc * 2 <= cc_max && T * (cc * 2 / 4) <= 256 && cc * 2 <= ((Cin + 3) / 4 * 4) && lds_of(cc * 2) <= 64 * 1024) cc *= 2;
     const size_t lds = lds_of(cc);
     MRFA_CHECK_ARG(lds <= 64 * 1024, "conv_fewout_wgrad: LDS tile too large");
-    int grid = ntiles < 512 ? ntiles : 512;
+    dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512), (unsigned)cdiv(Cin, cc));
     hipStream_t st = (hipStream_t)stream;
-#define WG(co) hipLaunchKernelGGL((conv_fewout_wgrad_kernel<co>), dim3(grid), dim3(256), lds, st, x, ldx, H, W, Cin, dy, lddy, Ho, Wo, R, pad, dw, \
+#define WG(co) hipLaunchKernelGGL((conv_fewout_wgrad_kernel<co>), grid, dim3(256), lds, st, x, ldx, H, W, Cin, dy, lddy, Ho, Wo, R, pad, dw, \
                                   dbias, tiles_x, tiles_y, ntiles, cc)
     switch (Cout) { case 1: WG(1); break; case 2: WG(2); break; case 3: WG(3); break; default: WG(4); break; }
 #undef WG

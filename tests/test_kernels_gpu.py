@@ -636,7 +636,7 @@ def test_layout_and_elementwise():
 
 @pytest.mark.parametrize("cfg", [dict(Cin=64, Cout=3, R=7, pad=3), dict(Cin=128, Cout=2, R=3, pad=1), dict(Cin=128, Cout=1, R=3, pad=1),
                                  dict(Cin=108, Cout=1, R=7, pad=3, H=20, W=17), dict(Cin=128, Cout=2, R=7, pad=3, mode7=True),
-                                 dict(Cin=36, Cout=4, R=7, pad=0, H=24, W=24)])
+                                 dict(Cin=36, Cout=4, R=7, pad=0, H=24, W=24), dict(Cin=128, Cout=2, R=3, pad=1, N=8, H=96, W=96)])
 def test_conv_fewout(cfg):
     """direct <=4-output-channel kernels (forward incl. accumulate, weight/bias gradient, pack modes 5/6/7)"""
     c = dict(N=2, H=33, W=40, mode7=False)
@@ -661,13 +661,15 @@ def test_conv_fewout(cfg):
         side.call("mrfa_conv_fewout_fwd", x.data_ptr(), Cin + 4, N, H, W, Cin, wp.data_ptr(), bias.data_ptr(), y.data_ptr(), 4, Cout, R, pad, 1)
         y2 = side.garbage((N * Ho * Wo, 4))
         side.call("mrfa_conv_fewout_fwd", x.data_ptr(), Cin + 4, N, H, W, Cin, wp.data_ptr(), None, y2.data_ptr(), 4, Cout, R, pad, 0)
+        y3 = side.garbage((N * Ho * Wo, 4))               # bias without accumulation (the channel-split launch initialises y with it)
+        side.call("mrfa_conv_fewout_fwd", x.data_ptr(), Cin + 4, N, H, W, Cin, wp.data_ptr(), bias.data_ptr(), y3.data_ptr(), 4, Cout, R, pad, 0)
         dy = side.t(f"{tag}/dy", (N * Ho * Wo, 4))
         dw = side.z((Cout * T * Cin,))
         db = side.z((Cout,))
         side.call("mrfa_conv_fewout_wgrad", x.data_ptr(), Cin + 4, N, H, W, Cin, dy.data_ptr(), 4, Cout, R, pad, dw.data_ptr(), db.data_ptr())
         g = side.t(f"{tag}/g0", (Cout, Cin, R, R))
         side.call("mrfa_pack_conv_weight", dw.data_ptr(), g.data_ptr(), Cout, Cin, R, R, 6)
-        return side.done(y[:, :Cout], y2[:, :Cout], dw, db, g, wp)
+        return side.done(y[:, :Cout], y2[:, :Cout], y3[:, :Cout], dw, db, g, wp)
     ref, got = both(run)
     assert_close(ref, got, tol=5e-4, what=tag)
 

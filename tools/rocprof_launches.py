@@ -21,5 +21,5 @@ for r in rows:
         continue
     n = names[r[0]]
     if any(p in n for p in pats):
-        short = n.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")
+        short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         print(f"{(r[1] - t0) / 1e6:9.3f} ms  {short:48s} {(r[2] - r[1]) / 1e3:9.1f} us  grid {r[3] if len(r) > 3 else ''}")
