@@ -37,6 +37,69 @@ DIRECT_PARAM_GRADS = False
 # into a hipGraph this becomes a parallel branch.  Correct (tests/test_graph_gpu.py passes with it) but measured SLOWER on
 # the benchmark step (97.0 vs 93.3 ms: the big kernels already fill the chip and then compete for L2), so it is off by default.
 WGRAD_STREAM = False
+
+
+class DeferredWgrads:
+    """The weight-gradient launches of the programs recorded under `defer_wgrads(d)` (dense motion + RaftFlow: ~100 launches, 22 ms of
+    kernels that fill the chip) are not issued where the backward tape reaches them but collected, and issued on ONE side stream when
+    the backward pass arrives at the next program that is NOT deferring -- the keypoint encoder, ~2 x 2 000 small latency-bound kernels
+    that leave most of the GPU idle for ~20 ms.  Nothing downstream reads a weight gradient before the optimizer, so the only ordering
+    needed is: after their dY (they are issued after the whole decoder backward), before `join()` (HotPath.join(), called after
+    backward() by train_step / GraphedTrainStep).  The thunks hold the activations and gradient buffers they read until join().
+    Direct-gradient mode only (DIRECT_PARAM_GRADS: the un-packing into .grad is deferred with them); anything else runs in line."""
+
+    def __init__(self):
+        self.thunks: List[Callable[[], None]] = []
+        self.stream: Optional["torch.cuda.Stream"] = None
+        self.flushed = False
+
+    def add(self, fn: Callable[[], None]):
+        self.thunks.append(fn)
+
+    def flush(self, dev: torch.device):
+        """issue everything collected so far on the side stream, ordered after the current stream"""
+        if not self.thunks:
+            return
+        if dev.type != "cuda":
+            for fn in self.thunks:
+                fn()
+            self.thunks = []
+            return
+        if self.stream is None or self.stream.device != dev:
+            self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for fn in self.thunks:
+                fn()
+        self.kept, self.thunks = self.thunks, []          # the closures own the buffers the side stream is still reading
+        self.flushed = True
+
+    def join(self, dev: torch.device):
+        self.flush(dev)                                   # (no non-deferring program ran its backward: nothing overlapped, still correct)
+        if self.flushed and dev.type == "cuda":
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+        self.kept, self.flushed = None, False
+
+
+WGRAD_DEFER: Optional[DeferredWgrads] = None           # programs whose forward runs under defer_wgrads(d) defer into d
+_PENDING_DEFERRED: List[DeferredWgrads] = []            # collections with thunks not yet issued
+
+
+class defer_wgrads:
+    def __init__(self, d: Optional[DeferredWgrads]):
+        self.d = d
+
+    def __enter__(self):
+        global WGRAD_DEFER
+        self.prev, WGRAD_DEFER = WGRAD_DEFER, self.d
+        return self.d
+
+    def __exit__(self, *exc):
+        global WGRAD_DEFER
+        WGRAD_DEFER = self.prev
+        return False
+
+
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones)
 FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "4")) << 20) // 4
@@ -557,6 +620,7 @@ class Ctx:
         self.split = self.L.mrfa_get_mfma_mode() in (1, 2)   # bf16x6 / bf16x3 kernels: also hand over pre-split weights
         self.in_backward = False
         self.deferred = SIDE_PASS            # not None: this program runs on the side stream next to another pass of its module
+        self.wdefer = WGRAD_DEFER            # not None: weight-gradient launches of this program are collected (DeferredWgrads)
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
         self.nbt = {}                    # BatchNorm module -> forward passes in train mode during this program
@@ -747,9 +811,16 @@ class Ctx:
                     if not out.has_grad:
                         return
                     dw, db = cw.grad_acc(self.pool32)
-                    self._chk(self.L.mrfa_conv_fewout_wgrad(self.s, x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, out.gptr, out.ld, cw.Cout, cw.R,
-                                                            cw.pad, dw.data_ptr(), db.data_ptr() if (bias is not None and db is not None) else None),
-                              "conv_fewout_wgrad")
+                    dyp = out.gptr
+
+                    def launch():
+                        self._chk(self.L.mrfa_conv_fewout_wgrad(hip.stream_ptr(), x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, dyp, out.ld, cw.Cout, cw.R,
+                                                                cw.pad, dw.data_ptr(), db.data_ptr() if (bias is not None and db is not None) else None),
+                                  "conv_fewout_wgrad")
+                    if self._defer_ok(cw):
+                        self.wdefer.add(launch)
+                    else:
+                        launch()
                     if need_dx:
                         self._conv_dgrad(x, cw, out, ups, pre)
                 self.tape.append(bwd_direct)
@@ -810,6 +881,11 @@ class Ctx:
                 self.touched_convs.append(cw)
         return out
 
+    def _defer_ok(self, cw: ConvW) -> bool:
+        """this weight gradient may go to the deferred side chain: a collection is active and the gradient is accumulated straight
+        into .grad (cw._direct, set by grad_acc): nothing hands it to autograd before the join"""
+        return self.wdefer is not None and cw._direct
+
     def _conv_wgrad(self, x: View, cw: ConvW, out: View, ups, pre, has_bias):
         dw, db = cw.grad_acc(self.pool32)
         q = hip.WgradParams()
@@ -828,7 +904,19 @@ class Ctx:
             ws = Ctx._wgrad_ws[(self.dev, self.s)] = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)      # 64 MiB scratch
         q.ws, q.ws_bytes = ws.data_ptr(), ws.numel() * 4
         prof = Ctx.profile
-        if prof is None and WGRAD_STREAM:
+        if prof is None and self._defer_ok(cw):
+            keep = (x, out, pre, dw, db)                   # alive until DeferredWgrads.join()
+
+            def launch():
+                st = hip.stream_ptr()
+                w2 = Ctx._wgrad_ws.get((self.dev, st))
+                if w2 is None:
+                    w2 = Ctx._wgrad_ws[(self.dev, st)] = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
+                q.ws, q.ws_bytes = w2.data_ptr(), w2.numel() * 4
+                assert keep[0].st.data is not None
+                self._chk(self.L.mrfa_conv2d_wgrad_nhwc(st, C.byref(q)), "wgrad(deferred)")
+            self.wdefer.add(launch)
+        elif prof is None and WGRAD_STREAM:
             main = torch.cuda.current_stream(self.dev)
             if Ctx._side is None or Ctx._side.device != self.dev:
                 Ctx._side = torch.cuda.Stream(device=self.dev)
@@ -1560,13 +1648,28 @@ class _ProgramFn(torch.autograd.Function):
             for g in gouts:
                 if g is not None and g.is_cuda:
                     g.record_stream(cur)
+        if ectx.wdefer is None and _PENDING_DEFERRED:
+            # the backward pass has left the deferring programs: their weight gradients start now, beside this program's backward
+            for d in _PENDING_DEFERRED:
+                d.flush(ectx.dev)
+            del _PENDING_DEFERRED[:]
         for seed, g in zip(actx.seeders, gouts):
             if g is not None and seed is not None:
                 seed(g)
         ectx.run_backward()
         pgrads = {}
-        unpack_direct([cw for cw in ectx.touched_convs if cw.dw_acc is not None and cw._direct])
+        direct_cws = [cw for cw in ectx.touched_convs if cw.dw_acc is not None and cw._direct]
+        skip = ()
+        if ectx.wdefer is not None and direct_cws:
+            ectx.wdefer.add(lambda: unpack_direct(direct_cws))        # after the deferred launches, on their stream
+            if ectx.wdefer not in _PENDING_DEFERRED:
+                _PENDING_DEFERRED.append(ectx.wdefer)
+            skip = {id(cw) for cw in direct_cws}
+        else:
+            unpack_direct(direct_cws)
         for cw in ectx.touched_convs:
+            if id(cw) in skip:
+                continue
             dw, db = cw.take_grads()
             if dw is not None:
                 pgrads[id(cw.conv.weight)] = dw

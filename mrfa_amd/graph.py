@@ -178,7 +178,8 @@ class GraphedTrainStep:
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
                  clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False,
-                 concurrent_encoder: Optional[bool] = None, loss_fn=None, overlap_exchange: Optional[bool] = None):
+                 concurrent_encoder: Optional[bool] = None, loss_fn=None, overlap_exchange: Optional[bool] = None,
+                 defer_wgrads: Optional[bool] = None):
         """loss_fn(model, source, driving) -> scalar loss; None = the surrogate mean|model(source, driving) - driving|.
         overlap_exchange: cut graph A at the encoder boundary and overlap the all-reduce with the encoder's backward (surrogate-loss step
         of a HotPath only).  OPT-IN (argument or MRFA_OVERLAP_EXCHANGE=1): measured on one MI355X with a one-rank RCCL group, cutting the
@@ -198,6 +199,14 @@ class GraphedTrainStep:
             env = os.environ.get("MRFA_OVERLAP_EXCHANGE", "0")     # "force": cut the graph even without an exchange (timing the cut alone)
             overlap_exchange = env == "force" or (self.exchange and env == "1")
         self.split = SplitBackward(model) if (overlap_exchange and SplitBackward.supported(model, loss_fn)) else None
+        # decoder / dense-motion weight gradients issued beside the encoder's backward (engine.DeferredWgrads): MTIA prior, direct
+        # parameter gradients (FlatAdam); not together with the cut graph, whose first all-reduce needs those gradients final.
+        # Measured (same box, 20 steps): 108.6 vs 111.2 ms.  (Giving the capture / encoder streams high priority on top of it made the
+        # replay 1.7x SLOWER -- 182 ms -- so stream priorities are left alone.)
+        if defer_wgrads is None:
+            defer_wgrads = (getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_DEFER_WGRADS", "1") == "1")
+        if hasattr(model, "defer_decoder_wgrads"):
+            model.defer_decoder_wgrads = bool(defer_wgrads) and self.split is None and getattr(optimizer, "fused_clip", False)
         self.src, self.drv = source.clone(), driving.clone()
         self.fused = getattr(optimizer, "fused_clip", False)      # mrfa_amd.optim.FlatAdam: owns the flat buffers
         self.grads = optimizer.grads if self.fused else FlatGradients(model.parameters())

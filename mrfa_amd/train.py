@@ -73,6 +73,14 @@ class HotPath(nn.Module):
         # sequential order: see engine.SIDE_PASS.  mrfa_amd.graph.GraphedTrainStep switches it on for the MTIA prior.
         self.concurrent_encoder = False
         object.__setattr__(self, "_sides", [])
+        # training with direct parameter gradients: the weight-gradient kernels of dense motion + decoder (~100 launches, 22 ms, each
+        # filling the chip) are collected during their backward and issued on a side stream when the backward reaches the keypoint
+        # encoder, whose small kernels leave most of the GPU idle (engine.DeferredWgrads).  join() orders them before the optimizer.
+        # mrfa_amd.graph.GraphedTrainStep switches it on for the MTIA prior.
+        self.defer_decoder_wgrads = False
+        from .engine import DeferredWgrads
+        object.__setattr__(self, "_wdefer", DeferredWgrads())
+        object.__setattr__(self, "_wdefer_dev", None)
 
     def encode_many(self, frames):
         """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234), in the reference's order as far as
@@ -111,15 +119,23 @@ class HotPath(nn.Module):
         return kp_s, kp_d
 
     def join(self):
-        """after backward(): the side stream's backward kernels are ordered before whatever the caller issues next"""
+        """after backward(): the side streams' backward kernels (second encoder pass, deferred weight gradients) are ordered before
+        whatever the caller issues next"""
         for st in self._sides:
             torch.cuda.current_stream(st.device).wait_stream(st)
+        if self._wdefer_dev is not None:
+            self._wdefer.join(self._wdefer_dev)
 
     def decode(self, source, kp_s, kp_d, bg_param=None):
         """dense motion + refinement + generator for given keypoints (model.py:188-210)"""
-        img_down = self.down(source)
-        dm = self.dense_motion(source, kp_d, kp_s, bg_param=bg_param)
-        gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
+        from . import engine
+        defer = self._wdefer if (self.defer_decoder_wgrads and self.training and torch.is_grad_enabled()) else None
+        if defer is not None:
+            object.__setattr__(self, "_wdefer_dev", source.device)
+        with engine.defer_wgrads(defer):
+            img_down = self.down(source)
+            dm = self.dense_motion(source, kp_d, kp_s, bg_param=bg_param)
+            gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
         return gen
 
     def forward(self, source, driving):

@@ -458,6 +458,43 @@ def test_overlapped_exchange_world2_matches_single_process(tmp_path):
     assert float((r0["w"] - w1).abs().mean()) <= 2e-6 and float((w1 - w2).abs().max()) <= 4.1e-4
 
 
+def test_deferred_decoder_wgrads_equal_inline():
+    """HotPath.defer_decoder_wgrads (engine.DeferredWgrads: the dense-motion / decoder weight-gradient launches collected during their
+    backward, issued when the backward reaches the keypoint encoder, un-packed into .grad behind them, joined by HotPath.join()):
+    same gradients and the same weights after the step as the in-line order; the collection really held launches."""
+    from mrfa_amd import engine
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
+    seen = {}
+
+    def run(defer):
+        with emulated_hip():
+            model = HotPath(VOX1, prior="fomm")
+            for mod, tag in ((model.encoder, "kp"), (model.dense_motion, "dm"), (model.decoder, "rf")):
+                mod.load_state_dict(cases.weights_for(mod.state_dict(), tag))
+            model.train(True)
+            model.defer_decoder_wgrads = defer
+            opt = make_optimizer(model, fused=True)
+            if defer:
+                orig = engine.DeferredWgrads.flush
+
+                def spy(self, dev):
+                    seen["thunks"] = max(seen.get("thunks", 0), len(self.thunks))
+                    return orig(self, dev)
+                engine.DeferredWgrads.flush = spy
+            try:
+                loss = train_step(model, opt, cases.images("dw/src", 1, 256), cases.images("dw/drv", 1, 256))
+            finally:
+                if defer:
+                    engine.DeferredWgrads.flush = orig
+            return opt.grads.flat.clone(), opt.flat_w.clone(), float(loss)
+    g0, w0, l0 = run(False)
+    g1, w1, l1 = run(True)
+    assert seen.get("thunks", 0) > 50, seen                 # ~90 convolutions + the un-packing
+    assert l0 == l1
+    assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
+    assert float((w1 - w0).abs().max()) <= 1e-7
+
+
 def test_flat_adam_matches_torch_adam_and_clip():
     """mrfa_amd.optim.FlatAdam (flat buffers + K20 entry points, emulated here) against torch.optim.Adam(betas=(0.5, 0.999))
     + clip_grad_norm_(norm_type=inf) as the reference's train.py:21,65-70 uses them: same weights after every step, with
