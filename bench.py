@@ -183,7 +183,17 @@ def run_inference(a):
             tot_b, tot_ms, n = tot_b + byt, tot_ms + t, n + 1
             levels.append({"C": C_, "res": r, "us": round(t * 1e3, 1), "GBps": round(byt / t / 1e6, 0)})
         ach = tot_b / tot_ms / 1e6
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+        traffic = tsrc = None
+        try:                                          # HBM bytes per six-level set from the committed PMC passes of this command
+            with open(os.path.join(ROOT, "profiles", "r2_config5_traffic.json")) as tf:
+                traffic = round(json.load(tf)["hbm_bytes_per_six_level_set"] / 1e9, 3)
+            tsrc = "profiles/r2_config5_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (B=4, 512), not this run"
+        except Exception:
+            pass
+        if (B, size) != (4, 512):
+            traffic = tsrc = None
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                "traffic_unit": "GB per six-level set (PMC)", "traffic_source": tsrc,
                 "kernel": "grid_sample_fwd (one six-level deformed-feature warp set, flow-in-pixels sampling; the forward runs three sets + the image warp)",
                 "algorithmic_GB_per_set": round(tot_b / 1e9, 3), "ms_per_set": round(tot_ms, 4), "launches_per_set": n, "levels": levels,
                 "whole_forward_algorithmic_tflops": round(gflop / ms, 2),
