@@ -377,7 +377,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     // small problems (the MTIA prior's layers): one wave per 32 x 32 weight block, no LDS staging, in-workgroup reduction (wgrad_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_wgrad_small_eligible(p, M)) return mrfa_wgrad_small_launch(st, p, M);
-    const int taps = flat ? 1 : p.R * p.S;
+    int taps = flat ? 1 : p.R * p.S;
     const int NTOT = flat ? p.kflat : p.Cin;
     // tile selection: (BM over Cout) x (BN over Cin or taps*Cin)
     auto pick = [](int n) {                 // padded size x small-tile penalty (loads ~ BM+BN, MFMAs ~ BM*BN)
@@ -402,7 +402,21 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     // 64 / 96-wide tiles even at the cost of padding (eligibility: chunked K, Wout % 32 == 0, aligned dY)
     const bool split_mode = mrfa_get_mfma_mode() >= 1 && !flat && (p.Wout % 8) == 0 && (M % WBK) == 0 && !dy_scalar && p.Cout >= 32 && NTOT >= 32;
     if (split_mode) { BM = p.Cout <= 64 ? 64 : 128; BN = NTOT <= 64 ? 64 : 128; if (BM == 64 && BN == 64) BN = 128; }
-    const int tiles_m = cdiv(p.Cout, BM), tiles_n = cdiv(NTOT, BN);
+    int tiles_m = cdiv(p.Cout, BM), tiles_n = cdiv(NTOT, BN);
+    int taps_arg = taps;
+    // split-operand kernel, several taps, Cin not a multiple of the tile width (64, 96, 160, 192 ...): tile the flattened [taps][Cin]
+    // axis with 128-wide tiles (wgrad_split.hip "chunk-flat") when that removes >= 15 % of the padded tile work
+    static const bool cflat_on = [] { const char* e = getenv("MRFA_WGRAD_CFLAT"); return !(e && e[0] == '0'); }();
+    if (cflat_on && split_mode && taps > 1 && (p.Cin % 4) == 0) {
+        // (a 64-wide tile does ~1.4x the work per column of a 128-wide one: measured 110 vs 190 TF/s)
+        const double per_tap = (double)taps * tiles_n * BN * (BN == 64 ? 1.4 : 1.0), flat_w = (double)cdiv(taps * p.Cin, 128) * 128;
+        if (flat_w <= 0.85 * per_tap) {
+            BN = 128;
+            tiles_n = cdiv(taps * p.Cin, 128);
+            taps = 1;                       // (the cost model below counts tiles_m * tiles_n * taps workgroups per split)
+            taps_arg = -1;
+        }
+    }
     const long long base = (long long)tiles_m * tiles_n * taps * nb;
     int nsplit = p.ksplit;
     if (nsplit <= 0) {
@@ -445,7 +459,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
         else WLAUNCH(bm, bn, wm, wn, false, false);                       \
     }
     if (split_mode) {
-        const int rc = mrfa_wgrad_split_launch(st, p, grid, M, kps, tiles_n, nsplit, inner, total_splits, taps, partial_stride, BM, BN);
+        const int rc = mrfa_wgrad_split_launch(st, p, grid, M, kps, tiles_n, nsplit, inner, total_splits, taps_arg, partial_stride, BM, BN);
         if (rc) return rc;
     }
     else if (BM == 128 && BN == 128 && !flat && rowal && !p.tile8_off) { WLAUNCH(128, 128, 2, 4, false, true); }

@@ -68,12 +68,17 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
         if (gsplit >= total_splits) return;
         t_in = blockIdx.x - gsplit * inner;
     }
-    const int tile = t_in / taps;
-    const int tap = t_in - tile * taps;
+    // taps < 0: "chunk-flat" N axis -- the tile's BN columns index (tap, ci) = divmod(column, Cin) of the flattened [taps][Cin] axis, so a
+    // 192- or 160-channel input needs ceil(9 * Cin / 128) column tiles instead of 9 * 2 half-empty ones (Cin % 4 == 0: a loader
+    // thread's channel quad never straddles two taps).  Only the loader's tap shift and the epilogue's address become per-column.
+    const bool cflat = taps < 0;
+    const int tps = cflat ? 1 : taps;
+    const int tile = t_in / tps;
+    const int tap = t_in - tile * tps;
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int co0 = tile_m * BM, ci0 = tile_n * BN;
     const int bz = gsplit / nsplit, split = gsplit - bz * nsplit;
-    const int r = tap / p.S, s = tap - r * p.S;
+    const int NF = cflat ? p.R * p.S * p.Cin : p.Cin;        // length of the N axis this launch tiles
 
     const float* __restrict__ x = p.x + (size_t)bz * p.x_bs;
     const float* __restrict__ dy = p.dy + (size_t)bz * p.dy_bs;
@@ -92,16 +97,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     const int col = cg * 4;
     const bool item = col < (is_a ? BM : BN);   // this thread has a column quad inside the tile
     const bool do_bias = (p.dbias != nullptr) && tap == 0 && tile_n == 0;
+    // B loader threads: tap (r, s) and first input channel of this thread's column quad
+    int r, s, bci;
+    {
+        const int nf = ci0 + col;
+        const int tp = cflat ? min(nf / p.Cin, p.R * p.S - 1) : tap;
+        bci = cflat ? nf - tp * p.Cin : nf;
+        r = tp / p.S;
+        s = tp - r * p.S;
+    }
 
     bool cm[4];                              // channel masks of this thread's quad
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cm[q] = item && (is_a ? (co0 + col + q) < p.Cout : (ci0 + col + q) < p.Cin);
+    for (int q = 0; q < 4; ++q) cm[q] = item && (is_a ? (co0 + col + q) < p.Cout : (ci0 + col + q) < NF);
     const bool any = cm[0];
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (!is_a && p.in_scale) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (cm[q]) { sc[q] = p.in_scale[ci0 + col + q]; sh[q] = p.in_shift[ci0 + col + q]; }
+            if (cm[q]) { sc[q] = p.in_scale[bci + q]; sh[q] = p.in_shift[bci + q]; }
     }
 
     f32x4 rg[8];                             // 8 pixel rows x 4 channels
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
             const int iy = t_oy + r - p.pad;
             const bool rowok = (unsigned)iy < (unsigned)Hv;
             const int iyc = rowok ? (iy >> p.ups) : 0;
-            const float* bp = x + ((size_t)t_n * p.Hin + iyc) * p.Win * p.ldx + (any ? ci0 + col : 0);
+            const float* bp = x + ((size_t)t_n * p.Hin + iyc) * p.Win * p.ldx + (any ? bci : 0);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int ix = ox + rr + s - p.pad;
@@ -246,15 +260,17 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const mrfa_wgrad_pa
     // ------------------------------------------------------------------ epilogue (as wgrad_mfma.hip)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int ci = ci0 + wn * (TN * 32) + j * 32 + (lane & 31);
-        if (ci >= p.Cin) continue;
+        const int nfc = ci0 + wn * (TN * 32) + j * 32 + (lane & 31);
+        if (nfc >= NF) continue;
+        const int etap = cflat ? nfc / p.Cin : tap;
+        const int ci = cflat ? nfc - etap * p.Cin : nfc;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int co = co0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
                 if (co < p.Cout) {
-                    const size_t idx = ((size_t)tap * p.Cout + co) * p.Cin + ci;
+                    const size_t idx = ((size_t)etap * p.Cout + co) * p.Cin + ci;
                     if (partial_stride) p.ws[(size_t)split * partial_stride + idx] = acc[i][j][q] * p.alpha;
                     else atomicAdd(dw + idx, acc[i][j][q] * p.alpha);
                 }

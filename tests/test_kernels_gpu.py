@@ -377,7 +377,11 @@ def test_wgrad(cfg):
                                  dict(N=2, H=32, W=64, Cin=64, Cout=128), dict(N=2, H=32, W=32, Cin=128, Cout=64, pro=True),
                                  dict(N=2, H=32, W=32, Cin=60, Cout=50), dict(N=1, H=32, W=64, Cin=128, Cout=64, ups=1),
                                  dict(N=8, H=16, W=16, Cin=512, Cout=512, pro=True), dict(N=8, H=8, W=8, Cin=256, Cout=128),
-                                 dict(N=4, H=12, W=16, Cin=128, Cout=128, ksplit=3), dict(N=2, H=8, W=8, Cin=128, Cout=128, ups=1)])
+                                 dict(N=4, H=12, W=16, Cin=128, Cout=128, ksplit=3), dict(N=2, H=8, W=8, Cin=128, Cout=128, ups=1),
+                                 # chunk-flat N axis (Cin not a multiple of 128, several taps): columns of one tile belong to different taps
+                                 dict(N=2, H=32, W=32, Cin=192, Cout=128), dict(N=2, H=32, W=64, Cin=160, Cout=126, pro=True),
+                                 dict(N=1, H=16, W=32, Cin=192, Cout=64, ups=1), dict(N=2, H=32, W=32, Cin=96, Cout=96, ksplit=5, ws=True),
+                                 dict(N=2, H=16, W=16, Cin=36, Cout=64, R=5, pad=2)])
 def test_wgrad_split_operand_mode(cfg):
     """mrfa_set_mfma_mode(1): the bf16x6 weight-gradient kernel (128 x 128 tiles, Wout % 32 == 0) against the CPU specification
     at the tolerance of the native fp32 MFMA kernel"""
