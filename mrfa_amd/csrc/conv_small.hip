@@ -31,7 +31,14 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     constexpr int WM = 16 * TMW, WN = 16 * TNW;
     __shared__ float sred[4][2][WN];                  // per-wave column sums for the BatchNorm statistics
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, kq = lane >> 4;
+    const int li = lane & 15, kq = lane >> 4;         // MFMA operand / result role of this lane: row (column) li, k-quad kq
+    // LOADER role: lane 4 r + q loads the float4 = k-quad q of row r, so four consecutive lanes read one contiguous 64-byte row segment
+    // and a wave-wide load touches 16 cache lines.  (With the loader in the MFMA role -- lane = 16 q + r -- consecutive lanes read 16
+    // different rows and every load instruction cost 64 L1 tag lookups: TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD = 64.5, and lookups
+    // + tag-conflict + pending-miss stalls added up to 97 % of the kernel's cycles per CU -- profiles/r2_pmc_conv_small_*.)  The
+    // registers then move to the MFMA role with one ds_bpermute_b32 per component: lane (kq, li) takes from lane 4 li + kq.
+    const int lr = lane >> 2, lk = lane & 3;
+    const int perm_src = (4 * li + kq) * 4;           // ds_bpermute byte address of the source lane
     const int tile_n = blockIdx.x % tiles_n;
     const long long wt_m = (long long)(blockIdx.x / tiles_n) * 4 + wave;          // this wave's row tile
     const bool wave_on = wt_m < wave_tiles_m;
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     bool a_ok[TMW];
 #pragma unroll
     for (int a = 0; a < TMW; ++a) {
-        const long long m = m0 + a * 16 + li;
+        const long long m = m0 + a * 16 + lr;
         a_ok[a] = wave_on && m < M;
         const long long mm = a_ok[a] ? m : 0;
         const int n_img = (int)(mm / HWo);
@@ -60,9 +67,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     const float* wrow[TNW];
 #pragma unroll
     for (int b = 0; b < TNW; ++b) {
-        int n = n0 + b * 16 + li;
+        int n = n0 + b * 16 + lr;
         if (n >= p.w_rows) n = p.w_rows - 1;          // (its products land in columns >= Cout, which are never stored)
-        wrow[b] = p.w + (size_t)n * p.w_ld + kq * 4;
+        wrow[b] = p.w + (size_t)n * p.w_ld + lk * 4;
     }
 
     f32x4v ra[DEPTH][TMW], rb[DEPTH][TNW];
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
             const int iy = a_oy[a] + dr, ix = a_ox[a] + ds;
             ainb[a] = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             const long long pix = ainb[a] ? a_img[a] + (long long)iy * p.Win + ix : a_img[a];
-            arow[a] = p.x + (size_t)pix * p.ldx + kq * 4;
+            arow[a] = p.x + (size_t)pix * p.ldx + lk * 4;
         }
     };
     set_tap();
@@ -110,25 +117,39 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     for (int a = 0; a < TMW; ++a)
 #pragma unroll
         for (int b = 0; b < TNW; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int slot) {
+    f32x4v pa[2][TMW], pb[2][TNW];                    // operands in the MFMA role, double-buffered: chunk q + 1 is permuted while q multiplies
+    auto permute = [&](int slot, int pbuf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int a = 0; a < TMW; ++a)
+                pa[pbuf][a][j] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(ra[slot][a][j])));
+#pragma unroll
+            for (int b = 0; b < TNW; ++b)
+                pb[pbuf][b][j] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(rb[slot][b][j])));
+        }
+    };
+    auto compute = [&](int pbuf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int a = 0; a < TMW; ++a)
 #pragma unroll
                 for (int b = 0; b < TNW; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][a][j], rb[slot][b][j], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[pbuf][a][j], pb[pbuf][b][j], acc[a][b], 0, 0, 0);
     };
 
     // register ring of DEPTH chunks: chunk q lives in slot q % DEPTH; the loop is unrolled by DEPTH so every index is static.
     // (waves past the last row tile run the loop on clamped addresses and store nothing: no divergent control flow around the loads)
 #pragma unroll
     for (int s = 0; s < DEPTH - 1; ++s) load_chunk(s);
+    permute(0, 0);
     for (int q0 = 0; q0 < nq; q0 += DEPTH) {
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
             load_chunk((s + DEPTH - 1) % DEPTH);
-            if (q0 + s < nq) compute(s);
+            permute((s + 1) % DEPTH, (s + 1) & 1);    // chunk q0 + s + 1 (past the end: a clamped re-read, never multiplied)
+            if (q0 + s < nq) compute(s & 1);
         }
     }
 
@@ -203,13 +224,15 @@ bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
 }
 
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M) {
-    // wave tile: the largest of 32x32 / 16x32 / 16x16 that still yields >= ~1 000 waves (4 per SIMD-pair of the chip)
+    // wave tile: the largest of 32x32 / 16x32 / 16x16 that still yields >= ~2 000 waves (two per SIMD: measured best once the loads coalesce)
     const int ncols = (p.Cout + 15) / 16 * 16;
     auto waves = [&](int wm, int wn) { return ((M + wm - 1) / wm) * ((ncols + wn - 1) / wn); };
     int tm = 2, tn = 2;
-    if (waves(32, 32) < 1024) { tm = 1; tn = 2; }
-    if (tm == 1 && waves(16, 32) < 1024) { tn = 1; }
+    if (waves(32, 32) < 2048) { tm = 1; tn = 2; }
+    if (tm == 1 && waves(16, 32) < 2048) { tn = 1; }
     if (ncols % 32 != 0 && tn == 2 && ncols < 32) tn = 1;
+    static const int force = [] { const char* e = getenv("MRFA_CS_TILE"); return e ? atoi(e) : 0; }();      // tuning: 22 / 12 / 11
+    if (force == 22) { tm = 2; tn = 2; } else if (force == 12) { tm = 1; tn = 2; } else if (force == 11) { tm = 1; tn = 1; }
     const int WM = 16 * tm, WN = 16 * tn;
     const int tiles_n = (ncols + WN - 1) / WN;
     const int wave_tiles_m = (int)((M + WM - 1) / WM);

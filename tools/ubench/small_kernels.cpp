@@ -31,7 +31,10 @@ int main() {
     const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 200;
     printf("%-28s %10s %8s | %10s %8s\n", "shape", "conv us", "TF/s", "wgrad us", "TF/s");
     const int nmul = getenv("NMUL") ? atoi(getenv("NMUL")) : 1;          // batch multiplier (how the kernels scale with rows)
+    const int only = getenv("SHAPE") ? atoi(getenv("SHAPE")) : -1;       // run one row of the table (PMC passes)
+    int shape_idx = -1;
     for (Shape s : shapes) {
+        if (++shape_idx != only && only >= 0) continue;
         s.N *= nmul;
         const long long M = (long long)s.N * s.H * s.W;
         const int T = s.R * s.R, cop = (s.Cout + 127) / 128 * 128;
