@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void conv_fewout_fwd_kernel(const float* __res
             const float* px = smem + ((ty + r) * HT + tx + s) * FPS;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
+                if (c0 + c4 * 4 >= Cin) break;       // (uniform) Cin % 16 != 0: no weights exist there -- reading on past the row would
+                                                     // multiply the staged zeros by whatever follows the weight buffer (NaN * 0)
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(px + c4 * 4);
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
