@@ -18,8 +18,12 @@ namespace {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+// SPATIAL: the conv has taps or a size change (false: 1x1 same-size, X row = dY row); POW2: Hout, Wout are powers of two (pixel ->
+// (image, y, x) by shifts).  Compile-time: as run-time flags they put 2-3 uniform branches around every load group, ~48 per trip of
+// the 4-chunk loop, and hipcc would not move loads across them.
+template <bool SPATIAL, bool POW2>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_params p, const long long M, const int chunks_per_wave, const int nblk_ci,
-                                                         const int nblk, const int pow2_w /* log2(Wout) or -1 */, const int pow2_hw) {
+                                                         const int nblk, const int pow2_w /* log2(Wout) */, const int pow2_hw) {
     __shared__ float sacc[4][32][33];                 // one 32 x 32 partial per wave (plain stores: LDS float atomics cost 11 us here)
     __shared__ float sbias[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,7 +38,6 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     const int Mi = (int)M;                                 // (eligibility: M <= 65536) 32-bit pixel arithmetic: 64-bit division is a branchy routine
     const int range = (4 * g + wave) * chunks_per_wave * 16;
     const int HWo = p.Hout * p.Wout;
-    const bool spatial = T > 1 || p.Hin != p.Hout || p.Win != p.Wout;
 
     if (threadIdx.x < 32) sbias[threadIdx.x] = 0.f;
     __syncthreads();
@@ -60,9 +63,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
             a[j] = ok ? av : f32x2v{0.f, 0.f};
             bool xok = ok;
             int xrow = m;
-            if (spatial) {
+            if (SPATIAL) {
                 int img, oy, ox;
-                if (pow2_w >= 0) {
+                if (POW2) {
                     img = m >> pow2_hw;
                     const int rem = m & ((1 << pow2_hw) - 1);
                     oy = rem >> pow2_w;
@@ -164,7 +167,10 @@ int mrfa_wgrad_small_launch(hipStream_t st, const mrfa_wgrad_params& p, long lon
     int pw = lg2(p.Wout), ph = lg2(p.Hout);
     if (ph < 0) pw = -1;
     dim3 grid((unsigned)(groups * T * nblk));
-    hipLaunchKernelGGL(wgrad_small_kernel, grid, dim3(256), 0, st, p, M, chunks_per_wave, nblk_ci, nblk, pw, pw >= 0 ? pw + ph : 0);
+    const bool spatial = T > 1 || p.Hin != p.Hout || p.Win != p.Wout;
+    if (!spatial) hipLaunchKernelGGL((wgrad_small_kernel<false, false>), grid, dim3(256), 0, st, p, M, chunks_per_wave, nblk_ci, nblk, 0, 0);
+    else if (pw >= 0) hipLaunchKernelGGL((wgrad_small_kernel<true, true>), grid, dim3(256), 0, st, p, M, chunks_per_wave, nblk_ci, nblk, pw, pw + ph);
+    else hipLaunchKernelGGL((wgrad_small_kernel<true, false>), grid, dim3(256), 0, st, p, M, chunks_per_wave, nblk_ci, nblk, 0, 0);
     MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc(small)");
     return 0;
 }
