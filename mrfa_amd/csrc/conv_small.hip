@@ -26,7 +26,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // DEPTH = k16 chunks in flight per wave: 4 for short K (a 12-chunk linear would mostly prefetch past its end), 8 for K >= 512 (the loop is
 // load-latency bound at one wave per SIMD: ~1.5 us per round trip under load)
-template <int TMW, int TNW, int DEPTH>
+// CK = k16 chunks per loop step (2: the 16 x 16 / 16 x 32 wave tiles, whose 4-8 MFMAs per k16 did not cover the per-step loader advance:
+// two scalar branches, the tap bookkeeping and a waitcnt per step)
+template <int TMW, int TNW, int DEPTH, int CK>
 __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int wave_tiles_m) {
     constexpr int WM = 16 * TMW, WN = 16 * TNW;
     __shared__ float sred[4][2][WN];                  // per-wave column sums for the BatchNorm statistics
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     const long long m0 = wt_m * WM;
     const int n0 = tile_n * WN;
     const int HWo = p.Hout * p.Wout;
-    const int KC = p.Cin >> 4;                        // k16 chunks per tap
+    const int KC = p.Cin / (16 * CK);                 // loop steps (CK k16 chunks each) per tap
     const int T = p.R * p.S;
     const int nq = T * KC;
 
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         wrow[b] = p.w + (size_t)n * p.w_ld + lk * 4;
     }
 
-    f32x4v ra[DEPTH][TMW], rb[DEPTH][TNW];
+    f32x4v ra[DEPTH][CK][TMW], rb[DEPTH][CK][TNW];
     // loader state: tap (l_r, l_s), chunk l_c; per-tap A row pointers.  BRANCH-FREE: a row outside the image reads a valid address
     // (its image's pixel 0) and is zeroed by a select -- a load inside a divergent branch makes hipcc wait vmcnt(0) at the join, i.e.
     // for the newest prefetch instead of the oldest (measured: 20 us per layer instead of 8).  Past the last chunk the loader keeps
@@ -93,14 +95,17 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     };
     set_tap();
     auto load_chunk = [&](int slot) {
-        const int c0 = l_c * 16;
+        const int c0 = l_c * 16 * CK;
 #pragma unroll
-        for (int a = 0; a < TMW; ++a) {
-            const f32x4v v = *reinterpret_cast<const f32x4v*>(arow[a] + c0);
-            ra[slot][a] = ainb[a] ? v : f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < CK; ++h) {
+#pragma unroll
+            for (int a = 0; a < TMW; ++a) {
+                const f32x4v v = *reinterpret_cast<const f32x4v*>(arow[a] + c0 + 16 * h);
+                ra[slot][h][a] = ainb[a] ? v : f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) rb[slot][h][b] = *reinterpret_cast<const f32x4v*>(wrow[b] + w_tap_off + c0 + 16 * h);
         }
-#pragma unroll
-        for (int b = 0; b < TNW; ++b) rb[slot][b] = *reinterpret_cast<const f32x4v*>(wrow[b] + w_tap_off + c0);
         if (l_q + 1 < nq) {                          // (uniform) advance; at the end: stay on the last chunk
             ++l_q;
             if (++l_c == KC) {
@@ -117,26 +122,30 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     for (int a = 0; a < TMW; ++a)
 #pragma unroll
         for (int b = 0; b < TNW; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    f32x4v pa[2][TMW], pb[2][TNW];                    // operands in the MFMA role, double-buffered: chunk q + 1 is permuted while q multiplies
+    f32x4v pa[2][CK][TMW], pb[2][CK][TNW];            // operands in the MFMA role, double-buffered: step q + 1 is permuted while q multiplies
     auto permute = [&](int slot, int pbuf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int h = 0; h < CK; ++h)
 #pragma unroll
-            for (int a = 0; a < TMW; ++a)
-                pa[pbuf][a][j] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(ra[slot][a][j])));
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int b = 0; b < TNW; ++b)
-                pb[pbuf][b][j] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(rb[slot][b][j])));
-        }
+                for (int a = 0; a < TMW; ++a)
+                    pa[pbuf][h][a][j] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(ra[slot][h][a][j])));
+#pragma unroll
+                for (int b = 0; b < TNW; ++b)
+                    pb[pbuf][h][b][j] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(rb[slot][h][b][j])));
+            }
     };
     auto compute = [&](int pbuf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int h = 0; h < CK; ++h)
 #pragma unroll
-            for (int a = 0; a < TMW; ++a)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int b = 0; b < TNW; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[pbuf][a][j], pb[pbuf][b][j], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < TMW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[pbuf][h][a][j], pb[pbuf][h][b][j], acc[a][b], 0, 0, 0);
     };
 
     // register ring of DEPTH chunks: chunk q lives in slot q % DEPTH; the loop is unrolled by DEPTH so every index is static.
@@ -239,10 +248,14 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
     const long long blocks = (long long)((wave_tiles_m + 3) / 4) * tiles_n;
     dim3 grid((unsigned)blocks);
     const bool deep = (long long)p.R * p.S * p.Cin >= 512;
-#define SMALL_LAUNCH(TM_, TN_)                                                                                                   \
-    do {                                                                                                                         \
-        if (deep) hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 8>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);      \
-        else hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 4>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);           \
+    // two k16 chunks per loop step: small wave tiles on deep K (measured: 64->64 3x3 14.8 -> 13.6 us, 128->128 15.6 -> 13.9, 576->192
+    // linear 14.4 -> 13.0; short K gets slower: 32->32 3x3 14.0 -> 15.6, 192->576 12.6 -> 15.1)
+    const bool ck2 = deep && (p.Cin % 32) == 0 && !(tm == 2 && tn == 2);
+#define SMALL_LAUNCH(TM_, TN_)                                                                                                    \
+    do {                                                                                                                          \
+        if (ck2) hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 4, 2>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);   \
+        else if (deep) hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 8, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);    \
+        else hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 4, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);              \
     } while (0)
     if (tm == 2 && tn == 2) SMALL_LAUNCH(2, 2);
     else if (tm == 1 && tn == 2) SMALL_LAUNCH(1, 2);
