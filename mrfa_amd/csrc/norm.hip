@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
 // row, so a wave streams 4 rows (4 x 256 B) per iteration and a workgroup 16; needs C % 4 == 0 and 16-byte aligned
 // views.  Same arithmetic as the scalar kernel above, element by element.  Phase 2 also folds the parameter-gradient
 // update (dgamma += sum du*xhat, dbeta += sum du) into the first row-block instead of a separate launch.
-template <int PHASE>
+// MODE 0: plain, 1: residual, 2: 2x2 pool, 3: occlusion blend -- compile-time, so that the row loop of the common (plain / residual)
+// case has no uniform branches between its loads (as run-time flags they kept hipcc from batching the x / dy / res loads of a row group)
+template <int PHASE, int MODE>
 __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+    constexpr bool POOL = MODE == 2, BLEND = MODE == 3, RES = MODE == 1;
     __shared__ float red[2][16][CH];
     __shared__ double redsum[2][CH];                         // phase 2: the MRFA_STATS_SLOTS partial sums of phase 1, added up once per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
     for (long long r = r0 + slot; r < r1; r += 16) {
         long long opix = r;
         float gmul = 1.f;
-        if (p.pool) {
+        if (POOL) {
             const int xx = (int)(r % p.W);
             const long long t = r / p.W;
             const int yy = (int)(t % p.H);
@@ -278,18 +281,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
             f32x4 da = *reinterpret_cast<const f32x4*>(p.dy + (size_t)opix * p.lddy + c);
             float o = 0.f;
             f32x4 A = {0, 0, 0, 0};
-            if (p.blend_a) {
+            if (BLEND) {
                 o = p.occ[(size_t)opix * p.ldo];
                 if (PHASE == 1) A = *reinterpret_cast<const f32x4*>(p.blend_a + (size_t)opix * p.lda + c);
             }
             f32x4 dA = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
-            if (p.res) rs = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + c);
+            if (RES) rs = *reinterpret_cast<const f32x4*>(p.res + (size_t)r * p.ldr + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float u = xv[k] * sc[k] + sh[k] + rs[k];
                 const float a = p.relu ? fmaxf(u, 0.f) : u;
                 float d = da[k] * gmul;
-                if (p.blend_a) {
+                if (BLEND) {
                     if (PHASE == 1) {
                         dA[k] = d * o;
                         docc_part += d * (A[k] - a);
@@ -298,13 +301,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
                 }
                 du[k] = (p.relu && u <= 0.f) ? 0.f : d;
             }
-            if (PHASE == 1 && p.dres) {
+            if (PHASE == 1 && RES && p.dres) {
                 f32x4* q = reinterpret_cast<f32x4*>(p.dres + (size_t)r * p.lddr + c);
                 f32x4 cur = *q;
                 cur += du;
                 *q = cur;
             }
-            if (PHASE == 1 && p.blend_a && p.dblend_a) {
+            if (PHASE == 1 && BLEND && p.dblend_a) {
                 f32x4* q = reinterpret_cast<f32x4*>(p.dblend_a + (size_t)opix * p.ldda + c);
                 f32x4 cur = *q;
                 cur += dA;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
             }
         }
         if (PHASE == 1) {
-            if (p.blend_a && p.docc) {
+            if (BLEND && p.docc) {
                 float t = docc_part;                         // sum over the 16 lanes (64 channels) of this row
 #pragma unroll
                 for (int o2 = 8; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2, 64);
@@ -431,12 +434,12 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
                      (!p.res || ((p.ldr % 4 == 0) && aligned16(p.res) && (!p.dres || ((p.lddr % 4 == 0) && aligned16(p.dres))))) &&
                      (!p.blend_a || ((p.lda % 4 == 0) && aligned16(p.blend_a) && (!p.dblend_a || ((p.ldda % 4 == 0) && aligned16(p.dblend_a)))));
     if (vec) {
-        if (p.phase == 1) {
-            hipLaunchKernelGGL((bn_act_bwd_vec_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
-        } else {
-            MRFA_CHECK_ARG(p.dx != nullptr, "bn_act_bwd: phase 2 needs dx");
-            hipLaunchKernelGGL((bn_act_bwd_vec_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
-        }
+        MRFA_CHECK_ARG(p.phase == 1 || p.dx != nullptr, "bn_act_bwd: phase 2 needs dx");
+        const int mode = p.pool ? 2 : (p.blend_a ? 3 : (p.res ? 1 : 0));
+#define BNB(PH, MD) hipLaunchKernelGGL((bn_act_bwd_vec_kernel<PH, MD>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb)
+        if (p.phase == 1) { if (mode == 0) BNB(1, 0); else if (mode == 1) BNB(1, 1); else if (mode == 2) BNB(1, 2); else BNB(1, 3); }
+        else { if (mode == 0) BNB(2, 0); else if (mode == 1) BNB(2, 1); else if (mode == 2) BNB(2, 2); else BNB(2, 3); }
+#undef BNB
         MRFA_CHECK_LAUNCH("bn_act_bwd(vec)");
         return 0;
     }
