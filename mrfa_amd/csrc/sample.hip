@@ -24,6 +24,34 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy) {
     return t;
 }
 
+
+// Branch-free tap set: the four tap addresses are always valid (out-of-image taps are clamped onto the neighbouring in-image tap,
+// a pixel wholly outside samples pixel (0, 0)) and the weights of the taps that do not exist are zero -- a load inside a divergent branch
+// makes hipcc wait for it (vmcnt(0)) at the join, which turned the four taps of a pixel into four serial memory round trips.
+struct Taps4 {
+    size_t o00, o01, o10, o11;      // pixel offsets (units of pixels) of the four taps
+    float w00, w01, w10, w11;       // bilinear weights, 0 for taps outside the image
+    float fx, fy;
+    bool ok00, ok01, ok10, ok11;
+};
+
+__device__ __forceinline__ Taps4 make_taps4(float ix, float iy, int Wi, int Hi) {
+    const bool inr = ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi;      // NaN / huge coordinates: "outside"
+    const Taps tp = make_taps(inr ? ix : 0.f, inr ? iy : 0.f);
+    const bool x0ok = inr && tp.x0 >= 0, x1ok = inr && tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
+    const int x0 = tp.x0 < 0 ? 0 : tp.x0, y0 = tp.y0 < 0 ? 0 : tp.y0;
+    const int x1 = tp.x0 + 1 < Wi ? tp.x0 + 1 : Wi - 1, y1 = tp.y0 + 1 < Hi ? tp.y0 + 1 : Hi - 1;
+    Taps4 t;
+    t.fx = tp.fx; t.fy = tp.fy;
+    t.ok00 = y0ok && x0ok; t.ok01 = y0ok && x1ok; t.ok10 = y1ok && x0ok; t.ok11 = y1ok && x1ok;
+    t.o00 = (size_t)y0 * Wi + x0; t.o01 = (size_t)y0 * Wi + x1; t.o10 = (size_t)y1 * Wi + x0; t.o11 = (size_t)y1 * Wi + x1;
+    t.w00 = t.ok00 ? (1.f - tp.fx) * (1.f - tp.fy) : 0.f;
+    t.w01 = t.ok01 ? tp.fx * (1.f - tp.fy) : 0.f;
+    t.w10 = t.ok10 ? (1.f - tp.fx) * tp.fy : 0.f;
+    t.w11 = t.ok11 ? tp.fx * tp.fy : 0.f;
+    return t;
+}
+
 __device__ __forceinline__ void sample_coords(const float* __restrict__ grid, int ldg, long long opix, int ox, int oy, int Wi, int Hi,
                                               int mode, float& ix, float& iy) {
     const float gx = grid[(size_t)opix * ldg], gy = grid[(size_t)opix * ldg + 1];
@@ -48,18 +76,9 @@ __global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __res
         const int n = (int)(t / Ho);
         float ix, iy;
         sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
-        float v = 0.f;
-        // NaN / huge coordinates fall through the bounds tests as "outside"
-        if (ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi) {
-            const Taps tp = make_taps(ix, iy);
-            const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
-            const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
-            const float w00 = (1.f - tp.fx) * (1.f - tp.fy), w01 = tp.fx * (1.f - tp.fy), w10 = (1.f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
-            if (y0ok && x0ok) v += w00 * base[((size_t)tp.y0 * Wi + tp.x0) * ldi];
-            if (y0ok && x1ok) v += w01 * base[((size_t)tp.y0 * Wi + tp.x0 + 1) * ldi];
-            if (y1ok && x0ok) v += w10 * base[((size_t)(tp.y0 + 1) * Wi + tp.x0) * ldi];
-            if (y1ok && x1ok) v += w11 * base[((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * ldi];
-        }
+        const Taps4 tp = make_taps4(ix, iy, Wi, Hi);
+        const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
+        const float v = tp.w00 * base[tp.o00 * ldi] + tp.w01 * base[tp.o01 * ldi] + tp.w10 * base[tp.o10 * ldi] + tp.w11 * base[tp.o11 * ldi];
         out[(size_t)opix * ldo + c] = v;
     }
 }
@@ -85,17 +104,11 @@ __global__ __launch_bounds__(256) void grid_sample_fwd_vec_kernel(const float* _
         const int n = (int)(t / Ho);
         float ix, iy;
         sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi) {
-            const Taps tp = make_taps(ix, iy);
-            const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
-            const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
-            const float w00 = (1.f - tp.fx) * (1.f - tp.fy), w01 = tp.fx * (1.f - tp.fy), w10 = (1.f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
-            if (y0ok && x0ok) v += w00 * *reinterpret_cast<const f32x4*>(base + ((size_t)tp.y0 * Wi + tp.x0) * ldi);
-            if (y0ok && x1ok) v += w01 * *reinterpret_cast<const f32x4*>(base + ((size_t)tp.y0 * Wi + tp.x0 + 1) * ldi);
-            if (y1ok && x0ok) v += w10 * *reinterpret_cast<const f32x4*>(base + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * ldi);
-            if (y1ok && x1ok) v += w11 * *reinterpret_cast<const f32x4*>(base + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * ldi);
-        }
+        const Taps4 tp = make_taps4(ix, iy, Wi, Hi);
+        const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
+        const f32x4 t00 = *reinterpret_cast<const f32x4*>(base + tp.o00 * ldi), t01 = *reinterpret_cast<const f32x4*>(base + tp.o01 * ldi);
+        const f32x4 t10 = *reinterpret_cast<const f32x4*>(base + tp.o10 * ldi), t11 = *reinterpret_cast<const f32x4*>(base + tp.o11 * ldi);
+        const f32x4 v = tp.w00 * t00 + tp.w01 * t01 + tp.w10 * t10 + tp.w11 * t11;
         *reinterpret_cast<f32x4*>(out + (size_t)opix * ldo + c) = v;
     }
 }
@@ -125,32 +138,31 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_vec_kernel(const float* _
         float ix, iy;
         sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
         float gxs = 0.f, gys = 0.f;
-        if (live && ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi) {
-            const Taps tp = make_taps(ix, iy);
-            const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
+        {
+            const Taps4 tp = make_taps4(live ? ix : -2.f, iy, Wi, Hi);       // dead items: every tap weight 0, nothing stored
             const f32x4 g = *reinterpret_cast<const f32x4*>(dout + (size_t)opix * lddo + c);
             const size_t ib = (size_t)(n / in_rep) * in_bstride + c;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v00 = (y0ok && x0ok) ? *reinterpret_cast<const f32x4*>(in + ib + ((size_t)tp.y0 * Wi + tp.x0) * ldi) : z;
-            const f32x4 v01 = (y0ok && x1ok) ? *reinterpret_cast<const f32x4*>(in + ib + ((size_t)tp.y0 * Wi + tp.x0 + 1) * ldi) : z;
-            const f32x4 v10 = (y1ok && x0ok) ? *reinterpret_cast<const f32x4*>(in + ib + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * ldi) : z;
-            const f32x4 v11 = (y1ok && x1ok) ? *reinterpret_cast<const f32x4*>(in + ib + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * ldi) : z;
+            const f32x4 l00 = *reinterpret_cast<const f32x4*>(in + ib + tp.o00 * ldi), l01 = *reinterpret_cast<const f32x4*>(in + ib + tp.o01 * ldi);
+            const f32x4 l10 = *reinterpret_cast<const f32x4*>(in + ib + tp.o10 * ldi), l11 = *reinterpret_cast<const f32x4*>(in + ib + tp.o11 * ldi);
+            const f32x4 v00 = tp.ok00 ? l00 : z, v01 = tp.ok01 ? l01 : z, v10 = tp.ok10 ? l10 : z, v11 = tp.ok11 ? l11 : z;
             if (din) {
                 float* db = din + (size_t)(n / in_rep) * din_bstride + c;
-                const float w00 = (1.f - tp.fx) * (1.f - tp.fy), w01 = tp.fx * (1.f - tp.fy), w10 = (1.f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (y0ok && x0ok) atomicAdd(db + ((size_t)tp.y0 * Wi + tp.x0) * lddi + q, g[q] * w00);
-                    if (y0ok && x1ok) atomicAdd(db + ((size_t)tp.y0 * Wi + tp.x0 + 1) * lddi + q, g[q] * w01);
-                    if (y1ok && x0ok) atomicAdd(db + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * lddi + q, g[q] * w10);
-                    if (y1ok && x1ok) atomicAdd(db + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * lddi + q, g[q] * w11);
+                    if (tp.ok00) atomicAdd(db + tp.o00 * lddi + q, g[q] * tp.w00);
+                    if (tp.ok01) atomicAdd(db + tp.o01 * lddi + q, g[q] * tp.w01);
+                    if (tp.ok10) atomicAdd(db + tp.o10 * lddi + q, g[q] * tp.w10);
+                    if (tp.ok11) atomicAdd(db + tp.o11 * lddi + q, g[q] * tp.w11);
                 }
             }
+            const bool any = tp.ok00 || tp.ok01 || tp.ok10 || tp.ok11;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 gxs += g[q] * ((v01[q] - v00[q]) * (1.f - tp.fy) + (v11[q] - v10[q]) * tp.fy);
                 gys += g[q] * ((v10[q] - v00[q]) * (1.f - tp.fx) + (v11[q] - v01[q]) * tp.fx);
             }
+            if (!any) { gxs = 0.f; gys = 0.f; }
         }
         if (dgrid) {
 #pragma unroll
@@ -193,24 +205,19 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float* __res
         float ix, iy;
         sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
         float gxs = 0.f, gys = 0.f;
-        if (ix > -1.f && iy > -1.f && ix < (float)Wi && iy < (float)Hi) {     // wave-uniform
-            const Taps tp = make_taps(ix, iy);
-            const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < Wi, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < Hi;
-            const float g = c_ok ? dout[(size_t)opix * lddo + c] : 0.f;
-            const size_t ib = (size_t)(n / in_rep) * in_bstride + c;
-            float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
-            if (c_ok) {
-                if (y0ok && x0ok) v00 = in[ib + ((size_t)tp.y0 * Wi + tp.x0) * ldi];
-                if (y0ok && x1ok) v01 = in[ib + ((size_t)tp.y0 * Wi + tp.x0 + 1) * ldi];
-                if (y1ok && x0ok) v10 = in[ib + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * ldi];
-                if (y1ok && x1ok) v11 = in[ib + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * ldi];
-            }
+        {
+            const Taps4 tp = make_taps4(ix, iy, Wi, Hi);                      // (wave-uniform: one pixel per wave)
+            const int cc = c_ok ? c : 0;                                      // lanes past C read channel 0 and contribute nothing
+            const float g = c_ok ? dout[(size_t)opix * lddo + cc] : 0.f;
+            const size_t ib = (size_t)(n / in_rep) * in_bstride + cc;
+            const float l00 = in[ib + tp.o00 * ldi], l01 = in[ib + tp.o01 * ldi], l10 = in[ib + tp.o10 * ldi], l11 = in[ib + tp.o11 * ldi];
+            const float v00 = tp.ok00 ? l00 : 0.f, v01 = tp.ok01 ? l01 : 0.f, v10 = tp.ok10 ? l10 : 0.f, v11 = tp.ok11 ? l11 : 0.f;
             if (din && c_ok) {
                 float* db = din + (size_t)(n / in_rep) * din_bstride + c;
-                if (y0ok && x0ok) atomicAdd(db + ((size_t)tp.y0 * Wi + tp.x0) * lddi, g * (1.f - tp.fx) * (1.f - tp.fy));
-                if (y0ok && x1ok) atomicAdd(db + ((size_t)tp.y0 * Wi + tp.x0 + 1) * lddi, g * tp.fx * (1.f - tp.fy));
-                if (y1ok && x0ok) atomicAdd(db + ((size_t)(tp.y0 + 1) * Wi + tp.x0) * lddi, g * (1.f - tp.fx) * tp.fy);
-                if (y1ok && x1ok) atomicAdd(db + ((size_t)(tp.y0 + 1) * Wi + tp.x0 + 1) * lddi, g * tp.fx * tp.fy);
+                if (tp.ok00) atomicAdd(db + tp.o00 * lddi, g * tp.w00);
+                if (tp.ok01) atomicAdd(db + tp.o01 * lddi, g * tp.w01);
+                if (tp.ok10) atomicAdd(db + tp.o10 * lddi, g * tp.w10);
+                if (tp.ok11) atomicAdd(db + tp.o11 * lddi, g * tp.w11);
             }
             // d val / d ix = (v01 - v00)(1-fy) + (v11 - v10) fy ; d val / d iy = (v10 - v00)(1-fx) + (v11 - v01) fx
             gxs = g * ((v01 - v00) * (1.f - tp.fy) + (v11 - v10) * tp.fy);
