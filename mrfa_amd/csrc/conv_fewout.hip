@@ -49,10 +49,11 @@ __global__ __launch_bounds__(256) void conv_fewout_fwd_kernel(const float* __res
             const int c4 = i & 3, pix = i >> 2;
             const int hy = pix / HT, hx = pix - hy * HT;
             const int iy = ty0 + hy - pad, ix = tx0 + hx - pad;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + c4 * 4 < Cin)
-                v = *reinterpret_cast<const f32x4*>(xin + ((size_t)iy * W + ix) * ldx + c0 + c4 * 4);
-            *reinterpret_cast<f32x4*>(smem + pix * FPS + c4 * 4) = v;
+            // branch-free: an out-of-image / past-Cin element reads a valid address and is zeroed by a select (a load inside a divergent
+            // branch is waited for at the join, one serial round trip per trip of this loop)
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + c4 * 4 < Cin;
+            const f32x4 ld = *reinterpret_cast<const f32x4*>(xin + (ok ? ((size_t)iy * W + ix) * ldx + c0 + c4 * 4 : (size_t)0));
+            *reinterpret_cast<f32x4*>(smem + pix * FPS + c4 * 4) = ok ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
         for (int tap = 0; tap < T; ++tap) {
@@ -137,10 +138,9 @@ __global__ __launch_bounds__(256) void conv_fewout_wgrad_kernel(const float* __r
                 const int gg = i % groups, pix = i / groups;
                 const int hy = pix / HT, hx = pix - hy * HT;
                 const int iy = ty0 + hy - pad, ix = tx0 + hx - pad;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + gg * 4 < Cin)
-                    v = *reinterpret_cast<const f32x4*>(xin + ((size_t)iy * W + ix) * ldx + c0 + gg * 4);
-                *reinterpret_cast<f32x4*>(xs + pix * ps + gg * 4) = v;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c0 + gg * 4 < Cin;      // branch-free, as in the forward
+                const f32x4 ld = *reinterpret_cast<const f32x4*>(xin + (ok ? ((size_t)iy * W + ix) * ldx + c0 + gg * 4 : (size_t)0));
+                *reinterpret_cast<f32x4*>(xs + pix * ps + gg * 4) = ok ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             {
                 const int py = tid >> 4, pxx = tid & 15;
