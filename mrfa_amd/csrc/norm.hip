@@ -263,6 +263,54 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
         }
     }
     f32x4 s1 = {0, 0, 0, 0}, s2 = s1;
+    if constexpr (MODE <= 1) {
+        // plain / residual (every BatchNorm of the keypoint encoders): two rows per trip, all loads of both rows issued before anything
+        // is consumed, no branch around a load (idle lanes of a partial channel chunk read channel 0; rows past the end re-read the
+        // last row).  With one row per trip inside `if (c_ok)` every trip was a serial L2 round trip.
+        const int cl = c_ok ? c : 0;
+        for (long long r = r0 + slot; r < r1; r += 32) {
+            long long rr[2];
+            bool live[2];
+            f32x4 xv[2], da[2], rs[2], cur[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                live[u] = r + 16 * u < r1;
+                rr[u] = live[u] ? r + 16 * u : r;
+                xv[u] = *reinterpret_cast<const f32x4*>(p.x + (size_t)rr[u] * p.ldx + cl);
+                da[u] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)rr[u] * p.lddy + cl);
+                rs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (RES) rs[u] = *reinterpret_cast<const f32x4*>(p.res + (size_t)rr[u] * p.ldr + cl);
+                cur[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PHASE == 1 && RES && p.dres) cur[u] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)rr[u] * p.lddr + cl);
+                if (PHASE == 2 && !p.dx_overwrite) cur[u] = *reinterpret_cast<const f32x4*>(p.dx + (size_t)rr[u] * p.lddx + cl);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 du;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float uu = xv[u][k] * sc[k] + sh[k] + rs[u][k];
+                    du[k] = (p.relu && uu <= 0.f) ? 0.f : da[u][k];
+                }
+                const bool st = c_ok && live[u];
+                if (PHASE == 1) {
+                    if (RES && p.dres && st) *reinterpret_cast<f32x4*>(p.dres + (size_t)rr[u] * p.lddr + c) = cur[u] + du;
+                    if (st) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            s1[k] += du[k];
+                            s2[k] += du[k] * (xv[u][k] - mean[k]) * invstd[k];
+                        }
+                    }
+                } else if (st) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        cur[u][k] += p.train ? gi[k] * (du[k] - k1[k] - (xv[u][k] - mean[k]) * invstd[k] * k2[k]) : du[k] * sc[k];
+                    *reinterpret_cast<f32x4*>(p.dx + (size_t)rr[u] * p.lddx + c) = cur[u];
+                }
+            }
+        }
+    } else
     for (long long r = r0 + slot; r < r1; r += 16) {
         long long opix = r;
         float gmul = 1.f;
