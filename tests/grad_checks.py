@@ -58,7 +58,9 @@ def _check_pgrads(mods, g, names, tag, rel_tol, extra=None):
             # of the same rounding noise the norms are gated on: it wandered between 1 % and 3.4 % of the largest entry from run to run)
             d = np.linalg.norm(P[n].grad.detach().cpu().numpy().astype(np.float64) - r) / max(np.linalg.norm(r.astype(np.float64)), 1e-30)
             a_n = allow if np.isscalar(allow) else allow[names[tag].index(n)]
-            assert d <= 2 * rel_tol + a_n, (key, d)
+            if key + "_noise_fp64" in g.files:      # the reference's own distance from the fp64 truth on THIS tensor (relative L2)
+                a_n = max(a_n, rel_tol + 3.0 * float(g[key + "_noise_fp64"][0]))
+            assert d <= 2 * rel_tol + a_n, (key, d, a_n)
     return rel
 
 
@@ -119,7 +121,10 @@ def check_chained_pipeline_gradients(golden_dir, train, b, DEV):
     loss.backward()
     assert abs(loss.item() - float(g[f"chain_{sfx}_loss"][0])) <= 2e-5
     gerr = np.abs(gen.detach().cpu()[:, :, ::4, ::4].numpy() - g[f"chain_{sfx}_gen_s4"])
-    assert gerr.mean() <= 1e-4 and gerr.max() <= 5e-3, (gerr.mean(), gerr.max())
+    # train-mode BatchNorm at B=4 amplifies fp32 summation order: the REFERENCE's own output is mean `noise` from an fp64 run of the same
+    # computation (stored next to it); the gate is the 1e-4 of the eval-mode tests plus three times that
+    nz = np.abs(g[f"chain_{sfx}_gen_s4"] - g[f"chain_{sfx}_gen_s4_fp64"]) if f"chain_{sfx}_gen_s4_fp64" in g.files else np.zeros(1)
+    assert gerr.mean() <= 1e-4 + 3.0 * nz.mean() and gerr.max() <= 5e-3 + 3.0 * nz.max(), (gerr.mean(), gerr.max(), nz.mean(), nz.max())
     mods = [("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)]
     rel = _check_pgrads(mods, g, names, f"chain_{sfx}", 1e-3, extra=_ref_noise(g, f"chain_{sfx}", names))
     print(f"chained {sfx}: per-parameter gradient-norm error vs reference: median {np.median(rel):.2e}, max {rel.max():.2e}")
