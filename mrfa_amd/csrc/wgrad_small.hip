@@ -24,7 +24,10 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <bool SPATIAL, bool POW2>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_params p, const long long M, const int chunks_per_wave, const int nblk_ci,
                                                          const int nblk, const int pow2_w /* log2(Wout) */, const int pow2_hw) {
-    __shared__ float sacc[4][32][33];                 // one 32 x 32 partial per wave (plain stores: LDS float atomics cost 11 us here)
+    // two 32 x 32 partial buffers (plain stores: LDS float atomics cost 11 us here), filled in two rounds: 8.4 KB instead of 16.9 KB, so a
+    // workgroup fits beside two resident 74 KB workgroups of the deferred wgrad_bf16x6 chain (12 KB of a CU's LDS stay free) instead of
+    // waiting ~250 us for one of them to retire (measured tail of this kernel during the overlap: up to 530 us for a 15 us launch)
+    __shared__ float sacc[2][32][33];
     __shared__ float sbias[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -120,7 +123,17 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[wave][2 * (kq * 4 + r) + t][2 * li + u] = acc[t][u][r];
+            for (int r = 0; r < 4; ++r)
+                if (wave < 2) sacc[wave][2 * (kq * 4 + r) + t][2 * li + u] = acc[t][u][r];
+    __syncthreads();
+    if (wave >= 2) {                                   // round 2: waves 2, 3 add on top of waves 0, 1 (each element has one owner)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[wave - 2][2 * (kq * 4 + r) + t][2 * li + u] += acc[t][u][r];
+    }
     if (p.dbias && tap == 0 && ci0 == 0) {
         // column sums of dY over this wave's pixels: lane (li, kq) summed channels 2 li + {0, 1} of its pixels
 #pragma unroll
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     float* dw = p.dw + ((size_t)tap * p.Cout + co0) * p.Cin + ci0;
     for (int i = threadIdx.x; i < 32 * 32; i += 256) {
         const int r = i >> 5, c = i & 31;
-        if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * (sacc[0][r][c] + sacc[1][r][c] + sacc[2][r][c] + sacc[3][r][c]));
+        if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * (sacc[0][r][c] + sacc[1][r][c]));
     }
     if (p.dbias && tap == 0 && ci0 == 0 && threadIdx.x < 32 && co0 + threadIdx.x < p.Cout) atomicAdd(p.dbias + co0 + threadIdx.x, sbias[threadIdx.x]);
 }
