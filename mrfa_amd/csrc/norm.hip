@@ -104,6 +104,23 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params
     }
 }
 
+// float4 form of the plain / residual case (every BatchNorm of the keypoint encoders): one thread = 4 consecutive channels of a pixel
+template <bool RES>
+__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const mrfa_bnact_params p, long long total4, int c4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long opix = i / c4;
+        const int c = (int)(i - opix * c4) * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c), sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)opix * p.ldx + c) * sc + sh;
+        if (RES) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)opix * p.ldr + c);
+        if (p.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.y + (size_t)opix * p.ldy + c) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // how many of the MRFA_STATS_SLOTS blocks of `red` a launch with `row_blocks` workgroups per channel chunk spreads its phase-1 atomics
 // over (both phases run the same grid): summing 32 blocks costs phase 2 ~1 us, which only pays when >= 64 workgroups would otherwise
@@ -462,6 +479,14 @@ extern "C" int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* pp) {
     MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)), "bn_act_fwd: residual excludes pool and blend");
     const long long opix = (long long)p.N * (p.pool ? p.H / 2 : p.H) * (p.pool ? p.W / 2 : p.W);
     const long long total = opix * p.C;
+    if (!p.pool && !p.blend_a && (p.C % 4) == 0 && (p.ldx % 4) == 0 && (p.ldy % 4) == 0 && aligned16(p.x) && aligned16(p.y) && aligned16(p.scale) &&
+        aligned16(p.shift) && (!p.res || ((p.ldr % 4) == 0 && aligned16(p.res)))) {
+        const long long total4 = total / 4;
+        if (p.res) hipLaunchKernelGGL((bn_act_fwd_vec_kernel<true>), dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, p, total4, p.C / 4);
+        else hipLaunchKernelGGL((bn_act_fwd_vec_kernel<false>), dim3(stream_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, p, total4, p.C / 4);
+        MRFA_CHECK_LAUNCH("bn_act_fwd(vec)");
+        return 0;
+    }
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p, total);
     MRFA_CHECK_LAUNCH("bn_act_fwd");
     return 0;
