@@ -349,41 +349,40 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     for (long long q = wave_id; q < Q; q += nwaves) {
         const float cx = coords[(size_t)q * ldc], cy = coords[(size_t)q * ldc + 1];
         float gx = 0.f, gy = 0.f;
+        const bool active = lane < nwin;
+        // both pyramid levels: tap sets first (branch-free: clamped addresses, zero weights -- see make_taps4), then all eight loads,
+        // then the arithmetic; idle lanes (lane >= nwin) sample far outside and contribute nothing
+        Taps4 tp[2];
+        float l[2][4], g[2];
 #pragma unroll
         for (int lvl = 0; lvl < 2; ++lvl) {
             const int H = Hs >> lvl, W = Ws >> lvl;
-            const float* vol = (lvl == 0 ? vol0 : vol1) + (size_t)q * H * W;
-            float* dvol = BWD ? ((lvl == 0 ? dvol0 : dvol1) + (size_t)q * H * W) : nullptr;
             const float inv = lvl == 0 ? 1.f : 0.5f;
             const float ix = cx * inv + (float)(a - radius), iy = cy * inv + (float)(b - radius);
-            float v = 0.f, dx = 0.f, dy = 0.f;
-            const bool active = lane < nwin;
-            if (active && ix > -1.f && iy > -1.f && ix < (float)W && iy < (float)H) {
-                const Taps tp = make_taps(ix, iy);
-                const bool x0ok = tp.x0 >= 0, x1ok = tp.x0 + 1 < W, y0ok = tp.y0 >= 0, y1ok = tp.y0 + 1 < H;
-                const float v00 = (y0ok && x0ok) ? vol[tp.y0 * W + tp.x0] : 0.f;
-                const float v01 = (y0ok && x1ok) ? vol[tp.y0 * W + tp.x0 + 1] : 0.f;
-                const float v10 = (y1ok && x0ok) ? vol[(tp.y0 + 1) * W + tp.x0] : 0.f;
-                const float v11 = (y1ok && x1ok) ? vol[(tp.y0 + 1) * W + tp.x0 + 1] : 0.f;
-                if (!BWD) {
-                    v = v00 * (1.f - tp.fx) * (1.f - tp.fy) + v01 * tp.fx * (1.f - tp.fy) + v10 * (1.f - tp.fx) * tp.fy + v11 * tp.fx * tp.fy;
-                } else {
-                    const float g = dout[(size_t)q * lddo + lvl * nwin + lane];
-                    if (dvol) {
-                        if (y0ok && x0ok) atomicAdd(dvol + tp.y0 * W + tp.x0, g * (1.f - tp.fx) * (1.f - tp.fy));
-                        if (y0ok && x1ok) atomicAdd(dvol + tp.y0 * W + tp.x0 + 1, g * tp.fx * (1.f - tp.fy));
-                        if (y1ok && x0ok) atomicAdd(dvol + (tp.y0 + 1) * W + tp.x0, g * (1.f - tp.fx) * tp.fy);
-                        if (y1ok && x1ok) atomicAdd(dvol + (tp.y0 + 1) * W + tp.x0 + 1, g * tp.fx * tp.fy);
-                    }
-                    dx = g * ((v01 - v00) * (1.f - tp.fy) + (v11 - v10) * tp.fy) * inv;
-                    dy = g * ((v10 - v00) * (1.f - tp.fx) + (v11 - v01) * tp.fx) * inv;
-                }
-            }
+            tp[lvl] = make_taps4(active ? ix : -2.f, iy, W, H);
+            const float* vol = (lvl == 0 ? vol0 : vol1) + (size_t)q * H * W;
+            l[lvl][0] = vol[tp[lvl].o00]; l[lvl][1] = vol[tp[lvl].o01]; l[lvl][2] = vol[tp[lvl].o10]; l[lvl][3] = vol[tp[lvl].o11];
+            g[lvl] = (BWD && active) ? dout[(size_t)q * lddo + lvl * nwin + lane] : 0.f;
+        }
+#pragma unroll
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            const int H = Hs >> lvl, W = Ws >> lvl;
+            const float inv = lvl == 0 ? 1.f : 0.5f;
+            const Taps4& t = tp[lvl];
+            const float v00 = t.ok00 ? l[lvl][0] : 0.f, v01 = t.ok01 ? l[lvl][1] : 0.f, v10 = t.ok10 ? l[lvl][2] : 0.f, v11 = t.ok11 ? l[lvl][3] : 0.f;
             if (!BWD) {
+                const float v = v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
                 if (active) out[(size_t)q * ldo + lvl * nwin + lane] = v;
             } else {
-                gx += dx;
-                gy += dy;
+                float* dvol = dvol0 ? ((lvl == 0 ? dvol0 : dvol1) + (size_t)q * H * W) : nullptr;
+                if (dvol) {
+                    if (t.ok00) atomicAdd(dvol + t.o00, g[lvl] * t.w00);
+                    if (t.ok01) atomicAdd(dvol + t.o01, g[lvl] * t.w01);
+                    if (t.ok10) atomicAdd(dvol + t.o10, g[lvl] * t.w10);
+                    if (t.ok11) atomicAdd(dvol + t.o11, g[lvl] * t.w11);
+                }
+                gx += g[lvl] * ((v01 - v00) * (1.f - t.fy) + (v11 - v10) * t.fy) * inv;
+                gy += g[lvl] * ((v10 - v00) * (1.f - t.fx) + (v11 - v01) * t.fx) * inv;
             }
         }
         if (BWD && dcoords) {
