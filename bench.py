@@ -107,12 +107,18 @@ def run_inference(a):
     from mrfa_amd.modules import RaftFlow
     from mrfa_amd.train import VOX1
     from mrfa_amd.utils.prng import det_uniform, fill_state_dict
-    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--inference: replicas only (no collective exists on the inference path); run one process per GPU"
+    # replicas only: no collective exists on the inference path.  With --gpus N every rank runs its own replica on its own GPU; the
+    # process group is used for the timing barrier and the max-over-ranks of the elapsed time, nothing else.
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     hip.lib()
     if a.mfma:
         hip.set_mfma_mode(a.mfma)
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://")
+        world = dist.get_world_size()
     B, size = a.batch, a.size
     h = size // 4
     cfg = copy.deepcopy(VOX1["raft_flow"])
@@ -148,16 +154,29 @@ def run_inference(a):
             launch = "hipGraph"
         for _ in range(a.warmup):
             out = step()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             out = step()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
     ms = 1e3 * dt / a.steps
     scale = (size / 256.0) ** 2
     gflop = (scale * (362.73 - 8.59) + 8.59 * scale * scale) * B          # conv FLOPs x (size/256)^2, correlation GEMM x (size/256)^4
     roof = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     if not a.no_roofline:
         ectx = Ctx(dev, train=False, record=False)
         ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -213,15 +232,138 @@ def run_inference(a):
                    "sample": f"1 x (B=1 RaftFlow forward at {size}x{size}) of the CPU oracle in {cdt:.1f}s"}
         except Exception as ex:
             cpu = {"error": repr(ex)}
-    line = {"metric": f"frames/sec ({size}x{size} source+driving pair) inference, generator path", "value": round(B * a.steps / dt, 3), "unit": "pairs/s",
-            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+    line = {"metric": f"frames/sec ({size}x{size} source+driving pair) inference, generator path", "value": round(world * B * a.steps / dt, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("bf16" if hip.mfma_mode() == "bf16" else "f32"), "data": "synthetic",
             "config": {"workload": f"vox1.yaml RaftFlow generator path (encode + correlation + 6-level refinement + warps + decode), {size}x{size}, "
-                                   f"bs={B}, inference only (eval-mode BN, no autograd)", "global_batch": B, "parallelism": "dp1",
+                                   f"bs={B}, inference only (eval-mode BN, no autograd)", "global_batch": world * B,
+                       "parallelism": f"dp{world}" + (" (independent replicas, no collective)" if world > 1 else ""),
                        "launch": launch, "mfma": hip.mfma_mode(), "out_finite": bool(torch.isfinite(out).all()),
                        "memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(line), flush=True)
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks here, the way the reference gets its ranks
+    from torch.distributed.launch (run.py:50-59, train.py:39-48).  This parent NEVER touches the GPU (no HIP call, no
+    torch.cuda.is_available(); device_count() only counts) -- each rank is a fresh child process with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set, rank 0 prints the one JSON line on the inherited stdout.  Any rank failing ends the others
+    and the exit code is non-zero: a run that silently used fewer ranks than asked cannot happen."""
+    import socket
+    import subprocess
+    dry = "--dry" in argv
+    if not dry:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n}: only {have} GPU(s) visible on this node", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()                      # exact children of this process, by handle
+        time.sleep(0.2)
+    return rc
+
+
+DRY_CFG = dict(   # --dry only: the VOX1 wiring at 64 x 64 with shallow hourglasses, small enough for the CPU emulator
+    fomm_kp_detector=dict(block_expansion=8, num_kp=10, num_channels=3, max_features=32, num_blocks=3, temperature=0.1,
+                          scale_factor=0.25, estimate_jacobian=True, estimate_occlusion=False),
+    dense_motion=dict(block_expansion=8, max_features=32, num_blocks=3, scale_factor=0.25, num_kp=10, num_channels=3,
+                      estimate_occlusion_map=True),
+    raft_flow=dict(prior_only=False, num_kp=10, dim=256, size=64,
+                   generator=dict(num_channels=3, block_expansion=64, max_features=512, num_up_blocks=5),
+                   driving_encoder=dict(in_features=10, block_expansion=8, max_features=32, num_blocks=3),
+                   source_encoder=dict(in_features=13, block_expansion=8, max_features=32, num_blocks=3)),
+    train_params=dict(lr=2.0e-4, clip=10.0, prior_model="fomm"))
+
+
+def run_dry(a):
+    """`--dry`: the launcher / rendezvous / exchange / timing / reporting control flow of the data-parallel bench WITHOUT a GPU -- gloo
+    instead of RCCL, CPU tensors, the HIP library replaced by the C-ABI emulator (tests/emu.py -> oracle/capi_emulator.py: test
+    infrastructure, which is why this leg is labelled `"dry": true` and its `value` is not a measurement).  The step is the schedule
+    GraphedTrainStep replays (train.train_step_overlapped: flat gradient buffer, all-reduce ranges, 1/world folded into FlatAdam),
+    issued eagerly on a 64 x 64 miniature of the VOX1 wiring.  Used by tests/test_bench_launcher.py."""
+    import torch.distributed as dist
+    from tests.emu import emulated_hip
+    from mrfa_amd.train import HotPath, make_optimizer, sync_bn_buffers, train_step_overlapped
+    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.set_num_threads(2)
+    if rank == a.dry_fail_rank:
+        sys.exit(7)
+    if world_env > 1:
+        dist.init_process_group(backend="gloo", init_method="env://")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != a.gpus:
+        raise SystemExit(f"[bench] --gpus {a.gpus} but the process group has {world} rank(s)")
+    with emulated_hip():
+        model = HotPath(DRY_CFG, prior="fomm")
+        for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+            mod.load_state_dict(fill_state_dict(mod.state_dict(), tag=pfx))
+        model.train(True)
+        opt = make_optimizer(model, fused=True)
+        B = a.batch
+        src = det_uniform(f"bench/src/r{rank}", (B, 3, 64, 64), 0, 1)
+        drv = det_uniform(f"bench/drv/r{rank}", (B, 3, 64, 64), 0, 1)
+        step = lambda: train_step_overlapped(model, opt, src, drv, world=world)
+        for _ in range(a.warmup):
+            loss = step()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        wsum = opt.flat_w.double().sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ws = [torch.zeros_like(wsum) for _ in range(world)]
+            dist.all_gather(ws, wsum)
+            replicas_equal = all(bool(torch.equal(w, ws[0])) for w in ws)
+            sync_bn_buffers(model)                         # what save_checkpoint does at N > 1: running statistics averaged over the ranks
+            bsum = torch.cat([b.double().flatten() for n_, b in model.named_buffers() if n_.endswith(("running_mean", "running_var"))]).sum().reshape(1)
+            bs = [torch.zeros_like(bsum) for _ in range(world)]
+            dist.all_gather(bs, bsum)
+            buffers_equal = all(bool(torch.equal(b, bs[0])) for b in bs)
+        else:
+            replicas_equal = buffers_equal = True
+        dt = float(tmax.item())
+    line = {"metric": "frames/sec (256x256 source+driving pair) fwd+bwd", "value": None, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "dry": True,
+            "config": {"workload": "DRY RUN (no GPU): 64x64 miniature of the vox1 wiring on CPU through the C-ABI emulator, gloo; checks the "
+                                   "launcher, the rendezvous, the flat gradient exchange and the reporting -- not a measurement",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "launch": "dry", "loss": float(f"{float(loss):.6f}"),
+                       "replicas_equal_after_steps": replicas_equal, "bn_buffers_equal_after_sync": buffers_equal,
+                       "dry_pairs_per_s": round(world * B * a.steps / dt, 3)},
+            "roofline": None, "cpu_baseline": None}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -256,7 +398,29 @@ def main():
                          "(fp32-accurate; default: MRFA_MFMA or the library default)")
     ap.add_argument("--wgrad-stream", action="store_true", help="graph mode: weight-gradient kernels as a parallel graph branch (measured slower)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + clip_grad_norm_ instead of the flat K20 optimizer kernels")
+    ap.add_argument("--allow-eager-fallback", action="store_true",
+                    help="N = 1 only: if the hipGraph capture or its verification fails, time eager launches instead of exiting non-zero "
+                         "(the line then says config.launch = eager)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU: run the multi-rank control flow (launcher, rendezvous, flat gradient exchange, timing, reporting) on CPU "
+                         "with gloo and the C-ABI emulator on a 64x64 miniature; the line carries \"dry\": true and no value")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # launcher test: this rank exits 7 before the rendezvous
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    # ---- ranks.  Under torch.distributed.run (the driver's N > 1 command) WORLD_SIZE is set and must equal --gpus; a bare
+    # `python bench.py --gpus N` starts its N ranks itself, BEFORE anything in this process touches the GPU.
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
+              f"(python bench.py --gpus N, or torch.distributed.run --nproc-per-node N bench.py --gpus N)", file=sys.stderr)
+        sys.exit(2)
+    if a.dry:
+        if a.batch is None:
+            a.batch = 1
+        return run_dry(a)
     if a.batch is None:
         a.batch = 4 if a.inference else 8
     if a.inference:
@@ -275,6 +439,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", init_method="env://")
+        world = dist.get_world_size()                # what RCCL sees, not what the command line says
+        if world != a.gpus:
+            raise SystemExit(f"[bench] --gpus {a.gpus} but the RCCL process group has {world} rank(s)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -325,12 +492,13 @@ def main():
         loss_fn = lambda m_, s_, d_: reference_loss(m_.module if hasattr(m_, "module") else m_, full, s_, d_)
     step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
     launch = "eager"
+    verify_retries = 0
     if use_graph:
         # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
         # (mrfa_amd/graph.py): graph A = pack + fwd + bwd, one flat RCCL all-reduce when N > 1, graph B = clip + Adam
         from mrfa_amd.graph import GraphedTrainStep
         loss = step()
-        ok = 1
+        ok, why = 1, None
         try:
             gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange),
                                      overlap_exchange=(True if a.overlap_exchange else None),
@@ -340,24 +508,27 @@ def main():
                 replay_noise = gstep.verify(loss_tol=ltol)    # replays must agree with each other and with eager passes, or the graph is not used
             except RuntimeError as ex:                # the noise band is a sampled, heavy-tailed quantity: a mis-ordered graph fails
                 print(f"[bench] verify() retry after: {ex}", file=sys.stderr)       # twice, an unlucky sample does not
+                verify_retries = 1
                 replay_noise = gstep.verify(loss_tol=ltol)
-        except Exception as ex:                       # keep the bench alive on a capture problem: eager path
-            print(f"[bench] hipGraph capture failed on rank {rank}: {ex!r}; falling back to eager launches", file=sys.stderr)
-            ok = 0
-        if world > 1:
+        except Exception as ex:
+            ok, why = 0, ex
+        if world > 1:                                 # every rank must know before anybody raises (the others sit in a collective)
             flag = torch.tensor([ok], device=dev)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             ok = int(flag.item())
         if ok:
             step = lambda: gstep(src, drv)
             launch = "hipGraph"
+        elif world > 1 or not a.allow_eager_fallback:
+            # a fallback would time a different program (at N > 1: DDP buckets instead of the flat exchange): fail instead
+            print(f"[bench] hipGraph capture / verification failed on rank {rank}: {why!r}", file=sys.stderr)
+            if world > 1:
+                torch.distributed.destroy_process_group()
+            sys.exit(3)
         else:
+            print(f"[bench] hipGraph capture failed: {why!r}; --allow-eager-fallback: timing eager launches", file=sys.stderr)
             for prm in model.parameters():
                 prm.grad = None
-            if world > 1:                         # (bucket views would unbind FlatAdam's flat .grad views)
-                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
-                                                                  broadcast_buffers=False, gradient_as_bucket_view=not fused)
-                step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
 
     for _ in range(a.warmup):
         loss = step()
@@ -520,7 +691,10 @@ def main():
                                    ("surrogate L1 loss" if a.loss == "surrogate" else
                                     "the reference's generator losses (VGG19 perceptual pyramid on random-init weights + equivariance, 3 encoder passes)"),
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "background_predictor": bool(a.background), "sync_bn": bool(a.sync_bn), "launch": launch,
-                       "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}")},
+                       "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}"),
+                       "verify_retries": verify_retries,
+                       "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; running buffers are averaged over the ranks "
+                                         "when a checkpoint is written (train.sync_bn_buffers)")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt, "bf16x3_path": alt3,
         }
     else:

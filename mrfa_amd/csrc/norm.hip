@@ -497,6 +497,7 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     MRFA_CHECK_ARG(p.x && p.dy && p.scale && p.shift && p.red, "bn_act_bwd: null pointer");
     MRFA_CHECK_ARG(!p.train || (p.mean && p.invstd && p.gamma), "bn_act_bwd: train mode needs mean/invstd/gamma");
     MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)) && !(p.dres && !p.res), "bn_act_bwd: residual excludes pool and blend");
+    MRFA_CHECK_ARG(!(p.pool && p.blend_a), "bn_act_bwd: pool and blend are exclusive (one compile-time MODE per launch)");
     const long long rows = (long long)p.N * p.H * p.W;
     const int chunks = cdiv(p.C, CH);
     const int rpb = pick_rows_per_block(rows, chunks, p.C);

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __res
         sample_coords(grid, ldg, opix, ox, oy, Wi, Hi, mode, ix, iy);
         const Taps4 tp = make_taps4(ix, iy, Wi, Hi);
         const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
-        const float v = tp.w00 * base[tp.o00 * ldi] + tp.w01 * base[tp.o01 * ldi] + tp.w10 * base[tp.o10 * ldi] + tp.w11 * base[tp.o11 * ldi];
+        // taps that do not exist read a clamped (valid) address and are SELECTED away, not multiplied by 0: a non-finite value
+        // at the clamped pixel must not leak into a zero-padded output (0 * inf = NaN)
+        const float l00 = base[tp.o00 * ldi], l01 = base[tp.o01 * ldi], l10 = base[tp.o10 * ldi], l11 = base[tp.o11 * ldi];
+        const float v = tp.w00 * (tp.ok00 ? l00 : 0.f) + tp.w01 * (tp.ok01 ? l01 : 0.f) + tp.w10 * (tp.ok10 ? l10 : 0.f) + tp.w11 * (tp.ok11 ? l11 : 0.f);
         out[(size_t)opix * ldo + c] = v;
     }
 }
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256) void grid_sample_fwd_vec_kernel(const float* _
         const float* base = in + (size_t)(n / in_rep) * in_bstride + c;
         const f32x4 t00 = *reinterpret_cast<const f32x4*>(base + tp.o00 * ldi), t01 = *reinterpret_cast<const f32x4*>(base + tp.o01 * ldi);
         const f32x4 t10 = *reinterpret_cast<const f32x4*>(base + tp.o10 * ldi), t11 = *reinterpret_cast<const f32x4*>(base + tp.o11 * ldi);
-        const f32x4 v = tp.w00 * t00 + tp.w01 * t01 + tp.w10 * t10 + tp.w11 * t11;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = tp.w00 * (tp.ok00 ? t00 : z) + tp.w01 * (tp.ok01 ? t01 : z) + tp.w10 * (tp.ok10 ? t10 : z) + tp.w11 * (tp.ok11 ? t11 : z);
         *reinterpret_cast<f32x4*>(out + (size_t)opix * ldo + c) = v;
     }
 }

@@ -50,11 +50,21 @@ class DeferredWgrads:
 
     def __init__(self):
         self.thunks: List[Callable[[], None]] = []
+        self.kept: Optional[List[Callable[[], None]]] = None
         self.stream: Optional["torch.cuda.Stream"] = None
         self.flushed = False
 
     def add(self, fn: Callable[[], None]):
         self.thunks.append(fn)
+
+    def reset(self):
+        """start of a step: drop whatever an aborted previous step left behind (a backward that raised between the decoder and the join
+        would otherwise have its stale weight-gradient / un-pack thunks flushed into the NEXT step's freshly zeroed .grad)"""
+        if self.flushed and self.stream is not None:
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)      # launches already issued finish first
+        self.thunks, self.kept, self.flushed = [], None, False
+        if self in _PENDING_DEFERRED:
+            _PENDING_DEFERRED.remove(self)
 
     def flush(self, dev: torch.device):
         """issue everything collected so far on the side stream, ordered after the current stream"""
@@ -1005,7 +1015,12 @@ class Ctx:
         if train and stats is not None:
             world = self._sync_world(bn)
             if world > 1:
-                torch.distributed.all_reduce(stats)          # sum / sum-of-squares over every rank's pixels
+                # sum / sum-of-squares over every rank's pixels: the slots are summed locally first, so the message is 2C doubles,
+                # not [STATS_SLOTS][2C] (bn_finalize sums the slots: slot 0 = the global sums, the others zero)
+                local = stats.view(hip.STATS_SLOTS, 2 * Cn).sum(0)
+                stats.zero_()
+                stats[:2 * Cn] = local
+                torch.distributed.all_reduce(stats[:2 * Cn])
                 count = count * world
         defer = train and self.deferred is not None            # side pass: the running statistics are updated after the join
         self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
@@ -1199,6 +1214,10 @@ class Ctx:
         kc, pc = self._cf(kp), self._cf(pos)
         B, K = kc.shape[0], kc.shape[1]
         assert out.C == K and out.N == B
+        if pc is not None and tuple(pc.shape[-3:]) != (K, out.H, out.W):
+            # the kernel indexes pos[(k*H + y)*W + x] with the OUTPUT's H, W (and the backward adds into dpos the same way); the reference
+            # raises a broadcast error here (raft.py:177-178 with a `size` that does not match the input resolution)
+            raise RuntimeError(f"kp_gaussian: pos_embedding {tuple(pc.shape)} does not match the heat-map view (.., {K}, {out.H}, {out.W})")
         self._chk(self.L.mrfa_kp_gaussian_fwd(self.s, kc.data_ptr(), pc.data_ptr() if pc is not None else None, B, K, out.H, out.W,
                                               float(variance), out.ptr, out.ld), "kp_gaussian_fwd")
         if self.record:

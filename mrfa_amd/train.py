@@ -131,6 +131,7 @@ class HotPath(nn.Module):
         from . import engine
         defer = self._wdefer if (self.defer_decoder_wgrads and self.training and torch.is_grad_enabled()) else None
         if defer is not None:
+            defer.reset()                  # nothing of an earlier (possibly aborted) step may reach this step's gradients
             object.__setattr__(self, "_wdefer_dev", source.device)
         with engine.defer_wgrads(defer):
             img_down = self.down(source)
@@ -316,6 +317,32 @@ def train_step_overlapped(model, optimizer, source, driving, world: int = 1):
     return loss.detach()
 
 
+def sync_bn_buffers(model) -> int:
+    """Data-parallel runs WITHOUT SyncBatchNorm (the hipGraph step: per-rank batch statistics, `broadcast_buffers=False`) let every
+    rank's BatchNorm running_mean / running_var drift apart: each is an exponential average over that rank's own batches.  Before a
+    checkpoint is written they are averaged over the ranks -- ONE all-reduce of all floating-point buffers flattened together -- so that
+    the file does not depend on which rank wrote it (for equal per-rank batch sizes the mean of the per-rank running means IS the
+    running mean over the global batches; the running variances average the within-rank variances, which is what
+    DistributedDataParallel(broadcast_buffers=True) without SyncBatchNorm would keep from rank 0 only).  No-op without a process
+    group / with one rank; with SyncBatchNorm (reference train.py:43) the buffers are already identical.  Returns the element count."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    m = model.module if hasattr(model, "module") else model
+    bufs = [b for n, b in m.named_buffers() if b.is_floating_point() and n.endswith(("running_mean", "running_var"))]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat)
+    flat.mul_(1.0 / dist.get_world_size())
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    return off
+
+
 def save_checkpoint(path: str, model, optimizer, epoch: int):
     """The reference's checkpoint file (logger.py:50-58, train.py:94): {'model': state_dict with DDP's 'module.' prefix,
     'optimizer': optimizer.state_dict(), 'epoch': int} -- readable by the reference's Logger.load_cpk and by load_checkpoint.
@@ -323,6 +350,10 @@ def save_checkpoint(path: str, model, optimizer, epoch: int):
     tests/golden/state_dict_manifest.json['MRFA']); a HotPath writes the networks only (no loss modules: the reference's strict
     loader then reports the missing `pyramid.*` / `vgg.*` keys, as it would for any file without them)."""
     m = model.module if hasattr(model, "module") else model
+    sync_bn_buffers(m)            # N > 1 without SyncBatchNorm: a collective -- every rank calls save_checkpoint, rank 0 writes the file
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return
     sd = {"module." + k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     torch.save({"model": sd, "optimizer": optimizer.state_dict(), "epoch": int(epoch)}, path)
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One PMC pass per counter over an eager training step (kernel-trace only), per-kernel means -> gpurun_out/pmc_step/<COUNTER>.csv
 #   bash tools/pmc_step.sh TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD ...
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_step; mkdir -p $O
+set -u; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/pmc_step; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
   rm -rf /tmp/ps_$c

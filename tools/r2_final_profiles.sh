@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 evidence run on one MI355X box (gpurun): tests, bench lines of every configuration, rocprofv3 kernel statistics and PMC
 # traffic passes.  Everything lands in gpurun_out/r2final/ (copied to profiles/ afterwards).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2final; mkdir -p $O
+set -u; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r2final; mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; tail -2 $O/gputest.log
 python bench.py --steps 10 --warmup 3 > $O/bench_default.log 2>&1
