@@ -640,14 +640,23 @@ def main():
             nprod = {"bf16x3": 3, "bf16": 1}.get(hip.mfma_mode(), 6)
             # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel, bit 2 = bf16x6 split-operand kernel)
             dom = (128 << 16) | (128 << 4) | (4 if split else 0)
-            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if (cfg & ~1) == dom]
+            HALO = 1 << 28                            # mrfa_conv2d_last_config bit 28: the patch-tiled 3x3 kernel (conv_halo.hip)
+            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0 and (cfg & HALO)]
+            row_tiled = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if (cfg & ~1) == dom]
+            dom_name = "conv_halo_kernel (3x3 patch-tiled split-operand tile, all variants: fwd + dgrad launches)"
+            if not sel:                               # --mfma f32 / bf16, MRFA_CONV_HALO=0: the row-tiled 128x128 tile is the dominant kernel
+                sel, dom_name = row_tiled, None
             allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0]
             if sel:
                 fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
                 achieved = fl / (ms * 1e-3) / 1e12
                 traffic, tsrc = None, None
                 try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-                    if split:                         # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
+                    if dom_name:                      # the patch-tiled kernel: round-3 PMC passes (launch-weighted mean over its variants)
+                        tsrc = "profiles/r3_traffic.json"
+                        with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as tf:
+                            tj = json.load(tf)["kernels"]["conv_halo_kernel"]
+                    elif split:                       # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
                         tsrc = "profiles/r2_traffic.json"
                         with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as tf:
                             tj = json.load(tf)["kernels"]["conv_bf16x6_kernel<false, true, 128, 6>"]
@@ -666,8 +675,11 @@ def main():
                         "peak_is": (f"bf16 dense MFMA peak 2500 / {nprod} split products (fp32-equivalent FLOPs)" if split
                                     else "fp32 dense MFMA peak"),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "kernel": ("conv_bf16x6_kernel 128x128 (fwd + dgrad launches)" if split
-                                   else "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)"),
+                        "kernel": dom_name or ("conv_bf16x6_kernel 128x128 (fwd + dgrad launches)" if split
+                                               else "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)"),
+                        "row_tiled_128x128": ({"launches_per_step": len(row_tiled) / nprof, "kernel_ms_per_step": round(sum(t for _, t in row_tiled) / nprof, 2),
+                                               "tflops": round(sum(f for f, _ in row_tiled) / max(sum(t for _, t in row_tiled), 1e-9) / 1e9, 2)}
+                                              if (dom_name and row_tiled) else None),
                         "launches_per_step": len(sel) / nprof, "avg_launch_ms": round(ms / len(sel), 4),
                         "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
                         "kernel_ms_per_step": round(ms / nprof, 2),

@@ -84,8 +84,17 @@ int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
  *      tiles", BASELINE config 4); bf16-autocast accuracy (2^-9 operand error), opt-in                              */
 int mrfa_set_mfma_mode(int mode);
 int mrfa_get_mfma_mode(void);
-/* (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) chosen by the most recent call on this thread (for roofline accounting) */
+/* (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) chosen by the most recent call on this thread (for roofline accounting);
+ * bit 2: split-operand kernel, bit 3: small-problem kernel, bit 28: patch-tiled 3x3 kernel (conv_halo.hip)                       */
 int mrfa_conv2d_last_config(void);
+/* Kernel-selection knobs (process-wide; tests and tuning -- the defaults are the measured choices).  Returns the previous value,
+ * -1 for an unknown key.  Keys:
+ *   "conv_halo"            1 / 0: patch-tiled 3x3 kernel on / off (default 1; also MRFA_CONV_HALO=0 in the environment)
+ *   "conv_halo_min_tiles"  fewest workgroups for which the patch-tiled kernel is chosen (default 256 = one per CU)
+ *   "conv_halo_pr"         0 = patch height by workgroup count (default), 4 / 8 = forced
+ *   "conv_halo_bn256"      1 / 0: 256-channel workgroup tiles where Cout pads to 256 anyway (default 1)
+ *   "conv_small"           1 / 0: one-wave-per-tile small-problem kernels on / off (default 1)                                    */
+int mrfa_set_tuning(const char* key, int value);
 
 /* weight-gradient (and TN GEMM): dW[tap][co][ci] += sum_p dY[p][co] * X'[p + tap][ci]   (X' = prologue(ups(x)))
  * Replaces the weight-gradient half of conv2d backward for every call site above, and d(k_s) of raft.py:185.    */

@@ -12,6 +12,10 @@ void mrfa_set_error(const char* fmt, ...);
 
 // conv_split.hip: the 128 x 128 chunked implicit-GEMM tile on the bf16 matrix pipe with exactly split fp32 operands
 int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, int splitk, int BN);
+// conv_halo.hip: 3x3 stride-1 convolutions tiled over 2-D output patches, the input halo split once per channel chunk (same arithmetic)
+bool mrfa_conv_halo_eligible(const mrfa_conv_params& p);
+int mrfa_conv_halo_launch(hipStream_t st, const mrfa_conv_params& p);
+int mrfa_tuning_conv_small();      // mrfa_set_tuning("conv_small", 0 / 1)
 // wgrad_split.hip: the 128 x 128 chunked, row-aligned weight-gradient tile in the same arithmetic
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
                             int total_splits, int taps, long long partial_stride, int BM, int BN);

@@ -361,9 +361,14 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
 
     // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
-    if (small_on && mrfa_conv_small_eligible(p, M)) {
+    if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
         return mrfa_conv_small_launch(st, p, M);
+    }
+    // ---- 3x3 stride-1 layers with 32-aligned rows in split-operand mode: patch-tiled kernel, input halo split once per chunk (conv_halo.hip)
+    if (!flat && mrfa_conv_halo_eligible(p)) {
+        g_last_tile = (128 << 16) | ((p.Cout <= 64 ? 64 : 128) << 4) | 4 | (1 << 28);       // bit 28: conv_halo
+        return mrfa_conv_halo_launch(st, p);
     }
     // ---- tile selection: largest BN whose padding waste is small, then BM by how many workgroups result
     int BN = 128;

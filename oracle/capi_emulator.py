@@ -354,6 +354,10 @@ class Emulator:
         self._mfma = mode            # the specification is the same fp32 convolution in every mode
         return 0
 
+    def mrfa_set_tuning(self, key, value):
+        """kernel-selection knobs change which kernel runs, never the result: nothing to emulate"""
+        return 0
+
     def mrfa_get_mfma_mode(self):
         return getattr(self, "_mfma", 0)
 

@@ -214,6 +214,88 @@ def test_conv2d_split_operand_mode(name, wsplit):
     assert_close(ref, got, what="split " + name)
 
 
+HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0; every epilogue / prologue option, both patch heights, tails
+    "pr8_c64_to_128": dict(N=2, H=16, W=32, Cin=64, Cout=128),
+    "pr8_pro_res_stats": dict(N=1, H=24, W=64, Cin=96, Cout=256, pro=True, res=True, stats=True, relu=False),
+    "pr4_tail_rows": dict(N=2, H=10, W=32, Cin=32, Cout=130, relu=True),              # H % 8 != 0 -> 4-row patches, last patch half empty
+    "pr8_ups": dict(N=1, H=8, W=16, Cin=128, Cout=64, ups=1, stats=True),           # BN = 64, fused nearest x2
+    "pr8_bn64_acc_alpha": dict(N=3, H=8, W=32, Cin=96, Cout=50, acc=True, alpha=0.37, relu=False, bias=False),
+    "pr8_affine_c32": dict(N=1, H=8, W=32, Cin=32, Cout=96, oaff=True),             # two 16-channel chunks (chunked mode: Cin % 32 == 0)
+    "pr8_wide_ld": dict(N=1, H=16, W=96, Cin=64, Cout=128, ldx_extra=8, ldy_extra=12),
+    "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True),                 # 256-wide workgroup tile, 64 padding columns
+    "bn256_c512_stats": dict(N=1, H=8, W=32, Cin=32, Cout=512, stats=True, relu=False, bias=False),
+    "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=256),   # chosen by the default heuristic
+}
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", list(HALO_CASES))
+def test_conv2d_patch_tiled_kernel(name, mode):
+    """conv_halo.hip (2-D output patches, the input halo split once per 16-channel chunk) against the CPU specification, in the
+    six-product (fp32-accurate) and the three-product mode"""
+    L = hip.lib()
+    kw = dict(HALO_CASES[name])
+    min_tiles = kw.pop("min_tiles", 1)
+    ref = conv_case(Side(False), tag=f"halo/{name}", **kw)
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", min_tiles)
+    L.mrfa_set_tuning(b"conv_small", 0)                     # (the small test shapes would otherwise go to conv_small.hip)
+    try:
+        got = conv_case(Side(True), tag=f"halo/{name}", wsplit=True, **kw)
+        assert L.mrfa_conv2d_last_config() & (1 << 28), "the patch-tiled kernel did not run"
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
+        L.mrfa_set_tuning(b"conv_small", 1)
+    assert_close(ref, got, tol=2e-4 if mode == 1 else 2e-3, what="halo " + name)
+
+
+def test_patch_tiled_kernel_equals_the_row_tiled_kernel_and_fp64():
+    """same arithmetic as conv_split.hip (exact three-way split, six products, fp32 accumulate): against fp64 the two kernels must be
+    equally accurate on wide-dynamic-range operands"""
+    L = hip.lib()
+    N, H, W, Cin, Cout = 1, 32, 32, 256, 128
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64) * torch.exp(2.0 * torch.randn(N, H, W, Cin, generator=g, dtype=torch.float64))).float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) * 0.05).float()
+    exact = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    side = Side(True)
+    xd, wd = x.reshape(-1, Cin).to(side.dev).contiguous(), w.to(side.dev)
+    wp = pack(side, wd, 0)
+    piece = 9 * 128 * Cin
+    wsb = torch.zeros(3 * piece, dtype=torch.int16, device=side.dev)
+    d = hip.PackDesc()
+    d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = wd.data_ptr(), Cout, Cin, 3, 3, 1
+    d.dst[0], d.mode[0] = wsb.data_ptr(), 8
+    side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
+    errs = {}
+    assert L.mrfa_set_mfma_mode(1) == 0
+    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 1)
+    L.mrfa_set_tuning(b"conv_small", 0)
+    try:
+        for halo in (0, 1):
+            L.mrfa_set_tuning(b"conv_halo", halo)
+            y = side.garbage((N * H * W, Cout))
+            p = hip.ConvParams()
+            p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = xd.data_ptr(), Cin, H, W, 0, N, Cin
+            p.w, p.w_ld, p.w_tap, p.kflat, p.w_rows = wp.data_ptr(), Cin, 128 * Cin, 0, 128
+            p.w_split, p.w_piece = wsb.data_ptr(), piece
+            p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), Cout, Cout, H, W
+            p.R, p.S, p.pad, p.alpha, p.nbatch, p.splitk = 3, 3, 1, 1.0, 1, 1
+            side.call("mrfa_conv2d_nhwc", C.byref(p))
+            assert bool(L.mrfa_conv2d_last_config() & (1 << 28)) == bool(halo)
+            torch.cuda.synchronize()
+            dlt = (y.double().cpu() - exact)
+            errs[halo] = (float(dlt.abs().max()), float(dlt.pow(2).mean().sqrt()))
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"conv_halo", 1)
+        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
+        L.mrfa_set_tuning(b"conv_small", 1)
+    scale = float(exact.abs().max())
+    assert errs[1][0] <= max(2.0 * errs[0][0], 1e-6 * scale) and errs[1][1] <= max(2.0 * errs[0][1], 1e-7 * scale), (errs, scale)
+
+
 def test_split_operand_mode_is_fp32_accurate():
     """error against an fp64 convolution: the bf16x6 kernel must be as accurate as the native fp32 MFMA kernel (K = 2304
     products per output, operands with a wide dynamic range so that all three bf16 pieces matter)"""

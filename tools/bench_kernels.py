@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--mfma", type=int, default=0, help="mrfa_set_mfma_mode: 0 native fp32 MFMA, 1 bf16x6 split-operand kernel")
     ap.add_argument("--tile", type=lambda v: int(v, 0), default=0, help="force mrfa_conv_params.tile, e.g. 0x808080 = 128x128 8-wave")
+    ap.add_argument("--ab-halo", action="store_true", help="3x3 layers: forward / dgrad with the patch-tiled kernel (conv_halo.hip) off and on")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import mrfa_amd.engine as eng
@@ -53,6 +54,10 @@ def main():
         ("gen.up4 128->64 3x3 ups @128->256", 128, 64, 3, 128, 1),
         ("gen.res 128->128 3x3 @128", 128, 128, 3, 128, 0),
         ("gen.chan 512->256 3x3 @64", 512, 256, 3, 64, 0),
+        ("refine heads fused 256->256 3x3 @256", 256, 256, 3, 256, 0),
+        ("refine heads fused 256->256 3x3 @128", 256, 256, 3, 128, 0),
+        ("gen.res 256->256 3x3 @64", 256, 256, 3, 64, 0),
+        ("gen.up 256->128 3x3 ups @64->128", 256, 128, 3, 64, 1),
         ("gen 512->512 3x3 @32", 512, 512, 3, 32, 0),
         ("gen 512->512 3x3 @8", 512, 512, 3, 8, 0),
         ("hg 1024->1024 3x3 @4", 1024, 1024, 3, 4, 0),
@@ -100,6 +105,22 @@ def main():
         t_w = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True), iters=a.iters)
         cw.dw_acc = None
         tf = lambda t: flops / t / 1e9
+        if a.ab_halo and k == 3:
+            L = _hip.lib()
+            res_ab = []
+            for on in (0, 8, 9, 0, 8, 9):                      # off, 8-row patches with <= 128-wide tiles, 8-row patches with 256-wide tiles allowed
+                L.mrfa_set_tuning(b"conv_halo", int(on > 0))
+                L.mrfa_set_tuning(b"conv_halo_bn256", int(on == 9))
+                tf_ = time_it(lambda: e.conv(x, conv, out=out, relu=True, ups=bool(ups)), iters=a.iters)
+                used = bool(L.mrfa_conv2d_last_config() & (1 << 28))
+                td_ = time_it(lambda: e._conv_dgrad(x, cw, out, bool(ups), None), iters=a.iters)
+                used_d = bool(L.mrfa_conv2d_last_config() & (1 << 28))
+                res_ab.append((f"{on}{'*' if used else ' '}{'*' if used_d else ' '}", used, tf_, td_))
+            L.mrfa_set_tuning(b"conv_halo", 1)
+            L.mrfa_set_tuning(b"conv_halo_bn256", 1)
+            print(f"{name:42s} " + " ".join(f"h={on} f {tf(tf_):5.1f} d {tf(td_):5.1f} |"
+                                             for on, used, tf_, td_ in res_ab), flush=True)
+            continue
         print(f"{name:42s} {t_f:8.3f} {tf(t_f):7.1f} {100*tf(t_f)/PEAK_TF:5.1f} | {t_d:8.3f} {tf(t_d):7.1f} | {t_w:8.3f} {tf(t_w):7.1f}", flush=True)
     if a.only:
         return
