@@ -93,6 +93,8 @@ int mrfa_conv2d_last_config(void);
  *   "conv_halo_min_tiles"  fewest workgroups for which the patch-tiled kernel is chosen (default 256 = one per CU)
  *   "conv_halo_pr"         0 = patch height by workgroup count (default), 4 / 8 = forced
  *   "conv_halo_bn256"      1 / 0: 256-channel workgroup tiles where Cout pads to 256 anyway (default 1)
+ *   "wgrad_halo"           1 / 0: all-taps weight-gradient kernel of the 3x3 layers on / off (default 1; MRFA_WGRAD_HALO=0)
+ *   "wgrad_halo_min_wgs"   fewest workgroups for which that kernel is chosen (default 192)
  *   "conv_small"           1 / 0: one-wave-per-tile small-problem kernels on / off (default 1)                                    */
 int mrfa_set_tuning(const char* key, int value);
 

@@ -20,6 +20,12 @@ int mrfa_tuning_conv_small();      // mrfa_set_tuning("conv_small", 0 / 1)
 int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 grid, long long M, long long kps, int tiles_n, int nsplit, int inner,
                             int total_splits, int taps, long long partial_stride, int BM, int BN);
 
+// wgrad_halo.hip: weight gradient of the 3x3 stride-1 layers, all nine taps from one staging of X / dY (transposing LDS reads)
+bool mrfa_wgrad_halo_eligible(const mrfa_wgrad_params& p);
+int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p);
+int mrfa_tuning_wgrad_halo_min(int set);   // mrfa_set_tuning("wgrad_halo_min_wgs", n)
+int mrfa_tuning_wgrad_halo(int set);       // mrfa_set_tuning("wgrad_halo", 0 / 1); set < 0: query
+
 // conv_small.hip: one wave per 16..32-row output tile, operands straight from L1/L2 into v_mfma_f32_16x16x4_f32 (small problems)
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M);
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M);

@@ -398,6 +398,8 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_halo_min_tiles")) { const int prev = g_halo_min_tiles; g_halo_min_tiles = value; return prev; }
     if (!strcmp(key, "conv_halo_bn256")) { const int prev = g_halo_bn256; g_halo_bn256 = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_pr")) { const int prev = g_halo_pr; g_halo_pr = value; return prev; }
+    if (!strcmp(key, "wgrad_halo")) return mrfa_tuning_wgrad_halo(value != 0);
+    if (!strcmp(key, "wgrad_halo_min_wgs")) return mrfa_tuning_wgrad_halo_min(value);
     if (!strcmp(key, "conv_small")) { const int prev = g_conv_small; g_conv_small = value != 0; return prev; }
     return -1;
 }

@@ -1,0 +1,373 @@
+// Weight gradient of the 3x3 stride-1 "same" convolutions on the bf16 matrix pipe with exactly split fp32 operands (the
+// arithmetic of wgrad_split.hip), ALL NINE TAPS from one staging of the operands:
+//
+//   dW[tap (r,s)][co][ci] += alpha * sum_{n,y,x} dY[n,y,x][co] * X'[n, y+r-1, x+s-1][ci]          X' = prologue(ups(x)), zero outside
+//
+// Why: wgrad_bf16x6_kernel computes one tap per workgroup, so every activation and every output gradient is loaded, transposed in
+// registers, split into its three bf16 pieces and stored to LDS nine times per (co, ci) tile: SQ_INSTS_VALU / MFMA = 6.1
+// (profiles/r2_pmc_SQ_*), well above the ~5 instructions a wave can issue for free per 32-cycle MFMA.
+//
+// Here a workgroup (8 waves) owns a 32-pixel-wide column segment of one image, one (BCO x BCI) block of the weights and all nine
+// taps, and walks down the segment one 32-pixel row strip at a time:
+//   * per strip ONE new row of X' (34 pixels x BCI channels) and one row of dY (32 x BCO) are loaded (full 128-byte lines),
+//     prologue'd, split and stored to LDS -- X' rows live in a 4-slot ring (rows y-1, y, y+1 in use, y+2 arriving), dY in two
+//     buffers; every staged element feeds 9 (X') / 9 x BCI/32 ... MFMA tiles instead of one.
+//   * LDS images stay PIXEL-major ([32-channel block][pixel][64 B]), i.e. exactly what the coalesced loads produce, and the
+//     K-major MFMA fragments (8 consecutive pixels of one channel per lane) are formed by ds_read_b64_tr_b16, the gfx950
+//     transposing LDS read: within a 16-lane group lane l supplies the address of (row l / 4, columns 4 (l % 4) ..) of a
+//     [4 pixel][16 channel] block and receives column l of it (probed: tools/ubench/probe_tr.hip).  A tap (r, s) is then a ring
+//     slot (r) plus a constant 64 * s byte offset -- no re-staging, no unaligned access.
+//   * wave (c, b) accumulates the nine 32 (co) x 32 (ci) tap tiles of co block c and ci block b: 144 accumulator registers, one
+//     dY fragment per k16 step serves all nine taps.  Per k16 step and wave: 60 transposing reads + 54 MFMAs.
+//   * the accumulators leave through fp32 atomics into dW[tap][Cout][Cin] once per workgroup (pixel-range split as in
+//     wgrad_split.hip), the bias gradient from the staged dY values.
+// Used when the conv is 3x3 / pad 1 / stride 1 with Wout % 32 == 0 and Cin % 32 == 0; everything else stays on wgrad_split.hip.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
+
+constexpr int NT = 512;
+constexpr int XPIX = 34;                       // 32 pixels of the strip + one halo pixel on either side
+constexpr int XBLK = XPIX * 64;                // one 32-channel block of an X' row: [34 pixels][32 bf16]
+constexpr int DYBLK = 32 * 64;                 // one 32-channel block of a dY row
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float chop_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float a = x[2 * q], b = x[2 * q + 1];
+        p1[q] = pack_hi16(a, b);
+        const float ra = chop_rest(a), rb = chop_rest(b);
+        p2[q] = pack_hi16(ra, rb);
+        p3[q] = pack_hi16(chop_rest(ra), chop_rest(rb));
+    }
+}
+
+// transposing fragment read: rows (pixels) k0 .. k0+7 of this lane's channel column as one MFMA operand (two b64 reads)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + 4 * 64));
+    bf16x8 r;
+    __builtin_memcpy(&r, &lo, 8);
+    __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &hi, 8);
+    return r;
+}
+
+// NBO x NBI = 8 waves: BCO = 32 NBO output channels x BCI = 32 NBI input channels per workgroup
+template <int NBO, int NBI, bool PRO, int NP>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_halo_kernel(const mrfa_wgrad_params p, const int tiles_ci,
+                                                                                               const int ntiles, const int HS, const int segs_y,
+                                                                                               const int tiles_x, const int total) {
+    static_assert(NBO * NBI == 8, "8 waves");
+    constexpr int NPC = NP == 6 ? 3 : 2;
+    constexpr int XROW = NPC * NBI * XBLK;         // one ring slot: [piece][block][34 pixels][64 B]
+    constexpr int DYROW = NPC * NBO * DYBLK;       // one dY buffer:  [piece][block][32 pixels][64 B]
+    constexpr int NDY = NBO * 256 / NT;            // float4 units per thread: dY row (32 pixels x NBO x 8 quads)
+    constexpr int NXU = NBI * XPIX * 8;            // units of an X' row
+    constexpr int NX = (NXU + NT - 1) / NT;
+    static_assert(NBO * 256 % NT == 0, "dY units fill whole rounds");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XROW + 2 * DYROW];
+    unsigned char* const smX = smem;
+    unsigned char* const smD = smem + 4 * XROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / NBI, wb = wave % NBI;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // the tiles of one segment share an XCD's L2
+    if (lin >= total) return;
+    const int tile = lin % ntiles;
+    int sg = lin / ntiles;
+    const int ys = sg % segs_y;
+    sg /= segs_y;
+    const int xt = sg % tiles_x;
+    const int n_img = sg / tiles_x;
+    const int tile_co = tile / tiles_ci, tile_ci = tile - tile_co * tiles_ci;
+    const int co0 = tile_co * (32 * NBO), ci0 = tile_ci * (32 * NBI);
+    const int y0 = ys * HS, y1 = min(p.Hout, y0 + HS), x0 = xt * 32;
+
+    const float* __restrict__ x = p.x;
+    const float* __restrict__ dy = p.dy;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    // ---- staging units of this thread.  dY: unit u = blk * 256 + px * 8 + quad;  X': u = blk * 272 + hp * 8 + quad
+    int d_goff[NDY], d_loff[NDY], d_nval[NDY];
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+        const int u = tid + j * NT;
+        const int blk = u >> 8, px = (u >> 3) & 31, quad = u & 7;
+        const int ch = co0 + blk * 32 + quad * 4;
+        d_nval[j] = min(max(p.Cout - ch, 0), 4);                  // ragged Cout (126): the quad's tail channels belong to somebody else
+        d_goff[j] = ((n_img * p.Hout) * p.Wout + x0 + px) * p.ldy + (d_nval[j] > 0 ? ch : co0);
+        d_loff[j] = blk * DYBLK + px * 64 + quad * 8;
+    }
+    int x_goff[NX], x_loff[NX];
+    bool x_ok[NX], x_val[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int u = tid + j * NT;
+        x_val[j] = u < NXU;
+        const int uu = x_val[j] ? u : 0;
+        const int blk = uu / (XPIX * 8), rem = uu - blk * (XPIX * 8);
+        const int hp = rem >> 3, quad = rem & 7;
+        const int ix = x0 - 1 + hp;
+        const int ch = ci0 + blk * 32 + quad * 4;
+        x_ok[j] = x_val[j] && (unsigned)ix < (unsigned)Wv && ch < p.Cin;          // (Cin % 32 == 0: whole quads)
+        x_goff[j] = (n_img * p.Hin * p.Win + (x_ok[j] ? (ix >> p.ups) : 0)) * p.ldx + (x_ok[j] ? ch : ci0);
+        x_loff[j] = blk * XBLK + hp * 64 + quad * 8;
+    }
+    f32x4 psc[NX], psh[NX];
+    if constexpr (PRO) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int ch = x_goff[j] - (x_goff[j] / p.ldx) * p.ldx;            // channel of this unit (valid address even when masked)
+            psc[j] = *reinterpret_cast<const f32x4*>(p.in_scale + ch);
+            psh[j] = *reinterpret_cast<const f32x4*>(p.in_shift + ch);
+        }
+    }
+
+    f32x4 rd[NDY], rx[NX];
+    f32x4 bsum[NDY];
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) bsum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (p.dbias != nullptr) && tile_ci == 0;
+
+    // rows: iy = input (virtual) row of X', oy = output row of dY; out-of-image X' rows are zero, loads of rows outside the image or the
+    // segment read a clamped (valid) row and are masked / never used
+    auto load_x = [&](int iy) {
+        const int yc = min(max(iy, 0), Hv - 1) >> p.ups;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) rx[j] = *reinterpret_cast<const f32x4*>(x + (size_t)x_goff[j] + (size_t)yc * p.Win * p.ldx);
+    };
+    auto store_x = [&](int iy) {
+        const bool row_ok = (unsigned)iy < (unsigned)Hv;
+        unsigned char* dst = smX + ((iy + 1) & 3) * XROW;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            f32x4 v = rx[j];
+            if constexpr (PRO) {
+                v = v * psc[j] + psh[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v = (row_ok && x_ok[j]) ? v : z;
+            u32x2 p1, p2, p3;
+            split3(v, p1, p2, p3);
+            if (x_val[j]) {
+                *reinterpret_cast<u32x2*>(dst + x_loff[j]) = p1;
+                *reinterpret_cast<u32x2*>(dst + NBI * XBLK + x_loff[j]) = p2;
+                if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * NBI * XBLK + x_loff[j]) = p3;
+            }
+        }
+    };
+    auto load_d = [&](int oy) {
+        const int yc = min(oy, p.Hout - 1);
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) rd[j] = *reinterpret_cast<const f32x4*>(dy + (size_t)d_goff[j] + (size_t)yc * p.Wout * p.ldy);
+    };
+    auto store_d = [&](int oy) {
+        const bool row_ok = oy < y1;
+        unsigned char* dst = smD + (oy & 1) * DYROW;
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            f32x4 v = rd[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (row_ok && e < d_nval[j]) ? v[e] : 0.f;
+            bsum[j] += v;
+            u32x2 p1, p2, p3;
+            split3(v, p1, p2, p3);
+            *reinterpret_cast<u32x2*>(dst + d_loff[j]) = p1;
+            *reinterpret_cast<u32x2*>(dst + NBO * DYBLK + d_loff[j]) = p2;
+            if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * NBO * DYBLK + d_loff[j]) = p3;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposing-read lane offset: 16-lane group g = lane >> 4: columns 16 (g & 1) .., pixel rows 8 (g >> 1) ..; lane l of the group
+    // supplies the address of (row l / 4, columns 4 (l % 4) ..)
+    const int l16 = lane & 15, grp = lane >> 4;
+    const int frag_off = (8 * (grp >> 1) + (l16 >> 2)) * 64 + (grp & 1) * 32 + (l16 & 3) * 8;
+    const int a_off = wc * DYBLK + frag_off;
+    const int b_off = wb * XBLK + frag_off;
+
+    auto compute = [&](int oy) {
+        const unsigned char* D = smD + (oy & 1) * DYROW + a_off;
+        const unsigned char* X0 = smX + ((oy + 0) & 3) * XROW + b_off;       // slot of input row oy - 1  (slot = (iy + 1) & 3)
+        const unsigned char* X1 = smX + ((oy + 1) & 3) * XROW + b_off;
+        const unsigned char* X2 = smX + ((oy + 2) & 3) * XROW + b_off;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[NPC];
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) a[pc] = tr_frag(D + pc * NBO * DYBLK + kk * 16 * 64);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const unsigned char* X = r == 0 ? X0 : (r == 1 ? X1 : X2);
+                bf16x8 b[NPC][3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) b[pc][s] = tr_frag(X + pc * NBI * XBLK + (kk * 16 + s) * 64);
+                // the three taps of this row interleave: no MFMA waits for its predecessor on the same accumulator
+#pragma unroll
+                for (int t = 6 - NP; t < 6; ++t)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], b[PB[t]][s], acc[r * 3 + s], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: X' rows y0-1, y0, y0+1 and dY row y0 into LDS; X' row y0+2 and dY row y0+1 into registers
+    load_x(y0 - 1);
+    store_x(y0 - 1);
+    load_x(y0);
+    store_x(y0);
+    load_x(y0 + 1);
+    load_d(y0);
+    store_x(y0 + 1);
+    store_d(y0);
+    load_x(y0 + 2);
+    load_d(y0 + 1);
+    __syncthreads();
+    // ---- strips.  Strip oy reads ring slots of rows oy-1, oy, oy+1 and dY buffer oy & 1; meanwhile row oy+2 / dY row oy+1 (registers, loaded one
+    // strip ago) go to the slot of row oy-2 / the other dY buffer (both last read in strip oy-1: barrier), and the next loads are issued.
+    for (int oy = y0; oy < y1; ++oy) {
+        store_x(oy + 2);
+        store_d(oy + 1);
+        load_x(oy + 3);
+        load_d(oy + 2);
+        compute(oy);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue: atomics into dW[tap][Cout][Cin]
+    float* __restrict__ dw = p.dw;
+    const int ci = ci0 + wb * 32 + (lane & 31);
+    const int half = lane >> 5;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < p.Cout) atomicAdd(dw + ((size_t)t * p.Cout + co) * p.Cin + ci, acc[t][r] * p.alpha);
+            }
+        }
+    }
+    if (do_bias) {
+        // bsum[j]: this thread's channel quad (blk, quad) over its pixel column px = (tid >> 3) & 31: reduce over px (lane bits 3..5, then
+        // the waves through LDS), one atomic per channel
+        float* red = reinterpret_cast<float*>(smem);          // the staging buffers are dead (all waves are past the last barrier)
+        __syncthreads();
+        for (int i = tid; i < 32 * NBO; i += NT) red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            f32x4 v = bsum[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = v[e];
+                s += __shfl_xor(s, 8, 64);
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                v[e] = s;
+            }
+            if ((lane >> 3) == 0) {
+                const int u = tid + j * NT;
+                const int c = (u >> 8) * 32 + (u & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(red + c + e, v[e]);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 32 * NBO; i += NT)
+            if (co0 + i < p.Cout) atomicAdd(p.dbias + co0 + i, red[i]);        // (alpha scales dW only)
+    }
+}
+
+int g_wgrad_halo_on = -1;
+int g_wgrad_halo_min = 192;
+
+}  // namespace
+
+int mrfa_tuning_wgrad_halo(int set) {
+    if (g_wgrad_halo_on < 0) { const char* e = getenv("MRFA_WGRAD_HALO"); g_wgrad_halo_on = !(e && e[0] == '0'); }
+    const int prev = g_wgrad_halo_on;
+    if (set >= 0) g_wgrad_halo_on = set != 0;
+    return prev;
+}
+
+int mrfa_tuning_wgrad_halo_min(int set) {
+    const int prev = g_wgrad_halo_min;
+    if (set >= 0) g_wgrad_halo_min = set;
+    return prev;
+}
+
+static void wgrad_halo_config(const mrfa_wgrad_params& p, int& NBO, int& HS, int& segs_y, long long& total) {
+    // block shape: 128 (co) x 64 (ci), or 64 x 128 when Cout <= 64 (half of a 128-row block would idle four waves)
+    NBO = p.Cout <= 64 ? 2 : 4;
+    const int NBI = 8 / NBO;
+    const int ntiles = cdiv(p.Cout, 32 * NBO) * cdiv(p.Cin, 32 * NBI);
+    const long long cols = (long long)p.N * (p.Wout / 32);
+    // segment height: enough workgroups for ~2 rounds of 256 CUs, at least 8 rows per segment (each segment re-reads 2 halo rows and
+    // ends in 144 atomics per lane)
+    HS = p.Hout;
+    while (HS > 8 && cols * ntiles * cdiv(p.Hout, HS) < 512 && (HS % 2) == 0) HS /= 2;
+    segs_y = cdiv(p.Hout, HS);
+    total = cols * segs_y * ntiles;
+}
+
+bool mrfa_wgrad_halo_eligible(const mrfa_wgrad_params& p) {
+    const int mode = mrfa_get_mfma_mode();
+    if (!mrfa_tuning_wgrad_halo(-1) || (mode != 1 && mode != 2)) return false;
+    if (p.kflat > 0 || p.R != 3 || p.S != 3 || p.pad != 1 || p.nbatch > 1 || p.ksplit > 0) return false;
+    if ((p.Wout % 32) != 0 || (p.Cin % 32) != 0 || p.Cout < 32 || p.Hout < 8) return false;
+    if (p.Hout != (p.Hin << p.ups) || p.Wout != (p.Win << p.ups)) return false;
+    if ((p.ldx % 4) != 0 || !aligned16(p.x) || (p.ldy % 4) != 0 || !aligned16(p.dy)) return false;
+    if ((long long)p.N * p.Hin * p.Win * p.ldx >= (1ll << 31) || (long long)p.N * p.Hout * p.Wout * p.ldy >= (1ll << 31)) return false;
+    if (p.in_scale && (!p.in_relu || !aligned16(p.in_scale) || !aligned16(p.in_shift))) return false;
+    int NBO, HS, segs_y;
+    long long total;
+    wgrad_halo_config(p, NBO, HS, segs_y, total);
+    return total >= g_wgrad_halo_min;                  // too few workgroups: the per-tap kernel splits the pixel range finer
+}
+
+int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p) {
+    int NBO, HS, segs_y;
+    long long total;
+    wgrad_halo_config(p, NBO, HS, segs_y, total);
+    const int NBI = 8 / NBO;
+    const int tiles_ci = cdiv(p.Cin, 32 * NBI), ntiles = cdiv(p.Cout, 32 * NBO) * tiles_ci;
+    dim3 grid((unsigned)(cdiv(total, 8) * 8));
+    const bool three = mrfa_get_mfma_mode() == 2;
+    const bool pro = p.in_scale != nullptr;
+#define WH(NBO_, NBI_, PRO_)                                                                                                                          \
+    do {                                                                                                                                              \
+        if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, PRO_, 3>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
+        else hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, PRO_, 6>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total);      \
+    } while (0)
+    if (NBO == 4) { if (pro) WH(4, 2, true); else WH(4, 2, false); }
+    else { if (pro) WH(2, 4, true); else WH(2, 4, false); }
+#undef WH
+    MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc(halo)");
+    return 0;
+}

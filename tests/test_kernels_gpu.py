@@ -453,6 +453,41 @@ def test_wgrad(cfg):
     assert_close(ref, got, tol=5e-4, what=tag)
 
 
+WGRAD_HALO_CASES = [       # wgrad_halo.hip: 3x3 / pad 1, Wout % 32 == 0, Cin % 32 == 0; both block shapes, prologue, upsample, ragged Cout, tails
+    dict(N=2, H=16, W=32, Cin=64, Cout=128), dict(N=1, H=24, W=64, Cin=128, Cout=256, pro=True),
+    dict(N=2, H=10, W=32, Cin=32, Cout=126), dict(N=1, H=8, W=16, Cin=128, Cout=64, ups=1),
+    dict(N=3, H=8, W=32, Cin=160, Cout=50, dbias=False), dict(N=1, H=40, W=32, Cin=96, Cout=96, pro=True),
+    dict(N=2, H=64, W=64, Cin=256, Cout=128, min_wgs=192),                      # chosen by the default heuristic, several segments per column
+]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cfg", WGRAD_HALO_CASES)
+def test_wgrad_all_taps_kernel(cfg, mode):
+    """wgrad_halo.hip (one staging of X / dY per row strip for all nine taps, transposing LDS reads) against the CPU specification"""
+    L = hip.lib()
+    cfg = dict(cfg)
+    min_wgs = cfg.pop("min_wgs", 1)
+    tag = "wgh/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+    ref = wgrad_case(Side(False), tag=tag, **cfg)
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    prev = L.mrfa_set_tuning(b"wgrad_halo_min_wgs", min_wgs)
+    L.mrfa_set_tuning(b"conv_small", 0)
+    try:
+        got = wgrad_case(Side(True), tag=tag, **cfg)
+        # the same call with the kernel off must give the same answer from the per-tap kernels (and proves the switch works)
+        L.mrfa_set_tuning(b"wgrad_halo", 0)
+        other = wgrad_case(Side(True), tag=tag, **cfg)
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"wgrad_halo", 1)
+        L.mrfa_set_tuning(b"wgrad_halo_min_wgs", prev)
+        L.mrfa_set_tuning(b"conv_small", 1)
+    assert_close(ref, got, tol=5e-4 if mode == 1 else 5e-3, what=tag)
+    assert_close(other, got, tol=5e-4 if mode == 1 else 5e-3, what=tag + " vs per-tap kernel")
+    assert any(float((g - o).abs().max()) > 0 for g, o in zip(got, other)), "identical bits: did the all-taps kernel run at all?"
+
+
 @pytest.mark.parametrize("cfg", [dict(N=2, H=32, W=32, Cin=256, Cout=128), dict(N=2, H=32, W=64, Cin=128, Cout=256, pro=True),
                                  dict(N=1, H=32, W=64, Cin=128, Cout=126, ups=1), dict(N=2, H=32, W=32, Cin=128, Cout=128, R=1, pad=0, dbias=False),
                                  dict(N=4, H=64, W=64, Cin=128, Cout=128, ksplit=40, ws=True), dict(N=2, H=32, W=32, Cin=100, Cout=130),

@@ -118,8 +118,15 @@ def main():
                 res_ab.append((f"{on}{'*' if used else ' '}{'*' if used_d else ' '}", used, tf_, td_))
             L.mrfa_set_tuning(b"conv_halo", 1)
             L.mrfa_set_tuning(b"conv_halo_bn256", 1)
+            wres = []
+            for on in (0, 1, 0, 1):
+                L.mrfa_set_tuning(b"wgrad_halo", on)
+                tw_ = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True), iters=a.iters)
+                cw.dw_acc = None
+                wres.append(f"wg{on} {tf(tw_):5.1f}")
+            L.mrfa_set_tuning(b"wgrad_halo", 1)
             print(f"{name:42s} " + " ".join(f"h={on} f {tf(tf_):5.1f} d {tf(td_):5.1f} |"
-                                             for on, used, tf_, td_ in res_ab), flush=True)
+                                             for on, used, tf_, td_ in res_ab) + "  " + " ".join(wres), flush=True)
             continue
         print(f"{name:42s} {t_f:8.3f} {tf(t_f):7.1f} {100*tf(t_f)/PEAK_TF:5.1f} | {t_d:8.3f} {tf(t_d):7.1f} | {t_w:8.3f} {tf(t_w):7.1f}", flush=True)
     if a.only:
