@@ -24,6 +24,7 @@ int mrfa_wgrad_split_launch(hipStream_t st, const mrfa_wgrad_params& p, dim3 gri
 bool mrfa_wgrad_halo_eligible(const mrfa_wgrad_params& p);
 int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p);
 int mrfa_tuning_wgrad_halo_min(int set);   // mrfa_set_tuning("wgrad_halo_min_wgs", n)
+int mrfa_tuning_wgrad_halo_target(int set);
 int mrfa_tuning_wgrad_halo(int set);       // mrfa_set_tuning("wgrad_halo", 0 / 1); set < 0: query
 
 // conv_small.hip: one wave per 16..32-row output tile, operands straight from L1/L2 into v_mfma_f32_16x16x4_f32 (small problems)

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 int g_wgrad_halo_on = -1;
 int g_wgrad_halo_min = 192;
+int g_wgrad_halo_target = 256;      // workgroups per round (one per CU)
 
 }  // namespace
 
@@ -322,16 +323,29 @@ int mrfa_tuning_wgrad_halo_min(int set) {
     return prev;
 }
 
+int mrfa_tuning_wgrad_halo_target(int set) {
+    const int prev = g_wgrad_halo_target;
+    if (set > 0) g_wgrad_halo_target = set;
+    return prev;
+}
+
 static void wgrad_halo_config(const mrfa_wgrad_params& p, int& NBO, int& HS, int& segs_y, long long& total) {
     // block shape: 128 (co) x 64 (ci), or 64 x 128 when Cout <= 64 (half of a 128-row block would idle four waves)
     NBO = p.Cout <= 64 ? 2 : 4;
     const int NBI = 8 / NBO;
     const int ntiles = cdiv(p.Cout, 32 * NBO) * cdiv(p.Cin, 32 * NBI);
     const long long cols = (long long)p.N * (p.Wout / 32);
-    // segment height: enough workgroups for ~2 rounds of 256 CUs, at least 8 rows per segment (each segment re-reads 2 halo rows and
-    // ends in 144 atomics per lane)
+    // segment height: every segment pays ~6 row-strips of fixed cost (three-row prologue, 144 atomics per lane at the end) and the launch
+    // runs in rounds of 256 workgroups (one per CU): minimise rounds x (HS + 6) over the power-of-two divisions of the column
+    // (measured on 192->128 @256^2: 384 workgroups = 1.5 rounds 209 TF/s, 768 = 3 rounds 228; 128->128 @128^2: 256 workgroups 188, 512: 154)
     HS = p.Hout;
-    while (HS > 8 && cols * ntiles * cdiv(p.Hout, HS) < 512 && (HS % 2) == 0) HS /= 2;
+    double best = 1e30;
+    for (int hs = p.Hout; hs >= 8; hs /= 2) {
+        const long long tot = cols * ntiles * cdiv(p.Hout, hs);
+        const double cost = (double)((tot + g_wgrad_halo_target - 1) / g_wgrad_halo_target) * (hs + 6);
+        if (cost < best) { best = cost; HS = hs; }
+        if (hs % 2) break;
+    }
     segs_y = cdiv(p.Hout, HS);
     total = cols * segs_y * ntiles;
 }

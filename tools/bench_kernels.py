@@ -58,6 +58,11 @@ def main():
         ("refine heads fused 256->256 3x3 @128", 256, 256, 3, 128, 0),
         ("gen.res 256->256 3x3 @64", 256, 256, 3, 64, 0),
         ("gen.up 256->128 3x3 ups @64->128", 256, 128, 3, 64, 1),
+        ("gen.down 128->256 3x3 @128", 128, 256, 3, 128, 0),
+        ("gen.down 256->512 3x3 @64", 256, 512, 3, 64, 0),
+        ("gen.chan 1024->512 3x3 @32", 1024, 512, 3, 32, 0),
+        ("gen.chan 256->128 3x3 @128", 256, 128, 3, 128, 0),
+        ("convf2 128->64 3x3 @256", 128, 64, 3, 256, 0),
         ("gen 512->512 3x3 @32", 512, 512, 3, 32, 0),
         ("gen 512->512 3x3 @8", 512, 512, 3, 8, 0),
         ("hg 1024->1024 3x3 @4", 1024, 1024, 3, 4, 0),
