@@ -64,12 +64,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
     return r;
 }
 
-// NBO x NBI = 8 waves: BCO = 32 NBO output channels x BCI = 32 NBI input channels per workgroup
-template <int NBO, int NBI, bool PRO, int NP>
+// NBO x NBI x TS = 8 waves: BCO = 32 NBO output channels x BCI = 32 NBI input channels per workgroup; TS = 2: the nine taps of a
+// (co, ci) block are split over two waves (taps 0..4 / 5..8) -- the 64 x 64 block shape for layers with <= 64 output channels (a
+// 64 x 128 block with all nine taps per wave needed 3 staging slots next to its 144 accumulators: 49 spilled registers, MFMA busy 29 %)
+template <int NBO, int NBI, int TS, bool PRO, int NP>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_halo_kernel(const mrfa_wgrad_params p, const int tiles_ci,
                                                                                                const int ntiles, const int HS, const int segs_y,
                                                                                                const int tiles_x, const int total) {
-    static_assert(NBO * NBI == 8, "8 waves");
+    static_assert(NBO * NBI * TS == 8 && (TS == 1 || TS == 2), "8 waves");
+    constexpr int NTAP = TS == 1 ? 9 : 5;            // accumulator tiles per wave
     constexpr int NPC = NP == 6 ? 3 : 2;
     constexpr int XROW = NPC * NBI * XBLK;         // one ring slot: [piece][block][34 pixels][64 B]
     constexpr int DYROW = NPC * NBO * DYBLK;       // one dY buffer:  [piece][block][32 pixels][64 B]
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned char* const smD = smem + 4 * XROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave / NBI, wb = wave % NBI;
+    const int wt = wave / (NBO * NBI);               // tap half (TS = 2)
+    const int wc = (wave / NBI) % NBO, wb = wave % NBI;
     const int per_xcd = (int)gridDim.x >> 3;
     const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // the tiles of one segment share an XCD's L2
     if (lin >= total) return;
@@ -193,9 +197,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -206,11 +210,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int a_off = wc * DYBLK + frag_off;
     const int b_off = wb * XBLK + frag_off;
 
-    auto compute = [&](int oy) {
+    // taps T0 .. T1-1 of this wave, in groups of <= 3 whose MFMAs interleave (no MFMA waits for its predecessor on the same accumulator)
+    auto compute_taps = [&](int oy, auto T0_, auto T1_) {
+        constexpr int T0 = decltype(T0_)::value, T1 = decltype(T1_)::value;
         const unsigned char* D = smD + (oy & 1) * DYROW + a_off;
-        const unsigned char* X0 = smX + ((oy + 0) & 3) * XROW + b_off;       // slot of input row oy - 1  (slot = (iy + 1) & 3)
-        const unsigned char* X1 = smX + ((oy + 1) & 3) * XROW + b_off;
-        const unsigned char* X2 = smX + ((oy + 2) & 3) * XROW + b_off;
+        const unsigned char* XR[3] = {smX + ((oy + 0) & 3) * XROW + b_off,       // slot of input row oy - 1  (slot = (iy + 1) & 3)
+                                      smX + ((oy + 1) & 3) * XROW + b_off, smX + ((oy + 2) & 3) * XROW + b_off};
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -219,20 +224,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) a[pc] = tr_frag(D + pc * NBO * DYBLK + kk * 16 * 64);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const unsigned char* X = r == 0 ? X0 : (r == 1 ? X1 : X2);
-                bf16x8 b[NPC][3];
+            for (int g0 = T0; g0 < T1; g0 += 3) {
+                constexpr int GMAX = 3;
+                bf16x8 b[NPC][GMAX];
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int q = 0; q < GMAX; ++q) {
+                    const int tap = g0 + q;
+                    if (tap < T1) {
 #pragma unroll
-                    for (int pc = 0; pc < NPC; ++pc) b[pc][s] = tr_frag(X + pc * NBI * XBLK + (kk * 16 + s) * 64);
-                // the three taps of this row interleave: no MFMA waits for its predecessor on the same accumulator
+                        for (int pc = 0; pc < NPC; ++pc) b[pc][q] = tr_frag(XR[tap / 3] + pc * NBI * XBLK + (kk * 16 + tap % 3) * 64);
+                    }
+                }
 #pragma unroll
                 for (int t = 6 - NP; t < 6; ++t)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s)
-                        acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], b[PB[t]][s], acc[r * 3 + s], 0, 0, 0);
+                    for (int q = 0; q < GMAX; ++q)
+                        if (g0 + q < T1)
+                            acc[g0 + q - T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], b[PB[t]][q], acc[g0 + q - T0], 0, 0, 0);
             }
+        }
+    };
+    auto compute = [&](int oy) {
+        if constexpr (TS == 1) {
+            compute_taps(oy, std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+        } else {
+            if (wt == 0) compute_taps(oy, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+            else compute_taps(oy, std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
         }
     };
 
@@ -264,12 +281,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int ci = ci0 + wb * 32 + (lane & 31);
     const int half = lane >> 5;
     if (ci < p.Cin) {
+        const int tap0 = TS == 1 ? 0 : 5 * wt, ntap = TS == 1 ? 9 : (wt == 0 ? 5 : 4);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NTAP; ++t) {
+            if (t < ntap) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < p.Cout) atomicAdd(dw + ((size_t)t * p.Cout + co) * p.Cin + ci, acc[t][r] * p.alpha);
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.Cout) atomicAdd(dw + ((size_t)(tap0 + t) * p.Cout + co) * p.Cin + ci, acc[t][r] * p.alpha);
+                }
             }
         }
     }
@@ -330,9 +350,9 @@ int mrfa_tuning_wgrad_halo_target(int set) {
 }
 
 static void wgrad_halo_config(const mrfa_wgrad_params& p, int& NBO, int& HS, int& segs_y, long long& total) {
-    // block shape: 128 (co) x 64 (ci), or 64 x 128 when Cout <= 64 (half of a 128-row block would idle four waves)
+    // block shape: 128 (co) x 64 (ci), or 64 x 64 with the taps split over two waves when Cout <= 64 (half of a 128-row block would idle)
     NBO = p.Cout <= 64 ? 2 : 4;
-    const int NBI = 8 / NBO;
+    const int NBI = 2;
     const int ntiles = cdiv(p.Cout, 32 * NBO) * cdiv(p.Cin, 32 * NBI);
     const long long cols = (long long)p.N * (p.Wout / 32);
     // segment height: every segment pays ~6 row-strips of fixed cost (three-row prologue, 144 atomics per lane at the end) and the launch
@@ -369,18 +389,18 @@ int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p) {
     int NBO, HS, segs_y;
     long long total;
     wgrad_halo_config(p, NBO, HS, segs_y, total);
-    const int NBI = 8 / NBO;
+    const int NBI = 2;
     const int tiles_ci = cdiv(p.Cin, 32 * NBI), ntiles = cdiv(p.Cout, 32 * NBO) * tiles_ci;
     dim3 grid((unsigned)(cdiv(total, 8) * 8));
     const bool three = mrfa_get_mfma_mode() == 2;
     const bool pro = p.in_scale != nullptr;
-#define WH(NBO_, NBI_, PRO_)                                                                                                                          \
+#define WH(NBO_, NBI_, TS_, PRO_)                                                                                                                          \
     do {                                                                                                                                              \
-        if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, PRO_, 3>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
-        else hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, PRO_, 6>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total);      \
+        if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 3>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
+        else hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 6>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total);      \
     } while (0)
-    if (NBO == 4) { if (pro) WH(4, 2, true); else WH(4, 2, false); }
-    else { if (pro) WH(2, 4, true); else WH(2, 4, false); }
+    if (NBO == 4) { if (pro) WH(4, 2, 1, true); else WH(4, 2, 1, false); }
+    else { if (pro) WH(2, 2, 2, true); else WH(2, 2, 2, false); }
 #undef WH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc(halo)");
     return 0;

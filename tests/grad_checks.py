@@ -22,20 +22,41 @@ def _pg(golden_dir):
 
 
 def _ref_noise(g, tag, names=None):
-    """3 x the relative distance of the fp32 reference's gradient norms from the fp64 oracle's (the same computation in double): a
-    kernel cannot be held closer to the reference than the reference is to the truth (train-mode BatchNorm amplifies rounding: the
-    reference's own keypoint-encoder gradients are median 4e-3 / max 1.9e-2 from fp64 in the chained train-mode case, 2e-4 in eval
-    mode).  The distance is a random sample per parameter, so the allowance of a parameter is the LARGEST distance within its
-    sub-network (`encoder.` / `dense_motion.` / `decoder.`; one group for a stand-alone module): the conditioning is a property of
-    the sub-network, not of one tensor."""
+    """Per-parameter allowance on top of rel_tol: 3 x the relative distance of the fp32 REFERENCE's gradient norm of THIS parameter from
+    the fp64 oracle's (the same computation in double) -- a kernel cannot be held closer to the reference than the reference is to the
+    truth (train-mode BatchNorm amplifies rounding: the reference's own keypoint-encoder gradients are median 4e-3 / max 1.9e-2 from
+    fp64 in the chained train-mode case, 2e-4 in eval mode) -- floored at the MEDIAN distance of the parameter's sub-network
+    (`encoder.` / `dense_motion.` / `decoder.`; one group for a stand-alone module): a parameter whose reference sample happens to
+    sit on the truth still carries its sub-network's typical rounding noise.  (Round 2 allowed every parameter the sub-network's
+    MAXIMUM, i.e. ~5.8e-2 for every encoder tensor in train mode: a 5 % error in one well-conditioned layer passed.)"""
     ref, truth = g[f"{tag}_pgrad_norms"].astype(np.float64), g[f"{tag}_pgrad_norms_fp64"].astype(np.float64)
     rel = np.abs(ref - truth) / np.maximum(ref, 1e-3 * ref.max())
     if names is None or not any(n.startswith(("encoder.", "dense_motion.", "decoder.")) for n in names[tag]):
-        return np.full_like(rel, 3.0 * rel.max())
+        return 3.0 * np.maximum(rel, np.median(rel))
     out = np.zeros_like(rel)
-    for grp in ("encoder.", "dense_motion.", "decoder."):
-        idx = [i for i, n in enumerate(names[tag]) if n.startswith(grp)]
-        out[idx] = 3.0 * rel[idx].max()
+    for grp in sorted({_subnet(n) for n in names[tag]}):
+        idx = [i for i, n in enumerate(names[tag]) if _subnet(n) == grp]
+        out[idx] = 3.0 * np.maximum(rel[idx], np.median(rel[idx]))
+    return out
+
+
+def _subnet(name: str) -> str:
+    """sub-network of a parameter of the chained pipeline: the first two components of its name (`decoder.kp_img`, `decoder.generator`,
+    `encoder.predictor`, `dense_motion.hourglass`, ...): the fp32-vs-fp64 distance of the reference differs by two orders of magnitude
+    between them (train mode: decoder.generator median 3e-5, encoder.predictor 4e-3)"""
+    return ".".join(name.split(".")[:2])
+
+
+def _run_to_run(n1, n2, ref, names_tag):
+    """measured on the spot: relative difference of the per-parameter gradient norms of TWO passes of this engine on the same inputs and
+    weights (the fp32 atomics of the split reductions and scatter backward kernels commit in a different order every time; 0 on the CPU
+    emulator).  Per parameter the larger of its own sample and the RMS of its sub-network (one pair is a noisy estimate of a noise level)."""
+    scale = np.maximum(ref, 1e-3 * ref.max())
+    d = np.abs(n1 - n2) / scale
+    out = np.zeros_like(d)
+    for grp in sorted({_subnet(n) for n in names_tag}):
+        idx = [i for i, n in enumerate(names_tag) if _subnet(n) == grp]
+        out[idx] = np.maximum(d[idx], np.sqrt(np.mean(d[idx] ** 2)))
     return out
 
 
@@ -48,6 +69,11 @@ def _check_pgrads(mods, g, names, tag, rel_tol, extra=None):
     scale = np.maximum(ref, 1e-3 * ref.max())
     allow = rel_tol + (0.0 if extra is None else extra)
     rel = np.abs(got - ref) / scale
+    if not np.isscalar(allow):
+        ratio = rel / allow
+        worst = np.argsort(-ratio)[:3]
+        print(f"{tag}: gradient-norm error / allowance: median {np.median(ratio):.2f}, worst " +
+              ", ".join(f"{names[tag][i]} {ratio[i]:.2f} (err {rel[i]:.1e}, allow {allow[i]:.1e})" for i in worst))
     bad = [(names[tag][i], rel[i], ref[i]) for i in np.argsort(-(rel - allow))[:5] if rel[i] > (allow if np.isscalar(allow) else allow[i])]
     assert not bad, (tag, bad)
     for key in g.files:
@@ -126,5 +152,21 @@ def check_chained_pipeline_gradients(golden_dir, train, b, DEV):
     nz = np.abs(g[f"chain_{sfx}_gen_s4"] - g[f"chain_{sfx}_gen_s4_fp64"]) if f"chain_{sfx}_gen_s4_fp64" in g.files else np.zeros(1)
     assert gerr.mean() <= 1e-4 + 3.0 * nz.mean() and gerr.max() <= 5e-3 + 3.0 * nz.max(), (gerr.mean(), gerr.max(), nz.mean(), nz.max())
     mods = [("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)]
-    rel = _check_pgrads(mods, g, names, f"chain_{sfx}", 1e-3, extra=_ref_noise(g, f"chain_{sfx}", names))
+    tag = f"chain_{sfx}"
+    P = {pfx + n: p for pfx, m in mods for n, p in m.named_parameters()}
+    norms = lambda: np.array([0.0 if P[n].grad is None else P[n].grad.norm().item() for n in names[tag]])
+    n1, keep = norms(), {n: p.grad for n, p in P.items()}
+    # second pass at the same weights and inputs: the engine's own run-to-run spread (train mode: the batch statistics are the same, the
+    # running buffers are not read), added per parameter to the allowance below
+    for p in P.values():
+        p.grad = None
+    kp_s2, kp_d2 = model.encoder(src), model.encoder(drv)
+    gen2, _, _ = model.decoder(kp_s2["kp"], kp_d2["kp"], model.dense_motion(src, kp_d2, kp_s2), img=model.down(src), img_full=src)
+    (gen2 - drv).abs().mean().backward()
+    n2 = norms()
+    for n, p in P.items():
+        p.grad = keep[n]
+    noise = _run_to_run(n1, n2, g[f"{tag}_pgrad_norms"].astype(np.float64), names[tag])
+    print(f"chained {sfx}: run-to-run spread of the gradient norms (two passes of this engine): median {np.median(noise):.2e}, max {noise.max():.2e}")
+    rel = _check_pgrads(mods, g, names, tag, 1e-3, extra=_ref_noise(g, tag, names) + 4.0 * noise)
     print(f"chained {sfx}: per-parameter gradient-norm error vs reference: median {np.median(rel):.2e}, max {rel.max():.2e}")
