@@ -95,7 +95,7 @@ def cpu_baseline(batch: int, max_seconds: float = 25.0, prior: str = "mtia", bac
             "sample": f"{n} x (B=1 fwd+bwd, train-mode BN, L1 loss) of the CPU oracle in {dt:.1f}s"}
 
 
-def run_inference(a):
+def run_inference(a, emit=True):
     """BASELINE.json configs[4]: vox1 512x512 inference-only generator path (RaftFlow forward: generator encode, 16 384^2 correlation
     volume, 6-level refinement, deformed-feature warps, decode), bs=4, one MI355X -- the HBM-bound grid_sample stress.  One JSON line:
     value = pairs/s of the hipGraph-replayed forward; roofline = the six-level feature-warp set (grid_sample_fwd, the kernel SURVEY 8(d)
@@ -241,6 +241,8 @@ def run_inference(a):
                        "launch": launch, "mfma": hip.mfma_mode(), "out_finite": bool(torch.isfinite(out).all()),
                        "memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "roofline": roof, "cpu_baseline": cpu}
+    if not emit:
+        return line
     print(json.dumps(line), flush=True)
 
 
@@ -493,6 +495,7 @@ def main():
     step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
     launch = "eager"
     verify_retries = 0
+    gstep = None
     if use_graph:
         # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
         # (mrfa_amd/graph.py): graph A = pack + fwd + bwd, one flat RCCL all-reduce when N > 1, graph B = clip + Adam
@@ -685,6 +688,21 @@ def main():
                         "kernel_ms_per_step": round(ms / nprof, 2),
                         "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / nprof, 2),
                         "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
+        c5 = None
+        if world == 1 and not a.no_forward and not a.background and a.loss == "surrogate":
+            # for the record (outside the timed region, N = 1 only): BASELINE configs[4], the 512x512 inference-only generator path at bs=4, so
+            # that the driver's default command times it too (`python bench.py --size 512 --batch 4 --inference` is the full line)
+            try:
+                import copy as _copy
+                a5 = _copy.copy(a)
+                a5.size, a5.batch, a5.steps, a5.warmup, a5.inference, a5.no_cpu_baseline = 512, 4, 10, 2, True, True
+                gstep = step = None                  # release the training graphs' private pool before the 12 GiB inference run
+                torch.cuda.empty_cache()
+                l5 = run_inference(a5, emit=False)
+                c5 = {"metric": l5["metric"], "value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "batch": 4,
+                      "launch": l5["config"]["launch"], "roofline": l5["roofline"]}
+            except Exception as ex:
+                c5 = {"error": repr(ex)}
         cpu = None
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the host cores are shared with N-1 busy ranks
             try:
@@ -708,6 +726,7 @@ def main():
                        "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; running buffers are averaged over the ranks "
                                          "when a checkpoint is written (train.sync_bn_buffers)")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt, "bf16x3_path": alt3,
+            "config5_512_inference": c5,
         }
     else:
         line = None
