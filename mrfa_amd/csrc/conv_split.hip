@@ -15,6 +15,7 @@
 //   both the 4-lanes-per-row writes and the 16-rows-per-group ds_read_b128 fragment reads are bank-conflict free with no
 //   padding (48 KB per workgroup, 3 workgroups = 12 waves per CU) -> 12 fragment reads and 24 MFMAs per k16 step per wave.
 // Epilogue identical to conv_mfma.hip (C/D layout of the 32x32 MFMAs does not depend on the input type).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -56,7 +57,10 @@ __device__ __forceinline__ void round1(const f32x4 v, u32x2& p1) {
 
 // BN = 128: waves 2 x 2, each 64 x 64.  BN = 64 (layers with 64 output channels: half of a 128-wide tile would be padding):
 // waves 2 x 2, each 64 x 32 -- same loaders, the B operand simply has 64 rows.
-template <bool PRO, bool WS, int BN, int NP = 6>
+// TR: transposed product (D = W * X^T) + 16-byte epilogue accesses -- every launch WITHOUT a K split.  Split-K launches keep the row-major
+// product: their epilogue is fp32 atomics, and with the transposed layout one atomic instruction would touch 64 cache lines (32 pixels x
+// 2 halves, ldy apart) instead of two 128-byte rows (measured: 512->512 @8^2 47 -> 224 us).
+template <bool PRO, bool WS, int BN, int NP = 6, bool TR = true>
 __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_params p, const int KT, const int kt_per_split, const long long M,
                                                             const int tiles_n, const int total_tiles) {
     constexpr int TM = 2, TN = BN / 64;
@@ -257,7 +261,11 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+                    // D = W * X^T (rows = output channels, columns = pixels): a lane ends up with 4 consecutive channels of one pixel per
+                    // accumulator quad -> 16-byte epilogue accesses (as conv_halo.hip; the short-K launches left on this kernel -- 1x1
+                    // layers, low-resolution levels -- are dominated by their store tail)
+                    if constexpr (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB[t]][j], a[PA[t]][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
     };
 
     const int kt_begin = blockIdx.z * kt_per_split;
@@ -292,7 +300,8 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------ epilogue (as conv_mfma.hip)
+    if constexpr (!TR) {
+    // ------------------------------------------------------------------ epilogue of the split-K launches (as conv_mfma.hip)
     const int half = lane >> 5;
     const bool splitk = p.splitk > 1;
 #pragma unroll
@@ -338,6 +347,112 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             }
         }
     }
+        return;
+    } else {
+    // ------------------------------------------------------------------ epilogue
+    // lane = (pixel row px = lane & 31 of row tile i, half); accumulator quad g of column tile j = channels cb + 8 g .. + 3 of that pixel
+    const int half = lane >> 5, px = lane & 31;
+    const bool splitk = p.splitk > 1;
+    const bool vec_ok = (p.ldy % 4) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                        (!p.res || ((p.ldr % 4) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cb = n0 + (wn * TN + j) * 32 + 4 * half;
+        float s1[16], s2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long m = m0 + (wm * TM + i) * 32 + px;
+            if (m < M) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cb + 8 * g;
+                    float* dst = y + (size_t)m * p.ldy + c0;
+                    float v[4], bias[4], osc[4], osh[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool c_ok = c0 + e < p.Cout && !splitk;
+                        bias[e] = (p.bias && c_ok) ? p.bias[c0 + e] : 0.f;
+                        osc[e] = (p.out_scale && c_ok) ? p.out_scale[c0 + e] : 1.f;
+                        osh[e] = (p.out_scale && c_ok) ? p.out_shift[c0 + e] : 0.f;
+                        v[e] = acc[i][j][4 * g + e] * p.alpha;
+                    }
+                    if (splitk) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < p.Cout) atomicAdd(dst + e, v[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias[e]) * osc[e] + osh[e];
+                        if (vec_ok && c0 + 3 < p.Cout) {
+                            if (p.res) {
+                                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + c0);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                            }
+                            if (p.relu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            if (p.accumulate) {
+                                const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += o4[e];
+                            }
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { s1[4 * g + e] += v[e]; s2[4 * g + e] += v[e] * v[e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (c0 + e < p.Cout) {
+                                    float u = v[e];
+                                    if (p.res) u += p.res[(size_t)m * p.ldr + c0 + e];
+                                    if (p.relu) u = fmaxf(u, 0.f);
+                                    if (p.accumulate) u += dst[e];
+                                    dst[e] = u;
+                                    s1[4 * g + e] += u;
+                                    s2[4 * g + e] += u * u;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (p.stats && !splitk) {
+            // per-channel sums over the 32 pixel lanes of a half: butterfly reduce-scatter (see conv_halo.hip); afterwards lane L holds
+            // channel index kk = 8 b4 + 4 b3 + 2 b2 + b1 (bN = bit N of L)
+            auto stage = [&](float (&v)[16], auto W) {
+                constexpr int w = decltype(W)::value;
+                const bool hi = (lane & (2 * w)) != 0;
+#pragma unroll
+                for (int k = 0; k < w; ++k) {
+                    const float send = hi ? v[k] : v[k + w];
+                    const float keep = hi ? v[k + w] : v[k];
+                    v[k] = keep + __shfl_xor(send, 2 * w, 64);
+                }
+            };
+            auto reduce16 = [&](float (&v)[16]) {
+                stage(v, std::integral_constant<int, 8>{});
+                stage(v, std::integral_constant<int, 4>{});
+                stage(v, std::integral_constant<int, 2>{});
+                stage(v, std::integral_constant<int, 1>{});
+                v[0] += __shfl_xor(v[0], 1, 64);
+            };
+            reduce16(s1);
+            reduce16(s2);
+            const int kk = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const int cch = cb + 8 * (kk >> 2) + (kk & 3);
+            if ((lane & 1) == 0 && cch < p.Cout) {
+                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                atomicAdd(st + cch, (double)s1[0]);
+                atomicAdd(st + p.Cout + cch, (double)s2[0]);
+            }
+        }
+    }
+    }
 }
 
 }  // namespace
@@ -354,12 +469,13 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
     if (p.in_scale && !p.in_relu) { mrfa_set_error("conv2d(bf16x6): in_scale without in_relu is not used by the path"); return 1; }
     const bool three = mrfa_get_mfma_mode() == 2;        // bf16x3
     const bool one = mrfa_get_mfma_mode() == 3;          // plain bf16
-#define SPLIT_LAUNCH(PRO_, WS_, BN_)                                                                                                          \
-    do {                                                                                                                                      \
-        if (one) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, false, BN_, 1>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);    \
-        else if (three) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 3>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);     \
-        else hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 6>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);          \
+#define SPLIT_LAUNCH_TR(PRO_, WS_, BN_, TR_)                                                                                                       \
+    do {                                                                                                                                           \
+        if (one) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, false, BN_, 1, TR_>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);    \
+        else if (three) hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 3, TR_>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles); \
+        else hipLaunchKernelGGL((conv_bf16x6_kernel<PRO_, WS_, BN_, 6, TR_>), grid, dim3(NT), 0, st, q, KT, kps, M, tiles_n, total_tiles);          \
     } while (0)
+#define SPLIT_LAUNCH(PRO_, WS_, BN_) do { if (splitk > 1) SPLIT_LAUNCH_TR(PRO_, WS_, BN_, false); else SPLIT_LAUNCH_TR(PRO_, WS_, BN_, true); } while (0)
     const bool pro = p.in_scale != nullptr, ws = p.w_split != nullptr;
     if (BN == 64) {
         if (pro && ws) SPLIT_LAUNCH(true, true, 64); else if (pro) SPLIT_LAUNCH(true, false, 64);
@@ -369,6 +485,7 @@ int mrfa_conv_split_launch(hipStream_t st, const mrfa_conv_params& p, int KT, lo
         else if (ws) SPLIT_LAUNCH(false, true, 128); else SPLIT_LAUNCH(false, false, 128);
     }
 #undef SPLIT_LAUNCH
+#undef SPLIT_LAUNCH_TR
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(bf16x6)");
     return 0;
 }
