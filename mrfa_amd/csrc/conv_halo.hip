@@ -408,7 +408,7 @@ bool mrfa_conv_halo_eligible(const mrfa_conv_params& p) {
     const int mode = mrfa_get_mfma_mode();
     if (!halo_on() || (mode != 1 && mode != 2)) return false;
     if (p.kflat > 0 || p.R != 3 || p.S != 3 || p.pad != 1 || !p.w_split || p.nbatch > 1 || p.splitk > 1 || p.tile) return false;
-    if ((p.Wout % PW) != 0 || p.Hout < 4 || (p.Cin % 16) != 0 || p.Cout < 32) return false;
+    if ((p.Wout % PW) != 0 || p.Hout < 4 || (p.Cin % 32) != 0 || p.Cout < 32) return false;
     if (p.Hout != (p.Hin << p.ups) || p.Wout != (p.Win << p.ups)) return false;
     if ((p.ldy % 4) != 0 || !aligned16(p.y) || (p.res && ((p.ldr % 4) != 0 || !aligned16(p.res)))) return false;       // float4 epilogue
     if ((p.ldx % 4) != 0 || !aligned16(p.x) || 3 * p.w_piece >= (1ll << 31) || p.w_tap >= (1ll << 31)) return false;

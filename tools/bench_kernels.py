@@ -36,12 +36,16 @@ def main():
     ap.add_argument("--mfma", type=int, default=0, help="mrfa_set_mfma_mode: 0 native fp32 MFMA, 1 bf16x6 split-operand kernel")
     ap.add_argument("--tile", type=lambda v: int(v, 0), default=0, help="force mrfa_conv_params.tile, e.g. 0x808080 = 128x128 8-wave")
     ap.add_argument("--ab-halo", action="store_true", help="3x3 layers: forward / dgrad with the patch-tiled kernel (conv_halo.hip) off and on")
+    ap.add_argument("--tune", action="append", default=[], help="mrfa_set_tuning key=value (repeatable), e.g. --tune conv_small=0 --tune conv_halo_min_tiles=64")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import mrfa_amd.engine as eng
     eng.FORCE_TILE = a.tile
     from mrfa_amd import hip as _hip
     _hip.check(_hip.lib().mrfa_set_mfma_mode(a.mfma), "set_mfma_mode")
+    for kv in a.tune:
+        k, v = kv.split("=")
+        print(f"tuning {k} = {v} (was {_hip.lib().mrfa_set_tuning(k.encode(), int(v))})")
     torch.manual_seed(0)
     e = Ctx(dev, train=True, record=True)
     B = a.b
