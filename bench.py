@@ -406,6 +406,8 @@ def main():
     ap.add_argument("--dry", action="store_true",
                     help="no GPU: run the multi-rank control flow (launcher, rendezvous, flat gradient exchange, timing, reporting) on CPU "
                          "with gloo and the C-ABI emulator on a 64x64 miniature; the line carries \"dry\": true and no value")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="mrfa_set_tuning knob (kernel selection only, never results), repeatable: A/B runs on one box, e.g. --tune conv_halo=0")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # launcher test: this rank exits 7 before the rendezvous
     a = ap.parse_args()
     if a.gpus < 1:
@@ -454,6 +456,10 @@ def main():
     hip.lib()                                       # fail loudly if the HIP library is missing
     if a.mfma:
         hip.set_mfma_mode(a.mfma)
+    for kv in a.tune:
+        k, v = kv.split("=")
+        if hip.lib().mrfa_set_tuning(k.encode(), int(v)) < 0:
+            raise SystemExit(f"[bench] --tune {kv}: unknown knob")
 
     model = HotPath(VOX1, prior=a.prior, background=a.background)
     init_weights(model)
@@ -722,7 +728,7 @@ def main():
                                     "the reference's generator losses (VGG19 perceptual pyramid on random-init weights + equivariance, 3 encoder passes)"),
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "background_predictor": bool(a.background), "sync_bn": bool(a.sync_bn), "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}"),
-                       "verify_retries": verify_retries,
+                       "verify_retries": verify_retries, "tuning": a.tune or None,
                        "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; running buffers are averaged over the ranks "
                                          "when a checkpoint is written (train.sync_bn_buffers)")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt, "bf16x3_path": alt3,

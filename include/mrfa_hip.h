@@ -95,6 +95,7 @@ int mrfa_conv2d_last_config(void);
  *   "conv_halo_bn256"      1 / 0: 256-channel workgroup tiles where Cout pads to 256 anyway (default 1)
  *   "wgrad_halo"           1 / 0: all-taps weight-gradient kernel of the 3x3 layers on / off (default 1; MRFA_WGRAD_HALO=0)
  *   "wgrad_halo_min_wgs"   fewest workgroups for which that kernel is chosen (default 192)
+ *   "conv_fewout3"         1 / 0: channel-lane kernels of the 3x3 layers with 1 / 2 output channels on / off (default 1)
  *   "conv_small"           1 / 0: one-wave-per-tile small-problem kernels on / off (default 1)                                    */
 int mrfa_set_tuning(const char* key, int value);
 
@@ -168,6 +169,12 @@ int mrfa_conv_fewout_fwd(void* stream, const float* x, int ldx, int N, int H, in
 /* dw [Cout][R*R][Cin] += sum_p dY[p][co] * X[p+tap-pad][ci] (atomics; caller zero-initialises); dbias optional    */
 int mrfa_conv_fewout_wgrad(void* stream, const float* x, int ldx, int N, int H, int W, int Cin, const float* dy, int lddy,
                            int Cout, int R, int pad, float* dw, float* dbias);
+/* data gradient of the few-output 3x3 layers: dx[p][ci] (+)= sum_{tap,co} dy[p - tap + pad][co] * w[co][tap][ci]   (w in pack mode 5;
+ * refine.conv2 / convo2, raft.py:76,78).  Only the shapes mrfa_conv_fewout_dgrad_supported() reports (3x3 / pad 1, Cout in {1, 2},
+ * Cin in {64, 128, 256}, lddx % 4 == 0): the caller takes the generic conv2d route (pack mode 2 / 3) otherwise.                      */
+int mrfa_conv_fewout_dgrad(void* stream, const float* dy, int lddy, int N, int H, int W, int Cout, const float* w, float* dx, int lddx,
+                           int Cin, int R, int pad, int accumulate);
+int mrfa_conv_fewout_dgrad_supported(int Cin, int Cout, int R, int pad, int W, int lddx);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K5/K6/K7: BatchNorm (train + eval) with fused ReLU / 2x2 avg-pool / occlusion blend.

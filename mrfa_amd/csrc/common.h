@@ -27,6 +27,11 @@ int mrfa_tuning_wgrad_halo_min(int set);   // mrfa_set_tuning("wgrad_halo_min_wg
 int mrfa_tuning_wgrad_halo_target(int set);
 int mrfa_tuning_wgrad_halo(int set);       // mrfa_set_tuning("wgrad_halo", 0 / 1); set < 0: query
 
+// conv_fewout3.hip: 3x3 layers with 1 / 2 output channels, channels across the lanes (true: handled, *rc = status)
+bool mrfa_fewout3_wgrad(hipStream_t st, const float* x, int ldx, int N, int H, int W, int Cin, const float* dy, int lddy, int Cout, int R, int pad,
+                        float* dw, float* dbias, int* rc);
+int mrfa_tuning_fewout3(int set);          // mrfa_set_tuning("conv_fewout3", 0 / 1)
+
 // conv_small.hip: one wave per 16..32-row output tile, operands straight from L1/L2 into v_mfma_f32_16x16x4_f32 (small problems)
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M);
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M);

@@ -223,6 +223,10 @@ extern "C" int mrfa_conv_fewout_wgrad(void* stream, const float* x, int ldx, int
                                       int Cout, int R, int pad, float* dw, float* dbias) {
     MRFA_CHECK_ARG(x && dy && dw && Cout >= 1 && Cout <= 4 && (Cin % 4) == 0 && (ldx % 4) == 0 && aligned16(x),
                    "conv_fewout_wgrad: needs Cout <= 4, Cin %% 4 == 0, 16-B aligned x");
+    {
+        int rc3 = 0;
+        if (mrfa_fewout3_wgrad((hipStream_t)stream, x, ldx, N, H, W, Cin, dy, lddy, Cout, R, pad, dw, dbias, &rc3)) return rc3;
+    }
     const int Ho = H + 2 * pad - R + 1, Wo = W + 2 * pad - R + 1;
     const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
     const int ntiles = N * tiles_x * tiles_y;

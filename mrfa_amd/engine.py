@@ -956,6 +956,12 @@ class Ctx:
             self._chk(self.L.mrfa_conv_fewout_fwd(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewin_dgrad_pack().data_ptr(),
                                                   None, x.gptr, x.ld, cw.Cin, cw.R, cw.R - 1 - cw.pad, 0 if first else 1), "conv_fewout(dgrad)")
             return
+        if (direct and cw.fewout and x.coff % 4 == 0 and
+                self.L.mrfa_conv_fewout_dgrad_supported(cw.Cin, cw.Cout, cw.R, cw.pad, x.W, x.ld)):
+            # 3x3 layer with one or two output channels: channel-lane kernel (csrc/conv_fewout3.hip) instead of a K = 9 Cout MFMA GEMM
+            self._chk(self.L.mrfa_conv_fewout_dgrad(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewout_pack().data_ptr(),
+                                                    x.gptr, x.ld, cw.Cin, cw.R, cw.pad, 0 if first else 1), "conv_fewout_dgrad")
+            return
         tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.gptr, out.ld, out.H, out.W, 0, out.N, cw.Cout

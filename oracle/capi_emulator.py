@@ -510,6 +510,18 @@ class Emulator:
             vec(dbias, Cout).add_(g.sum(dim=(0, 2, 3)))
         return 0
 
+    def mrfa_conv_fewout_dgrad(self, stream, dy, lddy, N, H, W, Cout, w, dx, lddx, Cin, R, pad, accumulate):
+        T = R * R
+        g = nhwc(dy, N, H, W, lddy, Cout).permute(0, 3, 1, 2).contiguous()
+        ww = _flat(w, Cout * T * Cin).view(Cout, T, Cin).permute(0, 2, 1).reshape(Cout, Cin, R, R).contiguous()
+        v = F.conv_transpose2d(g, ww, padding=pad).permute(0, 2, 3, 1)
+        o = nhwc(dx, N, H, W, lddx, Cin)
+        o.copy_(o + v if accumulate else v)
+        return 0
+
+    def mrfa_conv_fewout_dgrad_supported(self, Cin, Cout, R, pad, W, lddx):
+        return int(R == 3 and pad == 1 and Cout in (1, 2) and Cin in (64, 128, 256) and lddx % 4 == 0 and W >= 4)
+
     # ---------------------------------------------------------------- batch norm
     def mrfa_bn_stats(self, stream, x, ldx, rows, Cc, stats):
         v = mat(x, rows, ldx, Cc).double()

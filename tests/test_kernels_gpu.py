@@ -757,7 +757,10 @@ def test_layout_and_elementwise():
 
 @pytest.mark.parametrize("cfg", [dict(Cin=64, Cout=3, R=7, pad=3), dict(Cin=128, Cout=2, R=3, pad=1), dict(Cin=128, Cout=1, R=3, pad=1),
                                  dict(Cin=108, Cout=1, R=7, pad=3, H=20, W=17), dict(Cin=128, Cout=2, R=7, pad=3, mode7=True),
-                                 dict(Cin=36, Cout=4, R=7, pad=0, H=24, W=24), dict(Cin=128, Cout=2, R=3, pad=1, N=8, H=96, W=96)])
+                                 dict(Cin=36, Cout=4, R=7, pad=0, H=24, W=24), dict(Cin=128, Cout=2, R=3, pad=1, N=8, H=96, W=96),
+                                 # conv_fewout3.hip (channels across the lanes): 16 / 32 / 64 lanes per pixel, ragged rows, tiny images
+                                 dict(Cin=64, Cout=2, R=3, pad=1, H=9, W=21), dict(Cin=256, Cout=1, R=3, pad=1, N=1, H=8, W=8),
+                                 dict(Cin=128, Cout=2, R=3, pad=1, N=3, H=5, W=4)])
 def test_conv_fewout(cfg):
     """direct <=4-output-channel kernels (forward incl. accumulate, weight/bias gradient, pack modes 5/6/7)"""
     c = dict(N=2, H=33, W=40, mode7=False)
@@ -790,7 +793,14 @@ def test_conv_fewout(cfg):
         side.call("mrfa_conv_fewout_wgrad", x.data_ptr(), Cin + 4, N, H, W, Cin, dy.data_ptr(), 4, Cout, R, pad, dw.data_ptr(), db.data_ptr())
         g = side.t(f"{tag}/g0", (Cout, Cin, R, R))
         side.call("mrfa_pack_conv_weight", dw.data_ptr(), g.data_ptr(), Cout, Cin, R, R, 6)
-        return side.done(y[:, :Cout], y2[:, :Cout], y3[:, :Cout], dw, db, g, wp)
+        extra = []
+        if not c["mode7"] and side.L.mrfa_conv_fewout_dgrad_supported(Cin, Cout, R, pad, W, Cin + 4):
+            dx = side.garbage((N * H * W, Cin + 4))           # data gradient: overwrite, then accumulate on top
+            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx.data_ptr(), Cin + 4, Cin, R, pad, 0)
+            dx2 = side.t(f"{tag}/dx0", (N * H * W, Cin + 4))
+            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx2.data_ptr(), Cin + 4, Cin, R, pad, 1)
+            extra = [dx[:, :Cin], dx2[:, :Cin]]
+        return side.done(y[:, :Cout], y2[:, :Cout], y3[:, :Cout], dw, db, g, wp, *extra)
     ref, got = both(run)
     assert_close(ref, got, tol=5e-4, what=tag)
 

@@ -76,6 +76,8 @@ def main():
         ("convf1 2->128 7x7 @256 (flat)", 2, 128, 7, 256, 0),
         ("final 64->3 7x7 @256", 64, 3, 7, 256, 0),
         ("conv2 128->2 3x3 @256", 128, 2, 3, 256, 0),
+        ("convo2 128->1 3x3 @256", 128, 1, 3, 256, 0),
+        ("conv2 128->2 3x3 @64", 128, 2, 3, 64, 0),
         # TokenPose_B's HRNet stem (MTIA prior): ~0.6 GF each, 32 of each per stage-3 pass
         ("hr 32->32 3x3 @64", 32, 32, 3, 64, 0),
         ("hr 64->64 3x3 @32", 64, 64, 3, 32, 0),
@@ -107,11 +109,17 @@ def main():
         cw = convw(conv)
         flops = 2.0 * B * ro * ro * co * ci * k * k
         e.record = False
-        t_f = time_it(lambda: e.conv(x, conv, out=out, relu=True, ups=bool(ups)), iters=a.iters)
+        few = co <= 4                                  # few-output layers run the direct kernels (no ReLU in the model either)
+        t_f = time_it(lambda: e.conv(x, conv, out=out, relu=not few, ups=bool(ups)), iters=a.iters)
         out.st.grad_buf().normal_()
         x.st.grad_buf()
         t_d = time_it(lambda: e._conv_dgrad(x, cw, out, bool(ups), None), iters=a.iters)
-        t_w = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True), iters=a.iters)
+        if few:
+            dwf, dbf = cw.grad_acc(e.pool32)
+            t_w = time_it(lambda: e._chk(e.L.mrfa_conv_fewout_wgrad(e.s, x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, out.gptr, out.ld, cw.Cout, cw.R, cw.pad,
+                                                                      dwf.data_ptr(), dbf.data_ptr()), "fewout wgrad"), iters=a.iters)
+        else:
+            t_w = time_it(lambda: e._conv_wgrad(x, cw, out, bool(ups), None, True), iters=a.iters)
         cw.dw_acc = None
         tf = lambda t: flops / t / 1e9
         if a.ab_halo and k == 3:
