@@ -33,7 +33,10 @@ typedef struct {
     const float* x;        /* input NHWC view                                                                   */
     int ldx;               /* floats between consecutive input pixels                                           */
     int Hin, Win;          /* stored input spatial size                                                         */
-    int ups;               /* 1: fused nearest x2 upsample of the input (UpBlock2d, util.py:173)                */
+    int ups;               /* 1: fused nearest x2 upsample of the input (UpBlock2d, util.py:173); 2: the DATA GRADIENT of such a
+                              layer in phase form: x = gradient on the 2Hout x 2Wout grid, y = its 3x3 data gradient summed over
+                              the 2x2 pixels of every low-resolution pixel (needs w_phase in pack mode 13; only the shapes
+                              mrfa_conv2d_phase_dgrad_supported() reports)                                        */
     int N, Cin;
     const float* w;        /* packed weights, see mrfa_pack_conv_weight                                         */
     int w_ld;              /* floats between consecutive output-channel rows of the packed weight               */
@@ -65,6 +68,9 @@ typedef struct {
     int tile;              /* 0 = auto; else force a tile config (tests / tuning)                               */
     const void* w_split;   /* optional (chunked mode): the same weights pre-split into three bf16 pieces (pack modes 8 / 9);  */
     long long w_piece;     /*   bf16 elements between consecutive pieces.  Used by the split-operand kernel when present.     */
+    const void* w_phase;   /* optional, with ups = 1 and a 3x3 / pad 1 kernel: the 16 phase-tap weights of the four 2x2 convolutions */
+    long long w_phase_piece; /* that equal nearest-x2 + 3x3 (pack mode 12, bf16 pieces).  When present (and the patch-tiled kernel  */
+                           /*   applies) the layer runs 16 instead of 36 taps per low-resolution pixel -- same result up to fp32 rounding */
 } mrfa_conv_params;
 
 /* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS
@@ -74,6 +80,7 @@ typedef struct {
  * 2*C words cost 5-21 us per launch on the MTIA prior's 0.6-GFLOP layers (tools/ubench/small_kernels.cpp) -- more than the layer. */
 #define MRFA_STATS_SLOTS 32
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
+int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p);    /* 1: a call with these parameters (ups = 2) is implemented          */
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
  *   1  fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate
@@ -92,6 +99,7 @@ int mrfa_conv2d_last_config(void);
  *   "conv_halo"            1 / 0: patch-tiled 3x3 kernel on / off (default 1; also MRFA_CONV_HALO=0 in the environment)
  *   "conv_halo_min_tiles"  fewest workgroups for which the patch-tiled kernel is chosen (default 256 = one per CU)
  *   "conv_halo_pr"         0 = patch height by workgroup count (default), 4 / 8 = forced
+ *   "conv_halo_phase"      1 / 0: phase form (four 2x2 convolutions) of fused-upsample layers that carry w_phase (default 1)
  *   "conv_halo_bn256"      1 / 0: 256-channel workgroup tiles where Cout pads to 256 anyway (default 1)
  *   "wgrad_halo"           1 / 0: all-taps weight-gradient kernel of the 3x3 layers on / off (default 1; MRFA_WGRAD_HALO=0)
  *   "wgrad_halo_min_wgs"   fewest workgroups for which that kernel is chosen (default 192)
@@ -133,7 +141,11 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * modes 4|16 and 6|16: as 4 / 6 but overwriting (dst = ...) instead of accumulating
  * mode 8: as mode 0 but split for the bf16x6 kernels: three planes [piece][tap][CoutPad][CinPad] of bf16 with
  *         w = piece0 + piece1 + piece2 exactly (piece_k = top 16 bits of the residual); mode 9: likewise for mode 2
- *         (modes 8 / 9: batched entry point only)                                                                         */
+ *         (modes 8 / 9: batched entry point only)
+ * mode 13: mode 12 transposed ([piece][16][CinPad128][CoutPad32]) for the phase data gradient (ups = 2)
+ * mode 12: 3x3 only: the phase weights of UpBlock2d's nearest-x2 + conv (see mrfa_conv_params.w_phase): three bf16 planes
+ *         [piece][16 phase taps][CoutPad128][CinPad32], phase tap = (py*2+px)*4 + a*2+b, weight = sum of the 3x3 taps that read
+ *         the same low-resolution pixel (batched entry point only)                                                             */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 
 /* Batched forms: all layouts of many convolutions per launch (descriptor table passed by value in the kernel

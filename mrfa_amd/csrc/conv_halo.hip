@@ -69,7 +69,14 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     }
 }
 
-template <int PR, bool PRO, int BN, int NP>
+// PH: "phase" form of a fused nearest-x2 upsample (UpBlock2d, util.py:172-176): blockIdx.y = output phase (py, px); the patch lives on the
+// LOW-resolution input grid, every output pixel (2y + py, 2x + px) reads the 2x2 source pixels {y - 1 + py, y + py} x {x - 1 + px, x + px}
+// with the pre-summed phase weights of pack mode 12: four taps per chunk instead of nine on four times fewer patch pixels = 16 / 36 of the MACs
+// MODE 2 (PD): the DATA GRADIENT of such a layer, also in phase form: dx[y][x] (low resolution) = sum over the four phases of a 2x2
+// transposed convolution of the phase image dY[2t + py][2u + px]; the K loop runs over (chunk, phase) pairs -- each stages the halo of its
+// phase image (a stride-2 gather of the high-resolution gradient) and runs four taps with the transposed phase weights (pack mode 13).
+// Replaces the 3x3 data gradient on the high-resolution grid + the 2x2 sum-pooling pass.
+template <int PR, bool PRO, int BN, int NP, int MODE>
 __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(const mrfa_conv_params p, const int tiles_n, const int tiles_x, const int tiles_y,
                                                               const int total_tiles) {
     using G = Geo<PR>;
@@ -98,10 +105,17 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int n_img = t_ / tiles_y;
     const int y0 = ty * PR, x0 = tx * PW, n0 = tile_n * BN;
 
+    constexpr bool PH = MODE == 1, PD = MODE == 2;
+    constexpr int KT = (PH || PD) ? 4 : 9;         // taps (= pipeline steps) per 16-channel chunk
+    static_assert(!(PH || PD) || G::NU <= 3, "phase form: the halo units are loaded at tap 0 and stored at taps 1..3");
+    const int ph_y = PH ? (int)(blockIdx.y >> 1) : 0, ph_x = PH ? (int)(blockIdx.y & 1) : 0;
+    const int ush = (PH || PD) ? 0 : p.ups;        // phase forms: the patch is ON the low-resolution grid
     const float* __restrict__ x = p.x;
-    const unsigned short* __restrict__ ws = reinterpret_cast<const unsigned short*>(p.w_split);
-    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-    const int NC = p.Cin >> 4;
+    const unsigned short* __restrict__ ws = reinterpret_cast<const unsigned short*>((PH || PD) ? p.w_phase : p.w_split) +
+                                            (PH ? (size_t)(blockIdx.y * 4) * (size_t)p.w_tap : (size_t)0);
+    // PD: x is the high-resolution gradient (Hin x Win = 2 Hout x 2 Wout), the halo lives on the output (low-resolution) grid
+    const int Hv = PD ? p.Hout : (p.Hin << ush), Wv = PD ? p.Wout : (p.Win << ush);
+    const int NC = PD ? (p.Cin >> 4) * 4 : (p.Cin >> 4);         // PD: virtual chunks vc = 4 * (16-channel chunk) + phase
 
     // ---- halo units of this thread: (halo pixel hp, channel quad q); q = tid & 3 for every unit (NT % 4 == 0)
     const int q4 = tid & 3;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         a_inb[j] = a_val[j] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
         // out-of-image pixels read a valid address (pixel 0 of the image) and are zeroed after the prologue
-        const int pix = n_img * p.Hin * p.Win + (a_inb[j] ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0);
+        const int pix = n_img * p.Hin * p.Win + (a_inb[j] ? (PD ? (2 * iy) * p.Win + 2 * ix : (iy >> ush) * p.Win + (ix >> ush)) : 0);
         a_goff[j] = pix * p.ldx + q4 * 4;
         a_loff[j] = (q4 >> 1) * G::AHALF + hp * 16 + (q4 & 1) * 8;
     }
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int uu = b_val[j] ? u : 0;
         const int pc = uu / (BN * 2), rem = uu - pc * (BN * 2);
         const int row = rem >> 1, half = rem & 1;
-        b_goff[j] = pc * (int)p.w_piece + (n0 + row) * p.w_ld + half * 8;
+        b_goff[j] = pc * (int)((PH || PD) ? p.w_phase_piece : p.w_piece) + (n0 + row) * p.w_ld + half * 8;
         b_loff[j] = pc * BPLANE + half * BHALF + row * 16;
     }
 
@@ -138,7 +152,15 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     u32x4 rb[NBU];
     const int w_tap = (int)p.w_tap;
 
-    auto load_a = [&](int j, int c) { ra[j] = *reinterpret_cast<const f32x4*>(x + (size_t)a_goff[j] + c * 16); };
+    // PD: virtual chunk c = 4 * (channel chunk) + phase: phase image offset (py * Win + px) pixels, masked units stay on their valid address
+    auto load_a = [&](int j, int c) {
+        if constexpr (PD) {
+            const int po = a_inb[j] ? (((c >> 1) & 1) * p.Win + (c & 1)) * p.ldx : 0;
+            ra[j] = *reinterpret_cast<const f32x4*>(x + (size_t)a_goff[j] + po + (c >> 2) * 16);
+        } else {
+            ra[j] = *reinterpret_cast<const f32x4*>(x + (size_t)a_goff[j] + c * 16);
+        }
+    };
     auto load_pro = [&](int c) {
         if constexpr (PRO) {
             psc = *reinterpret_cast<const f32x4*>(p.in_scale + c * 16 + q4 * 4);
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
     auto load_b = [&](int c, int tap) {
-        const unsigned short* src = ws + (size_t)tap * w_tap + c * 16;
+        const unsigned short* src = PD ? ws + (size_t)((c & 3) * 4 + tap) * w_tap + (c >> 2) * 16 : ws + (size_t)tap * w_tap + c * 16;
 #pragma unroll
         for (int j = 0; j < NBU; ++j) rb[j] = *reinterpret_cast<const u32x4*>(src + b_goff[j]);
     };
@@ -183,13 +205,14 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fhalf = lane >> 5;
-    const int a_frag = fhalf * G::AHALF + (2 * wm * HP + frow) * 16;            // + ((i + r) * HP + s) * 16 per (row tile, tap)
+    const int a_frag = fhalf * G::AHALF + ((2 * wm + ph_y) * HP + frow + ph_x) * 16;      // + ((i + r) * HP + s) * 16 per (row tile, tap)
     const int b_frag = fhalf * BHALF + (wn * (TN * 32) + frow) * 16;            // + j * 512 per column tile
 
-    auto compute = [&](auto TAP, int abuf, int bbuf) {
+    auto compute = [&](auto TAP, int abuf, int bbuf, int vc) {
         constexpr int tap = decltype(TAP)::value;
-        constexpr int r = tap / 3, s = tap % 3;
-        const unsigned char* A = smA + abuf * G::ABUF + a_frag;
+        // PD: source of tap (a, b) of phase (py, px) is the phase-image pixel (y + 1 - py - a, x + 1 - px - b): halo offset (2 - a, 2 - b) minus the phase
+        constexpr int r = PD ? 2 - (tap >> 1) : (PH ? tap >> 1 : tap / 3), s = PD ? 2 - (tap & 1) : (PH ? tap & 1 : tap % 3);
+        const unsigned char* A = smA + abuf * G::ABUF + a_frag - (PD ? (((vc >> 1) & 1) * HP + (vc & 1)) * 16 : 0);
         const unsigned char* B = smB + bbuf * BSLAB + b_frag;
         constexpr int JG = TN < 2 ? TN : 2;          // column tiles per pass: BN = 256 runs two passes over the same A fragments
         bf16x8 a[NPC][2];
@@ -242,11 +265,19 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         auto step = [&](auto TAP) {
             constexpr int tap = decltype(TAP)::value;
             store_b(ubuf ^ 1);
-            if constexpr (tap + 2 < 9) load_b(c, tap + 2); else load_b(cn, tap + 2 - 9);
+            if constexpr (tap + 2 < KT) load_b(c, tap + 2); else load_b(cn, tap + 2 - KT);
             if constexpr (tap == 0) load_pro(cn);      // (the stores of chunk c's halo, which used the previous pair, are all behind us)
-            if constexpr (tap >= 2 && tap % 2 == 0 && (tap - 2) / 2 < G::NU) store_a((tap - 2) / 2, abuf ^ 1);
-            if constexpr (tap % 2 == 0 && tap / 2 < G::NU) load_a(tap / 2, cn);
-            compute(TAP, abuf, ubuf);
+            if constexpr (PH || PD) {                  // four steps per chunk: every unit of the next halo is loaded at tap 0, unit j stored at tap 1 + j
+                if constexpr (tap >= 1 && tap - 1 < G::NU) store_a(tap - 1, abuf ^ 1);
+                if constexpr (tap == 0) {
+#pragma unroll
+                    for (int j = 0; j < G::NU; ++j) load_a(j, cn);
+                }
+            } else {
+                if constexpr (tap >= 2 && tap % 2 == 0 && (tap - 2) / 2 < G::NU) store_a((tap - 2) / 2, abuf ^ 1);
+                if constexpr (tap % 2 == 0 && tap / 2 < G::NU) load_a(tap / 2, cn);
+            }
+            compute(TAP, abuf, ubuf, c);
             __syncthreads();
             ubuf ^= 1;
         };
@@ -254,11 +285,13 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
         step(std::integral_constant<int, 3>{});
-        step(std::integral_constant<int, 4>{});
-        step(std::integral_constant<int, 5>{});
-        step(std::integral_constant<int, 6>{});
-        step(std::integral_constant<int, 7>{});
-        step(std::integral_constant<int, 8>{});
+        if constexpr (KT == 9) {
+            step(std::integral_constant<int, 4>{});
+            step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{});
+            step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{});
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -273,9 +306,10 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int py = y0 + 2 * wm + i;
-            const long long m = ((long long)n_img * p.Hout + py) * p.Wout + x0 + px;
-            if (py < p.Hout) {
+            const int pyl = y0 + 2 * wm + i;             // patch row; phase form: output pixel (2 pyl + ph_y, 2 (x0 + px) + ph_x)
+            const long long m = PH ? ((long long)n_img * p.Hout + 2 * pyl + ph_y) * p.Wout + 2 * (x0 + px) + ph_x
+                                   : ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + px;
+            if (pyl < (PH ? p.Hin : p.Hout)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c0 = cb + 8 * g;
@@ -367,9 +401,23 @@ int g_halo_bn256 = 1;
 // (patch rows, BN): PR = 8 (8 waves, 1 workgroup / CU) when that still gives every CU a workgroup, else PR = 4 (4 waves, 2 workgroups
 // per CU); BN = 256 (each wave 64 pixels x 128 channels: the halo is staged once for twice the MFMAs, 18 instead of 24 fragment reads
 // per 48 MFMAs) when Cout pads to a multiple of 256 anyway and the workgroup count allows
+int g_halo_phase = 1;
+
+// the phase form of a fused upsample applies: pre-summed phase weights present, the LOW-resolution grid tiles into 8 x 32 patches
+bool halo_phase(const mrfa_conv_params& p) {
+    return g_halo_phase && p.ups == 1 && p.w_phase != nullptr && (p.Win % PW) == 0 && (p.Hin % 8) == 0 && 3 * p.w_phase_piece < (1ll << 31);
+}
+
 void halo_config(const mrfa_conv_params& p, int& PR, int& BN) {
     PR = 0;
     BN = p.Cout <= 64 ? 64 : 128;
+    if (halo_phase(p)) {                           // four phase workgroups per low-resolution patch
+        const long long patches = (long long)p.N * (p.Hin / 8) * (p.Win / PW) * 4;
+        if (g_halo_bn256 && p.Cout > 128 && cdiv(p.Cout, 256) * 256 == cdiv(p.Cout, 128) * 128 && patches * cdiv(p.Cout, 256) >= g_halo_min_tiles) {
+            PR = 8; BN = 256; return;
+        }
+        if (patches * cdiv(p.Cout, BN) >= g_halo_min_tiles) { PR = 8; return; }
+    }
     const long long patches8 = (long long)p.N * cdiv(p.Hout, 8) * (p.Wout / PW), patches4 = (long long)p.N * cdiv(p.Hout, 4) * (p.Wout / PW);
     if (g_halo_pr != 4 && p.Hout % 8 == 0) {
         if (g_halo_bn256 && p.Cout > 128 && cdiv(p.Cout, 256) * 256 == cdiv(p.Cout, 128) * 128 && patches8 * cdiv(p.Cout, 256) >= g_halo_min_tiles) {
@@ -380,6 +428,13 @@ void halo_config(const mrfa_conv_params& p, int& PR, int& BN) {
     // 4-row patches run two workgroups per CU: they need twice the workgroups to fill the chip (measured: 512->512 @32^2, 256 workgroups of
     // 4 rows lose to the row-tiled kernel with its K split)
     if (g_halo_pr != 8 && patches4 * cdiv(p.Cout, BN) >= 2ll * g_halo_min_tiles) PR = 4;
+}
+
+// (is the launch the phase form?  halo_config picks it first; it falls through to the plain form when the phase grid is too small)
+bool halo_uses_phase(const mrfa_conv_params& p, int PR, int BN) {
+    if (!halo_phase(p) || PR != 8) return false;
+    const long long patches = (long long)p.N * (p.Hin / 8) * (p.Win / PW) * 4;
+    return patches * cdiv(p.Cout, BN) >= g_halo_min_tiles;
 }
 
 }  // namespace
@@ -393,6 +448,7 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!key) return -1;
     if (!strcmp(key, "conv_halo")) { const int prev = halo_on(); g_halo_on = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_min_tiles")) { const int prev = g_halo_min_tiles; g_halo_min_tiles = value; return prev; }
+    if (!strcmp(key, "conv_halo_phase")) { const int prev = g_halo_phase; g_halo_phase = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_bn256")) { const int prev = g_halo_bn256; g_halo_bn256 = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_pr")) { const int prev = g_halo_pr; g_halo_pr = value; return prev; }
     if (!strcmp(key, "wgrad_halo")) return mrfa_tuning_wgrad_halo(value != 0);
@@ -405,7 +461,21 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
 
 int mrfa_tuning_conv_small() { return g_conv_small; }
 
+// ups == 2: phase DATA GRADIENT of a fused-upsample 3x3 layer (x = high-resolution gradient, y = low-resolution input gradient)
+static bool halo_phase_dgrad(const mrfa_conv_params& p) {
+    const int mode = mrfa_get_mfma_mode();
+    if (!halo_on() || !g_halo_phase || (mode != 1 && mode != 2)) return false;
+    if (p.ups != 2 || !p.w_phase || p.kflat > 0 || p.R != 3 || p.S != 3 || p.pad != 1 || p.nbatch > 1 || p.splitk > 1 || p.tile || p.in_scale) return false;
+    if (p.Hin != 2 * p.Hout || p.Win != 2 * p.Wout || (p.Wout % PW) != 0 || (p.Hout % 8) != 0 || (p.Cin % 32) != 0 || p.Cout < 32) return false;
+    if ((p.ldy % 4) != 0 || !aligned16(p.y) || (p.ldx % 4) != 0 || !aligned16(p.x) || 3 * p.w_phase_piece >= (1ll << 31) || p.w_tap >= (1ll << 31)) return false;
+    if ((long long)p.N * p.Hin * p.Win * p.ldx >= (1ll << 31)) return false;
+    return true;
+}
+
+extern "C" int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p) { return p && halo_phase_dgrad(*p) ? 1 : 0; }
+
 bool mrfa_conv_halo_eligible(const mrfa_conv_params& p) {
+    if (p.ups == 2) return halo_phase_dgrad(p);
     const int mode = mrfa_get_mfma_mode();
     if (!halo_on() || (mode != 1 && mode != 2)) return false;
     if (p.kflat > 0 || p.R != 3 || p.S != 3 || p.pad != 1 || !p.w_split || p.nbatch > 1 || p.splitk > 1 || p.tile) return false;
@@ -422,21 +492,36 @@ bool mrfa_conv_halo_eligible(const mrfa_conv_params& p) {
 
 int mrfa_conv_halo_launch(hipStream_t st, const mrfa_conv_params& p) {
     int PR, BN;
-    halo_config(p, PR, BN);
-    const int tiles_n = cdiv(p.Cout, BN), tiles_x = p.Wout / PW, tiles_y = cdiv(p.Hout, PR);
+    if (p.ups == 2) {                                // phase data gradient: 8-row patches on the output grid, <= 128-wide tiles
+        PR = 8;
+        BN = p.Cout <= 64 ? 64 : 128;
+    } else {
+        halo_config(p, PR, BN);
+    }
+    const bool phase = p.ups != 2 && halo_uses_phase(p, PR, BN);
+    const int tiles_n = cdiv(p.Cout, BN), tiles_x = (phase ? p.Win : p.Wout) / PW, tiles_y = cdiv(phase ? p.Hin : p.Hout, PR);
     const long long total = (long long)p.N * tiles_y * tiles_x * tiles_n;
-    dim3 grid((unsigned)(cdiv(total, 8) * 8));
+    dim3 grid((unsigned)(cdiv(total, 8) * 8), phase ? 4u : 1u);
     const bool three = mrfa_get_mfma_mode() == 2;
     const bool pro = p.in_scale != nullptr;
-#define HALO_LAUNCH(PR_, PRO_, BN_)                                                                                                                    \
-    do {                                                                                                                                              \
-        if (three) hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 3>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);  \
-        else hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 6>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);        \
+#define HALO_LAUNCH(PR_, PRO_, BN_, MODE_)                                                                                                                      \
+    do {                                                                                                                                                     \
+        if (three) hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 3, MODE_>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);    \
+        else hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 6, MODE_>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);          \
     } while (0)
-#define HALO_BN(PR_, PRO_) do { if (BN == 64) HALO_LAUNCH(PR_, PRO_, 64); else HALO_LAUNCH(PR_, PRO_, 128); } while (0)
-    if (PR == 8 && BN == 256) { if (pro) HALO_LAUNCH(8, true, 256); else HALO_LAUNCH(8, false, 256); }
-    else if (PR == 8) { if (pro) HALO_BN(8, true); else HALO_BN(8, false); }
-    else { if (pro) HALO_BN(4, true); else HALO_BN(4, false); }
+#define HALO_BN(PR_, PRO_, MODE_)                                                     \
+    do {                                                                              \
+        if (BN == 64) HALO_LAUNCH(PR_, PRO_, 64, MODE_);                              \
+        else if (BN == 256) HALO_LAUNCH(PR_, PRO_, 256, MODE_);                       \
+        else HALO_LAUNCH(PR_, PRO_, 128, MODE_);                                      \
+    } while (0)
+    if (p.ups == 2) { if (BN == 64) HALO_LAUNCH(8, false, 64, 2); else HALO_LAUNCH(8, false, 128, 2); }
+    else if (phase) { if (pro) HALO_BN(8, true, 1); else HALO_BN(8, false, 1); }
+    else if (PR == 8) { if (pro) HALO_BN(8, true, 0); else HALO_BN(8, false, 0); }
+    else {
+        if (BN == 64) { if (pro) HALO_LAUNCH(4, true, 64, 0); else HALO_LAUNCH(4, false, 64, 0); }
+        else { if (pro) HALO_LAUNCH(4, true, 128, 0); else HALO_LAUNCH(4, false, 128, 0); }
+    }
 #undef HALO_BN
 #undef HALO_LAUNCH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(halo)");

@@ -365,6 +365,11 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
         return mrfa_conv_small_launch(st, p, M);
     }
+    if (p.ups == 2 && !(!flat && mrfa_conv_halo_eligible(p))) {
+        mrfa_set_error("conv2d: ups = 2 (phase data gradient of a fused-upsample layer) is only implemented for the shapes "
+                       "mrfa_conv2d_phase_dgrad_supported() reports");
+        return 1;
+    }
     // ---- 3x3 stride-1 layers with 32-aligned rows in split-operand mode: patch-tiled kernel, input halo split once per chunk (conv_halo.hip)
     if (!flat && mrfa_conv_halo_eligible(p)) {
         g_last_tile = (128 << 16) | ((p.Cout <= 64 ? 64 : 128) << 4) | 4 | (1 << 28);       // bit 28: conv_halo

@@ -73,6 +73,49 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
     for (int k = 0; k < d.ndst; ++k) {
         const int mode = d.mode[k];
         float* __restrict__ dst = d.dst[k];
+        if (mode == 12 || mode == 13) {
+            // nearest-x2 upsample + 3x3 conv = four 2x2 "phase" convolutions on the low-resolution input (UpBlock2d, util.py:172-176): output
+            // pixel (2y + py, 2x + px) reads rows {y - 1 + py, y + py} x columns {x - 1 + px, x + px}; the weight of phase tap (a, b) is the
+            // sum of the 3x3 taps that land on that source pixel: rows R(py, a) = {0} {1,2} | {0,1} {2}, columns likewise.  Layout: three
+            // bf16 planes [piece][(py*2+px)*4 + a*2+b][CoutPad128][CinPad32] (mode 12: the split of mode 8 applied to the summed weights) or
+            // transposed [piece][..][CinPad128][CoutPad32] (mode 13: for the phase data gradient, the split of mode 9's role).
+            constexpr unsigned RM[4] = {0x1u, 0x6u, 0x3u, 0x4u};         // [py*2 + a] -> bit mask over r
+            const bool tr = mode == 13;
+            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(dst);
+            const int rowsP = tr ? rup(Cin, 128) : rup(Cout, 128), colsP = tr ? rup(Cout, 32) : rup(Cin, 32);
+            const long long piece = 16ll * rowsP * colsP;
+            const int nfast = tr ? nco : nci, nslow = tr ? nci : nco;     // fastest destination axis: ci (12) / co (13)
+            const int f0 = (threadIdx.x & 15) * 2;                        // pair along the fastest axis
+            for (int q = threadIdx.x >> 4; q < nslow * 16; q += 16) {
+                const int sl = q >> 4, pt = q & 15;
+                if (f0 >= nfast) continue;
+                const int ph = pt >> 2, a_ = (pt >> 1) & 1, b_ = pt & 1;
+                const unsigned rm = RM[(ph >> 1) * 2 + a_], sm = RM[(ph & 1) * 2 + b_];
+                float v[2] = {0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (f0 + e < nfast) {
+                        const int co_l = tr ? f0 + e : sl, ci_l = tr ? sl : f0 + e;
+                        const float* wl = lds + co_l * row + ci_l * T;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int s_ = 0; s_ < 3; ++s_)
+                                if (((rm >> r) & 1u) && ((sm >> s_) & 1u)) v[e] += wl[r * 3 + s_];
+                    }
+                }
+                const long long idx = tr ? ((long long)pt * rowsP + ci0 + sl) * colsP + co0 + f0 : ((long long)pt * rowsP + co0 + sl) * colsP + ci0 + f0;
+                float x0 = v[0], x1 = v[1];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const unsigned b0 = __float_as_uint(x0) & 0xffff0000u, b1 = __float_as_uint(x1) & 0xffff0000u;
+                    *reinterpret_cast<unsigned*>(d16 + pc * piece + idx) = (b0 >> 16) | b1;       // idx is even; a lone last element pairs with 0
+                    x0 -= __uint_as_float(b0);
+                    x1 -= __uint_as_float(b1);
+                }
+            }
+            continue;
+        }
         const bool ci_fast = mode == 0 || mode == 1 || mode == 5 || mode == 8;
         const bool bf = mode == 8 || mode == 9;
         const int nf = ci_fast ? nci : nco;                       // extent of the fastest (contiguous) destination axis in this tile
@@ -196,7 +239,7 @@ extern "C" int mrfa_pack_conv_weights_multi(void* stream, const mrfa_pack_desc* 
                        descs[i].ndst);
         for (int k = 0; k < descs[i].ndst; ++k) {
             const int m = descs[i].mode[k];
-            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9),
+            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9 || ((m == 12 || m == 13) && descs[i].R == 3 && descs[i].S == 3)),
                            "pack_conv_weights_multi: desc %d: null dst or mode %d", i, m);
         }
     }

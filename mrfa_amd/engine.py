@@ -112,6 +112,7 @@ class defer_wgrads:
 
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones)
+PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward of fused-upsample 3x3 layers as four 2x2 phase convolutions
 FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "4")) << 20) // 4
 # debug switch (MRFA_FRESH_NAN=1; tests set it together with FRESH_MIN_ELEMS = 0): every lazily initialised gradient buffer starts
 # as NaN instead of whatever the allocator hands out, so a kernel that READS a buffer no writer has covered -- or a first writer that
@@ -185,6 +186,10 @@ def prepare_packs(module: torch.nn.Module) -> bool:
             cw.split_pack("f", getattr(cw, "_fwd_padded", False))
         if getattr(cw, "_dg_s", None) is not None:
             cw.split_pack("d", getattr(cw, "_dg_padded", False))
+        if getattr(cw, "_fwd_ph", None) is not None:
+            cw.phase_pack()
+        if getattr(cw, "_dg_ph", None) is not None:
+            cw.phase_pack(dgrad=True)
         if cw._fo is not None:
             cw.fewout_pack()
         if cw._fi is not None:
@@ -426,6 +431,31 @@ class ConvW:
             setattr(self, ver, self._key())
         return buf, piece
 
+    def phase_pack(self, dgrad: bool = False) -> tuple:
+        """(buffer, elements per piece) of the 16 phase-tap weights of nearest-x2 + this 3x3 conv (pack mode 12: UpBlock2d as four 2x2
+        convolutions on the low-resolution input, util.py:172-176), pre-split into three bf16 pieces; dgrad: transposed (mode 13)"""
+        assert self.R == 3 and self.S == 3
+        attr, ver, mode = ("_dg_ph", "_ver_dph", 13) if dgrad else ("_fwd_ph", "_ver_ph", 12)
+        if dgrad:
+            assert not self.dgrad_flat
+            piece = 16 * ((self.Cin + 127) // 128 * 128) * self.Cout
+        else:
+            assert not self.fwd_flat
+            piece = 16 * ((self.Cout + 127) // 128 * 128) * self.Cin
+        buf = getattr(self, attr, None)
+        w = self.conv.weight.detach()
+        if buf is None or buf.numel() != 3 * piece or buf.device != w.device:
+            buf = torch.zeros(3 * piece, dtype=torch.int16, device=w.device)
+            setattr(self, attr, buf)
+            setattr(self, ver, None)
+        if getattr(self, ver, None) != self._key():
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.contiguous().data_ptr(), self.Cout, self.Cin, self.R, self.S, 1
+            d.dst[0], d.mode[0] = buf.data_ptr(), mode
+            hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack(phase)")
+            setattr(self, ver, self._key())
+        return buf, piece
+
     def _simple_pack(self, attr, ver_attr, mode):
         if getattr(self, attr) is None or getattr(self, ver_attr) != self._key():
             w = self.conv.weight.detach()
@@ -497,6 +527,10 @@ class PackPlan:
                 dsts.append((cw._fwd_s, 8))
             if getattr(cw, "_dg_s", None) is not None:
                 dsts.append((cw._dg_s, 9))
+            if getattr(cw, "_fwd_ph", None) is not None:
+                dsts.append((cw._fwd_ph, 12))
+            if getattr(cw, "_dg_ph", None) is not None:
+                dsts.append((cw._dg_ph, 13))
             if cw._fo is not None:
                 dsts.append((cw._fo, 5))
             if cw._fi is not None:
@@ -512,17 +546,18 @@ class PackPlan:
                 descs.append(d)
         self.n = len(descs)
         self.table = (hip.PackDesc * max(self.n, 1))(*descs)
-        self.ptrs = [(cw, cw.conv.weight.data_ptr(), id(cw._fwd), id(cw._dg), id(getattr(cw, "_fwd_s", None)), id(getattr(cw, "_dg_s", None)))
-                     for cw in self.cws]
+        self.ptrs = [(cw, cw.conv.weight.data_ptr(), id(cw._fwd), id(cw._dg), id(getattr(cw, "_fwd_s", None)), id(getattr(cw, "_dg_s", None)),
+                      id(getattr(cw, "_fwd_ph", None)), id(getattr(cw, "_dg_ph", None))) for cw in self.cws]
 
     def run(self):
         if self.n:
             hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), self.table, self.n), "pack_conv_weights_multi")
-        for cw, wptr, idf, idd, idfs, idds in self.ptrs:
+        for cw, wptr, idf, idd, idfs, idds, idph, iddph in self.ptrs:
             assert (cw.conv.weight.data_ptr() == wptr and id(cw._fwd) == idf and id(cw._dg) == idd and
-                    id(getattr(cw, "_fwd_s", None)) == idfs and id(getattr(cw, "_dg_s", None)) == idds), "PackPlan is stale: rebuild it"
+                    id(getattr(cw, "_fwd_s", None)) == idfs and id(getattr(cw, "_dg_s", None)) == idds and
+                    id(getattr(cw, "_fwd_ph", None)) == idph and id(getattr(cw, "_dg_ph", None)) == iddph), "PackPlan is stale: rebuild it"
             k = cw._key()
-            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = k
+            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = k
 
 
 def unpack_direct(cws: List["ConvW"]):
@@ -859,6 +894,10 @@ class Ctx:
             if self.split:
                 ws, p.w_piece = cw.split_pack("f", False)
                 p.w_split = ws.data_ptr()
+                if ups and cw.R == 3 and cw.S == 3 and cw.pad == 1 and PHASE_UPCONV:
+                    # UpBlock2d: the library may run nearest-x2 + 3x3 as four 2x2 phase convolutions (16 / 36 of the MACs, csrc/conv_halo.hip)
+                    wph, p.w_phase_piece = cw.phase_pack()
+                    p.w_phase = wph.data_ptr()
         p.w_rows = cop
         p.y, p.ldy, p.Cout, p.Hout, p.Wout = out.ptr, out.ld, cw.Cout, Ho, Wo
         p.R, p.S, p.pad = cw.R, cw.S, cw.pad
@@ -962,6 +1001,26 @@ class Ctx:
             self._chk(self.L.mrfa_conv_fewout_dgrad(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewout_pack().data_ptr(),
                                                     x.gptr, x.ld, cw.Cin, cw.R, cw.pad, 0 if first else 1), "conv_fewout_dgrad")
             return
+        if (ups and pre is None and self.split and PHASE_UPCONV and cw.R == 3 and cw.S == 3 and cw.pad == 1 and not cw.dgrad_flat
+                and x.coff % 4 == 0):
+            # UpBlock2d: data gradient in phase form (four transposed 2x2 convolutions of the phase images of dY, csrc/conv_halo.hip MODE 2)
+            # straight into x.grad -- instead of the 3x3 data gradient on the 2H x 2W grid + the 2x2 sum-pooling pass
+            q = hip.ConvParams()
+            q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = out.gptr, out.ld, out.H, out.W, 2, out.N, cw.Cout
+            wd = cw.dgrad_pack(False)                          # (fp32 pack: what the ABI's specification reads)
+            cipd = (cw.Cin + 127) // 128 * 128
+            q.w, q.w_ld, q.w_tap, q.kflat, q.w_rows = wd.data_ptr(), cw.Cout, cipd * cw.Cout, 0, cipd
+            wph, q.w_phase_piece = cw.phase_pack(dgrad=True)
+            q.w_phase = wph.data_ptr()
+            q.Cout, q.Hout, q.Wout = cw.Cin, x.H, x.W
+            q.R, q.S, q.pad = cw.R, cw.S, cw.R - 1 - cw.pad
+            q.alpha, q.nbatch = 1.0, 1
+            if self.L.mrfa_conv2d_phase_dgrad_supported(C.byref(q)):
+                first_ph = self._claim(x)
+                q.y, q.ldy = x.gptr, x.ld
+                q.accumulate = 0 if first_ph else 1
+                self._launch_conv(q, "dgrad(phase)", cw.Cout)
+                return
         tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.gptr, out.ld, out.H, out.W, 0, out.N, cw.Cout

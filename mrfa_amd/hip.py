@@ -35,6 +35,7 @@ class ConvParams(C.Structure):
         ("splitk", C.c_int),
         ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile", C.c_int),
         ("w_split", C.c_void_p), ("w_piece", C.c_longlong),
+        ("w_phase", C.c_void_p), ("w_phase_piece", C.c_longlong),
     ]
 
 
@@ -106,6 +107,7 @@ _SIGNATURES = {
     "mrfa_version": ([], C.c_int),
     "mrfa_last_error": ([], C.c_char_p),
     "mrfa_conv2d_nhwc": ([_V, C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_phase_dgrad_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_last_config": ([], C.c_int),
     "mrfa_set_mfma_mode": ([_I], C.c_int),
     "mrfa_get_mfma_mode": ([], C.c_int),

@@ -426,7 +426,7 @@ class Emulator:
             x = x * vec(p.in_scale, p.Cin).view(1, -1, 1, 1) + vec(p.in_shift, p.Cin).view(1, -1, 1, 1)
             if p.in_relu:
                 x = F.relu(x)
-        if p.ups:
+        if p.ups == 1:
             x = F.interpolate(x, scale_factor=2)
         return x
 
@@ -447,6 +447,8 @@ class Emulator:
                                       (p.w_tap, p.w_ld, 1))
                 w = wt.permute(1, 2, 0).reshape(p.Cout, p.Cin, p.R, p.S)
             acc = F.conv2d(x, w.contiguous(), None, padding=p.pad) * p.alpha
+            if p.ups == 2:           # data gradient of a fused-upsample layer: the 3x3 data gradient on the high-resolution grid, 2x2 sum-pooled
+                acc = F.avg_pool2d(acc, 2) * 4.0
             assert acc.shape[2] == p.Hout and acc.shape[3] == p.Wout, (acc.shape, p.Hout, p.Wout)
             v = acc.permute(0, 2, 3, 1)
             y = nhwc(yp, p.N, p.Hout, p.Wout, p.ldy, p.Cout)
@@ -518,6 +520,12 @@ class Emulator:
         o = nhwc(dx, N, H, W, lddx, Cin)
         o.copy_(o + v if accumulate else v)
         return 0
+
+    def mrfa_conv2d_phase_dgrad_supported(self, pref):
+        """mirrors the library's answer for shapes, independent of tuning knobs (the emulator computes the same result either way)"""
+        p = _obj(pref)
+        return int(p.ups == 2 and bool(p.w_phase) and p.R == 3 and p.S == 3 and p.pad == 1 and p.Hin == 2 * p.Hout and p.Win == 2 * p.Wout
+                   and p.Wout % 32 == 0 and p.Hout % 8 == 0 and p.Cin % 32 == 0 and not p.in_scale)
 
     def mrfa_conv_fewout_dgrad_supported(self, Cin, Cout, R, pad, W, lddx):
         return int(R == 3 and pad == 1 and Cout in (1, 2) and Cin in (64, 128, 256) and lddx % 4 == 0 and W >= 4)
@@ -863,6 +871,33 @@ class Emulator:
                         bits = r.view(torch.int32) & -65536
                         out[pc] = (bits >> 16).to(torch.int16)
                         r = r - bits.view(torch.float32)
+                    continue
+                if d.mode[k] in (12, 13):            # phase weights of nearest-x2 + 3x3 (see mrfa_conv_params.w_phase), split into three bf16 pieces
+                    assert d.R == 3 and d.S == 3     # 13: transposed (rows = input channels) for the phase data gradient
+                    tr = d.mode[k] == 13
+                    cop, cip = ((d.Cin + 127) // 128 * 128, (d.Cout + 31) // 32 * 32) if tr else ((d.Cout + 127) // 128 * 128, (d.Cin + 31) // 32 * 32)
+                    w = _flat(d.src, d.Cout * d.Cin * 9).view(d.Cout, d.Cin, 3, 3)
+                    sets = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}        # (phase bit, tap bit) -> 3x3 rows / columns summed
+                    full = torch.zeros(16, cop, cip, dtype=torch.float32)
+                    for py in range(2):
+                        for px in range(2):
+                            for a_ in range(2):
+                                for b_ in range(2):
+                                    acc = torch.zeros(d.Cout, d.Cin, dtype=torch.float32)
+                                    for r in sets[(py, a_)]:          # same summation order as the kernel: r outer, s inner, fp32
+                                        for s_ in sets[(px, b_)]:
+                                            acc = acc + w[:, :, r, s_]
+                                    if tr:
+                                        full[(py * 2 + px) * 4 + a_ * 2 + b_, :d.Cin, :d.Cout] = acc.t()
+                                    else:
+                                        full[(py * 2 + px) * 4 + a_ * 2 + b_, :d.Cout, :d.Cin] = acc
+                    nn_ = 16 * cop * cip
+                    out = torch.frombuffer((C.c_short * (3 * nn_)).from_address(d.dst[k]), dtype=torch.int16).view(3, nn_)
+                    r_ = full.reshape(-1)
+                    for pc in range(3):
+                        bits = r_.view(torch.int32) & -65536
+                        out[pc] = (bits >> 16).to(torch.int16)
+                        r_ = r_ - bits.view(torch.float32)
                     continue
                 rc = self.mrfa_pack_conv_weight(stream, d.src, d.dst[k], d.Cout, d.Cin, d.R, d.S, d.mode[k])
                 if rc:

@@ -81,7 +81,7 @@ def ktab(side, Cc, R, S, pad):
 
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
-              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, tag="c"):
+              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -112,6 +112,15 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
             side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
             keep.append(wsb)
             p.w_split, p.w_piece = wsb.data_ptr(), piece
+        if wphase:                  # the 16 phase-tap weights of nearest-x2 + 3x3 (pack mode 12)
+            ppiece = 16 * cop * Cin
+            wpb = torch.zeros(3 * ppiece, dtype=torch.int16, device=side.dev)
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, S, 1
+            d.dst[0], d.mode[0] = wpb.data_ptr(), 12
+            side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
+            keep.append(wpb)
+            p.w_phase, p.w_phase_piece = wpb.data_ptr(), ppiece
     p.w_rows = cop
     p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), ldy, Cout, Ho, Wo
     p.R, p.S, p.pad = R, S, pad
@@ -225,6 +234,10 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True),                 # 256-wide workgroup tile, 64 padding columns
     "bn256_c512_stats": dict(N=1, H=8, W=32, Cin=32, Cout=512, stats=True, relu=False, bias=False),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=256),   # chosen by the default heuristic
+    # phase form of the fused upsample (four 2x2 convolutions on the low-resolution grid, pre-summed weights of pack mode 12)
+    "phase_up_c64": dict(N=2, H=8, W=32, Cin=128, Cout=64, ups=1, stats=True, wphase=True),
+    "phase_up_c256_pro_res": dict(N=1, H=16, W=32, Cin=64, Cout=256, ups=1, pro=True, res=True, relu=False, wphase=True),
+    "phase_up_c130_acc": dict(N=1, H=8, W=64, Cin=32, Cout=130, ups=1, acc=True, alpha=0.5, bias=False, wphase=True),
 }
 
 
@@ -248,6 +261,50 @@ def test_conv2d_patch_tiled_kernel(name, mode):
         L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
         L.mrfa_set_tuning(b"conv_small", 1)
     assert_close(ref, got, tol=2e-4 if mode == 1 else 2e-3, what="halo " + name)
+
+
+@pytest.mark.parametrize("cfg", [dict(N=2, H=8, W=32, Cin=64, Cout=128), dict(N=1, H=16, W=32, Cin=128, Cout=64, acc=True),
+                                 dict(N=1, H=8, W=64, Cin=32, Cout=96)])
+def test_phase_data_gradient_of_fused_upsample(cfg):
+    """mrfa_conv2d_nhwc with ups = 2 (conv_halo.hip MODE 2): the data gradient of nearest-x2 + 3x3 as four transposed 2x2 convolutions of
+    the phase images of dY, against the specification (3x3 data gradient on the 2H x 2W grid, 2x2 sum-pooled) and against autograd"""
+    L = hip.lib()
+    N, H, W, Cin, Cout, acc = cfg["N"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"], cfg.get("acc", False)
+    tag = "phd/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+
+    def run(side):
+        w = side.t(f"{tag}/w", (Cout, Cin, 3, 3), -0.2, 0.2)
+        dy = side.t(f"{tag}/dy", (N * 2 * H * 2 * W, Cout + 4))
+        dx = side.t(f"{tag}/dx0", (N * H * W, Cin + 4)) if acc else side.garbage((N * H * W, Cin + 4))
+        cip = (Cin + 127) // 128 * 128
+        wd = pack(side, w, 2)
+        wpb = torch.zeros(3 * 16 * cip * Cout, dtype=torch.int16, device=side.dev)
+        d = hip.PackDesc()
+        d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, 3, 3, 1
+        d.dst[0], d.mode[0] = wpb.data_ptr(), 13
+        side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
+        q = hip.ConvParams()
+        q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = dy.data_ptr(), Cout + 4, 2 * H, 2 * W, 2, N, Cout
+        q.w, q.w_ld, q.w_tap, q.kflat, q.w_rows = wd.data_ptr(), Cout, cip * Cout, 0, cip
+        q.w_phase, q.w_phase_piece = wpb.data_ptr(), 16 * cip * Cout
+        q.y, q.ldy, q.Cout, q.Hout, q.Wout = dx.data_ptr(), Cin + 4, Cin, H, W
+        q.R, q.S, q.pad, q.alpha, q.nbatch, q.accumulate = 3, 3, 1, 1.0, 1, int(acc)
+        assert side.L.mrfa_conv2d_phase_dgrad_supported(C.byref(q)) == 1
+        side.call("mrfa_conv2d_nhwc", C.byref(q))
+        return side.done(dx[:, :Cin], dy[:, :Cout], w)
+    ref = run(Side(False))
+    assert L.mrfa_set_mfma_mode(1) == 0
+    try:
+        got = run(Side(True))
+        assert L.mrfa_conv2d_last_config() & (1 << 28)
+    finally:
+        L.mrfa_set_mfma_mode(0)
+    assert_close(ref[:1], got[:1], what=tag)
+    if not acc:                                     # and the specification itself against autograd through the upsample
+        x = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2), ref[2].double(), padding=1)
+        (gx,) = torch.autograd.grad(y, x, ref[1].reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2).double())
+        assert_close([gx.permute(0, 2, 3, 1).reshape(-1, Cin)], got[:1], what=tag + " vs autograd")
 
 
 def test_patch_tiled_kernel_equals_the_row_tiled_kernel_and_fp64():
