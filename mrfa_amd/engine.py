@@ -110,10 +110,12 @@ class defer_wgrads:
         return False
 
 
+PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
-# zero arena (one fill instead of hundreds of tiny ones)
-PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward of fused-upsample 3x3 layers as four 2x2 phase convolutions
-FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "4")) << 20) // 4
+# zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
+# channels @64^2, B = 8) are mostly first touched by accumulating kernels (residual gradients, sub-sampling, GELU, attention), i.e. each
+# paid its own fill launch on a latency-bound chain -- 259 fill launches per step; A/B on one box 89.2 -> 88.5 ms.
+FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "9")) << 20) // 4
 # debug switch (MRFA_FRESH_NAN=1; tests set it together with FRESH_MIN_ELEMS = 0): every lazily initialised gradient buffer starts
 # as NaN instead of whatever the allocator hands out, so a kernel that READS a buffer no writer has covered -- or a first writer that
 # does not cover all of it -- shows up as a non-finite gradient instead of passing by luck
