@@ -97,7 +97,8 @@ int mrfa_conv2d_last_config(void);
 /* Kernel-selection knobs (process-wide; tests and tuning -- the defaults are the measured choices).  Returns the previous value,
  * -1 for an unknown key.  Keys:
  *   "conv_halo"            1 / 0: patch-tiled 3x3 kernel on / off (default 1; also MRFA_CONV_HALO=0 in the environment)
- *   "conv_halo_min_tiles"  fewest workgroups for which the patch-tiled kernel is chosen (default 256 = one per CU)
+ *   "conv_halo_min_tiles"  workgroup-count unit of the patch-tiled kernel's selection rule (default 128: 2x = one per CU in general,
+ *                          1x for <= 128-wide tiles on >= 64-pixel-wide, >= 64-channel layers)
  *   "conv_halo_pr"         0 = patch height by workgroup count (default), 4 / 8 = forced
  *   "conv_halo_phase"      1 / 0: phase form (four 2x2 convolutions) of fused-upsample layers that carry w_phase (default 1)
  *   "conv_halo_bn256"      1 / 0: 256-channel workgroup tiles where Cout pads to 256 anyway (default 1)

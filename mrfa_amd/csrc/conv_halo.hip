@@ -392,7 +392,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 int g_halo_on = -1;              // -1: not initialised (MRFA_CONV_HALO)
-int g_halo_min_tiles = 256;
+int g_halo_min_tiles = 128;       // see halo_enough()
 int g_halo_pr = 0;               // 0 = by workgroup count, 4 / 8 = forced patch height
 int g_conv_small = 1;
 
@@ -408,33 +408,39 @@ bool halo_phase(const mrfa_conv_params& p) {
     return g_halo_phase && p.ups == 1 && p.w_phase != nullptr && (p.Win % PW) == 0 && (p.Hin % 8) == 0 && 3 * p.w_phase_piece < (1ll << 31);
 }
 
+// enough workgroups for a launch with `tiles` workgroups of width bn?  One per CU (2 x g_halo_min_tiles = 256) in general; half a chip's worth is
+// still better than the row-tiled kernel for <= 128-wide tiles on >= 64-pixel-wide outputs with >= 64 channels on both sides (measured: 256->128
+// @64^2 forward 174 -> 148 us, 192->128 152 -> 115, the dense-motion up block 512->128 @32->64 in phase form 284 -> 145; but 512->512 @32^2
+// 259 -> 285 and 32->32 @64^2 15 -> 23 us)
+bool halo_enough(const mrfa_conv_params& p, long long tiles, int bn) {
+    if (tiles >= 2ll * g_halo_min_tiles) return true;
+    return bn <= 128 && tiles >= g_halo_min_tiles && p.Wout >= 64 && p.Cin >= 64 && p.Cout >= 64;
+}
+
 void halo_config(const mrfa_conv_params& p, int& PR, int& BN) {
     PR = 0;
     BN = p.Cout <= 64 ? 64 : 128;
+    const bool wide = g_halo_bn256 && p.Cout > 128 && cdiv(p.Cout, 256) * 256 == cdiv(p.Cout, 128) * 128;
     if (halo_phase(p)) {                           // four phase workgroups per low-resolution patch
         const long long patches = (long long)p.N * (p.Hin / 8) * (p.Win / PW) * 4;
-        if (g_halo_bn256 && p.Cout > 128 && cdiv(p.Cout, 256) * 256 == cdiv(p.Cout, 128) * 128 && patches * cdiv(p.Cout, 256) >= g_halo_min_tiles) {
-            PR = 8; BN = 256; return;
-        }
-        if (patches * cdiv(p.Cout, BN) >= g_halo_min_tiles) { PR = 8; return; }
+        if (wide && halo_enough(p, patches * cdiv(p.Cout, 256), 256)) { PR = 8; BN = 256; return; }
+        if (halo_enough(p, patches * cdiv(p.Cout, BN), BN)) { PR = 8; return; }
     }
     const long long patches8 = (long long)p.N * cdiv(p.Hout, 8) * (p.Wout / PW), patches4 = (long long)p.N * cdiv(p.Hout, 4) * (p.Wout / PW);
     if (g_halo_pr != 4 && p.Hout % 8 == 0) {
-        if (g_halo_bn256 && p.Cout > 128 && cdiv(p.Cout, 256) * 256 == cdiv(p.Cout, 128) * 128 && patches8 * cdiv(p.Cout, 256) >= g_halo_min_tiles) {
-            PR = 8; BN = 256; return;
-        }
-        if (patches8 * cdiv(p.Cout, BN) >= g_halo_min_tiles) { PR = 8; return; }
+        if (wide && halo_enough(p, patches8 * cdiv(p.Cout, 256), 256)) { PR = 8; BN = 256; return; }
+        if (halo_enough(p, patches8 * cdiv(p.Cout, BN), BN)) { PR = 8; return; }
     }
     // 4-row patches run two workgroups per CU: they need twice the workgroups to fill the chip (measured: 512->512 @32^2, 256 workgroups of
     // 4 rows lose to the row-tiled kernel with its K split)
-    if (g_halo_pr != 8 && patches4 * cdiv(p.Cout, BN) >= 2ll * g_halo_min_tiles) PR = 4;
+    if (g_halo_pr != 8 && patches4 * cdiv(p.Cout, BN) >= 4ll * g_halo_min_tiles) PR = 4;
 }
 
 // (is the launch the phase form?  halo_config picks it first; it falls through to the plain form when the phase grid is too small)
 bool halo_uses_phase(const mrfa_conv_params& p, int PR, int BN) {
     if (!halo_phase(p) || PR != 8) return false;
     const long long patches = (long long)p.N * (p.Hin / 8) * (p.Win / PW) * 4;
-    return patches * cdiv(p.Cout, BN) >= g_halo_min_tiles;
+    return halo_enough(p, patches * cdiv(p.Cout, BN), BN);
 }
 
 }  // namespace

@@ -233,7 +233,7 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "pr8_wide_ld": dict(N=1, H=16, W=96, Cin=64, Cout=128, ldx_extra=8, ldy_extra=12),
     "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True),                 # 256-wide workgroup tile, 64 padding columns
     "bn256_c512_stats": dict(N=1, H=8, W=32, Cin=32, Cout=512, stats=True, relu=False, bias=False),
-    "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=256),   # chosen by the default heuristic
+    "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=128),   # chosen by the default heuristic
     # phase form of the fused upsample (four 2x2 convolutions on the low-resolution grid, pre-summed weights of pack mode 12)
     "phase_up_c64": dict(N=2, H=8, W=32, Cin=128, Cout=64, ups=1, stats=True, wphase=True),
     "phase_up_c256_pro_res": dict(N=1, H=16, W=32, Cin=64, Cout=256, ups=1, pro=True, res=True, relu=False, wphase=True),
@@ -248,7 +248,7 @@ def test_conv2d_patch_tiled_kernel(name, mode):
     six-product (fp32-accurate) and the three-product mode"""
     L = hip.lib()
     kw = dict(HALO_CASES[name])
-    min_tiles = kw.pop("min_tiles", 1)
+    min_tiles = kw.pop("min_tiles", 0)              # 0: every eligible shape, whatever its workgroup count
     ref = conv_case(Side(False), tag=f"halo/{name}", **kw)
     assert L.mrfa_set_mfma_mode(mode) == 0
     prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", min_tiles)
@@ -327,7 +327,7 @@ def test_patch_tiled_kernel_equals_the_row_tiled_kernel_and_fp64():
     side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
     errs = {}
     assert L.mrfa_set_mfma_mode(1) == 0
-    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 1)
+    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
     L.mrfa_set_tuning(b"conv_small", 0)
     try:
         for halo in (0, 1):

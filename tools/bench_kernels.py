@@ -67,6 +67,11 @@ def main():
         ("gen.chan 1024->512 3x3 @32", 1024, 512, 3, 32, 0),
         ("gen.chan 256->128 3x3 @128", 256, 128, 3, 128, 0),
         ("convf2 128->64 3x3 @256", 128, 64, 3, 256, 0),
+        ("refine 256->128 3x3 @64", 256, 128, 3, 64, 0),
+        ("refine 192->128 3x3 @64", 192, 128, 3, 64, 0),
+        ("corr 160->126 3x3 @64", 160, 126, 3, 64, 0),
+        ("refine 256->128 3x3 @32", 256, 128, 3, 32, 0),
+        ("dm.up 512->128 3x3 ups @32->64", 512, 128, 3, 32, 1),
         ("gen 512->512 3x3 @32", 512, 512, 3, 32, 0),
         ("gen 512->512 3x3 @8", 512, 512, 3, 8, 0),
         ("hg 1024->1024 3x3 @4", 1024, 1024, 3, 4, 0),
