@@ -466,7 +466,9 @@ def main():
     if a.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.to(dev).train(True)
-    use_graph = not (a.no_graph or a.sync_bn or a.force_ddp)
+    # SyncBatchNorm issues one collective per BatchNorm layer and direction; captured into the hipGraph when MRFA_SYNCBN_GRAPH=1 (RCCL
+    # collectives are capturable), else the step is launched eagerly
+    use_graph = not (a.no_graph or (a.sync_bn and os.environ.get("MRFA_SYNCBN_GRAPH", "1") != "1") or a.force_ddp)
     ddp = (world > 1 or a.force_ddp) and not use_graph
     if ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,

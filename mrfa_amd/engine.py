@@ -110,6 +110,7 @@ class defer_wgrads:
         return False
 
 
+SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -1075,13 +1076,19 @@ class Ctx:
             return torch.distributed.get_world_size()
         return 1
 
+    @staticmethod
+    def _sync_collective(world: int) -> bool:
+        """issue the statistics exchange?  Always with > 1 rank; MRFA_SYNCBN_FORCE_COLLECTIVE=1 also issues it in a one-rank group (a sum over
+        one rank: the identity) so that the captured-collective schedule can be exercised on a single-GPU box"""
+        return world > 1 or (SYNCBN_FORCE and torch.distributed.is_available() and torch.distributed.is_initialized())
+
     def _bn_finalize(self, bn, stats, count):
         Cn = bn.num_features
         scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
         train = self.train
         if train and stats is not None:
             world = self._sync_world(bn)
-            if world > 1:
+            if self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
                 # sum / sum-of-squares over every rank's pixels: the slots are summed locally first, so the message is 2C doubles,
                 # not [STATS_SLOTS][2C] (bn_finalize sums the slots: slot 0 = the global sums, the others zero)
                 local = stats.view(hip.STATS_SLOTS, 2 * Cn).sum(0)
@@ -1172,7 +1179,7 @@ class Ctx:
         q.phase = 1
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
         world = self._sync_world(bn) if train else 1
-        if world > 1:
+        if train and self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
             # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums
             Cn = x.C
             local = red.view(hip.STATS_SLOTS, 2 * Cn).sum(0)

@@ -192,6 +192,11 @@ class GraphedTrainStep:
         self.loss_fn = loss_fn
         if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
             concurrent_encoder = getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_CONCURRENT_ENCODER", "1") == "1"
+            if any(isinstance(m, nn.SyncBatchNorm) for m in model.modules()) and (world > 1 or engine.SYNCBN_FORCE):
+                # SyncBatchNorm's statistics collectives are captured into the graph (RCCL ops are capturable): every rank must enqueue them in
+                # ONE order on the communicator, so the two encoder passes stay on one stream (the side-stream pass would interleave its
+                # collectives with the main stream's in an order the hardware, not the program, decides)
+                concurrent_encoder = False
         if hasattr(model, "concurrent_encoder"):
             model.concurrent_encoder = bool(concurrent_encoder)
         self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the graphs

@@ -300,3 +300,60 @@ def test_overlapped_exchange_graph_step_equals_the_single_graph_step():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+def test_sync_batchnorm_collectives_are_captured_into_the_graph(monkeypatch):
+    """SyncBatchNorm (reference train.py:43) no longer drops the step to eager launches: its statistics all-reduces (one per BatchNorm layer
+    and direction) are captured into graph A.  One-rank RCCL group with the collectives FORCED (engine.SYNCBN_FORCE: a sum over one rank is
+    the identity), FOMM prior: the capture verifies against eager passes (GraphedTrainStep.verify), ~150 collectives are issued while capturing
+    and none by the replays, and the step trains like the same model without SyncBatchNorm (identical arithmetic at world 1; both runs have
+    taken an eager step, the capture's warm-up and one replay by then -- a chaotic trajectory at random initialisation, so the losses are
+    held to 3 %, the weights to a few Adam steps of lr 2e-4)."""
+    import os
+    import bench
+    import torch.distributed as dist
+    from mrfa_amd import engine
+    from mrfa_amd.graph import GraphedTrainStep
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(36100 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    monkeypatch.setattr(engine, "SYNCBN_FORCE", True)
+    try:
+        src, drv = _pairs(2, "g/sbn")
+
+        def run(sync):
+            torch.manual_seed(0)
+            model = HotPath(VOX1, prior="fomm")
+            bench.init_weights(model)
+            if sync:
+                model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            model.to(DEV).train(True)
+            opt = make_optimizer(model, fused=True)
+            train_step(model, opt, src, drv)
+            calls = []
+            real = dist.all_reduce
+            monkeypatch.setattr(dist, "all_reduce", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+            step = GraphedTrainStep(model, opt, src, drv, world=1, exchange=False)
+            captured = len(calls)
+            step.verify()                                    # (its eager comparison passes issue their collectives from Python)
+            before = len(calls)
+            loss = float(step(src, drv))
+            torch.cuda.synchronize()
+            during_replay = len(calls) - before
+            monkeypatch.setattr(dist, "all_reduce", real)
+            return loss, opt.flat_w.clone(), captured, during_replay
+        l1, w1, cap1, rep1 = run(True)
+        l0, w0, cap0, rep0 = run(False)
+        assert cap1 >= 100 and cap0 == 0, (cap1, cap0)          # ~75 BatchNorm layers x (forward + backward), issued while capturing ...
+        assert rep1 == 0, rep1                                    # ... and replayed from the graph, not re-issued from Python
+        assert abs(l1 - l0) <= 3e-2 * max(1.0, abs(l0)), (l1, l0)
+        assert torch.isfinite(w1).all() and float((w1 - w0).abs().max()) <= 50 * 2e-4
+    finally:
+        import gc
+        gc.collect()                       # graphs that hold captured RCCL kernels go before their communicator does
+        torch.cuda.synchronize()
+        if own_group:
+            dist.destroy_process_group()
