@@ -143,6 +143,8 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * mode 8: as mode 0 but split for the bf16x6 kernels: three planes [piece][tap][CoutPad][CinPad] of bf16 with
  *         w = piece0 + piece1 + piece2 exactly (piece_k = top 16 bits of the residual); mode 9: likewise for mode 2
  *         (modes 8 / 9: batched entry point only)
+ * modes 14 / 15: the layouts of modes 8 / 9 as ONE bf16 plane rounded to nearest even (plain bf16 mode, mrfa_set_mfma_mode(3));
+ *         passed through mrfa_conv_params.w_split with w_piece = 0 (batched entry point only)
  * mode 13: mode 12 transposed ([piece][16][CinPad128][CoutPad32]) for the phase data gradient (ups = 2)
  * mode 12: 3x3 only: the phase weights of UpBlock2d's nearest-x2 + conv (see mrfa_conv_params.w_phase): three bf16 planes
  *         [piece][16 phase taps][CoutPad128][CinPad32], phase tap = (py*2+px)*4 + a*2+b, weight = sum of the 3x3 taps that read

@@ -40,6 +40,16 @@ struct GeoB {
     static constexpr int BSLAB = 3 * BPLANE;
 };
 
+// plain bf16 operands (NP = 1): round-to-nearest-even of the fp32 value, one product -- the arithmetic of a bf16 autocast
+__device__ __forceinline__ unsigned rne16(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void round1(const f32x4 v, u32x2& p1) {
+    p1[0] = rne16(v.x) | (rne16(v.y) << 16);
+    p1[1] = rne16(v.z) | (rne16(v.w) << 16);
+}
+
 template <int PR>
 struct Geo {
     static constexpr int NT = PR * 64;             // (PR / 2) x 2 waves, each 64 pixels (2 patch rows) x BN / 2 channels
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int BHALF = GeoB<BN>::BHALF, BPLANE = GeoB<BN>::BPLANE, BSLAB = GeoB<BN>::BSLAB;
     constexpr int NT = G::NT;
     constexpr int TN = BN / 64;                    // 32-column MFMA tiles per wave along N
-    constexpr int NPC = NP == 6 ? 3 : 2;           // bf16 pieces needed (bf16x3 drops the third)
+    constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);     // bf16 pieces needed (bf16x3 drops the third; plain bf16: one rounded plane)
     constexpr int BUNITS = NPC * BN * 2;           // 16-byte units of one weight slab
     constexpr int NBU = (BUNITS + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::ABUF + 2 * BSLAB];
@@ -177,11 +187,11 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         v = a_inb[j] ? v : z;
         u32x2 p1, p2, p3;
-        split3(v, p1, p2, p3);
+        if constexpr (NP == 1) round1(v, p1); else split3(v, p1, p2, p3);
         if (a_val[j]) {
             unsigned char* dst = smA + buf * G::ABUF + a_loff[j];
             *reinterpret_cast<u32x2*>(dst) = p1;
-            *reinterpret_cast<u32x2*>(dst + G::APLANE) = p2;
+            if constexpr (NPC >= 2) *reinterpret_cast<u32x2*>(dst + G::APLANE) = p2;
             if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * G::APLANE) = p3;
         }
     };
@@ -405,7 +415,8 @@ int g_halo_phase = 1;
 
 // the phase form of a fused upsample applies: pre-summed phase weights present, the LOW-resolution grid tiles into 8 x 32 patches
 bool halo_phase(const mrfa_conv_params& p) {
-    return g_halo_phase && p.ups == 1 && p.w_phase != nullptr && (p.Win % PW) == 0 && (p.Hin % 8) == 0 && 3 * p.w_phase_piece < (1ll << 31);
+    const int mode = mrfa_get_mfma_mode();
+    return (mode == 1 || mode == 2) && g_halo_phase && p.ups == 1 && p.w_phase != nullptr && (p.Win % PW) == 0 && (p.Hin % 8) == 0 && 3 * p.w_phase_piece < (1ll << 31);
 }
 
 // enough workgroups for a launch with `tiles` workgroups of width bn?  One per CU (2 x g_halo_min_tiles = 256) in general; half a chip's worth is
@@ -483,7 +494,7 @@ extern "C" int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p) { re
 bool mrfa_conv_halo_eligible(const mrfa_conv_params& p) {
     if (p.ups == 2) return halo_phase_dgrad(p);
     const int mode = mrfa_get_mfma_mode();
-    if (!halo_on() || (mode != 1 && mode != 2)) return false;
+    if (!halo_on() || (mode != 1 && mode != 2 && mode != 3)) return false;       // (mode 3: w_split = ONE plane rounded to nearest even, pack modes 14 / 15)
     if (p.kflat > 0 || p.R != 3 || p.S != 3 || p.pad != 1 || !p.w_split || p.nbatch > 1 || p.splitk > 1 || p.tile) return false;
     if ((p.Wout % PW) != 0 || p.Hout < 4 || (p.Cin % 32) != 0 || p.Cout < 32) return false;
     if (p.Hout != (p.Hin << p.ups) || p.Wout != (p.Win << p.ups)) return false;
@@ -508,10 +519,13 @@ int mrfa_conv_halo_launch(hipStream_t st, const mrfa_conv_params& p) {
     const int tiles_n = cdiv(p.Cout, BN), tiles_x = (phase ? p.Win : p.Wout) / PW, tiles_y = cdiv(phase ? p.Hin : p.Hout, PR);
     const long long total = (long long)p.N * tiles_y * tiles_x * tiles_n;
     dim3 grid((unsigned)(cdiv(total, 8) * 8), phase ? 4u : 1u);
-    const bool three = mrfa_get_mfma_mode() == 2;
+    const bool three = mrfa_get_mfma_mode() == 2, one = mrfa_get_mfma_mode() == 3;
     const bool pro = p.in_scale != nullptr;
 #define HALO_LAUNCH(PR_, PRO_, BN_, MODE_)                                                                                                                      \
     do {                                                                                                                                                     \
+        if constexpr ((MODE_) == 0) {                                                                                                                        \
+            if (one) { hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 1, 0>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total); break; } \
+        }                                                                                                                                                    \
         if (three) hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 3, MODE_>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);    \
         else hipLaunchKernelGGL((conv_halo_kernel<PR_, PRO_, BN_, 6, MODE_>), grid, dim3(PR_ * 64), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);          \
     } while (0)

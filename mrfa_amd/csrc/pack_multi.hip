@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
             }
             continue;
         }
-        const bool ci_fast = mode == 0 || mode == 1 || mode == 5 || mode == 8;
-        const bool bf = mode == 8 || mode == 9;
+        const bool ci_fast = mode == 0 || mode == 1 || mode == 5 || mode == 8 || mode == 14;
+        const bool bf = mode == 8 || mode == 9 || mode == 14 || mode == 15;
+        const bool rne1 = mode == 14 || mode == 15;               // ONE plane, round-to-nearest-even (plain bf16 mode), layout of mode 8 / 9
         const int nf = ci_fast ? nci : nco;                       // extent of the fastest (contiguous) destination axis in this tile
         const int lanes_f = bf ? 16 : 32;                         // threads along it (bf16: two elements each)
         const int f0 = (threadIdx.x & (lanes_f - 1)) * (bf ? 2 : 1);
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
         const int n_inner = ci_fast ? T : nci;
         const int n_rows = ci_fast ? nco * T : T * nci;
         int outer = r0 / n_inner, inner = r0 - outer * n_inner;
-        const int base_mode = mode == 8 ? 0 : (mode == 9 ? 2 : mode);
+        const int base_mode = (mode == 8 || mode == 14) ? 0 : ((mode == 9 || mode == 15) ? 2 : mode);
         unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(dst);
-        const long long piece = mode == 8 ? (long long)T * rup(Cout, 128) * rup(Cin, 32) : (long long)T * rup(Cin, 128) * rup(Cout, 32);
+        const long long piece = base_mode == 0 ? (long long)T * rup(Cout, 128) * rup(Cin, 32) : (long long)T * rup(Cin, 128) * rup(Cout, 32);
         for (int q = r0; q < n_rows; q += rows_per_pass) {
             if (f0 < nf) {
                 const int co_l = ci_fast ? outer : f0, t = ci_fast ? inner : outer, ci_l = ci_fast ? f0 : inner;
@@ -142,6 +143,15 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
                 } else {
                     const bool two = f0 + 1 < nf;
                     const float v1 = two ? lds[co_l * row + ci_l * T + t + lstep] : 0.f;
+                    if (rne1) {
+                        const unsigned ua = __float_as_uint(v0), ub = __float_as_uint(v1);
+                        const unsigned ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16, rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+                        if (two) *reinterpret_cast<unsigned*>(d16 + idx) = ra | (rb << 16);
+                        else d16[idx] = (unsigned short)ra;
+                        inner += rows_per_pass;
+                        while (inner >= n_inner) { inner -= n_inner; ++outer; }
+                        continue;
+                    }
                     unsigned h[3], l[3];
                     float a = v0, b = v1;
 #pragma unroll
@@ -239,7 +249,7 @@ extern "C" int mrfa_pack_conv_weights_multi(void* stream, const mrfa_pack_desc* 
                        descs[i].ndst);
         for (int k = 0; k < descs[i].ndst; ++k) {
             const int m = descs[i].mode[k];
-            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9 || ((m == 12 || m == 13) && descs[i].R == 3 && descs[i].S == 3)),
+            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9 || m == 14 || m == 15 || ((m == 12 || m == 13) && descs[i].R == 3 && descs[i].S == 3)),
                            "pack_conv_weights_multi: desc %d: null dst or mode %d", i, m);
         }
     }

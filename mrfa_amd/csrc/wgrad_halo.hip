@@ -53,6 +53,15 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     }
 }
 
+__device__ __forceinline__ unsigned rne16(float x) {          // plain bf16 (NP = 1): round to nearest even
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void round1(const f32x4 v, u32x2& p1) {
+    p1[0] = rne16(v.x) | (rne16(v.y) << 16);
+    p1[1] = rne16(v.z) | (rne16(v.w) << 16);
+}
+
 // transposing fragment read: rows (pixels) k0 .. k0+7 of this lane's channel column as one MFMA operand (two b64 reads)
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
     typedef __attribute__((address_space(3))) bf16x4_t* lds4;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                                                                const int tiles_x, const int total) {
     static_assert(NBO * NBI * TS == 8 && (TS == 1 || TS == 2), "8 waves");
     constexpr int NTAP = TS == 1 ? 9 : 5;            // accumulator tiles per wave
-    constexpr int NPC = NP == 6 ? 3 : 2;
+    constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
     constexpr int XROW = NPC * NBI * XBLK;         // one ring slot: [piece][block][34 pixels][64 B]
     constexpr int DYROW = NPC * NBO * DYBLK;       // one dY buffer:  [piece][block][32 pixels][64 B]
     constexpr int NDY = NBO * 256 / NT;            // float4 units per thread: dY row (32 pixels x NBO x 8 quads)
@@ -167,10 +176,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             v = (row_ok && x_ok[j]) ? v : z;
             u32x2 p1, p2, p3;
-            split3(v, p1, p2, p3);
+            if constexpr (NP == 1) round1(v, p1); else split3(v, p1, p2, p3);
             if (x_val[j]) {
                 *reinterpret_cast<u32x2*>(dst + x_loff[j]) = p1;
-                *reinterpret_cast<u32x2*>(dst + NBI * XBLK + x_loff[j]) = p2;
+                if constexpr (NPC >= 2) *reinterpret_cast<u32x2*>(dst + NBI * XBLK + x_loff[j]) = p2;
                 if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * NBI * XBLK + x_loff[j]) = p3;
             }
         }
@@ -190,9 +199,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int e = 0; e < 4; ++e) v[e] = (row_ok && e < d_nval[j]) ? v[e] : 0.f;
             bsum[j] += v;
             u32x2 p1, p2, p3;
-            split3(v, p1, p2, p3);
+            if constexpr (NP == 1) round1(v, p1); else split3(v, p1, p2, p3);
             *reinterpret_cast<u32x2*>(dst + d_loff[j]) = p1;
-            *reinterpret_cast<u32x2*>(dst + NBO * DYBLK + d_loff[j]) = p2;
+            if constexpr (NPC >= 2) *reinterpret_cast<u32x2*>(dst + NBO * DYBLK + d_loff[j]) = p2;
             if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * NBO * DYBLK + d_loff[j]) = p3;
         }
     };
@@ -372,7 +381,7 @@ static void wgrad_halo_config(const mrfa_wgrad_params& p, int& NBO, int& HS, int
 
 bool mrfa_wgrad_halo_eligible(const mrfa_wgrad_params& p) {
     const int mode = mrfa_get_mfma_mode();
-    if (!mrfa_tuning_wgrad_halo(-1) || (mode != 1 && mode != 2)) return false;
+    if (!mrfa_tuning_wgrad_halo(-1) || (mode != 1 && mode != 2 && mode != 3)) return false;
     if (p.kflat > 0 || p.R != 3 || p.S != 3 || p.pad != 1 || p.nbatch > 1 || p.ksplit > 0) return false;
     if ((p.Wout % 32) != 0 || (p.Cin % 32) != 0 || p.Cout < 32 || p.Hout < 8) return false;
     if (p.Hout != (p.Hin << p.ups) || p.Wout != (p.Win << p.ups)) return false;
@@ -392,11 +401,12 @@ int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p) {
     const int NBI = 2;
     const int tiles_ci = cdiv(p.Cin, 32 * NBI), ntiles = cdiv(p.Cout, 32 * NBO) * tiles_ci;
     dim3 grid((unsigned)(cdiv(total, 8) * 8));
-    const bool three = mrfa_get_mfma_mode() == 2;
+    const bool three = mrfa_get_mfma_mode() == 2, one = mrfa_get_mfma_mode() == 3;
     const bool pro = p.in_scale != nullptr;
 #define WH(NBO_, NBI_, TS_, PRO_)                                                                                                                          \
     do {                                                                                                                                              \
-        if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 3>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
+        if (one) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 1>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
+        else if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 3>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
         else hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 6>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total);      \
     } while (0)
     if (NBO == 4) { if (pro) WH(4, 2, 1, true); else WH(4, 2, 1, false); }

@@ -189,6 +189,10 @@ def prepare_packs(module: torch.nn.Module) -> bool:
             cw.split_pack("f", getattr(cw, "_fwd_padded", False))
         if getattr(cw, "_dg_s", None) is not None:
             cw.split_pack("d", getattr(cw, "_dg_padded", False))
+        if getattr(cw, "_fwd_r", None) is not None:
+            cw.split_pack("f", getattr(cw, "_fwd_padded", False), rne=True)
+        if getattr(cw, "_dg_r", None) is not None:
+            cw.split_pack("d", getattr(cw, "_dg_padded", False), rne=True)
         if getattr(cw, "_fwd_ph", None) is not None:
             cw.phase_pack()
         if getattr(cw, "_dg_ph", None) is not None:
@@ -410,29 +414,32 @@ class ConvW:
             self._ver_d = self._key()
         return self._dg
 
-    def split_pack(self, which: str, padded: bool) -> tuple:
+    def split_pack(self, which: str, padded: bool, rne: bool = False) -> tuple:
         """(buffer, elements per piece) of the weights pre-split into three bf16 pieces for the bf16x6 kernels (pack mode 8
         = forward layout, 9 = data-gradient layout); chunked layouts only"""
         fwd = which == "f"
         attr, ver = ("_fwd_s", "_ver_fs") if fwd else ("_dg_s", "_ver_ds")
+        if rne:                              # plain bf16 mode: ONE plane rounded to nearest even (pack modes 14 / 15)
+            attr, ver = ("_fwd_r", "_ver_fr") if fwd else ("_dg_r", "_ver_dr")
         if fwd:
             rows, cols = (self.Cout + 127) // 128 * 128, (self.Cin + 31) // 32 * 32
         else:
             rows, cols = (self.Cin + 127) // 128 * 128, (self.Cout + 31) // 32 * 32
         piece = self.T * rows * cols
+        npl = 1 if rne else 3
         buf = getattr(self, attr, None)
         w = self.conv.weight.detach()
-        if buf is None or buf.numel() != 3 * piece or buf.device != w.device:
-            buf = torch.zeros(3 * piece, dtype=torch.int16, device=w.device)
+        if buf is None or buf.numel() != npl * piece or buf.device != w.device:
+            buf = torch.zeros(npl * piece, dtype=torch.int16, device=w.device)
             setattr(self, attr, buf)
             setattr(self, ver, None)
         if getattr(self, ver, None) != self._key():
             d = hip.PackDesc()
             d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.contiguous().data_ptr(), self.Cout, self.Cin, self.R, self.S, 1
-            d.dst[0], d.mode[0] = buf.data_ptr(), 8 if fwd else 9
+            d.dst[0], d.mode[0] = buf.data_ptr(), ((14 if fwd else 15) if rne else (8 if fwd else 9))
             hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack(split)")
             setattr(self, ver, self._key())
-        return buf, piece
+        return buf, (0 if rne else piece)
 
     def phase_pack(self, dgrad: bool = False) -> tuple:
         """(buffer, elements per piece) of the 16 phase-tap weights of nearest-x2 + this 3x3 conv (pack mode 12: UpBlock2d as four 2x2
@@ -530,6 +537,10 @@ class PackPlan:
                 dsts.append((cw._fwd_s, 8))
             if getattr(cw, "_dg_s", None) is not None:
                 dsts.append((cw._dg_s, 9))
+            if getattr(cw, "_fwd_r", None) is not None:
+                dsts.append((cw._fwd_r, 14))
+            if getattr(cw, "_dg_r", None) is not None:
+                dsts.append((cw._dg_r, 15))
             if getattr(cw, "_fwd_ph", None) is not None:
                 dsts.append((cw._fwd_ph, 12))
             if getattr(cw, "_dg_ph", None) is not None:
@@ -560,7 +571,7 @@ class PackPlan:
                     id(getattr(cw, "_fwd_s", None)) == idfs and id(getattr(cw, "_dg_s", None)) == idds and
                     id(getattr(cw, "_fwd_ph", None)) == idph and id(getattr(cw, "_dg_ph", None)) == iddph), "PackPlan is stale: rebuild it"
             k = cw._key()
-            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = k
+            cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = cw._ver_fr = cw._ver_dr = k
 
 
 def unpack_direct(cws: List["ConvW"]):
@@ -666,6 +677,7 @@ class Ctx:
         self.tape: List[Callable[[], None]] = []
         self.L = hip.lib()
         self.split = self.L.mrfa_get_mfma_mode() in (1, 2)   # bf16x6 / bf16x3 kernels: also hand over pre-split weights
+        self.bf16 = self.L.mrfa_get_mfma_mode() == 3         # plain bf16 products: the patch-tiled kernels take ONE rounded weight plane
         self.in_backward = False
         self.deferred = SIDE_PASS            # not None: this program runs on the side stream next to another pass of its module
         self.wdefer = WGRAD_DEFER            # not None: weight-gradient launches of this program are collected (DeferredWgrads)
@@ -885,8 +897,8 @@ class Ctx:
             cip32 = (cw.Cin + 31) // 32 * 32
             p.Cin = cip32
             p.w_ld, p.w_tap, p.kflat = cip32, cop * cip32, 0
-            if self.split:
-                ws, p.w_piece = cw.split_pack("f", True)
+            if self.split or self.bf16:
+                ws, p.w_piece = cw.split_pack("f", True, rne=self.bf16)
                 p.w_split = ws.data_ptr()
         elif cw.fwd_flat:
             kp = (cw.T * cw.Cin + 31) // 32 * 32
@@ -894,10 +906,10 @@ class Ctx:
             p.ktab = cw.ktab_fwd().data_ptr()
         else:
             p.w_ld, p.w_tap, p.kflat = cw.Cin, cop * cw.Cin, 0
-            if self.split:
-                ws, p.w_piece = cw.split_pack("f", False)
+            if self.split or self.bf16:
+                ws, p.w_piece = cw.split_pack("f", False, rne=self.bf16)
                 p.w_split = ws.data_ptr()
-                if ups and cw.R == 3 and cw.S == 3 and cw.pad == 1 and PHASE_UPCONV:
+                if self.split and ups and cw.R == 3 and cw.S == 3 and cw.pad == 1 and PHASE_UPCONV:
                     # UpBlock2d: the library may run nearest-x2 + 3x3 as four 2x2 phase convolutions (16 / 36 of the MACs, csrc/conv_halo.hip)
                     wph, p.w_phase_piece = cw.phase_pack()
                     p.w_phase = wph.data_ptr()
@@ -1037,8 +1049,8 @@ class Ctx:
         if padded:
             p.Cin = co32
             p.w_ld, p.w_tap, p.kflat = co32, cip * co32, 0
-            if self.split:
-                ws, p.w_piece = cw.split_pack("d", True)
+            if self.split or self.bf16:
+                ws, p.w_piece = cw.split_pack("d", True, rne=self.bf16)
                 p.w_split = ws.data_ptr()
         elif cw.dgrad_flat:
             kp = (cw.T * cw.Cout + 31) // 32 * 32
@@ -1046,8 +1058,8 @@ class Ctx:
             p.ktab = cw.ktab_dgrad().data_ptr()
         else:
             p.w_ld, p.w_tap, p.kflat = cw.Cout, cip * cw.Cout, 0
-            if self.split:
-                ws, p.w_piece = cw.split_pack("d", False)
+            if self.split or self.bf16:
+                ws, p.w_piece = cw.split_pack("d", False, rne=self.bf16)
                 p.w_split = ws.data_ptr()
         p.w_rows = cip
         p.y, p.ldy = (tgt.gptr if direct else tgt.ptr), tgt.ld

@@ -872,6 +872,19 @@ class Emulator:
                         out[pc] = (bits >> 16).to(torch.int16)
                         r = r - bits.view(torch.float32)
                     continue
+                if d.mode[k] in (14, 15):            # one bf16 plane, round-to-nearest-even, in the layout of mode 8 / 9
+                    T = d.R * d.S
+                    if d.mode[k] == 14:
+                        n = T * ((d.Cout + 127) // 128 * 128) * ((d.Cin + 31) // 32 * 32)
+                    else:
+                        n = T * ((d.Cin + 127) // 128 * 128) * ((d.Cout + 31) // 32 * 32)
+                    tmp = torch.zeros(n, dtype=torch.float32)
+                    rc = self.mrfa_pack_conv_weight(stream, d.src, tmp.data_ptr(), d.Cout, d.Cin, d.R, d.S, 0 if d.mode[k] == 14 else 2)
+                    if rc:
+                        return rc
+                    out = torch.frombuffer((C.c_short * n).from_address(d.dst[k]), dtype=torch.int16)
+                    out.copy_(tmp.to(torch.bfloat16).view(torch.int16))
+                    continue
                 if d.mode[k] in (12, 13):            # phase weights of nearest-x2 + 3x3 (see mrfa_conv_params.w_phase), split into three bf16 pieces
                     assert d.R == 3 and d.S == 3     # 13: transposed (rows = input channels) for the phase data gradient
                     tr = d.mode[k] == 13
