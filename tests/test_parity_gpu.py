@@ -331,6 +331,52 @@ def test_config4_celebvhq_bs16_bf16_vs_oracle():
     assert d.mean().item() <= 2e-2 and d.max().item() <= 0.3, (d.mean().item(), d.max().item())
 
 
+def test_config4_celebvhq_bs16_bf16_training_step_vs_fp32():
+    """The TRAINING step of BASELINE configs[3] (celebvhq wiring, bs=16, bf16 MFMA products): forward + backward in
+    `bf16` mode against the same step in the fp32-accurate `bf16x6` mode (itself held to the reference's goldens by the tests below), on
+    identical weights and inputs, eval-mode BatchNorm (batch statistics at random initialisation amplify ANY perturbation chaotically; the
+    arithmetic under test is the same).  Band, stated: loss within 2e-2 absolute (the forward gate of the test above); gradient of dense_motion /
+    decoder / bg_predictor: norm within 15 %, direction cos >= 0.95 (measured: 0.98-0.99, cos 0.9994-1.0000); gradient of the keypoint
+    ENCODER: norm within 25 %, cos >= 0.7 (measured 1.075 / 0.84: its only input is d(loss)/d(keypoints), 10 x 6 numbers per sample that are
+    sums of large cancelling terms over the whole image -- the part of the step a bf16 product perturbs most).  A bf16 autocast of the
+    REFERENCE sits at L1 1.4e-2 on the output."""
+    import bench
+    from mrfa_amd.train import VOX1, HotPath, l1_loss
+    b = 16
+    src, drv = cases.images("c4t/src", b, 256).to(DEV), cases.images("c4t/drv", b, 256).to(DEV)
+    model = HotPath(VOX1, prior="mtia", background=True)
+    bench.init_weights(model)
+    model.to(DEV).eval()
+    prev = hip.mfma_mode()
+
+    def grads(mode):
+        hip.set_mfma_mode(mode)
+        for p_ in model.parameters():
+            p_.grad = None
+        loss = l1_loss(model(src, drv), drv)
+        loss.backward()
+        model.join()
+        torch.cuda.synchronize()
+        out = {}
+        for grp in ("encoder", "dense_motion", "decoder", "bg_predictor"):
+            out[grp] = torch.cat([p_.grad.reshape(-1).double() for p_ in getattr(model, grp).parameters() if p_.grad is not None])
+        return float(loss), out
+    try:
+        l6, g6 = grads("bf16x6")
+        l1_, g1 = grads("bf16")
+    finally:
+        hip.set_mfma_mode(prev)
+    print(f"config 4 training step: loss fp32-accurate {l6:.5f} / bf16 {l1_:.5f}; " + ", ".join(
+        f"{k}: norm ratio {float(g1[k].norm() / g6[k].norm()):.3f} cos {float(torch.dot(g1[k], g6[k]) / (g1[k].norm() * g6[k].norm())):.4f}" for k in g6))
+    assert abs(l1_ - l6) <= 2e-2, (l1_, l6)
+    for k in g6:
+        assert torch.isfinite(g1[k]).all(), k
+        ratio = float(g1[k].norm() / g6[k].norm())
+        cos = float(torch.dot(g1[k], g6[k]) / (g1[k].norm() * g6[k].norm()))
+        lo, hi, cmin = (0.75, 1.25, 0.7) if k == "encoder" else (0.85, 1.15, 0.95)
+        assert lo <= ratio <= hi and cos >= cmin, (k, ratio, cos)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Backward parity of the prior stage and of the chained pipeline (VERDICT r1 'weak' item 1): tests/grad_checks.py
 @pytest.mark.parametrize("train,b", [(False, 2), (True, 4)])
