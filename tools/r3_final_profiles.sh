@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-3 evidence run on one MI355X box (gpurun): tests, bench lines of every configuration, rocprofv3 kernel statistics (whole run + steady-state
+# window) and the PMC passes behind profiles/r3_pmc_summary.json.  Everything lands in gpurun_out/r3final/ (copied to profiles/ afterwards).
+set -u; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r3final; mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; grep -E "passed|failed" $O/gputest.log | tail -1
+python bench.py --steps 10 --warmup 3 > $O/bench_default.log 2>$O/bench_default.err
+python bench.py --steps 10 --warmup 3 --prior fomm --no-cpu-baseline > $O/bench_fomm.log 2>/dev/null
+python bench.py --steps 10 --warmup 3 --loss reference --no-cpu-baseline --no-forward > $O/bench_refloss.log 2>/dev/null
+python bench.py --steps 10 --warmup 3 --background --mfma bf16 --batch 16 --no-cpu-baseline --no-forward > $O/bench_config4.log 2>/dev/null
+python bench.py --size 512 --batch 4 --inference --steps 20 --warmup 3 > $O/bench_config5.log 2>/dev/null
+MRFA_SYNCBN_FORCE_COLLECTIVE=1 python bench.py --sync-bn --force-exchange --steps 5 --warmup 2 --no-cpu-baseline --no-forward --no-roofline > $O/bench_syncbn_graph_one_rank.log 2>/dev/null
+for f in default fomm refloss config4 config5 syncbn_graph_one_rank; do tail -1 $O/bench_$f.log | cut -c1-220; done
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_def
+rocprofv3 --kernel-trace -d /tmp/p_def -o rp -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-forward --no-roofline > $O/prof_default.log 2>&1
+DB=$(find /tmp/p_def -name "*.db" | head -1)
+python3 $R/tools/rocprof_summary.py $DB $O/r3_final_bench_b8_kernel_stats.csv >> $O/prof_default.log 2>&1
+python3 $R/tools/rocprof_replay_window.py $DB $O/r3_final_replay_per_step.csv 10 >> $O/prof_default.log 2>&1
+python3 $R/tools/step_timeline.py $DB 2 > $O/r3_final_step_timeline.txt 2>&1
+tail -2 $O/prof_default.log
+cd $R
+bash tools/pmc_step.sh SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE 2>&1 | tail -3
+ls $O
