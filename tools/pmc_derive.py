@@ -16,7 +16,8 @@ for f in os.listdir(src):
     if f.endswith(".csv"):
         with open(os.path.join(src, f)) as fh:
             tabs[f[:-4]] = {r["kernel"]: (int(r["dispatches"]), float(r["mean_KB_per_dispatch"])) for r in csv.DictReader(fh)}
-kernels = sorted({k for t in tabs.values() for k in t if any(s in k for s in subs)})
+kernels = sorted(k for k in tabs["SQ_VALU_MFMA_BUSY_CYCLES"] if any(s in k for s in subs)     # (stale tables of older passes may name other kernels)
+                 and all(k in tabs.get(c, {}) for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE")))
 res = {}
 for k in kernels:
     g = lambda c: tabs.get(c, {}).get(k, (0, float("nan")))[1]
