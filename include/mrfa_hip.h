@@ -68,6 +68,9 @@ typedef struct {
     int tile;              /* 0 = auto; else force a tile config (tests / tuning)                               */
     const void* w_split;   /* optional (chunked mode): the same weights pre-split into three bf16 pieces (pack modes 8 / 9);  */
     long long w_piece;     /*   bf16 elements between consecutive pieces.  Used by the split-operand kernel when present.     */
+    const float* mask;     /* optional (data-gradient launches): forward values of the tensor whose gradient this launch writes, a ReLU   */
+    int ldm;               /*   output: the result is multiplied by (mask > 0) BEFORE any accumulation -- the ReLU backward of the producer, */
+                           /*   fused into its consumer's data gradient (only where mrfa_conv2d_mask_supported() says so)                    */
     const void* w_phase;   /* optional, with ups = 1 and a 3x3 / pad 1 kernel: the 16 phase-tap weights of the four 2x2 convolutions */
     long long w_phase_piece; /* that equal nearest-x2 + 3x3 (pack mode 12, bf16 pieces).  When present (and the patch-tiled kernel  */
                            /*   applies) the layer runs 16 instead of 36 taps per low-resolution pixel -- same result up to fp32 rounding */
@@ -80,6 +83,7 @@ typedef struct {
  * 2*C words cost 5-21 us per launch on the MTIA prior's 0.6-GFLOP layers (tools/ubench/small_kernels.cpp) -- more than the layer. */
 #define MRFA_STATS_SLOTS 32
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
+int mrfa_conv2d_mask_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters honours `mask`                    */
 int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p);    /* 1: a call with these parameters (ups = 2) is implemented          */
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
@@ -142,7 +146,9 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * modes 4|16 and 6|16: as 4 / 6 but overwriting (dst = ...) instead of accumulating
  * mode 8: as mode 0 but split for the bf16x6 kernels: three planes [piece][tap][CoutPad][CinPad] of bf16 with
  *         w = piece0 + piece1 + piece2 exactly (piece_k = top 16 bits of the residual); mode 9: likewise for mode 2
- *         (modes 8 / 9: batched entry point only)
+ *         (modes 8 / 9: batched entry point only).  Every bf16 plane (modes 8, 9, 12, 13, 14, 15) stores a tap's [rows][cols] matrix
+ *         K16-CHUNK-MAJOR: element (row r, column f) at (f / 16) * (rows * 16) + r * 16 + f % 16 -- the 16-channel slab of a tap that a
+ *         conv workgroup stages is one contiguous run of rows x 32 bytes (mrfa_conv_params.w_rows = rows must be set with w_split / w_phase)
  * modes 14 / 15: the layouts of modes 8 / 9 as ONE bf16 plane rounded to nearest even (plain bf16 mode, mrfa_set_mfma_mode(3));
  *         passed through mrfa_conv_params.w_split with w_piece = 0 (batched entry point only)
  * mode 13: mode 12 transposed ([piece][16][CinPad128][CoutPad32]) for the phase data gradient (ups = 2)
@@ -188,7 +194,7 @@ int mrfa_conv_fewout_wgrad(void* stream, const float* x, int ldx, int N, int H, 
  * refine.conv2 / convo2, raft.py:76,78).  Only the shapes mrfa_conv_fewout_dgrad_supported() reports (3x3 / pad 1, Cout in {1, 2},
  * Cin in {64, 128, 256}, lddx % 4 == 0): the caller takes the generic conv2d route (pack mode 2 / 3) otherwise.                      */
 int mrfa_conv_fewout_dgrad(void* stream, const float* dy, int lddy, int N, int H, int W, int Cout, const float* w, float* dx, int lddx,
-                           int Cin, int R, int pad, int accumulate);
+                           int Cin, int R, int pad, int accumulate, const float* mask /* optional, as mrfa_conv_params.mask */, int ldm);
 int mrfa_conv_fewout_dgrad_supported(int Cin, int Cout, int R, int pad, int W, int lddx);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ __device__ __forceinline__ void load_col(const float* __restrict__ base, int ld,
 template <int COUT, int LPP>
 __global__ __launch_bounds__(256) void fewout3_dgrad_kernel(const float* __restrict__ dy, int lddy, int N, int H, int W, int Cin,
                                                            const float* __restrict__ w, float* __restrict__ dx, int lddx, int accumulate,
-                                                           long long units, int runs_x) {
+                                                           long long units, int runs_x, const float* __restrict__ mask, int ldm) {
     constexpr int G = 64 / LPP;
     const int lane = threadIdx.x & 63, cl = lane % LPP, grp = lane / LPP;
     const int c = cl * 4;
@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256) void fewout3_dgrad_kernel(const float* __restr
                 for (int r = 0; r < 3; ++r)          // window row r' = y - 1 + r' is the source of tap row r = 2 - r'; column slot likewise
                     a += wr[co][(2 - r) * 3 + 2] * c0[r][co] + wr[co][(2 - r) * 3 + 1] * c1[r][co] + wr[co][(2 - r) * 3 + 0] * c2[r][co];
             if (xo < W) {
-                float* d = dx + ((size_t)(ut.n * H + ut.y) * W + xo) * lddx + c;
+                const size_t pixo = (size_t)(ut.n * H + ut.y) * W + xo;
+                float* d = dx + pixo * lddx + c;
+                if (mask) {                          // fused ReLU backward of the producer of x (mrfa_conv_params.mask semantics)
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + pixo * ldm + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = mk[e] > 0.f ? a[e] : 0.f;
+                }
                 if (accumulate) a += *reinterpret_cast<const f32x4*>(d);
                 *reinterpret_cast<f32x4*>(d) = a;
             }
@@ -210,7 +216,7 @@ bool mrfa_fewout3_wgrad(hipStream_t st, const float* x, int ldx, int N, int H, i
 }
 
 extern "C" int mrfa_conv_fewout_dgrad(void* stream, const float* dy, int lddy, int N, int H, int W, int Cout, const float* w, float* dx, int lddx,
-                                      int Cin, int R, int pad, int accumulate) {
+                                      int Cin, int R, int pad, int accumulate, const float* mask, int ldm) {
     MRFA_CHECK_ARG(dy && w && dx, "conv_fewout_dgrad: null pointer");
     MRFA_CHECK_ARG(eligible(dx, lddx, Cin, Cout, R, pad, W) && aligned16(w),
                    "conv_fewout_dgrad: 3x3 / pad 1, Cout in {1, 2}, Cin in {64, 128, 256}, 16-B aligned dx / w with lddx %% 4 == 0 (got Cin %d Cout %d R %d)",
@@ -218,7 +224,8 @@ extern "C" int mrfa_conv_fewout_dgrad(void* stream, const float* dy, int lddy, i
     hipStream_t st = (hipStream_t)stream;
     const int runs_x = cdiv(W, RUN);
     const long long units = (long long)N * H * runs_x;
-    FEW3(fewout3_dgrad_kernel, dy, lddy, N, H, W, Cin, w, dx, lddx, accumulate, units, runs_x);
+    MRFA_CHECK_ARG(!mask || ((ldm % 4) == 0 && aligned16(mask)), "conv_fewout_dgrad: mask must be a 16-B aligned view with ldm %% 4 == 0");
+    FEW3(fewout3_dgrad_kernel, dy, lddy, N, H, W, Cin, w, dx, lddx, accumulate, units, runs_x, mask, ldm);
     MRFA_CHECK_LAUNCH("conv_fewout_dgrad");
     return 0;
 }

@@ -154,13 +154,16 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int uu = b_val[j] ? u : 0;
         const int pc = uu / (BN * 2), rem = uu - pc * (BN * 2);
         const int row = rem >> 1, half = rem & 1;
-        b_goff[j] = pc * (int)((PH || PD) ? p.w_phase_piece : p.w_piece) + (n0 + row) * p.w_ld + half * 8;
+        // pre-split planes are k16-chunk-major (pack_multi.hip chunk_major()): the slab of (tap, chunk) = w_rows consecutive rows of 32 bytes,
+        // ONE contiguous run (row-major planes gave 32 bytes out of every row: a quarter of each 128-byte line fetched from L2; +3-5 %)
+        b_goff[j] = pc * (int)((PH || PD) ? p.w_phase_piece : p.w_piece) + (n0 + row) * 16 + half * 8;
         b_loff[j] = pc * BPLANE + half * BHALF + row * 16;
     }
 
     f32x4 ra[G::NU], psc, psh;
     u32x4 rb[NBU];
     const int w_tap = (int)p.w_tap;
+    const int chunk_stride = p.w_rows * 16;        // elements between the k16 chunks of one tap
 
     // PD: virtual chunk c = 4 * (channel chunk) + phase: phase image offset (py * Win + px) pixels, masked units stay on their valid address
     auto load_a = [&](int j, int c) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
     auto load_b = [&](int c, int tap) {
-        const unsigned short* src = PD ? ws + (size_t)((c & 3) * 4 + tap) * w_tap + (c >> 2) * 16 : ws + (size_t)tap * w_tap + c * 16;
+        const unsigned short* src = PD ? ws + (size_t)((c & 3) * 4 + tap) * w_tap + (size_t)(c >> 2) * chunk_stride : ws + (size_t)tap * w_tap + (size_t)c * chunk_stride;
 #pragma unroll
         for (int j = 0; j < NBU; ++j) rb[j] = *reinterpret_cast<const u32x4*>(src + b_goff[j]);
     };
@@ -332,6 +335,11 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         const float osc = (p.out_scale && c_ok) ? p.out_scale[c0 + e] : 1.f;
                         const float osh = (p.out_scale && c_ok) ? p.out_shift[c0 + e] : 0.f;
                         v[e] = (acc[i][j][4 * g + e] * p.alpha + bias) * osc + osh;
+                    }
+                    if (p.mask) {                              // fused ReLU backward of the producer of this gradient (data-gradient launches)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < p.Cout) v[e] = p.mask[(size_t)m * p.ldm + c0 + e] > 0.f ? v[e] : 0.f;
                     }
                     if (c0 + 3 < p.Cout) {                      // whole quad inside Cout: 16-byte accesses (ldy, ldr % 4 == 0, 16-B aligned bases)
                         if (p.res) {
@@ -490,6 +498,7 @@ static bool halo_phase_dgrad(const mrfa_conv_params& p) {
 }
 
 extern "C" int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p) { return p && halo_phase_dgrad(*p) ? 1 : 0; }
+extern "C" int mrfa_conv2d_mask_supported(const mrfa_conv_params* p) { return p && p->kflat == 0 && mrfa_conv_halo_eligible(*p) ? 1 : 0; }
 
 bool mrfa_conv_halo_eligible(const mrfa_conv_params& p) {
     if (p.ups == 2) return halo_phase_dgrad(p);

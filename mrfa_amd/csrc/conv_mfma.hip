@@ -365,6 +365,10 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
         return mrfa_conv_small_launch(st, p, M);
     }
+    if (p.mask && !(!flat && mrfa_conv_halo_eligible(p))) {
+        mrfa_set_error("conv2d: `mask` is only honoured by the patch-tiled kernel: ask mrfa_conv2d_mask_supported() first");
+        return 1;
+    }
     if (p.ups == 2 && !(!flat && mrfa_conv_halo_eligible(p))) {
         mrfa_set_error("conv2d: ups = 2 (phase data gradient of a fused-upsample layer) is only implemented for the shapes "
                        "mrfa_conv2d_phase_dgrad_supported() reports");

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
 // 1: the shape runs here.  Chunked (non-flat) layout, no fused upsample / pre-activation prologue / batched GEMM, channels in
 // multiples of 16, and a problem small enough that the 128-row workgroup tiles cannot fill the chip.
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
-    if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.tile || p.splitk > 1) return false;
+    if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.tile || p.splitk > 1 || p.mask) return false;
     if ((p.Cin & 15) || (p.ldx & 3) || (p.w_ld & 3)) return false;
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const long long ktot = (long long)p.R * p.S * p.Cin;

@@ -145,11 +145,12 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
         }
         if constexpr (WS) {
             if (b_loader) {
-                const unsigned short* src = l_ws + (size_t)(n0 + brow) * p.w_ld + l_c * 32 + bhalf * 8;
+                // k16-chunk-major planes (pack_multi.hip chunk_major()): chunk 2 l_c + h of this tap, row n0 + brow, half bhalf
+                const unsigned short* src = l_ws + (size_t)(2 * l_c) * (p.w_rows * 16) + (size_t)(n0 + brow) * 16 + bhalf * 8;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) wsp[h][pc] = *reinterpret_cast<const u32x4*>(src + (size_t)pc * p.w_piece + h * 16);
+                    for (int pc = 0; pc < 3; ++pc) wsp[h][pc] = *reinterpret_cast<const u32x4*>(src + (size_t)pc * p.w_piece + (size_t)h * (p.w_rows * 16));
             }
         } else {
             const float* wt = l_w + c0;

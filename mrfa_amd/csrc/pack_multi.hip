@@ -40,6 +40,13 @@ __device__ __forceinline__ long long dst_index(int mode, int co, int ci, int t, 
     }
 }
 
+// bf16 planes (modes 8 / 9 / 12 / 13 / 14 / 15) are K16-CHUNK-MAJOR: element (tap tt, row r, column f) of a [taps][rowsP][colsP] matrix sits at
+// tt * rowsP * colsP + (f / 16) * (rowsP * 16) + r * 16 + f % 16: the 16-channel slab of a tap that a conv workgroup stages is ONE contiguous run
+// of rows x 32 bytes (with row-major planes it was 32 bytes out of every row's Cin * 2: a quarter of each 128-byte line fetched from L2)
+__device__ __forceinline__ long long chunk_major(int tt, int r, int f, int rowsP, int colsP) {
+    return (long long)tt * rowsP * colsP + (long long)(f >> 4) * (rowsP * 16) + r * 16 + (f & 15);
+}
+
 __device__ __forceinline__ int find_desc(const int* prefix, int n, int b) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -78,7 +85,8 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
             // pixel (2y + py, 2x + px) reads rows {y - 1 + py, y + py} x columns {x - 1 + px, x + px}; the weight of phase tap (a, b) is the
             // sum of the 3x3 taps that land on that source pixel: rows R(py, a) = {0} {1,2} | {0,1} {2}, columns likewise.  Layout: three
             // bf16 planes [piece][(py*2+px)*4 + a*2+b][CoutPad128][CinPad32] (mode 12: the split of mode 8 applied to the summed weights) or
-            // transposed [piece][..][CinPad128][CoutPad32] (mode 13: for the phase data gradient, the split of mode 9's role).
+            // transposed [piece][..][CinPad128][CoutPad32] (mode 13: for the phase data gradient, the split of mode 9's role), each tap's matrix
+            // k16-chunk-major (chunk_major()).
             constexpr unsigned RM[4] = {0x1u, 0x6u, 0x3u, 0x4u};         // [py*2 + a] -> bit mask over r
             const bool tr = mode == 13;
             unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(dst);
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
                                 if (((rm >> r) & 1u) && ((sm >> s_) & 1u)) v[e] += wl[r * 3 + s_];
                     }
                 }
-                const long long idx = tr ? ((long long)pt * rowsP + ci0 + sl) * colsP + co0 + f0 : ((long long)pt * rowsP + co0 + sl) * colsP + ci0 + f0;
+                const long long idx = tr ? chunk_major(pt, ci0 + sl, co0 + f0, rowsP, colsP) : chunk_major(pt, co0 + sl, ci0 + f0, rowsP, colsP);
                 float x0 = v[0], x1 = v[1];
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
@@ -137,7 +145,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
                 // neighbour along the fastest axis: +1 in ci (stride T in LDS) or +1 in co (stride `row`)
                 const int lstep = ci_fast ? T : row;
                 const float v0 = lds[co_l * row + ci_l * T + t];
-                const long long idx = dst_index(base_mode, co0 + co_l, ci0 + ci_l, t, Cout, Cin, T);
+                const long long idx = !bf ? dst_index(base_mode, co0 + co_l, ci0 + ci_l, t, Cout, Cin, T)
+                                      : (base_mode == 0 ? chunk_major(t, co0 + co_l, ci0 + ci_l, rup(Cout, 128), rup(Cin, 32))
+                                                        : chunk_major(T - 1 - t, ci0 + ci_l, co0 + co_l, rup(Cin, 128), rup(Cout, 32)));
                 if (!bf) {
                     dst[idx] = v0;
                 } else {

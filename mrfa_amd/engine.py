@@ -112,6 +112,7 @@ class defer_wgrads:
 
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
+RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
 # channels @64^2, B = 8) are mostly first touched by accumulating kernels (residual gradients, sub-sampling, GELU, attention), i.e. each
@@ -226,7 +227,7 @@ def _r4(c: int) -> int:
 # ------------------------------------------------------------------------------------------------- storage / views
 class Storage:
     """[rows, ld] fp32 buffer + lazily allocated gradient buffer of the same geometry."""
-    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh")
+    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh", "bwd_masked")
 
     def __init__(self, data: torch.Tensor):
         assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
@@ -241,6 +242,10 @@ class Storage:
         # it through grad_buf() / View.gptr like every other op, gets it zero-filled first.  A producer that finds its output still
         # fresh knows that no consumer sent a gradient (View.has_grad is False) and skips its backward.
         self.fresh = False
+        # True: the buffer holds ReLU outputs whose ONLY consumer is a conv called with relu_in=True: that consumer's data gradient
+        # applies the ReLU mask (fused into its epilogue where the library can, a masking pass of its own otherwise), so the
+        # producers skip their ReLU-backward pass
+        self.bwd_masked = False
 
     def grad_buf(self) -> torch.Tensor:
         if self.grad is None:
@@ -851,9 +856,15 @@ class Ctx:
 
     # -- convolution ------------------------------------------------------------------------------------------
     def conv(self, x: View, conv: torch.nn.Conv2d, out: Optional[View] = None, *, relu=False, ups=False, pre=None,
-             stats: Optional[torch.Tensor] = None, res: Optional[View] = None, need_dx=True, use_bias=True) -> View:
-        """y = conv(pre(ups(x))) (+bias)(+res)(ReLU).  pre = (scale, shift) tensors of a pre-activation BN+ReLU."""
+             stats: Optional[torch.Tensor] = None, res: Optional[View] = None, need_dx=True, use_bias=True, relu_in=False) -> View:
+        """y = conv(pre(ups(x))) (+bias)(+res)(ReLU).  pre = (scale, shift) tensors of a pre-activation BN+ReLU.
+        relu_in: the caller states that x (all of its storage) holds ReLU outputs and that this conv is their only consumer: the ReLU
+        backward of x's producers then rides in this conv's data gradient (mrfa_conv_params.mask) instead of a pass of its own."""
         cw = convw(conv)
+        relu_in = bool(relu_in and RELU_IN and self.record and need_dx and pre is None and not ups)
+        if relu_in:
+            assert x.coff == 0 and x.C == x.st.ld, "relu_in: the view must cover its storage (every producer skips its ReLU backward)"
+            x.st.bwd_masked = True
         assert x.C == cw.Cin, (x.C, cw.Cin)
         Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
         Ho, Wo = Hv + 2 * cw.pad - cw.R + 1, Wv + 2 * cw.pad - cw.S + 1
@@ -882,7 +893,7 @@ class Ctx:
                     else:
                         launch()
                     if need_dx:
-                        self._conv_dgrad(x, cw, out, ups, pre)
+                        self._conv_dgrad(x, cw, out, ups, pre, relu_in)
                 self.tape.append(bwd_direct)
                 if cw not in self.touched_convs:
                     self.touched_convs.append(cw)
@@ -931,7 +942,7 @@ class Ctx:
             def bwd():
                 if not out.has_grad:
                     return
-                if relu:
+                if relu and not out.st.bwd_masked:
                     self._chk(self.L.mrfa_act_bwd(self.s, out.ptr, out.ld, out.gptr, out.ld, out.rows, out.C, 1, out.gptr, out.ld, 0),
                               "relu_bwd")
                 if res is not None:
@@ -939,7 +950,7 @@ class Ctx:
                 if conv.weight.requires_grad:              # frozen weights (the VGG19 of the perceptual loss): data gradient only
                     self._conv_wgrad(x, cw, out, ups, pre, bias is not None)
                 if need_dx:
-                    self._conv_dgrad(x, cw, out, ups, pre)
+                    self._conv_dgrad(x, cw, out, ups, pre, relu_in)
             self.tape.append(bwd)
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
@@ -999,22 +1010,31 @@ class Ctx:
             flops = 2.0 * q.N * q.Hout * q.Wout * q.Cout * q.Cin * q.R * q.S
             prof.append((-1, flops, e0, e1, f"wgrad {q.Cin}->{q.Cout} {q.R}x{q.S} @{q.Hout}x{q.Wout} N={q.N} ups={q.ups} flat={int(q.kflat > 0)} ldx={q.ldx} ldy={q.ldy} xal={x.ptr % 16} dyal={out.gptr % 16} bias={int(bool(q.dbias))} pre={int(pre is not None)}"))
 
-    def _conv_dgrad(self, x: View, cw: ConvW, out: View, ups, pre):
+    def _relu_mask_pass(self, x: View):
+        """x.grad *= (x > 0): the ReLU backward of x's producers as a pass of its own (where no kernel fuses it)"""
+        self._chk(self.L.mrfa_act_bwd(self.s, x.ptr, x.ld, x.gptr, x.ld, x.rows, x.C, 1, x.gptr, x.ld, 0), "relu_bwd(consumer)")
+
+    def _conv_dgrad(self, x: View, cw: ConvW, out: View, ups, pre, relu_in=False):
         """x.grad += conv_transpose(out.grad); with ups the hi-res gradient is sum-pooled; with pre it is pushed
-        through the pre-activation BN+ReLU by the caller-registered closure (see prebn)."""
+        through the pre-activation BN+ReLU by the caller-registered closure (see prebn).  relu_in (see conv): this is the only
+        consumer of the ReLU outputs in x, whose mask (x > 0) is applied here."""
         Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
         direct = (not ups) and pre is None
+        assert direct or not relu_in
         first = direct and self._claim(x)             # first writer of x.grad covering all of it: overwrite, no zero fill needed
         if direct and cw.fewin and out.ld % 4 == 0 and out.coff % 4 == 0:
             # few input channels: the data gradient is a few-output conv over dY
             self._chk(self.L.mrfa_conv_fewout_fwd(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewin_dgrad_pack().data_ptr(),
                                                   None, x.gptr, x.ld, cw.Cin, cw.R, cw.R - 1 - cw.pad, 0 if first else 1), "conv_fewout(dgrad)")
+            if relu_in:
+                self._relu_mask_pass(x)
             return
         if (direct and cw.fewout and x.coff % 4 == 0 and
                 self.L.mrfa_conv_fewout_dgrad_supported(cw.Cin, cw.Cout, cw.R, cw.pad, x.W, x.ld)):
             # 3x3 layer with one or two output channels: channel-lane kernel (csrc/conv_fewout3.hip) instead of a K = 9 Cout MFMA GEMM
             self._chk(self.L.mrfa_conv_fewout_dgrad(self.s, out.gptr, out.ld, out.N, out.H, out.W, cw.Cout, cw.fewout_pack().data_ptr(),
-                                                    x.gptr, x.ld, cw.Cin, cw.R, cw.pad, 0 if first else 1), "conv_fewout_dgrad")
+                                                    x.gptr, x.ld, cw.Cin, cw.R, cw.pad, 0 if first else 1,
+                                                    x.ptr if relu_in else None, x.ld), "conv_fewout_dgrad")
             return
         if (ups and pre is None and self.split and PHASE_UPCONV and cw.R == 3 and cw.S == 3 and cw.pad == 1 and not cw.dgrad_flat
                 and x.coff % 4 == 0):
@@ -1067,7 +1087,15 @@ class Ctx:
         p.R, p.S, p.pad = cw.R, cw.S, cw.R - 1 - cw.pad
         p.alpha, p.nbatch = 1.0, 1
         p.accumulate = 1 if (direct and not first) else 0
+        fused = False
+        if relu_in:
+            p.mask, p.ldm = x.ptr, x.ld
+            fused = bool(self.L.mrfa_conv2d_mask_supported(C.byref(p)))
+            if not fused:
+                p.mask, p.ldm = None, 0
         self._launch_conv(p, "dgrad", cw.Cout)
+        if relu_in and not fused:
+            self._relu_mask_pass(x)
         if direct:
             return
         cur = tgt            # holds d(pre(ups(x))) as DATA

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libmrfa_hip.so")
+# MRFA_HIP_LIB: another build of the same library (kernel A/B experiments: tools/ab_lib.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("MRFA_HIP_LIB") or os.path.join(_HERE, "_lib", "libmrfa_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
@@ -35,6 +36,7 @@ class ConvParams(C.Structure):
         ("splitk", C.c_int),
         ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile", C.c_int),
         ("w_split", C.c_void_p), ("w_piece", C.c_longlong),
+        ("mask", C.c_void_p), ("ldm", C.c_int),
         ("w_phase", C.c_void_p), ("w_phase_piece", C.c_longlong),
     ]
 
@@ -115,7 +117,8 @@ _SIGNATURES = {
     "mrfa_conv2d_wgrad_nhwc": ([_V, C.POINTER(WgradParams)], C.c_int),
     "mrfa_conv_fewout_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_conv_fewout_wgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _V], C.c_int),
-    "mrfa_conv_fewout_dgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, _I, _I, _I, _I], C.c_int),
+    "mrfa_conv_fewout_dgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
+    "mrfa_conv2d_mask_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv_fewout_dgrad_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weights_multi": ([_V, C.POINTER(PackDesc), _I], C.c_int),

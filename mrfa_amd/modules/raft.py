@@ -73,10 +73,11 @@ class BasicMotionEncoder(nn.Module):
         """writes [conv(126) | flow(2)] into `out` (128 channels of the RefineFlow input buffer)"""
         cor1 = e.conv(corr, self.convc1, relu=True)
         corflo = e.new(flow.N, flow.H, flow.W, 160)
-        e.conv(cor1, self.convc2, out=corflo.slice(0, 96), relu=True)
+        # relu_in: cor1 / flo1 / corflo are ReLU outputs with one consumer each -- their ReLU backward rides in the consumer's data gradient
+        e.conv(cor1, self.convc2, out=corflo.slice(0, 96), relu=True, relu_in=True)
         flo1 = e.conv(flow, self.convf1, relu=True)
-        e.conv(flo1, self.convf2, out=corflo.slice(96, 160), relu=True)
-        e.conv(corflo, self.conv, out=out.slice(0, 126), relu=True)
+        e.conv(flo1, self.convf2, out=corflo.slice(96, 160), relu=True, relu_in=True)
+        e.conv(corflo, self.conv, out=out.slice(0, 126), relu=True, relu_in=True)
         e.copy(flow, out=out.slice(126, 128))
 
     def forward(self, delta_flow, corr):
@@ -102,14 +103,15 @@ class RefineFlow(nn.Module):
         self.convo1 = nn.Conv2d(256, 128, 3, padding=1)
         self.convo2 = nn.Conv2d(128, 1, 3, padding=1)
 
-    def run(self, e: Ctx, inp: View, ctx: View) -> View:
-        """inp: 256-channel buffer whose first 128 channels hold the motion features; returns d_flow (.,.,.,3)"""
-        e.conv(ctx, self.convc1, out=inp.slice(128, 256), relu=True)
+    def run(self, e: Ctx, inp: View, ctx: View, ctx_relu=False) -> View:
+        """inp: 256-channel buffer whose first 128 channels hold the motion features; returns d_flow (.,.,.,3).
+        ctx_relu: ctx is a ReLU output consumed only here (the to_context conv of RaftFlow.run): see Ctx.conv's relu_in"""
+        e.conv(ctx, self.convc1, out=inp.slice(128, 256), relu=True, relu_in=ctx_relu)
         h1 = e.conv(inp, self.conv1, relu=True)
         d = e.new(inp.N, inp.H, inp.W, 3)
-        e.conv(h1, self.conv2, out=d.slice(0, 2))
+        e.conv(h1, self.conv2, out=d.slice(0, 2), relu_in=True)
         h2 = e.conv(inp, self.convo1, relu=True)
-        e.conv(h2, self.convo2, out=d.slice(2, 3))
+        e.conv(h2, self.convo2, out=d.slice(2, 3), relu_in=True)
         return d
 
     def forward(self, m_f, warp_f):
@@ -313,7 +315,7 @@ class RaftFlow(nn.Module):
             self.corr_enc.run(e, flow, cfeat, inp)
             ctx = e.grid_sample(f, flow, 1)
             ctx = e.conv(ctx, self.to_context[i], relu=True)
-            d_flow = self.refine.run(e, inp, ctx)
+            d_flow = self.refine.run(e, inp, ctx, ctx_relu=True)
             flow_w = e.copy(flow)
             e.copy(d_flow.slice(0, 2), out=flow_w, acc=True)
             occ_new = e.copy(occ)

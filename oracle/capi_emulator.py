@@ -462,6 +462,8 @@ class Emulator:
                 v = v + nhwc(p.res, p.N, p.Hout, p.Wout, p.ldr, p.Cout)
             if p.relu:
                 v = F.relu(v)
+            if p.mask:               # fused ReLU backward of the producer of the tensor whose gradient this launch writes
+                v = v * (nhwc(p.mask, p.N, p.Hout, p.Wout, p.ldm, p.Cout) > 0)
             if p.accumulate:
                 v = v + y
             y.copy_(v)
@@ -512,11 +514,19 @@ class Emulator:
             vec(dbias, Cout).add_(g.sum(dim=(0, 2, 3)))
         return 0
 
-    def mrfa_conv_fewout_dgrad(self, stream, dy, lddy, N, H, W, Cout, w, dx, lddx, Cin, R, pad, accumulate):
+    def mrfa_conv2d_mask_supported(self, pref):
+        """shape rule of the library's patch-tiled kernel (the emulator itself honours `mask` everywhere)"""
+        p = _obj(pref)
+        return int(p.kflat == 0 and p.R == 3 and p.S == 3 and p.pad == 1 and p.Wout % 32 == 0 and p.Cin % 32 == 0 and p.Cout >= 32
+                   and p.ldy % 4 == 0 and p.nbatch <= 1)
+
+    def mrfa_conv_fewout_dgrad(self, stream, dy, lddy, N, H, W, Cout, w, dx, lddx, Cin, R, pad, accumulate, mask=None, ldm=0):
         T = R * R
         g = nhwc(dy, N, H, W, lddy, Cout).permute(0, 3, 1, 2).contiguous()
         ww = _flat(w, Cout * T * Cin).view(Cout, T, Cin).permute(0, 2, 1).reshape(Cout, Cin, R, R).contiguous()
         v = F.conv_transpose2d(g, ww, padding=pad).permute(0, 2, 3, 1)
+        if mask:
+            v = v * (nhwc(mask, N, H, W, ldm, Cin) > 0)
         o = nhwc(dx, N, H, W, lddx, Cin)
         o.copy_(o + v if accumulate else v)
         return 0
@@ -851,6 +861,11 @@ class Emulator:
         return 0
 
     # ---------------------------------------------------------------- batched (un)packing
+    @staticmethod
+    def _chunk_major(flat, taps, rows, cols):
+        """[taps][rows][cols] row-major -> the k16-chunk-major order of the bf16 planes: [taps][cols / 16][rows][16]"""
+        return flat.view(taps, rows, cols // 16, 16).permute(0, 2, 1, 3).reshape(-1)
+
     def mrfa_pack_conv_weights_multi(self, stream, descs, n):
         for i in range(n):
             d = descs[i]
@@ -866,7 +881,9 @@ class Emulator:
                     if rc:
                         return rc
                     out = torch.frombuffer((C.c_short * (3 * n)).from_address(d.dst[k]), dtype=torch.int16).view(3, n)
-                    r = tmp
+                    rows_, cols_ = ((d.Cout + 127) // 128 * 128, (d.Cin + 31) // 32 * 32) if d.mode[k] == 8 else \
+                        ((d.Cin + 127) // 128 * 128, (d.Cout + 31) // 32 * 32)
+                    r = self._chunk_major(tmp, T, rows_, cols_)
                     for pc in range(3):
                         bits = r.view(torch.int32) & -65536
                         out[pc] = (bits >> 16).to(torch.int16)
@@ -883,7 +900,9 @@ class Emulator:
                     if rc:
                         return rc
                     out = torch.frombuffer((C.c_short * n).from_address(d.dst[k]), dtype=torch.int16)
-                    out.copy_(tmp.to(torch.bfloat16).view(torch.int16))
+                    rows_, cols_ = ((d.Cout + 127) // 128 * 128, (d.Cin + 31) // 32 * 32) if d.mode[k] == 14 else \
+                        ((d.Cin + 127) // 128 * 128, (d.Cout + 31) // 32 * 32)
+                    out.copy_(self._chunk_major(tmp, T, rows_, cols_).to(torch.bfloat16).view(torch.int16))
                     continue
                 if d.mode[k] in (12, 13):            # phase weights of nearest-x2 + 3x3 (see mrfa_conv_params.w_phase), split into three bf16 pieces
                     assert d.R == 3 and d.S == 3     # 13: transposed (rows = input channels) for the phase data gradient
@@ -906,7 +925,7 @@ class Emulator:
                                         full[(py * 2 + px) * 4 + a_ * 2 + b_, :d.Cout, :d.Cin] = acc
                     nn_ = 16 * cop * cip
                     out = torch.frombuffer((C.c_short * (3 * nn_)).from_address(d.dst[k]), dtype=torch.int16).view(3, nn_)
-                    r_ = full.reshape(-1)
+                    r_ = self._chunk_major(full.reshape(-1), 16, cop, cip)
                     for pc in range(3):
                         bits = r_.view(torch.int32) & -65536
                         out[pc] = (bits >> 16).to(torch.int16)

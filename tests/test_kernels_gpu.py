@@ -81,7 +81,8 @@ def ktab(side, Cc, R, S, pad):
 
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
-              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, tag="c"):
+              stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
+              tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -145,7 +146,13 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     st = side.z((hip.STATS_SLOTS, 2 * Cout), torch.float64)          # [MRFA_STATS_SLOTS][2C], summed by the consumer
     if stats:
         p.stats = st.data_ptr()
+    if mask:                        # fused ReLU backward: the result is multiplied by (mask > 0) before the accumulation
+        mk = side.t(f"{tag}/mask", (N * Ho * Wo, Cout + 8))
+        keep.append(mk)
+        p.mask, p.ldm = mk.data_ptr(), Cout + 8
     p.alpha, p.accumulate, p.nbatch, p.splitk, p.tile = alpha, int(acc), 1, splitk, tile
+    if mask and side.gpu:
+        assert side.L.mrfa_conv2d_mask_supported(C.byref(p)) == 1
     side.call("mrfa_conv2d_nhwc", C.byref(p))
     return side.done(y[:, :Cout], st.sum(0))
 
@@ -235,11 +242,37 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True),                 # 256-wide workgroup tile, 64 padding columns
     "bn256_c512_stats": dict(N=1, H=8, W=32, Cin=32, Cout=512, stats=True, relu=False, bias=False),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=128),   # chosen by the default heuristic
+    # data-gradient launches carrying the ReLU backward of the tensor they write (mrfa_conv_params.mask)
+    "mask_acc_c160": dict(N=1, H=16, W=32, Cin=128, Cout=160, mask=True, acc=True, relu=False, bias=False),
+    "mask_c192_pr4": dict(N=2, H=12, W=32, Cin=128, Cout=192, mask=True, relu=False, bias=False),
+    "mask_ragged_c98": dict(N=1, H=8, W=64, Cin=32, Cout=98, mask=True, acc=True, relu=False, bias=False),
     # phase form of the fused upsample (four 2x2 convolutions on the low-resolution grid, pre-summed weights of pack mode 12)
     "phase_up_c64": dict(N=2, H=8, W=32, Cin=128, Cout=64, ups=1, stats=True, wphase=True),
     "phase_up_c256_pro_res": dict(N=1, H=16, W=32, Cin=64, Cout=256, ups=1, pro=True, res=True, relu=False, wphase=True),
     "phase_up_c130_acc": dict(N=1, H=8, W=64, Cin=32, Cout=130, ups=1, acc=True, alpha=0.5, bias=False, wphase=True),
 }
+
+
+@pytest.mark.parametrize("name", ["auto_256_to_128", "phase_up_c64", "mask_acc_c160", "pr4_tail_rows"])
+def test_patch_tiled_kernel_is_run_to_run_identical(name):
+    """no atomics on the output path: eight launches on the same operands must agree bit for bit (a missing barrier between the grouped
+    weight-slab buffers / the halo double buffer of conv_halo.hip would show up here as a sporadic difference)"""
+    L = hip.lib()
+    kw = dict(HALO_CASES[name])
+    kw.pop("min_tiles", None)
+    kw["stats"] = False
+    assert L.mrfa_set_mfma_mode(1) == 0
+    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
+    L.mrfa_set_tuning(b"conv_small", 0)
+    try:
+        outs = [conv_case(Side(True), tag=f"halo/{name}", wsplit=True, **kw)[0] for _ in range(8)]
+        assert L.mrfa_conv2d_last_config() & (1 << 28), "the patch-tiled kernel did not run"
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
+        L.mrfa_set_tuning(b"conv_small", 1)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
@@ -858,10 +891,14 @@ def test_conv_fewout(cfg):
         extra = []
         if not c["mode7"] and side.L.mrfa_conv_fewout_dgrad_supported(Cin, Cout, R, pad, W, Cin + 4):
             dx = side.garbage((N * H * W, Cin + 4))           # data gradient: overwrite, then accumulate on top
-            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx.data_ptr(), Cin + 4, Cin, R, pad, 0)
+            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx.data_ptr(), Cin + 4, Cin, R, pad, 0, None, 0)
             dx2 = side.t(f"{tag}/dx0", (N * H * W, Cin + 4))
-            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx2.data_ptr(), Cin + 4, Cin, R, pad, 1)
-            extra = [dx[:, :Cin], dx2[:, :Cin]]
+            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx2.data_ptr(), Cin + 4, Cin, R, pad, 1, None, 0)
+            mk = side.t(f"{tag}/mask", (N * H * W, Cin + 8))  # ... and with the ReLU mask of the tensor the gradient belongs to
+            dx3 = side.t(f"{tag}/dx0", (N * H * W, Cin + 4))
+            side.call("mrfa_conv_fewout_dgrad", dy.data_ptr(), 4, N, H, W, Cout, wp.data_ptr(), dx3.data_ptr(), Cin + 4, Cin, R, pad, 1,
+                      mk.data_ptr(), Cin + 8)
+            extra = [dx[:, :Cin], dx2[:, :Cin], dx3[:, :Cin]]
         return side.done(y[:, :Cout], y2[:, :Cout], y3[:, :Cout], dw, db, g, wp, *extra)
     ref, got = both(run)
     assert_close(ref, got, tol=5e-4, what=tag)
@@ -898,7 +935,7 @@ def test_flat_clip_adam(gmag, clip_slot):
 
 
 def test_pack_split_pieces():
-    """pack modes 8 / 9: three bf16 pieces whose sum is the fp32 weight exactly, in the mode 0 / 2 layouts"""
+    """pack modes 8 / 9: three bf16 pieces whose sum is the fp32 weight exactly, the mode 0 / 2 matrices in k16-chunk-major order"""
     shapes = [(130, 64, 3), (128, 100, 1), (96, 256, 3)]
 
     def run(side):
@@ -914,9 +951,12 @@ def test_pack_split_pieces():
             d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, R, 2
             d.dst[0], d.mode[0], d.dst[1], d.mode[1] = b8.data_ptr(), 8, b9.data_ptr(), 9
             side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
-            for b, n, mode in ((b8, n8, 0), (b9, n9, 2)):
+            for b, n, mode, rows, cols in ((b8, n8, 0, (Cout + 127) // 128 * 128, (Cin + 31) // 32 * 32),
+                                           (b9, n9, 2, (Cin + 127) // 128 * 128, (Cout + 31) // 32 * 32)):
                 pieces = (b.view(3, n).to(torch.int32) << 16).view(torch.float32)
-                outs += [pieces[0], pieces[1], pieces[2], pieces.double().sum(0).float() - pack(side, w, mode)]
+                # the bf16 planes are k16-chunk-major: [tap][cols / 16][rows][16] (include/mrfa_hip.h, pack modes)
+                w32 = pack(side, w, mode).view(T, rows, cols // 16, 16).permute(0, 2, 1, 3).reshape(-1)
+                outs += [pieces[0], pieces[1], pieces[2], pieces.double().sum(0).float() - w32]
         return side.done(*outs)
     ref, got = both(run)
     for r, g in zip(ref, got):
