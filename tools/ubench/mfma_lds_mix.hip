@@ -11,6 +11,7 @@
 //   hipcc --offload-arch=gfx950 -O3 mfma_lds_mix.hip -o mfma_lds_mix && ./mfma_lds_mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -21,16 +22,16 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 #define WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 template <int V>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k(float* out, int iters) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k(float* out, int iters, int rnd) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
-    for (int i = threadIdx.x; i < 65536 / 4; i += 512) reinterpret_cast<unsigned*>(lds)[i] = 0x3f803f80u + (i & 3);
+    for (int i = threadIdx.x; i < 65536 / 4; i += 512) reinterpret_cast<unsigned*>(lds)[i] = rnd ? (((unsigned)i * 2654435761u) ^ ((unsigned)i >> 3) * 40503u) & 0xbfffbfffu : 0x3f803f80u + (i & 3);   // (rnd: random mantissas and signs, exponents kept finite)
     __syncthreads();
     const unsigned addr = (unsigned)(size_t)lds + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 4096;     // conflict-free 16-byte slots
     f32x16 c0, c1, c2, c3;
     for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = c3[r] = 0.f;
     i32x4 a[6], b[6], a2[6], b2[6], d[12];
     i32x2 e[24];
-    for (int i = 0; i < 6; ++i) for (int q = 0; q < 4; ++q) { a[i][q] = 0x3f803f80 + i; b[i][q] = 0x3e803e80 + q; a2[i][q] = a[i][q]; b2[i][q] = b[i][q]; }
+    for (int i = 0; i < 6; ++i) for (int q = 0; q < 4; ++q) { a[i][q] = rnd ? (int)((((unsigned)(threadIdx.x * 24 + i * 4 + q) * 2654435761u) & 0xbfffbfffu) | 0x30003000u) & 0xbfffbfff : 0x3f803f80 + i; b[i][q] = rnd ? (int)((((unsigned)(threadIdx.x * 31 + i * 4 + q + 7) * 2246822519u) & 0xbfffbfffu) | 0x30003000u) & 0xbfffbfff : 0x3e803e80 + q; a2[i][q] = a[i][q]; b2[i][q] = b[i][q]; }
     for (int i = 0; i < 12; ++i) for (int q = 0; q < 4; ++q) d[i][q] = 0;
     for (int i = 0; i < 24; ++i) for (int q = 0; q < 2; ++q) e[i][q] = 0;
     // 24 MFMAs on fragment sets (A, B): products (pa, pb) of the six-product pattern, accumulators cycling c0..c3
@@ -75,16 +76,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+static int g_rnd = 0;          // argv[2] = 1: random operand bits (the constant operands of the default run toggle few wires: lower power)
+static int g_scale = 1;        // argv[1]: run length multiplier (x10 = 130 ms per launch: long enough for the power management to settle)
 template <int V> void run(float* d, const char* name) {
-    const int grid = 256, iters = 20000;
+    const int grid = 256, iters = 20000 * g_scale;
     const double per_iter = (V == 3 || V == 7) ? 48.0 : 24.0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<V>, dim3(grid), dim3(512), 0, 0, d, 2000);
+    hipLaunchKernelGGL(k<V>, dim3(grid), dim3(512), 0, 0, d, 2000, g_rnd);
     hipDeviceSynchronize();
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<V>, dim3(grid), dim3(512), 0, 0, d, (V == 3 || V == 7) ? iters / 2 : iters);
+        hipLaunchKernelGGL(k<V>, dim3(grid), dim3(512), 0, 0, d, (V == 3 || V == 7) ? iters / 2 : iters, g_rnd);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -93,7 +96,10 @@ template <int V> void run(float* d, const char* name) {
     const double flops = mf * (2.0 * 32 * 32 * 16);
     printf("%-78s %7.2f ms  %5.0f TFLOP/s bf16 (/6 = %3.0f)\n", name, best, flops / best / 1e9, flops / best / 1e9 / 6);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_scale = atoi(argv[1]);
+    if (argc > 2) g_rnd = atoi(argv[2]);
+    printf("run length x%d, %s operands\n", g_scale, g_rnd ? "random" : "constant");
     float* d; hipMalloc(&d, 4096 * 512 * 4);
     run<0>(d, "V0 24 MFMA, register operands");
     run<1>(d, "V1 + 12 ds_read_b128 into unused registers, one per 2 MFMA");
