@@ -227,7 +227,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr int r = PD ? 2 - (tap >> 1) : (PH ? tap >> 1 : tap / 3), s = PD ? 2 - (tap & 1) : (PH ? tap & 1 : tap % 3);
         const unsigned char* A = smA + abuf * G::ABUF + a_frag - (PD ? (((vc >> 1) & 1) * HP + (vc & 1)) * 16 : 0);
         const unsigned char* B = smB + bbuf * BSLAB + b_frag;
-        constexpr int JG = TN < 2 ? TN : 2;          // column tiles per pass: BN = 256 runs two passes over the same A fragments
+        constexpr int JG = TN == 3 ? 3 : (TN < 2 ? TN : 2);      // column tiles per pass: BN = 256 runs two passes over the same A fragments
         bf16x8 a[NPC][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -415,6 +415,7 @@ int g_halo_pr = 0;               // 0 = by workgroup count, 4 / 8 = forced patch
 int g_conv_small = 1;
 
 int g_halo_bn256 = 1;
+int g_halo_bn192 = 1;
 
 // (patch rows, BN): PR = 8 (8 waves, 1 workgroup / CU) when that still gives every CU a workgroup, else PR = 4 (4 waves, 2 workgroups
 // per CU); BN = 256 (each wave 64 pixels x 128 channels: the halo is staged once for twice the MFMAs, 18 instead of 24 fragment reads
@@ -447,6 +448,12 @@ void halo_config(const mrfa_conv_params& p, int& PR, int& BN) {
     }
     const long long patches8 = (long long)p.N * cdiv(p.Hout, 8) * (p.Wout / PW), patches4 = (long long)p.N * cdiv(p.Hout, 4) * (p.Wout / PW);
     if (g_halo_pr != 4 && p.Hout % 8 == 0) {
+        // 192-wide tiles where they pad less than 128- / 256-wide ones (data gradients into 160 / 192 channels: 256 -> 192 columns of MFMA work)
+        if (g_halo_bn192 && !p.in_scale && cdiv(p.Cout, 192) * 192 < cdiv(p.Cout, 128) * 128 && halo_enough(p, patches8 * cdiv(p.Cout, 192), 192)) {
+            PR = 8;
+            BN = 192;
+            return;
+        }
         if (wide && halo_enough(p, patches8 * cdiv(p.Cout, 256), 256)) { PR = 8; BN = 256; return; }
         if (halo_enough(p, patches8 * cdiv(p.Cout, BN), BN)) { PR = 8; return; }
     }
@@ -475,6 +482,7 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_halo_min_tiles")) { const int prev = g_halo_min_tiles; g_halo_min_tiles = value; return prev; }
     if (!strcmp(key, "conv_halo_phase")) { const int prev = g_halo_phase; g_halo_phase = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_bn256")) { const int prev = g_halo_bn256; g_halo_bn256 = value != 0; return prev; }
+    if (!strcmp(key, "conv_halo_bn192")) { const int prev = g_halo_bn192; g_halo_bn192 = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_pr")) { const int prev = g_halo_pr; g_halo_pr = value; return prev; }
     if (!strcmp(key, "wgrad_halo")) return mrfa_tuning_wgrad_halo(value != 0);
     if (!strcmp(key, "wgrad_halo_min_wgs")) return mrfa_tuning_wgrad_halo_min(value);
@@ -546,6 +554,7 @@ int mrfa_conv_halo_launch(hipStream_t st, const mrfa_conv_params& p) {
     } while (0)
     if (p.ups == 2) { if (BN == 64) HALO_LAUNCH(8, false, 64, 2); else HALO_LAUNCH(8, false, 128, 2); }
     else if (phase) { if (pro) HALO_BN(8, true, 1); else HALO_BN(8, false, 1); }
+    else if (PR == 8 && BN == 192) HALO_LAUNCH(8, false, 192, 0);
     else if (PR == 8) { if (pro) HALO_BN(8, true, 0); else HALO_BN(8, false, 0); }
     else {
         if (BN == 64) { if (pro) HALO_LAUNCH(4, true, 64, 0); else HALO_LAUNCH(4, false, 64, 0); }

@@ -208,6 +208,8 @@ SPLIT_CASES = {
     "conv1x1_affine": dict(R=1, pad=0, Cin=256, Cout=128, oaff=True, N=4, H=16, W=16, tile=(128 << 16) | 128),
     "splitk4": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, tile=(128 << 16) | 128),
     "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False, Cin=64, Cout=128, tile=(128 << 16) | 128),
+    "bn192_c160_acc": dict(N=1, H=16, W=64, Cin=128, Cout=160, acc=True, relu=False, bias=False, mask=True),     # 192-wide tile, 32 padding columns
+    "bn192_c192_res": dict(N=2, H=8, W=32, Cin=64, Cout=192, res=True, stats=True),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128),
     "bn64_c64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True),
     "bn64_c50_pro": dict(N=2, H=16, W=48, Cin=64, Cout=50, tile=(128 << 16) | 64, pro=True),
@@ -239,7 +241,7 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "pr8_bn64_acc_alpha": dict(N=3, H=8, W=32, Cin=96, Cout=50, acc=True, alpha=0.37, relu=False, bias=False),
     "pr8_affine_c32": dict(N=1, H=8, W=32, Cin=32, Cout=96, oaff=True),             # two 16-channel chunks (chunked mode: Cin % 32 == 0)
     "pr8_wide_ld": dict(N=1, H=16, W=96, Cin=64, Cout=128, ldx_extra=8, ldy_extra=12),
-    "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True),                 # 256-wide workgroup tile, 64 padding columns
+    "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True, bn192=0),        # 256-wide workgroup tile, 64 padding columns
     "bn256_c512_stats": dict(N=1, H=8, W=32, Cin=32, Cout=512, stats=True, relu=False, bias=False),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=128),   # chosen by the default heuristic
     # data-gradient launches carrying the ReLU backward of the tensor they write (mrfa_conv_params.mask)
@@ -260,6 +262,7 @@ def test_patch_tiled_kernel_is_run_to_run_identical(name):
     L = hip.lib()
     kw = dict(HALO_CASES[name])
     kw.pop("min_tiles", None)
+    kw.pop("bn192", None)
     kw["stats"] = False
     assert L.mrfa_set_mfma_mode(1) == 0
     prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
@@ -285,10 +288,12 @@ def test_conv2d_patch_tiled_kernel(name, mode):
     if mode == 3 and kw.get("wphase"):
         pytest.skip("the phase form of the fused upsample exists for the split-operand modes")
     min_tiles = kw.pop("min_tiles", 0)              # 0: every eligible shape, whatever its workgroup count
+    bn192 = kw.pop("bn192", 1)
     ref = conv_case(Side(False), tag=f"halo/{name}", **kw)
     assert L.mrfa_set_mfma_mode(mode) == 0
     prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", min_tiles)
     L.mrfa_set_tuning(b"conv_small", 0)                     # (the small test shapes would otherwise go to conv_small.hip)
+    L.mrfa_set_tuning(b"conv_halo_bn192", bn192)
     try:
         got = conv_case(Side(True), tag=f"halo/{name}", wsplit=("rne" if mode == 3 else True), **kw)
         assert L.mrfa_conv2d_last_config() & (1 << 28), "the patch-tiled kernel did not run"
@@ -296,6 +301,7 @@ def test_conv2d_patch_tiled_kernel(name, mode):
         L.mrfa_set_mfma_mode(0)
         L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
         L.mrfa_set_tuning(b"conv_small", 1)
+        L.mrfa_set_tuning(b"conv_halo_bn192", 1)
     # mode 3: both operands rounded to 8 significand bits (2^-9 each), K = 288 .. 2304 products per output
     assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="halo " + name)
 
