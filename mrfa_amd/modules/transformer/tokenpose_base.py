@@ -6,7 +6,8 @@ Parameter containers mirror the reference's nesting (transformer.layers.<i>.<0|1
 Computation per layer on (B*tokens) x dim row matrices:
   LayerNorm (K21) -> to_qkv as a 1x1 convolution (K1) -> fused attention (K21, softmax never leaves the CU) -> to_out
   convolution with the residual added in its epilogue -> LayerNorm -> fc1 -> GELU (K21) -> fc2 + residual.
-Token assembly (patches, keypoint tokens, positional embedding) and the two 10-token heads are tiny torch islands.
+Token assembly (patches, keypoint tokens, positional embedding) is a tiny torch island; the two heads run LayerNorm / Linear as engine
+kernels on the gathered keypoint-token rows and leave only slicing + 2*sigmoid-1 to torch.
 """
 from __future__ import annotations
 
@@ -225,24 +226,26 @@ class TokenPose_TB_base(nn.Module):
                 object.__setattr__(self, "_pos_rows_key", key)
             pos_rows = e.wrap_nhwc(self._pos_rows)
         xv = self.transformer.run(e, x.view(), pos_rows)
-        heads = [self.mlp_head] + ([self.mlp_head_jacobian] if self.mlp_head_jacobian is not None else [])
-        params = [p for hd in heads for p in hd.parameters()]
         jac_tok, affine = self.jacobian_token, self.affine_jacobian
+        # heads (tokenpose_base.py:424-466): the 2K keypoint / Jacobian token rows are gathered once (a copy), then LayerNorm and the
+        # Linear layers run as the engine's own kernels (K21 / the few-output direct convolution) -- not as torch layer_norm + rocBLAS GEMMs
+        # on 10-token matrices; what is left to torch is slicing and the closing element-wise maps on (B, K, 2 | 4) values
+        (toks,) = e.island(lambda xt: [xt[:, :, :nk]], [xv])
 
-        def head_fn(xt, *ps):                             # tokenpose_base.py:424-466
-            it = iter(ps)
+        def apply(hd, t: View) -> View:
+            for m in hd:
+                t = e.layernorm(t, m) if isinstance(m, nn.LayerNorm) else e.conv(t, m)
+            return t
+        head_outs = [apply(self.mlp_head, toks.view())]
+        if self.mlp_head_jacobian is not None:
+            head_outs.append(apply(self.mlp_head_jacobian, toks.view()))
 
-            def apply(hd, t):
-                for m in hd:
-                    wgt, b = next(it), next(it)
-                    t = torch.nn.functional.layer_norm(t, (t.shape[-1],), wgt, b, m.eps) if isinstance(m, nn.LayerNorm) \
-                        else torch.nn.functional.linear(t, wgt, b)
-                return t
-            xt = xt[:, 0]
-            x_kp = xt[:, 0:nk // 2] if jac_tok else xt[:, 0:nk]
-            outs = [2 * torch.sigmoid(apply(self.mlp_head, x_kp)) - 1]
-            if self.mlp_head_jacobian is not None:
-                jac = apply(self.mlp_head_jacobian, xt[:, nk // 2:nk] if jac_tok else x_kp)
+        def finish(o_kp, *o_jac):                          # (B,1,2K,2) [, (B,1,2K,4)]
+            o_kp = o_kp[:, 0]
+            outs = [2 * torch.sigmoid(o_kp[:, 0:nk // 2] if jac_tok else o_kp[:, 0:nk]) - 1]
+            if o_jac:
+                jac = o_jac[0][:, 0]
+                jac = jac[:, nk // 2:nk] if jac_tok else jac[:, 0:nk]
                 if affine:
                     theta = jac[:, :, 0:2]
                     theta = theta / (torch.norm(theta, p=2, dim=-1, keepdim=True) + 1e-10)
@@ -256,7 +259,7 @@ class TokenPose_TB_base(nn.Module):
                     jac = jac.reshape(B, -1, 2, 2)
                 outs.append(jac)
             return outs
-        return e.island(head_fn, [xv] + params)
+        return e.island(finish, head_outs)
 
     def forward(self, feature, mask=None):
         assert mask is None
