@@ -416,6 +416,7 @@ int g_conv_small = 1;
 
 int g_halo_bn256 = 1;
 int g_halo_bn192 = 1;
+int g_halo_bn64_fill = 1;
 
 // (patch rows, BN): PR = 8 (8 waves, 1 workgroup / CU) when that still gives every CU a workgroup, else PR = 4 (4 waves, 2 workgroups
 // per CU); BN = 256 (each wave 64 pixels x 128 channels: the halo is staged once for twice the MFMAs, 18 instead of 24 fragment reads
@@ -455,6 +456,14 @@ void halo_config(const mrfa_conv_params& p, int& PR, int& BN) {
             return;
         }
         if (wide && halo_enough(p, patches8 * cdiv(p.Cout, 256), 256)) { PR = 8; BN = 256; return; }
+        // too few 128-wide tiles for one workgroup per CU but enough 64-wide ones: fill the chip with the narrower tile (more fragment reads per
+        // MFMA, twice the workgroups) -- the low-resolution levels (512 -> 512 @32^2, 256 -> 128 @64^2)
+        if (g_halo_bn64_fill && BN == 128 && patches8 * cdiv(p.Cout, 128) < 2ll * g_halo_min_tiles &&
+            patches8 * cdiv(p.Cout, 64) >= 2ll * g_halo_min_tiles) {
+            PR = 8;
+            BN = 64;
+            return;
+        }
         if (halo_enough(p, patches8 * cdiv(p.Cout, BN), BN)) { PR = 8; return; }
     }
     // 4-row patches run two workgroups per CU: they need twice the workgroups to fill the chip (measured: 512->512 @32^2, 256 workgroups of
@@ -482,6 +491,7 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_halo_min_tiles")) { const int prev = g_halo_min_tiles; g_halo_min_tiles = value; return prev; }
     if (!strcmp(key, "conv_halo_phase")) { const int prev = g_halo_phase; g_halo_phase = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_bn256")) { const int prev = g_halo_bn256; g_halo_bn256 = value != 0; return prev; }
+    if (!strcmp(key, "conv_halo_bn64_fill")) { const int prev = g_halo_bn64_fill; g_halo_bn64_fill = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_bn192")) { const int prev = g_halo_bn192; g_halo_bn192 = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_pr")) { const int prev = g_halo_pr; g_halo_pr = value; return prev; }
     if (!strcmp(key, "wgrad_halo")) return mrfa_tuning_wgrad_halo(value != 0);

@@ -210,6 +210,9 @@ SPLIT_CASES = {
     "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False, Cin=64, Cout=128, tile=(128 << 16) | 128),
     "bn192_c160_acc": dict(N=1, H=16, W=64, Cin=128, Cout=160, acc=True, relu=False, bias=False, mask=True),     # 192-wide tile, 32 padding columns
     "bn192_c192_res": dict(N=2, H=8, W=32, Cin=64, Cout=192, res=True, stats=True),
+    # too few 128-wide tiles for the chip, enough 64-wide ones (the rule is stated in workgroups: min_tiles scales it down to test size)
+    "fill64_c256_pro": dict(N=1, H=16, W=64, Cin=64, Cout=256, pro=True, stats=True, min_tiles=5),
+    "fill64_c126_acc": dict(N=1, H=16, W=64, Cin=96, Cout=126, acc=True, relu=False, min_tiles=3),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128),
     "bn64_c64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True),
     "bn64_c50_pro": dict(N=2, H=16, W=48, Cin=64, Cout=50, tile=(128 << 16) | 64, pro=True),
