@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+SUSTAINED_X6_TFLOPS = 257.0            # fp32-equivalent TF/s of the split-operand step on random operand bits (see roofline.sustained_ceiling_random_operands)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: BF16 dense (not the 2:1-sparsity figure)
 
 
@@ -686,6 +687,10 @@ def main():
                         "peak_is": (f"bf16 dense MFMA peak 2500 / {nprod} split products (fp32-equivalent FLOPs)" if split
                                     else "fp32 dense MFMA peak"),
                         "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                        # measured, not nominal: what the kernel's [12 ds_read_b128 + 24 MFMA] step sustains on this part with random operand
+                        # bits (power-limited; the register-only MFMA loop: 291) -- tools/ubench/mfma_lds_mix.hip, profiles/r3_mfma_lds_mix.txt
+                        "sustained_ceiling_random_operands": ({"tflops": SUSTAINED_X6_TFLOPS, "frac": round(achieved / SUSTAINED_X6_TFLOPS, 4),
+                                                               "source": "profiles/r3_mfma_lds_mix.txt"} if (split and nprod == 6) else None),
                         "kernel": dom_name or ("conv_bf16x6_kernel 128x128 (fwd + dgrad launches)" if split
                                                else "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)"),
                         "row_tiled_128x128": ({"launches_per_step": len(row_tiled) / nprof, "kernel_ms_per_step": round(sum(t for _, t in row_tiled) / nprof, 2),
