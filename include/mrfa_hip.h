@@ -74,6 +74,8 @@ typedef struct {
     const void* w_phase;   /* optional, with ups = 1 and a 3x3 / pad 1 kernel: the 16 phase-tap weights of the four 2x2 convolutions */
     long long w_phase_piece; /* that equal nearest-x2 + 3x3 (pack mode 12, bf16 pieces).  When present (and the patch-tiled kernel  */
                            /*   applies) the layer runs 16 instead of 36 taps per low-resolution pixel -- same result up to fp32 rounding */
+    int stride;            /* 0 / 1: stride 1.  2: strided convolution, Hout = (Hin + 2 pad - R) / 2 + 1 (HRNet's downsampling 3x3 layers,       */
+                           /*   hr_base.py:241,253,302,305,365) -- only where mrfa_conv2d_stride_supported() says so                             */
 } mrfa_conv_params;
 
 /* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS
@@ -83,6 +85,7 @@ typedef struct {
  * 2*C words cost 5-21 us per launch on the MTIA prior's 0.6-GFLOP layers (tools/ubench/small_kernels.cpp) -- more than the layer. */
 #define MRFA_STATS_SLOTS 32
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
+int mrfa_conv2d_stride_supported(const mrfa_conv_params* p);         /* 1: a call with these parameters honours stride = 2                */
 int mrfa_conv2d_mask_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters honours `mask`                    */
 int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p);    /* 1: a call with these parameters (ups = 2) is implemented          */
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
@@ -129,9 +132,12 @@ typedef struct {
     int tile8_off;         /* tuning: 1 disables the 8-wave variant of the 128x128 tile                         */
     float* ws;             /* optional scratch for the two-stage split reduction (used when many splits hit few   */
     long long ws_bytes;    /*   weights: 1x1 / few-channel layers); NULL => atomics only                          */
+    int stride;            /* as mrfa_conv_params.stride: dY pixel (oy, ox) pairs with X pixel (stride * oy + r - pad, ...); only where   */
+                           /*   mrfa_conv2d_wgrad_stride_supported() says so                                                                 */
 } mrfa_wgrad_params;
 
 int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
+int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p);  /* 1: a call with these parameters honours stride = 2                       */
 
 /* weight (un)packing between the reference's OIHW parameter layout and the kernel layouts.
  * mode 0: OIHW -> fwd  chunked [tap][CoutPad][CinPad]            (CoutPad % 128 == 0, CinPad % 32 == 0)

@@ -339,6 +339,13 @@ static thread_local int g_last_tile = 0;
 // (BM << 16) | (BN << 4) | (flat << 1) | (splitk > 1) of the most recent mrfa_conv2d_nhwc launch on this thread
 extern "C" int mrfa_conv2d_last_config(void) { return g_last_tile; }
 
+extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
+    if (!p || p->stride != 2 || !mrfa_tuning_conv_small()) return 0;
+    if (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1) return 0;
+    static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
+}
+
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     const mrfa_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
@@ -364,6 +371,10 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
         return mrfa_conv_small_launch(st, p, M);
+    }
+    if (p.stride > 1) {
+        mrfa_set_error("conv2d: stride = %d is only implemented by the one-wave-per-tile kernel: ask mrfa_conv2d_stride_supported() first", p.stride);
+        return 1;
     }
     if (p.mask && !(!flat && mrfa_conv_halo_eligible(p))) {
         mrfa_set_error("conv2d: `mask` is only honoured by the patch-tiled kernel: ask mrfa_conv2d_mask_supported() first");

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     const int KC = p.Cin / (16 * CK);                 // loop steps (CK k16 chunks each) per tap
     const int T = p.R * p.S;
     const int nq = T * KC;
+    const int cstride = p.stride > 1 ? p.stride : 1;
 
     int a_oy[TMW], a_ox[TMW];
     long long a_img[TMW];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         const int dr = l_r - p.pad, ds = l_s - p.pad;
 #pragma unroll
         for (int a = 0; a < TMW; ++a) {
-            const int iy = a_oy[a] + dr, ix = a_ox[a] + ds;
+            const int iy = a_oy[a] * cstride + dr, ix = a_ox[a] * cstride + ds;        // (strided layers: hr_base.py:241,253,302,305,365)
             ainb[a] = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             const long long pix = ainb[a] ? a_img[a] + (long long)iy * p.Win + ix : a_img[a];
             arow[a] = p.x + (size_t)pix * p.ldx + lk * 4;
@@ -219,14 +220,17 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
 // multiples of 16, and a problem small enough that the 128-row workgroup tiles cannot fill the chip.
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
     if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.tile || p.splitk > 1 || p.mask) return false;
+    if (p.stride > 2) return false;
+    const bool strided = p.stride == 2;              // the only kernel with a strided gather: takes every such layer that fits its addressing
     if ((p.Cin & 15) || (p.ldx & 3) || (p.w_ld & 3)) return false;
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const long long ktot = (long long)p.R * p.S * p.Cin;
     // what the big tiles do well stays there: long K with >= 256 row tiles of 128, or wide outputs at large M
     const long long big_tiles = ((M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.Cout > 640 || ktot > 1152) return false;
-    if (big_tiles >= 512 && p.Cout > 64) return false;
     if (M > 65536) return false;
+    if (strided) return true;
+    if (big_tiles >= 512 && p.Cout > 64) return false;
     // ~1.3 GFLOP at most: beyond that the LDS-tiled 128-row tiles (operand reuse across 4-8 waves, bf16 pipe) are the faster kernels
     if (2.0 * (double)M * p.Cout * (double)ktot > 1.3e9) return false;
     return true;

@@ -377,6 +377,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     // small problems (the MTIA prior's layers): one wave per 32 x 32 weight block, no LDS staging, in-workgroup reduction (wgrad_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_wgrad_small_eligible(p, M)) return mrfa_wgrad_small_launch(st, p, M);
+    MRFA_CHECK_ARG(p.stride <= 1, "wgrad: stride = %d is only implemented by the small-problem kernel: ask mrfa_conv2d_wgrad_stride_supported() first", p.stride);
     if (!flat && mrfa_wgrad_halo_eligible(p)) return mrfa_wgrad_halo_launch(st, p);      // 3x3 stride-1 layers: all nine taps per staging (wgrad_halo.hip)
     int taps = flat ? 1 : p.R * p.S;
     const int NTOT = flat ? p.kflat : p.Cin;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     const int Mi = (int)M;                                 // (eligibility: M <= 65536) 32-bit pixel arithmetic: 64-bit division is a branchy routine
     const int range = (4 * g + wave) * chunks_per_wave * 16;
     const int HWo = p.Hout * p.Wout;
+    const int wstride = p.stride > 1 ? p.stride : 1;       // strided layers (hr_base.py:241,253,302,305,365): dY pixel (oy, ox) <-> X pixel (s oy + r - pad, ..)
 
     if (threadIdx.x < 32) sbias[threadIdx.x] = 0.f;
     __syncthreads();
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
                     oy = rem / p.Wout;
                     ox = rem - oy * p.Wout;
                 }
-                const int iy = oy + dr, ix = ox + ds;
+                const int iy = oy * wstride + dr, ix = ox * wstride + ds;
                 const bool inb = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 xok = ok && inb;
                 xrow = inb ? (img * p.Hin + iy) * p.Win + ix : img * p.Hin * p.Win;
@@ -156,14 +157,21 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
 }  // namespace
 
 bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M) {
-    if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.ksplit > 0) return false;
+    if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.ksplit > 0 || p.stride > 2) return false;
     if ((p.Cin & 31) || (p.Cout & 31) || (p.ldx & 1) || (p.ldy & 1)) return false;
     if ((reinterpret_cast<uintptr_t>(p.x) & 7) || (reinterpret_cast<uintptr_t>(p.dy) & 7)) return false;
     if (M > 65536 || p.Cout > 640 || p.Cin > 640) return false;
     // what the 128-wide tiles do well stays there: >= 128 x 128 weights per tap over many pixels
-    if (p.Cout >= 128 && p.Cin >= 128 && M > 4096) return false;
+    if (p.stride == 2) return true;                  // (the only weight-gradient kernel with a strided gather)
+    if (p.Cout >= 128 && p.Cin >= 128 && M > 4096) return false;                  // (the only weight-gradient kernel with a strided gather)
     if (2.0 * (double)M * p.Cout * (double)p.Cin * p.R * p.S > 1.3e9) return false;
     return true;
+}
+
+extern "C" int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p) {
+    if (!p || p->stride != 2) return 0;
+    if (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1) return 0;
+    return mrfa_wgrad_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
 
 int mrfa_wgrad_small_launch(hipStream_t st, const mrfa_wgrad_params& p, long long M) {

@@ -112,6 +112,7 @@ class defer_wgrads:
 
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
+NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2 layers as one strided launch (conv_small / wgrad_small) instead of stride 1 + sub-sampling
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -1535,8 +1536,69 @@ class Ctx:
         if cw.stride == 1:
             st = self.bn_stats_buf(bn)
             return self.conv(x, conv, stats=st, need_dx=need_dx), st
+        if cw.stride == 2 and NATIVE_STRIDE and not cw.fwd_flat and conv.bias is None:
+            got = self._conv_strided(x, conv, cw, self.bn_stats_buf(bn), need_dx)
+            if got is not None:
+                return got
         raw = self.subsample(self.conv(x, conv, need_dx=need_dx), cw.stride)
         return raw, self.bn_stats(raw, bn)
+
+    def _conv_strided(self, x: View, conv, cw: ConvW, stats, need_dx):
+        """stride-2 convolution as ONE launch with a strided gather and the BatchNorm statistics in its epilogue (hr_base.py:241,253,302,305,365)
+        instead of the stride-1 convolution + sub-sampling + statistics passes: a quarter of the MACs forward and in the weight gradient.  The
+        data gradient stays the stride-1 one over the zero-stuffed dY.  None: the library has no strided kernel for this shape."""
+        Ho, Wo = (x.H + 2 * cw.pad - cw.R) // 2 + 1, (x.W + 2 * cw.pad - cw.S) // 2 + 1
+        cop = (cw.Cout + 127) // 128 * 128
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, 0, x.N, cw.Cin
+        p.w_ld, p.w_tap, p.kflat, p.w_rows = cw.Cin, cop * cw.Cin, 0, cop
+        p.Cout, p.Hout, p.Wout = cw.Cout, Ho, Wo
+        p.R, p.S, p.pad, p.stride = cw.R, cw.S, cw.pad, 2
+        p.alpha, p.nbatch = 1.0, 1
+        p.y, p.ldy = x.ptr, _r4(cw.Cout)              # (placeholders of the right alignment for the query)
+        p.w = x.ptr
+        if not self.L.mrfa_conv2d_stride_supported(C.byref(p)):
+            return None
+        out = self.new(x.N, Ho, Wo, cw.Cout)
+        p.w = cw.fwd_pack(False).data_ptr()
+        p.y, p.ldy = out.ptr, out.ld
+        if stats is not None:
+            p.stats = stats.data_ptr()
+        self._launch_conv(p, "conv2d(stride 2)", cw.Cin)
+        if self.record:
+            def bwd():
+                if not out.has_grad:
+                    return
+                if conv.weight.requires_grad:
+                    dw, db = cw.grad_acc(self.pool32)
+                    q = hip.WgradParams()
+                    q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = x.ptr, x.ld, x.H, x.W, 0, x.N, cw.Cin
+                    q.dy, q.ldy, q.Cout, q.Hout, q.Wout = out.gptr, out.ld, cw.Cout, Ho, Wo
+                    q.R, q.S, q.pad, q.stride = cw.R, cw.S, cw.pad, 2
+                    q.dw, q.alpha, q.nbatch, q.ksplit = dw.data_ptr(), 1.0, 1, 0
+                    if self.L.mrfa_conv2d_wgrad_stride_supported(C.byref(q)):
+                        self._chk(self.L.mrfa_conv2d_wgrad_nhwc(self.s, C.byref(q)), "wgrad(stride 2)")
+                        full = None
+                    else:
+                        full = self._zero_stuffed(out, x.H, x.W)
+                        self._conv_wgrad(x, cw, full, False, None, False)
+                else:
+                    full = None
+                if need_dx:
+                    full = full or self._zero_stuffed(out, x.H, x.W)
+                    self._conv_dgrad(x, cw, full, False, None)
+            self.tape.append(bwd)
+            if cw not in self.touched_convs:
+                self.touched_convs.append(cw)
+        return out, stats
+
+    def _zero_stuffed(self, out: View, H: int, W: int) -> View:
+        """(backward) a stride-1-sized view whose GRADIENT is out.grad at the even pixels and zero elsewhere: dY of the equivalent
+        stride-1 convolution + sub-sampling"""
+        full = self.new(out.N, H, W, out.C)
+        full.st.grad = torch.zeros_like(full.st.data)
+        self._chk(self.L.mrfa_subsample_bwd(self.s, out.gptr, out.ld, out.N, H, W, out.C, 2, full.st.grad.data_ptr(), full.ld), "subsample_bwd")
+        return full
 
     def ups_add(self, lo: View, base: View, factor: int = 1, relu: bool = False, out: Optional[View] = None) -> View:
         """out = act(base + nearest_upsample(lo, factor))"""

@@ -38,6 +38,7 @@ class ConvParams(C.Structure):
         ("w_split", C.c_void_p), ("w_piece", C.c_longlong),
         ("mask", C.c_void_p), ("ldm", C.c_int),
         ("w_phase", C.c_void_p), ("w_phase_piece", C.c_longlong),
+        ("stride", C.c_int),
     ]
 
 
@@ -52,6 +53,7 @@ class WgradParams(C.Structure):
         ("nbatch", C.c_int), ("x_bs", C.c_longlong), ("dy_bs", C.c_longlong), ("dw_bs", C.c_longlong),
         ("ksplit", C.c_int), ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile8_off", C.c_int),
         ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
+        ("stride", C.c_int),
     ]
 
 
@@ -119,6 +121,8 @@ _SIGNATURES = {
     "mrfa_conv_fewout_wgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _V], C.c_int),
     "mrfa_conv_fewout_dgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
     "mrfa_conv2d_mask_supported": ([C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_stride_supported": ([C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_wgrad_stride_supported": ([C.POINTER(WgradParams)], C.c_int),
     "mrfa_conv_fewout_dgrad_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weights_multi": ([_V, C.POINTER(PackDesc), _I], C.c_int),

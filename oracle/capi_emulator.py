@@ -446,7 +446,7 @@ class Emulator:
                 wt = torch.as_strided(_flat(wp, (T - 1) * p.w_tap + (p.Cout - 1) * p.w_ld + p.Cin), (T, p.Cout, p.Cin),
                                       (p.w_tap, p.w_ld, 1))
                 w = wt.permute(1, 2, 0).reshape(p.Cout, p.Cin, p.R, p.S)
-            acc = F.conv2d(x, w.contiguous(), None, padding=p.pad) * p.alpha
+            acc = F.conv2d(x, w.contiguous(), None, padding=p.pad, stride=max(p.stride, 1)) * p.alpha
             if p.ups == 2:           # data gradient of a fused-upsample layer: the 3x3 data gradient on the high-resolution grid, 2x2 sum-pooled
                 acc = F.avg_pool2d(acc, 2) * 4.0
             assert acc.shape[2] == p.Hout and acc.shape[3] == p.Wout, (acc.shape, p.Hout, p.Wout)
@@ -483,7 +483,7 @@ class Emulator:
             dy = nhwc(p.dy + 4 * b * p.dy_bs, p.N, p.Hout, p.Wout, p.ldy, p.Cout).permute(0, 3, 1, 2)
             with torch.enable_grad():
                 w = torch.zeros(p.Cout, p.Cin, p.R, p.S, requires_grad=True)
-                y = F.conv2d(x, w, None, padding=p.pad)
+                y = F.conv2d(x, w, None, padding=p.pad, stride=max(p.stride, 1))
                 (gw,) = torch.autograd.grad(y, w, dy.contiguous())
             dw = _flat(p.dw + 4 * b * p.dw_bs, T * p.Cout * p.Cin).view(T, p.Cout, p.Cin)
             dw += p.alpha * gw.reshape(p.Cout, p.Cin, T).permute(2, 0, 1)
@@ -513,6 +513,17 @@ class Emulator:
         if dbias:
             vec(dbias, Cout).add_(g.sum(dim=(0, 2, 3)))
         return 0
+
+    def mrfa_conv2d_stride_supported(self, pref):
+        """shape rule of the library's one-wave-per-tile kernel (the emulator itself honours `stride` everywhere)"""
+        p = _obj(pref)
+        return int(p.stride == 2 and p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and p.ldx % 4 == 0 and p.nbatch <= 1
+                   and p.N * p.Hout * p.Wout <= 65536 and p.Cout <= 640 and p.R * p.S * p.Cin <= 1152)
+
+    def mrfa_conv2d_wgrad_stride_supported(self, pref):
+        p = _obj(pref)
+        return int(p.stride == 2 and p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 32 == 0 and p.Cout % 32 == 0 and p.nbatch <= 1
+                   and p.N * p.Hout * p.Wout <= 65536 and p.Cout <= 640 and p.Cin <= 640)
 
     def mrfa_conv2d_mask_supported(self, pref):
         """shape rule of the library's patch-tiled kernel (the emulator itself honours `mask` everywhere)"""

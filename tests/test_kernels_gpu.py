@@ -82,13 +82,13 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              tag="c"):
+              stride=1, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
     flat = (Cin % 32) != 0
     Hv, Wv = H << ups, W << ups
-    Ho, Wo = Hv + 2 * pad - R + 1, Wv + 2 * pad - S + 1
+    Ho, Wo = (Hv + 2 * pad - R) // stride + 1, (Wv + 2 * pad - S) // stride + 1
     ldy = (Cout + 3) // 4 * 4 + ldy_extra
     y = side.t(f"{tag}/y0", (N * Ho * Wo, ldy)) if acc else side.garbage((N * Ho * Wo, ldy))
     p = hip.ConvParams()
@@ -151,6 +151,9 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         keep.append(mk)
         p.mask, p.ldm = mk.data_ptr(), Cout + 8
     p.alpha, p.accumulate, p.nbatch, p.splitk, p.tile = alpha, int(acc), 1, splitk, tile
+    if stride > 1:
+        p.stride = stride
+        assert side.L.mrfa_conv2d_stride_supported(C.byref(p)) == 1
     if mask and side.gpu:
         assert side.L.mrfa_conv2d_mask_supported(C.byref(p)) == 1
     side.call("mrfa_conv2d_nhwc", C.byref(p))
@@ -192,6 +195,9 @@ CONV_CASES = {
     "small_linear_576_192_affine": dict(N=1, H=1, W=276, Cin=576, Cout=192, R=1, pad=0, oaff=True),
     "small_ragged": dict(N=1, H=7, W=9, Cin=48, Cout=40, stats=True),
     "small_wide_m": dict(N=8, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False),
+    # strided gather (HRNet's downsampling layers: hr_base.py:241,253,302,305,365), even and odd input sizes
+    "small_stride2_stem": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False),
+    "small_stride2_fuse_odd": dict(N=1, H=13, W=17, Cin=32, Cout=128, stride=2, stats=True, relu=False, bias=False),
 }
 
 
@@ -208,11 +214,6 @@ SPLIT_CASES = {
     "conv1x1_affine": dict(R=1, pad=0, Cin=256, Cout=128, oaff=True, N=4, H=16, W=16, tile=(128 << 16) | 128),
     "splitk4": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, tile=(128 << 16) | 128),
     "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False, Cin=64, Cout=128, tile=(128 << 16) | 128),
-    "bn192_c160_acc": dict(N=1, H=16, W=64, Cin=128, Cout=160, acc=True, relu=False, bias=False, mask=True),     # 192-wide tile, 32 padding columns
-    "bn192_c192_res": dict(N=2, H=8, W=32, Cin=64, Cout=192, res=True, stats=True),
-    # too few 128-wide tiles for the chip, enough 64-wide ones (the rule is stated in workgroups: min_tiles scales it down to test size)
-    "fill64_c256_pro": dict(N=1, H=16, W=64, Cin=64, Cout=256, pro=True, stats=True, min_tiles=5),
-    "fill64_c126_acc": dict(N=1, H=16, W=64, Cin=96, Cout=126, acc=True, relu=False, min_tiles=3),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128),
     "bn64_c64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True),
     "bn64_c50_pro": dict(N=2, H=16, W=48, Cin=64, Cout=50, tile=(128 << 16) | 64, pro=True),
@@ -246,6 +247,11 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "pr8_wide_ld": dict(N=1, H=16, W=96, Cin=64, Cout=128, ldx_extra=8, ldy_extra=12),
     "bn256_c192": dict(N=1, H=8, W=64, Cin=64, Cout=192, res=True, bn192=0),        # 256-wide workgroup tile, 64 padding columns
     "bn256_c512_stats": dict(N=1, H=8, W=32, Cin=32, Cout=512, stats=True, relu=False, bias=False),
+    "bn192_c160_acc": dict(N=1, H=16, W=64, Cin=128, Cout=160, acc=True, relu=False, bias=False, mask=True),     # 192-wide tile, 32 padding columns
+    "bn192_c192_res": dict(N=2, H=8, W=32, Cin=64, Cout=192, res=True, stats=True),
+    # too few 128-wide tiles for the chip, enough 64-wide ones (the rule is stated in workgroups: min_tiles scales it down to test size)
+    "fill64_c256_pro": dict(N=1, H=16, W=64, Cin=64, Cout=256, pro=True, stats=True, min_tiles=5),
+    "fill64_c126_acc": dict(N=1, H=16, W=64, Cin=96, Cout=126, acc=True, relu=False, min_tiles=3),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, min_tiles=128),   # chosen by the default heuristic
     # data-gradient launches carrying the ReLU backward of the tensor they write (mrfa_conv_params.mask)
     "mask_acc_c160": dict(N=1, H=16, W=32, Cin=128, Cout=160, mask=True, acc=True, relu=False, bias=False),
@@ -505,10 +511,11 @@ def test_dgrad_matches_autograd(cfg):
     assert_close([gx.permute(0, 2, 3, 1).reshape(-1, c["Cin"])], [got], what=tag)
 
 
-def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, tag="w"):
+def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, stride=1,
+               tag="w"):
     x = side.t(f"{tag}/x", (N * H * W, (Cin + 3) // 4 * 4))
     Hv, Wv = H << ups, W << ups
-    Ho, Wo = Hv + 2 * pad - R + 1, Wv + 2 * pad - R + 1
+    Ho, Wo = (Hv + 2 * pad - R) // stride + 1, (Wv + 2 * pad - R) // stride + 1
     dy = side.t(f"{tag}/dy", (N * Ho * Wo, (Cout + dy_off + 3) // 4 * 4))
     dw = side.z((R * R * Cout * Cin,))
     db = side.z((Cout,))
@@ -532,6 +539,9 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         kt = ktab(side, Cin, R, R, pad)
         keep.append(kt)
         q.ktab, q.kflat = kt.data_ptr(), R * R * Cin
+    if stride > 1:
+        q.stride = stride
+        assert side.L.mrfa_conv2d_wgrad_stride_supported(C.byref(q)) == 1
     side.call("mrfa_conv2d_wgrad_nhwc", C.byref(q))
     return side.done(dw, db)
 
@@ -545,6 +555,8 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
                                  dict(N=2, H=32, W=32, Cin=160, Cout=126, pro=True), dict(N=1, H=32, W=64, Cin=64, Cout=128, ups=1),
                                  dict(N=4, H=64, W=64, Cin=98, Cout=128, R=1, pad=0, ksplit=40, ws=True),
                                  dict(N=2, H=64, W=64, Cin=2, Cout=128, R=7, pad=3, ksplit=32, ws=True),
+                                 # strided layers (wgrad_small.hip's gather with stride 2)
+                                 dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, dbias=False), dict(N=1, H=13, W=17, Cin=32, Cout=128, stride=2, dbias=False),
                                  # wgrad_small.hip: one wave per 32 x 32 weight block of one tap (the MTIA prior's shapes)
                                  dict(N=2, H=16, W=16, Cin=32, Cout=32), dict(N=4, H=32, W=32, Cin=64, Cout=64),
                                  dict(N=2, H=16, W=16, Cin=128, Cout=128), dict(N=2, H=1, W=276, Cin=192, Cout=576, R=1, pad=0),
