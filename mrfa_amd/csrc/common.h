@@ -25,6 +25,7 @@ bool mrfa_wgrad_halo_eligible(const mrfa_wgrad_params& p);
 int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p);
 int mrfa_tuning_wgrad_halo_min(int set);   // mrfa_set_tuning("wgrad_halo_min_wgs", n)
 int mrfa_tuning_wgrad_halo_target(int set);
+int mrfa_tuning_wgrad_halo_phase(int set);
 int mrfa_tuning_wgrad_halo(int set);       // mrfa_set_tuning("wgrad_halo", 0 / 1); set < 0: query
 
 // conv_fewout3.hip: 3x3 layers with 1 / 2 output channels, channels across the lanes (true: handled, *rc = status)

@@ -76,12 +76,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
 // NBO x NBI x TS = 8 waves: BCO = 32 NBO output channels x BCI = 32 NBI input channels per workgroup; TS = 2: the nine taps of a
 // (co, ci) block are split over two waves (taps 0..4 / 5..8) -- the 64 x 64 block shape for layers with <= 64 output channels (a
 // 64 x 128 block with all nine taps per wave needed 3 staging slots next to its 144 accumulators: 49 spilled registers, MFMA busy 29 %)
-template <int NBO, int NBI, int TS, bool PRO, int NP>
+// PH: the weight gradient of a fused nearest-x2 upsample + 3x3 layer (ups = 1) in PHASE form (see conv_halo.hip): blockIdx.y = phase (py, px) of the
+// output grid; the workgroup walks the LOW-resolution grid, dY is the phase image dY[2y + py][2x + px] (a stride-2 gather), X' the plain input, and
+// only the four taps (py + a, px + b), a, b in {0, 1}, of the 3x3 neighbourhood are computed: 16 instead of 36 MACs per low-resolution pixel and
+// channel pair.  The four accumulators are then added to every 3x3 tap (r, s) that reads the same source pixel: rows {0} | {1,2} for py = 0,
+// {0,1} | {2} for py = 1, columns likewise -- the transpose of pack mode 12's weight sums.  No weights involved: same sums, different order.
+template <int NBO, int NBI, int TS, bool PRO, int NP, bool PH = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_halo_kernel(const mrfa_wgrad_params p, const int tiles_ci,
                                                                                                const int ntiles, const int HS, const int segs_y,
                                                                                                const int tiles_x, const int total) {
     static_assert(NBO * NBI * TS == 8 && (TS == 1 || TS == 2), "8 waves");
-    constexpr int NTAP = TS == 1 ? 9 : 5;            // accumulator tiles per wave
+    constexpr int NTAP = PH ? (TS == 1 ? 4 : 2) : (TS == 1 ? 9 : 5);            // accumulator tiles per wave
     constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
     constexpr int XROW = NPC * NBI * XBLK;         // one ring slot: [piece][block][34 pixels][64 B]
     constexpr int DYROW = NPC * NBO * DYBLK;       // one dY buffer:  [piece][block][32 pixels][64 B]
@@ -107,11 +112,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int n_img = sg / tiles_x;
     const int tile_co = tile / tiles_ci, tile_ci = tile - tile_co * tiles_ci;
     const int co0 = tile_co * (32 * NBO), ci0 = tile_ci * (32 * NBI);
-    const int y0 = ys * HS, y1 = min(p.Hout, y0 + HS), x0 = xt * 32;
+    const int ph_y = PH ? (int)(blockIdx.y >> 1) : 0, ph_x = PH ? (int)(blockIdx.y & 1) : 0;
+    const int Hgrid = PH ? p.Hin : p.Hout;           // rows of the grid the workgroup walks (PH: the low-resolution one)
+    const int y0 = ys * HS, y1 = min(Hgrid, y0 + HS), x0 = xt * 32;
 
     const float* __restrict__ x = p.x;
     const float* __restrict__ dy = p.dy;
-    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    const int ush = PH ? 0 : p.ups;
+    const int Hv = p.Hin << ush, Wv = p.Win << ush;
 
     // ---- staging units of this thread.  dY: unit u = blk * 256 + px * 8 + quad;  X': u = blk * 272 + hp * 8 + quad
     int d_goff[NDY], d_loff[NDY], d_nval[NDY];
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int blk = u >> 8, px = (u >> 3) & 31, quad = u & 7;
         const int ch = co0 + blk * 32 + quad * 4;
         d_nval[j] = min(max(p.Cout - ch, 0), 4);                  // ragged Cout (126): the quad's tail channels belong to somebody else
-        d_goff[j] = ((n_img * p.Hout) * p.Wout + x0 + px) * p.ldy + (d_nval[j] > 0 ? ch : co0);
+        d_goff[j] = ((n_img * p.Hout) * p.Wout + (PH ? 2 * (x0 + px) + ph_x : x0 + px)) * p.ldy + (d_nval[j] > 0 ? ch : co0);
         d_loff[j] = blk * DYBLK + px * 64 + quad * 8;
     }
     int x_goff[NX], x_loff[NX];
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int ix = x0 - 1 + hp;
         const int ch = ci0 + blk * 32 + quad * 4;
         x_ok[j] = x_val[j] && (unsigned)ix < (unsigned)Wv && ch < p.Cin;          // (Cin % 32 == 0: whole quads)
-        x_goff[j] = (n_img * p.Hin * p.Win + (x_ok[j] ? (ix >> p.ups) : 0)) * p.ldx + (x_ok[j] ? ch : ci0);
+        x_goff[j] = (n_img * p.Hin * p.Win + (x_ok[j] ? (ix >> ush) : 0)) * p.ldx + (x_ok[j] ? ch : ci0);
         x_loff[j] = blk * XBLK + hp * 64 + quad * 8;
     }
     f32x4 psc[NX], psh[NX];
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // rows: iy = input (virtual) row of X', oy = output row of dY; out-of-image X' rows are zero, loads of rows outside the image or the
     // segment read a clamped (valid) row and are masked / never used
     auto load_x = [&](int iy) {
-        const int yc = min(max(iy, 0), Hv - 1) >> p.ups;
+        const int yc = min(max(iy, 0), Hv - 1) >> ush;
 #pragma unroll
         for (int j = 0; j < NX; ++j) rx[j] = *reinterpret_cast<const f32x4*>(x + (size_t)x_goff[j] + (size_t)yc * p.Win * p.ldx);
     };
@@ -185,7 +193,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
     auto load_d = [&](int oy) {
-        const int yc = min(oy, p.Hout - 1);
+        const int yg = min(oy, Hgrid - 1);
+        const int yc = PH ? 2 * yg + ph_y : yg;
 #pragma unroll
         for (int j = 0; j < NDY; ++j) rd[j] = *reinterpret_cast<const f32x4*>(dy + (size_t)d_goff[j] + (size_t)yc * p.Wout * p.ldy);
     };
@@ -253,8 +262,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     };
+    // PH: the four taps (a, b) of this phase: X' row oy - 1 + ph_y + a = ring slot (oy + ph_y + a) & 3, pixel offset ph_x + b
+    auto compute_phase = [&](int oy, auto Q0_, auto Q1_) {
+        constexpr int Q0 = decltype(Q0_)::value, Q1 = decltype(Q1_)::value, NQ = Q1 - Q0;
+        const unsigned char* D = smD + (oy & 1) * DYROW + a_off;
+        const unsigned char* XR[2] = {smX + ((oy + ph_y) & 3) * XROW + b_off + ph_x * 64, smX + ((oy + ph_y + 1) & 3) * XROW + b_off + ph_x * 64};
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[NPC], b[NPC][NQ];
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) a[pc] = tr_frag(D + pc * NBO * DYBLK + kk * 16 * 64);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int pc = 0; pc < NPC; ++pc) b[pc][q] = tr_frag(XR[(Q0 + q) >> 1] + pc * NBI * XBLK + (kk * 16 + ((Q0 + q) & 1)) * 64);
+#pragma unroll
+            for (int t = 6 - NP; t < 6; ++t)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], b[PB[t]][q], acc[q], 0, 0, 0);
+        }
+    };
     auto compute = [&](int oy) {
-        if constexpr (TS == 1) {
+        if constexpr (PH) {
+            if constexpr (TS == 1) {
+                compute_phase(oy, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            } else {
+                if (wt == 0) compute_phase(oy, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                else compute_phase(oy, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            }
+        } else if constexpr (TS == 1) {
             compute_taps(oy, std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
         } else {
             if (wt == 0) compute_taps(oy, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
@@ -289,7 +327,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float* __restrict__ dw = p.dw;
     const int ci = ci0 + wb * 32 + (lane & 31);
     const int half = lane >> 5;
-    if (ci < p.Cin) {
+    if constexpr (PH) {
+        if (ci < p.Cin) {
+            constexpr unsigned RM[4] = {0x1u, 0x6u, 0x3u, 0x4u};       // [phase bit * 2 + tap bit] -> mask over the 3x3 rows / columns that read that source pixel
+            const int q0 = TS == 1 ? 0 : 2 * wt;
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int q = q0 + t;
+                const unsigned rm = RM[ph_y * 2 + (q >> 1)], sm = RM[ph_x * 2 + (q & 1)];
+#pragma unroll 1
+                for (int t9 = 0; t9 < 9; ++t9) {             // (not unrolled: 4 x 9 x 16 guarded atomics with hoisted addresses spilled 100 registers)
+                    const int r3 = t9 / 3, s3 = t9 - 3 * r3;
+                        if (((rm >> r3) & 1u) && ((sm >> s3) & 1u)) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                                if (co < p.Cout) atomicAdd(dw + ((size_t)t9 * p.Cout + co) * p.Cin + ci, acc[t][r] * p.alpha);
+                            }
+                        }
+                }
+            }
+        }
+    } else if (ci < p.Cin) {
         const int tap0 = TS == 1 ? 0 : 5 * wt, ntap = TS == 1 ? 9 : (wt == 0 ? 5 : 4);
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
@@ -336,6 +395,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 int g_wgrad_halo_on = -1;
 int g_wgrad_halo_min = 192;
 int g_wgrad_halo_target = 256;      // workgroups per round (one per CU)
+int g_wgrad_halo_phase = 1;         // weight gradient of fused-upsample layers in phase form
 
 }  // namespace
 
@@ -352,31 +412,44 @@ int mrfa_tuning_wgrad_halo_min(int set) {
     return prev;
 }
 
+int mrfa_tuning_wgrad_halo_phase(int set) {
+    const int prev = g_wgrad_halo_phase;
+    if (set >= 0) g_wgrad_halo_phase = set != 0;
+    return prev;
+}
+
 int mrfa_tuning_wgrad_halo_target(int set) {
     const int prev = g_wgrad_halo_target;
     if (set > 0) g_wgrad_halo_target = set;
     return prev;
 }
 
+// fused-upsample layer whose LOW-resolution grid tiles into 32-pixel strips: phase form (wgrad_halo_kernel<..., PH = true>)
+static bool wgrad_halo_phase(const mrfa_wgrad_params& p) {
+    return g_wgrad_halo_phase && p.ups == 1 && !p.in_scale && (p.Win % 32) == 0 && p.Hin >= 8;
+}
+
 static void wgrad_halo_config(const mrfa_wgrad_params& p, int& NBO, int& HS, int& segs_y, long long& total) {
     // block shape: 128 (co) x 64 (ci), or 64 x 64 with the taps split over two waves when Cout <= 64 (half of a 128-row block would idle)
     NBO = p.Cout <= 64 ? 2 : 4;
     const int NBI = 2;
-    const int ntiles = cdiv(p.Cout, 32 * NBO) * cdiv(p.Cin, 32 * NBI);
-    const long long cols = (long long)p.N * (p.Wout / 32);
+    const bool ph = wgrad_halo_phase(p);
+    const int Hg = ph ? p.Hin : p.Hout, Wg = ph ? p.Win : p.Wout;        // the grid a workgroup walks
+    const int ntiles = cdiv(p.Cout, 32 * NBO) * cdiv(p.Cin, 32 * NBI) * (ph ? 4 : 1);       // (x 4 phase workgroups per segment and block)
+    const long long cols = (long long)p.N * (Wg / 32);
     // segment height: every segment pays ~6 row-strips of fixed cost (three-row prologue, 144 atomics per lane at the end) and the launch
     // runs in rounds of 256 workgroups (one per CU): minimise rounds x (HS + 6) over the power-of-two divisions of the column
     // (measured on 192->128 @256^2: 384 workgroups = 1.5 rounds 209 TF/s, 768 = 3 rounds 228; 128->128 @128^2: 256 workgroups 188, 512: 154)
-    HS = p.Hout;
+    HS = Hg;
     double best = 1e30;
-    for (int hs = p.Hout; hs >= 8; hs /= 2) {
-        const long long tot = cols * ntiles * cdiv(p.Hout, hs);
+    for (int hs = Hg; hs >= 8; hs /= 2) {
+        const long long tot = cols * ntiles * cdiv(Hg, hs);
         const double cost = (double)((tot + g_wgrad_halo_target - 1) / g_wgrad_halo_target) * (hs + 6);
         if (cost < best) { best = cost; HS = hs; }
         if (hs % 2) break;
     }
-    segs_y = cdiv(p.Hout, HS);
-    total = cols * segs_y * ntiles;
+    segs_y = cdiv(Hg, HS);
+    total = cols * segs_y * ntiles;                  // (phase form: counts the four phase workgroups)
 }
 
 bool mrfa_wgrad_halo_eligible(const mrfa_wgrad_params& p) {
@@ -400,17 +473,21 @@ int mrfa_wgrad_halo_launch(hipStream_t st, const mrfa_wgrad_params& p) {
     wgrad_halo_config(p, NBO, HS, segs_y, total);
     const int NBI = 2;
     const int tiles_ci = cdiv(p.Cin, 32 * NBI), ntiles = cdiv(p.Cout, 32 * NBO) * tiles_ci;
-    dim3 grid((unsigned)(cdiv(total, 8) * 8));
+    const bool ph = wgrad_halo_phase(p);
+    if (ph) total /= 4;                              // per phase (blockIdx.y)
+    dim3 grid((unsigned)(cdiv(total, 8) * 8), ph ? 4u : 1u);
+    const int tiles_x = (ph ? p.Win : p.Wout) / 32;
     const bool three = mrfa_get_mfma_mode() == 2, one = mrfa_get_mfma_mode() == 3;
     const bool pro = p.in_scale != nullptr;
-#define WH(NBO_, NBI_, TS_, PRO_)                                                                                                                          \
+#define WH(NBO_, NBI_, TS_, PRO_, PH_)                                                                                                                     \
     do {                                                                                                                                              \
-        if (one) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 1>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
-        else if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 3>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total); \
-        else hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 6>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, p.Wout / 32, (int)total);      \
+        if (one) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 1, PH_>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, tiles_x, (int)total); \
+        else if (three) hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 3, PH_>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, tiles_x, (int)total); \
+        else hipLaunchKernelGGL((wgrad_halo_kernel<NBO_, NBI_, TS_, PRO_, 6, PH_>), grid, dim3(NT), 0, st, p, tiles_ci, ntiles, HS, segs_y, tiles_x, (int)total);      \
     } while (0)
-    if (NBO == 4) { if (pro) WH(4, 2, 1, true); else WH(4, 2, 1, false); }
-    else { if (pro) WH(2, 2, 2, true); else WH(2, 2, 2, false); }
+    if (ph) { if (NBO == 4) WH(4, 2, 1, false, true); else WH(2, 2, 2, false, true); }
+    else if (NBO == 4) { if (pro) WH(4, 2, 1, true, false); else WH(4, 2, 1, false, false); }
+    else { if (pro) WH(2, 2, 2, true, false); else WH(2, 2, 2, false, false); }
 #undef WH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_wgrad_nhwc(halo)");
     return 0;

@@ -573,6 +573,8 @@ WGRAD_HALO_CASES = [       # wgrad_halo.hip: 3x3 / pad 1, Wout % 32 == 0, Cin % 
     dict(N=2, H=10, W=32, Cin=32, Cout=126), dict(N=1, H=8, W=16, Cin=128, Cout=64, ups=1),
     dict(N=3, H=8, W=32, Cin=160, Cout=50, dbias=False), dict(N=1, H=40, W=32, Cin=96, Cout=96, pro=True),
     dict(N=2, H=64, W=64, Cin=256, Cout=128, min_wgs=192),                      # chosen by the default heuristic, several segments per column
+    # fused-upsample layers whose low-resolution grid is 32 pixels wide: phase form (four taps per phase workgroup, both block shapes)
+    dict(N=1, H=8, W=32, Cin=128, Cout=64, ups=1), dict(N=2, H=16, W=32, Cin=64, Cout=130, ups=1), dict(N=1, H=24, W=64, Cin=32, Cout=128, ups=1, dbias=False),
 ]
 
 
@@ -590,17 +592,27 @@ def test_wgrad_all_taps_kernel(cfg, mode):
     L.mrfa_set_tuning(b"conv_small", 0)
     try:
         got = wgrad_case(Side(True), tag=tag, **cfg)
+        plain = None
+        if cfg.get("ups"):           # the phase form of a fused-upsample layer against the nine-tap form of the same kernel
+            L.mrfa_set_tuning(b"wgrad_halo_phase", 0)
+            plain = wgrad_case(Side(True), tag=tag, **cfg)
+            L.mrfa_set_tuning(b"wgrad_halo_phase", 1)
         # the same call with the kernel off must give the same answer from the per-tap kernels (and proves the switch works)
         L.mrfa_set_tuning(b"wgrad_halo", 0)
         other = wgrad_case(Side(True), tag=tag, **cfg)
     finally:
         L.mrfa_set_mfma_mode(0)
         L.mrfa_set_tuning(b"wgrad_halo", 1)
+        L.mrfa_set_tuning(b"wgrad_halo_phase", 1)
         L.mrfa_set_tuning(b"wgrad_halo_min_wgs", prev)
         L.mrfa_set_tuning(b"conv_small", 1)
     tol = {1: 5e-4, 2: 5e-3, 3: 3e-2}[mode]
     assert_close(ref, got, tol=tol, what=tag)
     assert_close(other, got, tol=tol, what=tag + " vs per-tap kernel")
+    if plain is not None:
+        assert_close(plain, got, tol=tol, what=tag + " phase form vs nine-tap form")
+        if cfg["W"] % 32 == 0:
+            assert any(float((g - o).abs().max()) > 0 for g, o in zip(got, plain)), "identical bits: did the phase form run at all?"
     assert any(float((g - o).abs().max()) > 0 for g, o in zip(got, other)), "identical bits: did the all-taps kernel run at all?"
 
 
