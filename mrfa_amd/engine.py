@@ -48,40 +48,62 @@ class DeferredWgrads:
     backward() by train_step / GraphedTrainStep).  The thunks hold the activations and gradient buffers they read until join().
     Direct-gradient mode only (DIRECT_PARAM_GRADS: the un-packing into .grad is deferred with them); anything else runs in line."""
 
-    def __init__(self):
+    def __init__(self, fanout: int = 1):
         self.thunks: List[Callable[[], None]] = []
+        self.finals: List[Callable[[], None]] = []          # run after every thunk (the un-packing of the accumulators they add into)
         self.kept: Optional[List[Callable[[], None]]] = None
         self.stream: Optional["torch.cuda.Stream"] = None
+        self.fan: List["torch.cuda.Stream"] = []
+        # > 1: the launches are dealt round-robin onto that many side streams (the keypoint encoder's ~400 small weight-gradient launches,
+        # independent of each other, issued after its backward chain instead of inside it); the finals wait for all of them
+        self.fanout = max(1, int(fanout))
         self.flushed = False
 
-    def add(self, fn: Callable[[], None]):
-        self.thunks.append(fn)
+    def add(self, fn: Callable[[], None], final: bool = False):
+        (self.finals if final else self.thunks).append(fn)
 
     def reset(self):
         """start of a step: drop whatever an aborted previous step left behind (a backward that raised between the decoder and the join
         would otherwise have its stale weight-gradient / un-pack thunks flushed into the NEXT step's freshly zeroed .grad)"""
         if self.flushed and self.stream is not None:
             torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)      # launches already issued finish first
-        self.thunks, self.kept, self.flushed = [], None, False
+        self.thunks, self.finals, self.kept, self.flushed = [], [], None, False
         if self in _PENDING_DEFERRED:
             _PENDING_DEFERRED.remove(self)
 
     def flush(self, dev: torch.device):
         """issue everything collected so far on the side stream, ordered after the current stream"""
-        if not self.thunks:
+        if not self.thunks and not self.finals:
             return
         if dev.type != "cuda":
-            for fn in self.thunks:
+            for fn in self.thunks + self.finals:
                 fn()
-            self.thunks = []
+            self.thunks, self.finals = [], []
             return
         if self.stream is None or self.stream.device != dev:
             self.stream = torch.cuda.Stream(device=dev)
-        self.stream.wait_stream(torch.cuda.current_stream(dev))
+            self.fan = []
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        if self.fanout > 1 and len(self.thunks) > self.fanout:
+            while len(self.fan) < self.fanout - 1:
+                self.fan.append(torch.cuda.Stream(device=dev))
+            lanes = [self.stream] + self.fan[:self.fanout - 1]
+            for st in lanes[1:]:
+                st.wait_stream(cur)
+            for i, fn in enumerate(self.thunks):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    fn()
+            for st in lanes[1:]:
+                self.stream.wait_stream(st)
+        else:
+            with torch.cuda.stream(self.stream):
+                for fn in self.thunks:
+                    fn()
         with torch.cuda.stream(self.stream):
-            for fn in self.thunks:
+            for fn in self.finals:
                 fn()
-        self.kept, self.thunks = self.thunks, []          # the closures own the buffers the side stream is still reading
+        self.kept, self.thunks, self.finals = self.thunks + self.finals, [], []          # the closures own the buffers the side streams are still reading
         self.flushed = True
 
     def join(self, dev: torch.device):
@@ -1843,11 +1865,12 @@ class _ProgramFn(torch.autograd.Function):
             for g in gouts:
                 if g is not None and g.is_cuda:
                     g.record_stream(cur)
-        if ectx.wdefer is None and _PENDING_DEFERRED:
-            # the backward pass has left the deferring programs: their weight gradients start now, beside this program's backward
-            for d in _PENDING_DEFERRED:
+        if _PENDING_DEFERRED and any(d is not ectx.wdefer for d in _PENDING_DEFERRED):
+            # the backward pass has left the programs deferring into another collection: their weight gradients start now, beside this
+            # program's backward (this program's own collection, if it has one, waits for HotPath.join())
+            for d in [d for d in _PENDING_DEFERRED if d is not ectx.wdefer]:
                 d.flush(ectx.dev)
-            del _PENDING_DEFERRED[:]
+                _PENDING_DEFERRED.remove(d)
         for seed, g in zip(actx.seeders, gouts):
             if g is not None and seed is not None:
                 seed(g)
@@ -1856,7 +1879,9 @@ class _ProgramFn(torch.autograd.Function):
         direct_cws = [cw for cw in ectx.touched_convs if cw.dw_acc is not None and cw._direct]
         skip = ()
         if ectx.wdefer is not None and direct_cws:
-            ectx.wdefer.add(lambda: unpack_direct(direct_cws))        # after the deferred launches, on their stream
+            # after the deferred launches, on their stream (idempotent: two programs deferring into one collection -- the two encoder passes --
+            # share the accumulators of their convolutions, the first un-packing takes them all)
+            ectx.wdefer.add(lambda: unpack_direct([cw for cw in direct_cws if cw.dw_acc is not None]), final=True)
             if ectx.wdefer not in _PENDING_DEFERRED:
                 _PENDING_DEFERRED.append(ectx.wdefer)
             skip = {id(cw) for cw in direct_cws}
