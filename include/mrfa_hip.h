@@ -236,13 +236,17 @@ typedef struct {
     float* dx; int lddx;                         /* += BN input gradient                                         */
     float* dgamma; float* dbeta;                 /* += (phase 2)                                                 */
     int train;                                   /* 0: eval-mode BN (no batch-statistics terms)                  */
-    int phase;                                   /* 1: reductions, 2: apply                                      */
+    int phase;                                   /* 1: reductions, 2: apply, 3: both in ONE launch with a grid-wide barrier
+                                                    between them (needs `sync`; only where mrfa_bn_act_bwd_fused_supported()
+                                                    says so; not with a cross-rank reduction of `red` in between)     */
     int dx_overwrite;                            /* phase 2: dx = ... instead of dx += ... (this BN is the only writer
                                                     of its input's gradient: no zero fill, no read of dx)              */
     const float* res; int ldr;                   /* the forward's residual (needed for the ReLU mask)            */
     float* dres; int lddr;                       /* += gradient wrt the residual (phase 1), may be null          */
+    unsigned int* sync;                          /* phase 3: one zero-initialised word (the barrier's arrival counter) */
 } mrfa_bnbwd_params;
 int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
+int mrfa_bn_act_bwd_fused_supported(const mrfa_bnbwd_params* p);     /* 1: phase = 3 is implemented for these parameters       */
 
 /* ------------------------------------------------------------------------------------------------------------
  * K10: bilinear grid_sample, zeros padding, NHWC, channel-vectorised.

@@ -223,11 +223,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
 // update (dgamma += sum du*xhat, dbeta += sum du) into the first row-block instead of a separate launch.
 // MODE 0: plain, 1: residual, 2: 2x2 pool, 3: occlusion blend -- compile-time, so that the row loop of the common (plain / residual)
 // case has no uniform branches between its loads (as run-time flags they kept hipcc from batching the x / dy / res loads of a row group)
-template <int PHASE, int MODE>
-__global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+// COHERENT: the phase-2 part of the fused (phase 3) launch: the partial sums were written by other workgroups of the SAME launch, so they are read
+// with agent-scope atomic loads (the per-XCD L2s are not coherent for plain loads inside one kernel)
+template <int PHASE, int MODE, bool COHERENT = false>
+__device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long long rows, int rows_per_block, float (&red)[2][16][CH],
+                                            double (&redsum)[2][CH]) {
     constexpr bool POOL = MODE == 2, BLEND = MODE == 3, RES = MODE == 1;
-    __shared__ float red[2][16][CH];
-    __shared__ double redsum[2][CH];                         // phase 2: the MRFA_STATS_SLOTS partial sums of phase 1, added up once per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cg = lane & 15, rsub = lane >> 4;
     const int slot = wave * 4 + rsub;                       // 16 row slots per workgroup
@@ -242,7 +243,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
         for (int which = 0; which < 2; ++which) {
             double t = 0.0;
             if (cc < p.C) {
-                for (int s = q; s < nslots; s += 4) t += p.red[(size_t)s * 2 * p.C + which * p.C + cc];
+                for (int s = q; s < nslots; s += 4) {
+                    const double* src = p.red + (size_t)s * 2 * p.C + which * p.C + cc;
+                    if constexpr (COHERENT) {
+                        const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t += __longlong_as_double((long long)bits);
+                    } else {
+                        t += *src;
+                    }
+                }
             }
             t += __shfl_xor(t, 1, 64);
             t += __shfl_xor(t, 2, 64);
@@ -423,6 +432,34 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
     }
 }
 
+template <int PHASE, int MODE>
+__global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+    __shared__ float red[2][16][CH];
+    __shared__ double redsum[2][CH];                         // phase 2: the MRFA_STATS_SLOTS partial sums of phase 1, added up once per workgroup
+    bn_bwd_body<PHASE, MODE>(p, rows, rows_per_block, red, redsum);
+}
+
+// phase 3: reductions, a grid-wide barrier, apply -- ONE launch instead of two for the small tensors of the keypoint encoder, whose backward is a
+// chain of ~1 500 launches per pass at 8-13 us each (the tensor is still in L2 when the second half re-reads it).  The barrier is an arrival counter
+// (`sync`, zeroed by the caller): every workgroup of the launch must become resident, so the host only takes this path for grids of at most one
+// workgroup per CU; other kernels may hold CUs for a while (concurrent streams), they do not depend on this one, so the spinning workgroups only wait.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+    __shared__ float red[2][16][CH];
+    __shared__ double redsum[2][CH];
+    bn_bwd_body<1, MODE>(p, rows, rows_per_block, red, redsum);
+    __syncthreads();                                         // this workgroup's atomics into `red` (and its dres stores) are issued
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);             // ... and visible device-wide before the arrival
+        __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned total = gridDim.x * gridDim.y;
+        while (__hip_atomic_load(p.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < total) __builtin_amdgcn_s_sleep(4);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+    bn_bwd_body<2, MODE, true>(p, rows, rows_per_block, red, redsum);
+}
+
 __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                      int train, const float* __restrict__ rmean, const float* __restrict__ rvar, float eps) {
     // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
@@ -492,6 +529,23 @@ extern "C" int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* pp) {
     return 0;
 }
 
+// the fused launch: train-mode plain / residual BatchNorm whose grid fits one workgroup per CU (all workgroups resident: the barrier needs them)
+static bool bn_bwd_fused_ok(const mrfa_bnbwd_params& p, dim3 grid) {
+    return p.train && !p.pool && !p.blend_a && (long long)grid.x * grid.y <= 256;
+}
+
+extern "C" int mrfa_bn_act_bwd_fused_supported(const mrfa_bnbwd_params* pp) {
+    if (!pp || !pp->x || !pp->dy || !pp->dx) return 0;
+    const mrfa_bnbwd_params& p = *pp;
+    const long long rows = (long long)p.N * p.H * p.W;
+    const int chunks = cdiv(p.C, CH);
+    dim3 grid(chunks, cdiv(rows, pick_rows_per_block(rows, chunks, p.C)));
+    const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && (p.lddx % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.dx) &&
+                     aligned16(p.scale) && aligned16(p.shift) && p.mean && aligned16(p.mean) && aligned16(p.invstd) && p.gamma && aligned16(p.gamma) &&
+                     (!p.res || ((p.ldr % 4 == 0) && aligned16(p.res) && (!p.dres || ((p.lddr % 4 == 0) && aligned16(p.dres)))));
+    return vec && bn_bwd_fused_ok(p, grid) ? 1 : 0;
+}
+
 extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     const mrfa_bnbwd_params& p = *pp;
     MRFA_CHECK_ARG(p.x && p.dy && p.scale && p.shift && p.red, "bn_act_bwd: null pointer");
@@ -502,11 +556,19 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     const int chunks = cdiv(p.C, CH);
     const int rpb = pick_rows_per_block(rows, chunks, p.C);
     dim3 grid(chunks, cdiv(rows, rpb));
+    MRFA_CHECK_ARG(p.phase >= 1 && p.phase <= 3, "bn_act_bwd: phase %d", p.phase);
     const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.scale) &&
                      aligned16(p.shift) && (!p.mean || (aligned16(p.mean) && aligned16(p.invstd))) && (!p.gamma || aligned16(p.gamma)) &&
                      (p.phase == 1 || ((p.lddx % 4 == 0) && aligned16(p.dx))) &&
                      (!p.res || ((p.ldr % 4 == 0) && aligned16(p.res) && (!p.dres || ((p.lddr % 4 == 0) && aligned16(p.dres))))) &&
                      (!p.blend_a || ((p.lda % 4 == 0) && aligned16(p.blend_a) && (!p.dblend_a || ((p.ldda % 4 == 0) && aligned16(p.dblend_a)))));
+    if (p.phase == 3) {
+        MRFA_CHECK_ARG(vec && bn_bwd_fused_ok(p, grid) && p.sync && p.dx, "bn_act_bwd: phase 3 is not implemented for these parameters: ask mrfa_bn_act_bwd_fused_supported()");
+        if (p.res) hipLaunchKernelGGL((bn_act_bwd_fused_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
+        else hipLaunchKernelGGL((bn_act_bwd_fused_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
+        MRFA_CHECK_LAUNCH("bn_act_bwd(fused)");
+        return 0;
+    }
     if (vec) {
         MRFA_CHECK_ARG(p.phase == 1 || p.dx != nullptr, "bn_act_bwd: phase 2 needs dx");
         const int mode = p.pool ? 2 : (p.blend_a ? 3 : (p.res ? 1 : 0));

@@ -135,6 +135,10 @@ class defer_wgrads:
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
 NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2 layers as one strided launch (conv_small / wgrad_small) instead of stride 1 + sub-sampling
+# BatchNorm backward of small tensors as ONE launch (grid barrier between its phases, mrfa_bn_act_bwd phase 3).  OFF: measured on the training step
+# 84.3 -> 90.0 ms -- the barrier needs every workgroup of the launch resident, and beside the deferred decoder weight gradients (one 256-VGPR
+# workgroup per CU for hundreds of microseconds) the last workgroups of each of the ~340 launches wait for a CU while the others spin
+BN_BWD_FUSED = os.environ.get("MRFA_BN_BWD_FUSED", "0") == "1"
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -1222,7 +1226,8 @@ class Ctx:
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
         dg, db = bg.acc(self.pool32)
-        red = self.f64z(hip.STATS_SLOTS * 2 * x.C)          # slotted like the statistics buffers (MRFA_STATS_SLOTS)
+        nred = hip.STATS_SLOTS * 2 * x.C
+        red = self.f64z(nred + 2)                           # slotted like the statistics buffers (MRFA_STATS_SLOTS) + the fused launch's barrier word
         q = hip.BnBwdParams()
         q.x, q.ldx, q.N, q.H, q.W, q.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
         q.scale, q.shift, q.relu, q.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
@@ -1239,16 +1244,24 @@ class Ctx:
         q.dx, q.lddx = dx_view.gptr, dx_view.ld
         q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
         q.train = int(train)
+        world = self._sync_world(bn) if train else 1
+        synced = train and self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm)
+        if train and not synced and BN_BWD_FUSED:
+            # small tensors (the keypoint encoder's ~170 BatchNorms per pass): reductions + grid barrier + apply in ONE launch
+            q.sync = red.data_ptr() + 8 * nred
+            if self.L.mrfa_bn_act_bwd_fused_supported(C.byref(q)):
+                q.phase = 3
+                self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(fused)")
+                return
         q.phase = 1
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
-        world = self._sync_world(bn) if train else 1
-        if train and self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
+        if synced:
             # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums
             Cn = x.C
-            local = red.view(hip.STATS_SLOTS, 2 * Cn).sum(0)
+            local = red[:nred].view(hip.STATS_SLOTS, 2 * Cn).sum(0)
             db.add_(local[:Cn].float())
             dg.add_(local[Cn:].float())
-            red_g = torch.zeros_like(red)
+            red_g = torch.zeros_like(red[:nred])
             red_g[:2 * Cn] = local
             torch.distributed.all_reduce(red_g[:2 * Cn])
             red_g.div_(world)                                # kernel divides by the LOCAL row count

@@ -87,6 +87,7 @@ class BnBwdParams(C.Structure):
         ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
         ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int), ("dx_overwrite", C.c_int),
         ("res", C.c_void_p), ("ldr", C.c_int), ("dres", C.c_void_p), ("lddr", C.c_int),
+        ("sync", C.c_void_p),
     ]
 
 
@@ -122,6 +123,7 @@ _SIGNATURES = {
     "mrfa_conv_fewout_dgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
     "mrfa_conv2d_mask_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_stride_supported": ([C.POINTER(ConvParams)], C.c_int),
+    "mrfa_bn_act_bwd_fused_supported": ([C.POINTER(BnBwdParams)], C.c_int),
     "mrfa_conv2d_wgrad_stride_supported": ([C.POINTER(WgradParams)], C.c_int),
     "mrfa_conv_fewout_dgrad_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),

@@ -605,8 +605,20 @@ class Emulator:
         nhwc(p.y, p.N, Ho, Wo, p.ldy, p.C).copy_(u)
         return 0
 
+    def mrfa_bn_act_bwd_fused_supported(self, pref):
+        p = _obj(pref)
+        return int(bool(p.train) and not p.pool and not p.blend_a and p.C % 4 == 0 and p.N * p.H * p.W * p.C <= (4 << 20))
+
     def mrfa_bn_act_bwd(self, stream, pref):
         p = _obj(pref)
+        if p.phase == 3:             # both phases in one launch (the library puts a grid-wide barrier between them)
+            assert p.sync
+            p.phase = 1
+            rc = self.mrfa_bn_act_bwd(stream, pref)
+            p.phase = 2
+            rc = rc or self.mrfa_bn_act_bwd(stream, pref)
+            p.phase = 3
+            return rc
         Cc = p.C
         x = nhwc(p.x, p.N, p.H, p.W, p.ldx, Cc)
         sc, sh = vec(p.scale, Cc), vec(p.shift, Cc)

@@ -1087,6 +1087,55 @@ def test_bn_residual(Cc, ld):
     assert_close(ref, got, tol=5e-4, what="bn_residual")
 
 
+@pytest.mark.parametrize("Cc,N,H,W,res", [(32, 8, 64, 64, False), (64, 8, 32, 32, True), (128, 8, 16, 16, True), (96, 2, 8, 6, False)])
+def test_bn_backward_fused_launch(Cc, N, H, W, res):
+    """phase 3 of mrfa_bn_act_bwd (reductions, a grid-wide barrier, apply: ONE launch; the keypoint encoder's shapes, up to 64 workgroups)
+    against the two-launch form on the same operands, both against the CPU specification; repeated launches must not hang or differ"""
+    def run(side, fused):
+        rows = N * H * W
+        x = side.t("bnf/x", (rows, Cc), -2, 2)
+        rs = side.t("bnf/res", (rows, Cc))
+        gamma, beta = side.t("bnf/g", (Cc,), 0.5, 1.5), side.t("bnf/b", (Cc,))
+        rm, rv = side.t("bnf/rm", (Cc,)), side.t("bnf/rv", (Cc,), 0.5, 1.5)
+        st = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
+        side.call("mrfa_bn_stats", x.data_ptr(), Cc, rows, Cc, st.data_ptr())
+        sc, sh, mean, inv = (side.z((Cc,)) for _ in range(4))
+        side.call("mrfa_bn_finalize", st.data_ptr(), rows, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, Cc, 1,
+                  sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr())
+        dy = side.t("bnf/dy", (rows, Cc))
+        outs = []
+        for rep in range(3 if fused else 1):
+            dx, dres = side.garbage((rows, Cc)), side.t("bnf/dr0", (rows, Cc))
+            dg, dbt = side.z((Cc,)), side.z((Cc,))
+            nred = hip.STATS_SLOTS * 2 * Cc
+            red = side.z((nred + 2,), torch.float64)
+            q = hip.BnBwdParams()
+            q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), Cc, N, H, W, Cc
+            q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), 1, 0
+            q.mean, q.invstd, q.gamma = mean.data_ptr(), inv.data_ptr(), gamma.data_ptr()
+            q.dy, q.lddy = dy.data_ptr(), Cc
+            if res:
+                q.res, q.ldr, q.dres, q.lddr = rs.data_ptr(), Cc, dres.data_ptr(), Cc
+            q.red, q.dx, q.lddx, q.dgamma, q.dbeta, q.train, q.dx_overwrite = red.data_ptr(), dx.data_ptr(), Cc, dg.data_ptr(), dbt.data_ptr(), 1, 1
+            if fused:
+                q.sync = red.data_ptr() + 8 * nred
+                assert side.L.mrfa_bn_act_bwd_fused_supported(C.byref(q)) == 1
+                q.phase = 3
+                side.call("mrfa_bn_act_bwd", C.byref(q))
+            else:
+                for ph in (1, 2):
+                    q.phase = ph
+                    side.call("mrfa_bn_act_bwd", C.byref(q))
+            outs.append(side.done(dx, dres, dg, dbt))
+        return outs
+    ref = run(Side(False), True)[0]
+    two = run(Side(True), False)[0]
+    reps = run(Side(True), True)
+    for got in reps:
+        assert_close(ref, got, tol=5e-4, what="bn fused vs specification")
+        assert_close(two, got, tol=2e-5, what="bn fused vs two launches")
+
+
 def test_subsample_and_upsample_add():
     def run(side):
         N, H, W, Cc, ld = 2, 8, 12, 32, 36
