@@ -48,7 +48,10 @@ class DeferredWgrads:
     backward() by train_step / GraphedTrainStep).  The thunks hold the activations and gradient buffers they read until join().
     Direct-gradient mode only (DIRECT_PARAM_GRADS: the un-packing into .grad is deferred with them); anything else runs in line."""
 
-    def __init__(self, fanout: int = 1):
+    def __init__(self, fanout: int = 1, manual: bool = False):
+        # manual: flushed only by join() (never by the backward of the next program): the keypoint encoder's collection -- its programs run their
+        # backward on several streams, and only HotPath.join() has ordered all of them before the stream the flush forks from
+        self.manual = manual
         self.thunks: List[Callable[[], None]] = []
         self.finals: List[Callable[[], None]] = []          # run after every thunk (the un-packing of the accumulators they add into)
         self.kept: Optional[List[Callable[[], None]]] = None
@@ -103,7 +106,10 @@ class DeferredWgrads:
         with torch.cuda.stream(self.stream):
             for fn in self.finals:
                 fn()
-        self.kept, self.thunks, self.finals = self.thunks + self.finals, [], []          # the closures own the buffers the side streams are still reading
+        # the closures own the buffers the side streams are still reading -- ALL flushes of the step (a collection can be flushed more than once:
+        # the third encoder pass of the reference objective finishes its backward before the decoder's starts) until join() / reset()
+        self.kept = (self.kept or []) + self.thunks + self.finals
+        self.thunks, self.finals = [], []
         self.flushed = True
 
     def join(self, dev: torch.device):
@@ -1895,7 +1901,7 @@ class _ProgramFn(torch.autograd.Function):
             # after the deferred launches, on their stream (idempotent: two programs deferring into one collection -- the two encoder passes --
             # share the accumulators of their convolutions, the first un-packing takes them all)
             ectx.wdefer.add(lambda: unpack_direct([cw for cw in direct_cws if cw.dw_acc is not None]), final=True)
-            if ectx.wdefer not in _PENDING_DEFERRED:
+            if ectx.wdefer not in _PENDING_DEFERRED and not ectx.wdefer.manual:
                 _PENDING_DEFERRED.append(ectx.wdefer)
             skip = {id(cw) for cw in direct_cws}
         else:

@@ -358,3 +358,42 @@ def test_sync_batchnorm_collectives_are_captured_into_the_graph(monkeypatch):
         torch.cuda.synchronize()
         if own_group:
             dist.destroy_process_group()
+
+
+def test_encoder_weight_gradients_dealt_onto_side_streams_match_the_inline_order():
+    """HotPath._wdefer_enc (the keypoint encoder's ~400 weight-gradient launches collected during its two concurrent backward passes and dealt onto
+    four side streams afterwards, their un-packing last): one eager forward + backward with the fan-out on and off; a randomly initialised
+    train-mode model amplifies summation-order noise to percents of the encoder's gradient, so the yardstick is the distance of two runs with the
+    fan-out OFF -- the on/off distance of every sub-network must stay within 3 x that noise."""
+    import bench
+    from mrfa_amd import engine
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, l1_loss
+    src, drv = _pairs(2, "g/fan")
+
+    def run(fanout):
+        torch.manual_seed(0)
+        m = HotPath(VOX1, prior="mtia")
+        bench.init_weights(m)
+        m.to(DEV).train(True)
+        m.concurrent_encoder, m.defer_decoder_wgrads = True, True
+        m._wdefer_enc.fanout = fanout
+        make_optimizer(m, fused=True)                         # flat gradient buffers: the direct-gradient mode the deferral needs
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        with engine.direct_param_grads():
+            loss = l1_loss(m(src, drv), drv)
+            loss.backward()
+        m.join()
+        torch.cuda.synchronize()
+        assert (fanout > 1) == bool(m._wdefer_enc.fan), "the fan-out did not run / ran when it was off"
+        groups = {}
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                groups.setdefault(n.split(".")[0], []).append(p.grad.detach().flatten().double())
+        return {k: torch.cat(v) for k, v in groups.items()}
+    a, a2, b = run(0), run(0), run(4)
+    for k in a:
+        noise = float((a[k] - a2[k]).norm() / a[k].norm())
+        onoff = float((a[k] - b[k]).norm() / a[k].norm())
+        assert onoff <= 3.0 * noise + 1e-4, (k, onoff, noise)
