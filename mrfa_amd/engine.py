@@ -612,17 +612,19 @@ class PackPlan:
             cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = cw._ver_fr = cw._ver_dr = k
 
 
-def unpack_direct(cws: List["ConvW"]):
-    """direct-gradient mode: weight.grad += un-packed accumulator for all given convolutions in one batched launch"""
+def unpack_direct(cws: List["ConvW"], accs: Optional[List[torch.Tensor]] = None):
+    """direct-gradient mode: weight.grad += un-packed accumulator for all given convolutions in one batched launch.  accs: the accumulators
+    themselves (a deferring program detaches them from its ConvW objects when its backward ends, so that no later program shares them)"""
     if not cws:
         return
     table = (hip.UnpackDesc * len(cws))()
-    for d, cw in zip(table, cws):
-        d.src, d.dst = cw.dw_acc.data_ptr(), cw.conv.weight.grad.data_ptr()
+    for i, (d, cw) in enumerate(zip(table, cws)):
+        d.src, d.dst = (accs[i] if accs is not None else cw.dw_acc).data_ptr(), cw.conv.weight.grad.data_ptr()
         d.Cout, d.Cin, d.T, d.fewout = cw.Cout, cw.Cin, cw.T, int(cw.fewout)
     hip.check(hip.lib().mrfa_unpack_wgrads_multi(hip.stream_ptr(), table, len(cws)), "unpack_wgrads_multi")
-    for cw in cws:
-        cw.dw_acc = cw.db_acc = None
+    if accs is None:
+        for cw in cws:
+            cw.dw_acc = cw.db_acc = None
 
 
 def convw(conv: torch.nn.Conv2d) -> ConvW:
@@ -1898,9 +1900,13 @@ class _ProgramFn(torch.autograd.Function):
         direct_cws = [cw for cw in ectx.touched_convs if cw.dw_acc is not None and cw._direct]
         skip = ()
         if ectx.wdefer is not None and direct_cws:
-            # after the deferred launches, on their stream (idempotent: two programs deferring into one collection -- the two encoder passes --
-            # share the accumulators of their convolutions, the first un-packing takes them all)
-            ectx.wdefer.add(lambda: unpack_direct([cw for cw in direct_cws if cw.dw_acc is not None]), final=True)
+            # after the deferred launches, on their stream.  The accumulators leave their ConvW objects NOW: the next program that touches these
+            # convolutions (the other encoder pass, deferring or not) gets accumulators of its own -- shared ones would be un-packed (and dropped)
+            # by whichever program finishes first while deferred launches still add into them
+            accs = [cw.dw_acc for cw in direct_cws]
+            for cw in direct_cws:
+                cw.dw_acc = cw.db_acc = None
+            ectx.wdefer.add(lambda: unpack_direct(direct_cws, accs), final=True)
             if ectx.wdefer not in _PENDING_DEFERRED and not ectx.wdefer.manual:
                 _PENDING_DEFERRED.append(ectx.wdefer)
             skip = {id(cw) for cw in direct_cws}

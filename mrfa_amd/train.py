@@ -96,13 +96,10 @@ class HotPath(nn.Module):
         from . import engine
         first = frames[0]
         enc_defer = None
-        # two passes only: with the reference objective's third pass the captured schedule failed GraphedTrainStep.verify() (replayed encoder
-        # gradients 50 % off the eager ones, which tools/dbg_defer.py shows to be right).  Bisected: deferring the two side-stream passes alone
-        # verifies, any combination that defers the main-stream pass does not; passes that defer and passes that do not must never be mixed anyway --
-        # they share the per-convolution accumulators, and the in-line pass's un-packing would take them away from the deferred launches.  Not
-        # resolved: that configuration keeps its weight gradients in line.
+        # (every deferring pass owns its accumulators: engine._ProgramFn.backward detaches them from the ConvW objects when the pass's backward ends.
+        # With accumulators shared between the passes the three-pass schedule of the reference objective failed GraphedTrainStep.verify().)
         if (self.defer_decoder_wgrads and self.defer_encoder_wgrads and self._wdefer_enc.fanout > 1 and self.training and torch.is_grad_enabled()
-                and first.is_cuda and len(frames) == 2):
+                and first.is_cuda and len(frames) >= 2):
             enc_defer = self._wdefer_enc
             enc_defer.reset()
         with engine.defer_wgrads(enc_defer):
