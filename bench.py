@@ -250,15 +250,15 @@ def run_inference(a, emit=True):
 def spawn_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks here, the way the reference gets its ranks
     from torch.distributed.launch (run.py:50-59, train.py:39-48).  This parent NEVER touches the GPU (no HIP call, no
-    torch.cuda.is_available(); device_count() only counts) -- each rank is a fresh child process with RANK / LOCAL_RANK / WORLD_SIZE /
+    torch.cuda.is_available(), no device_count(): the GPUs are counted from the KFD sysfs topology, visible_gpus()) -- each rank is a fresh child process with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / MASTER_PORT set, rank 0 prints the one JSON line on the inherited stdout.  Any rank failing ends the others
-    and the exit code is non-zero: a run that silently used fewer ranks than asked cannot happen."""
+    (SIGTERM, SIGKILL after KILL_GRACE_S) and the exit code is non-zero: a run that silently used fewer ranks than asked cannot happen."""
     import socket
     import subprocess
     dry = "--dry" in argv
     if not dry:
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             print(f"[bench] --gpus {n}: only {have} GPU(s) visible on this node", file=sys.stderr)
             return 2
     with socket.socket() as s:
@@ -271,6 +271,7 @@ def spawn_ranks(n: int, argv) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     alive = set(range(n))
+    deadline = None                                   # set when a rank failed: the others get SIGTERM, then SIGKILL after the grace period
     while alive:
         for r in sorted(alive):
             code = procs[r].poll()
@@ -282,8 +283,43 @@ def spawn_ranks(n: int, argv) -> int:
                 print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
                 for o in alive:
                     procs[o].terminate()                      # exact children of this process, by handle
+                deadline = time.monotonic() + KILL_GRACE_S
+        if deadline is not None and alive and time.monotonic() > deadline:
+            # a rank stuck inside an RCCL collective can ignore SIGTERM for ever: escalate (still the exact child handles)
+            for o in sorted(alive):
+                print(f"[bench] rank {o} did not exit {KILL_GRACE_S:.0f} s after SIGTERM: SIGKILL", file=sys.stderr)
+                procs[o].kill()
+            deadline = None
         time.sleep(0.2)
     return rc
+
+
+KILL_GRACE_S = float(os.environ.get("MRFA_BENCH_KILL_GRACE_S", "20"))
+
+
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising HIP in the launcher (it fork/execs the rank children next; on ROCm builds
+    without amdsmi torch.cuda.device_count() is hipGetDeviceCount): the KFD topology's nodes with SIMDs, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None = unknown (no KFD sysfs): the ranks then find out at set_device()."""
+    import glob
+    nodes = 0
+    found = False
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        found = True
+        try:
+            with open(prop) as f:
+                for ln in f:
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        nodes += 1
+        except OSError:
+            pass
+    if not found:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            nodes = min(nodes, len([x for x in v.split(",") if x.strip() != ""]))
+    return nodes
 
 
 DRY_CFG = dict(   # --dry only: the VOX1 wiring at 64 x 64 with shallow hourglasses, small enough for the CPU emulator
@@ -345,7 +381,7 @@ def run_dry(a):
             ws = [torch.zeros_like(wsum) for _ in range(world)]
             dist.all_gather(ws, wsum)
             replicas_equal = all(bool(torch.equal(w, ws[0])) for w in ws)
-            sync_bn_buffers(model)                         # what save_checkpoint does at N > 1: running statistics averaged over the ranks
+            sync_bn_buffers(model)                         # what every rank calls before rank 0 writes a checkpoint: running statistics averaged over the ranks
             bsum = torch.cat([b.double().flatten() for n_, b in model.named_buffers() if n_.endswith(("running_mean", "running_var"))]).sum().reshape(1)
             bs = [torch.zeros_like(bsum) for _ in range(world)]
             dist.all_gather(bs, bsum)
@@ -467,9 +503,10 @@ def main():
     if a.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.to(dev).train(True)
-    # SyncBatchNorm issues one collective per BatchNorm layer and direction; captured into the hipGraph when MRFA_SYNCBN_GRAPH=1 (RCCL
-    # collectives are capturable), else the step is launched eagerly
-    use_graph = not (a.no_graph or (a.sync_bn and os.environ.get("MRFA_SYNCBN_GRAPH", "1") != "1") or a.force_ddp)
+    # SyncBatchNorm issues its statistics collectives per BatchNorm layer (group) and direction.  They CAN be captured into the hipGraph
+    # (MRFA_SYNCBN_GRAPH=1; RCCL collectives are capturable) but that schedule has only ever run with a forced one-rank group:
+    # until it has run at N > 1 the default for --sync-bn is eager launches (DistributedDataParallel at N > 1)
+    use_graph = not (a.no_graph or (a.sync_bn and os.environ.get("MRFA_SYNCBN_GRAPH", "0") != "1") or a.force_ddp)
     ddp = (world > 1 or a.force_ddp) and not use_graph
     if ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
@@ -503,7 +540,6 @@ def main():
         loss_fn = lambda m_, s_, d_: reference_loss(m_.module if hasattr(m_, "module") else m_, full, s_, d_)
     step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
     launch = "eager"
-    verify_retries = 0
     gstep = None
     if use_graph:
         # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
@@ -516,12 +552,9 @@ def main():
                                      overlap_exchange=(True if a.overlap_exchange else None),
                                      overlap_wgrad=a.wgrad_stream, loss_fn=loss_fn)
             ltol = 5e-3 if hip.mfma_mode() == "bf16" else 1e-4
-            try:
-                replay_noise = gstep.verify(loss_tol=ltol)    # replays must agree with each other and with eager passes, or the graph is not used
-            except RuntimeError as ex:                # the noise band is a sampled, heavy-tailed quantity: a mis-ordered graph fails
-                print(f"[bench] verify() retry after: {ex}", file=sys.stderr)       # twice, an unlucky sample does not
-                verify_retries = 1
-                replay_noise = gstep.verify(loss_tol=ltol)
+            # replays must agree with each other and with eager passes, or the graph is not used.  ONE attempt: a failure fails the run (a
+            # retry decided per rank would issue an extra round of collectives on that rank only and desynchronise the communicator)
+            replay_noise = gstep.verify(loss_tol=ltol)
         except Exception as ex:
             ok, why = 0, ex
         if world > 1:                                 # every rank must know before anybody raises (the others sit in a collective)
@@ -735,9 +768,9 @@ def main():
                                     "the reference's generator losses (VGG19 perceptual pyramid on random-init weights + equivariance, 3 encoder passes)"),
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "background_predictor": bool(a.background), "sync_bn": bool(a.sync_bn), "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}"),
-                       "verify_retries": verify_retries, "tuning": a.tune or None,
-                       "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; running buffers are averaged over the ranks "
-                                         "when a checkpoint is written (train.sync_bn_buffers)")},
+                       "tuning": a.tune or None,
+                       "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; train.sync_bn_buffers (explicit collective) averages the running "
+                                         "buffers over the ranks before a checkpoint is written")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt, "bf16x3_path": alt3,
             "config5_512_inference": c5,
         }

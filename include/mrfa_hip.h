@@ -22,6 +22,15 @@ extern "C" {
 #endif
 
 const char* mrfa_last_error(void);
+/* ABI version of THIS header; mrfa_version() returns the one the library was built from and a client must refuse a mismatch (the
+ * ctypes binding mrfa_amd/hip.py does): parameter structs are passed by pointer without a size field, so a client compiled against an
+ * older header would hand over a shorter struct.
+ *   1  rounds 1-2.
+ *   3  round 3 (shipped as "1"): mrfa_conv_params += mask, ldm, w_phase, w_phase_piece, stride; mrfa_wgrad_params += stride;
+ *      mrfa_bnbwd_params += sync; pack modes 8 / 9 (pre-split bf16 weight planes) became k16-chunk-major -- plane[tap][k16 chunk][row][16]
+ *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
+ *   4  round 4: see the per-struct notes below ("v4").                                                                               */
+#define MRFA_ABI_VERSION 4
 int mrfa_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -13,4 +13,4 @@ void mrfa_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mrfa_last_error(void) { return g_err; }
-extern "C" int mrfa_version(void) { return 1; }
+extern "C" int mrfa_version(void) { return MRFA_ABI_VERSION; }

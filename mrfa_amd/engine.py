@@ -598,16 +598,22 @@ class PackPlan:
                 descs.append(d)
         self.n = len(descs)
         self.table = (hip.PackDesc * max(self.n, 1))(*descs)
-        self.ptrs = [(cw, cw.conv.weight.data_ptr(), id(cw._fwd), id(cw._dg), id(getattr(cw, "_fwd_s", None)), id(getattr(cw, "_dg_s", None)),
-                      id(getattr(cw, "_fwd_ph", None)), id(getattr(cw, "_dg_ph", None))) for cw in self.cws]
+        self.ptrs = [(cw, cw.conv.weight.data_ptr()) + self._buffer_ids(cw) for cw in self.cws]
+
+    _PLANES = ("_fwd", "_dg", "_fwd_s", "_dg_s", "_fwd_r", "_dg_r", "_fwd_ph", "_dg_ph", "_fo", "_fi")
+
+    @classmethod
+    def _buffer_ids(cls, cw) -> tuple:
+        """identity of every packed layout the plan may write: a layout created (or re-allocated) after the plan was built is not in
+        the plan's table, and stamping its version below would make the engine skip the pack it needs -- stale weights under replay"""
+        return tuple(id(getattr(cw, a, None)) for a in cls._PLANES)
 
     def run(self):
         if self.n:
             hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), self.table, self.n), "pack_conv_weights_multi")
-        for cw, wptr, idf, idd, idfs, idds, idph, iddph in self.ptrs:
-            assert (cw.conv.weight.data_ptr() == wptr and id(cw._fwd) == idf and id(cw._dg) == idd and
-                    id(getattr(cw, "_fwd_s", None)) == idfs and id(getattr(cw, "_dg_s", None)) == idds and
-                    id(getattr(cw, "_fwd_ph", None)) == idph and id(getattr(cw, "_dg_ph", None)) == iddph), "PackPlan is stale: rebuild it"
+        for rec in self.ptrs:
+            cw, wptr, ids = rec[0], rec[1], rec[2:]
+            assert cw.conv.weight.data_ptr() == wptr and self._buffer_ids(cw) == ids, "PackPlan is stale: rebuild it"
             k = cw._key()
             cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = cw._ver_fr = cw._ver_dr = k
 

@@ -190,9 +190,14 @@ class GraphedTrainStep:
         graph_replay_safe("GraphedTrainStep")
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         self.loss_fn = loss_fn
+        syncbn_collectives = any(isinstance(m, nn.SyncBatchNorm) for m in model.modules()) and (world > 1 or engine.SYNCBN_FORCE)
+        if concurrent_encoder and syncbn_collectives:
+            raise ValueError("GraphedTrainStep(concurrent_encoder=True) with SyncBatchNorm: the side-stream encoder pass would interleave its "
+                             "statistics collectives with the main stream's in a hardware-decided order, different on every rank "
+                             "(communicator deadlock); leave concurrent_encoder=None / False")
         if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
             concurrent_encoder = getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_CONCURRENT_ENCODER", "1") == "1"
-            if any(isinstance(m, nn.SyncBatchNorm) for m in model.modules()) and (world > 1 or engine.SYNCBN_FORCE):
+            if syncbn_collectives:
                 # SyncBatchNorm's statistics collectives are captured into the graph (RCCL ops are capturable): every rank must enqueue them in
                 # ONE order on the communicator, so the two encoder passes stay on one stream (the side-stream pass would interleave its
                 # collectives with the main stream's in an order the hardware, not the program, decides)

@@ -183,6 +183,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+ABI_VERSION = 4        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None
 
@@ -204,6 +205,9 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI and the header drift apart
             fn.argtypes = argtypes
             fn.restype = restype
+        if L.mrfa_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} speaks ABI version {L.mrfa_version()}, this binding was written against {ABI_VERSION} "
+                               "(include/mrfa_hip.h MRFA_ABI_VERSION): rebuild the library (`python -m mrfa_amd.build --force`)")
         _lib = L
         mode = os.environ.get("MRFA_MFMA", DEFAULT_MFMA)
         if mode not in MFMA_MODES:

@@ -344,8 +344,9 @@ def sync_bn_buffers(model) -> int:
     checkpoint is written they are averaged over the ranks -- ONE all-reduce of all floating-point buffers flattened together -- so that
     the file does not depend on which rank wrote it (for equal per-rank batch sizes the mean of the per-rank running means IS the
     running mean over the global batches; the running variances average the within-rank variances, which is what
-    DistributedDataParallel(broadcast_buffers=True) without SyncBatchNorm would keep from rank 0 only).  No-op without a process
-    group / with one rank; with SyncBatchNorm (reference train.py:43) the buffers are already identical.  Returns the element count."""
+    DistributedDataParallel(broadcast_buffers=True) without SyncBatchNorm would keep from rank 0 only).  A COLLECTIVE: every rank must
+    call it (it is never issued implicitly -- save_checkpoint is rank-local unless asked).  No-op without a process group / with one
+    rank; with SyncBatchNorm (reference train.py:43) the buffers are already identical and callers skip it.  Returns the element count."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
@@ -364,17 +365,25 @@ def sync_bn_buffers(model) -> int:
     return off
 
 
-def save_checkpoint(path: str, model, optimizer, epoch: int):
+def save_checkpoint(path: str, model, optimizer, epoch: int, collective: bool = False):
     """The reference's checkpoint file (logger.py:50-58, train.py:94): {'model': state_dict with DDP's 'module.' prefix,
     'optimizer': optimizer.state_dict(), 'epoch': int} -- readable by the reference's Logger.load_cpk and by load_checkpoint.
     `model` = mrfa_amd.modules.MRFA gives the reference MRFA's exact key set (`pyramid.*`, `vgg.*`, `encoder.*`, ...: pinned by
     tests/golden/state_dict_manifest.json['MRFA']); a HotPath writes the networks only (no loss modules: the reference's strict
-    loader then reports the missing `pyramid.*` / `vgg.*` keys, as it would for any file without them)."""
+    loader then reports the missing `pyramid.*` / `vgg.*` keys, as it would for any file without them).
+
+    RANK-LOCAL by default, like the reference (train.py:89-94 saves under `if local_rank == 0`): the caller decides which rank writes, no
+    collective is issued here, the live BatchNorm buffers are not touched.  Data-parallel runs with per-rank batch statistics that want
+    a rank-independent file either call `sync_bn_buffers(model)` on EVERY rank first, or pass collective=True on every rank: the
+    buffers are then averaged over the ranks (one all-reduce; skipped when the model holds SyncBatchNorm layers, whose buffers are
+    already identical) and only rank 0 writes."""
     m = model.module if hasattr(model, "module") else model
-    sync_bn_buffers(m)            # N > 1 without SyncBatchNorm: a collective -- every rank calls save_checkpoint, rank 0 writes the file
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
-        return
+    if collective:
+        import torch.distributed as dist
+        if not any(isinstance(x, nn.SyncBatchNorm) for x in m.modules()):
+            sync_bn_buffers(m)
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
     sd = {"module." + k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     torch.save({"model": sd, "optimizer": optimizer.state_dict(), "epoch": int(epoch)}, path)
 

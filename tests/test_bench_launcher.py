@@ -30,7 +30,7 @@ def test_bare_command_spawns_its_ranks_and_reports_the_group_size():
     assert line["n_gpus"] == 2 and line["dry"] is True and line["value"] is None
     assert line["config"]["global_batch"] == 2 and line["config"]["parallelism"] == "dp2"
     assert line["config"]["replicas_equal_after_steps"] is True        # the exchange ran: both ranks hold the same weights after Adam
-    assert line["config"]["bn_buffers_equal_after_sync"] is True       # train.sync_bn_buffers (what save_checkpoint does at N > 1)
+    assert line["config"]["bn_buffers_equal_after_sync"] is True       # train.sync_bn_buffers (the explicit collective every rank issues before rank 0 saves)
 
 
 def test_driver_command_form_through_torch_distributed_run():

@@ -32,7 +32,7 @@ def _cmp(got, ref, max_tol=1e-3, mean_tol=1e-4, what=""):
 
 def test_native_library_is_loaded():
     L = hip.lib()
-    assert L.mrfa_version() >= 1
+    assert L.mrfa_version() == hip.ABI_VERSION
     assert os.path.basename(hip.LIB_PATH) == "libmrfa_hip.so"
 
 

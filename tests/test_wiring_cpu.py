@@ -55,7 +55,8 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/mrfa_hip.h but not exported"
     assert declared == set(hip.EXPORTED_SYMBOLS), declared ^ set(hip.EXPORTED_SYMBOLS)
-    assert lib.mrfa_version() >= 1
+    # the library, the header and the ctypes binding state ONE ABI version (a stale library is refused by hip.lib())
+    assert lib.mrfa_version() == int(re.search(r"#define MRFA_ABI_VERSION (\d+)", header).group(1)) == hip.ABI_VERSION
 
 
 def test_product_fails_loudly_without_the_hip_library(monkeypatch):
@@ -620,6 +621,63 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
         fake_step(d, od, 2)
         for (n, p), (_, q) in zip(a.named_parameters(), d.named_parameters()):
             assert (p - q).abs().max().item() <= 4e-7, n
+
+
+CKPT_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from tests.emu import emulated_hip
+from mrfa_amd.modules.util import Hourglass
+from mrfa_amd.train import save_checkpoint, sync_bn_buffers
+from mrfa_amd.utils.prng import fill_state_dict
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+with emulated_hip():
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = Hourglass(block_expansion=8, in_features=3, num_blocks=2, max_features=32)
+    m = Tiny()
+    m.load_state_dict(fill_state_dict(m.state_dict(), "ck"))
+    for n, b in m.named_buffers():                      # per-rank running statistics that drifted apart
+        if n.endswith("running_mean"):
+            b.fill_(float(rank + 1))
+    opt = torch.optim.Adam(m.parameters())
+    before = {n: b.clone() for n, b in m.named_buffers()}
+    # (1) the reference's pattern (train.py:89-94): ONLY rank 0 saves.  A collective inside save_checkpoint would hang here.
+    if rank == 0:
+        save_checkpoint(out + ".local", m, opt, epoch=1)
+    assert all(torch.equal(b, before[n]) for n, b in m.named_buffers()), "a rank-local save must not touch the live buffers"
+    dist.barrier()
+    # (2) the explicit collective form: every rank calls, rank 0 writes the rank-independent file
+    save_checkpoint(out + ".coll", m, opt, epoch=2, collective=True)
+    assert (rank == 0) == os.path.exists(out + ".coll") or rank != 0
+    # (3) SyncBatchNorm models: buffers are identical by construction, no collective is issued even with collective=True
+    sm = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Tiny())
+    if rank == 0:                                         # only rank 0 calls: must not block
+        save_checkpoint(out + ".sync", sm, torch.optim.Adam(sm.parameters()), epoch=3, collective=True)
+    dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_save_checkpoint_is_rank_local_and_the_buffer_average_is_explicit(tmp_path):
+    """save_checkpoint must not be a hidden collective (the reference saves under `if local_rank == 0`, train.py:89-94).
+    Two gloo ranks: rank 0 alone saves without hanging and without touching its live BatchNorm buffers; collective=True on every rank
+    averages the running statistics over the ranks first; SyncBatchNorm models never issue the collective."""
+    script = tmp_path / "worker.py"
+    script.write_text(CKPT_WORKER)
+    out = str(tmp_path / "ck.pt")
+    port = str(37500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    local, coll = torch.load(out + ".local"), torch.load(out + ".coll")
+    k = next(k for k in local["model"] if k.endswith("running_mean"))
+    assert float(local["model"][k].mean()) == 1.0           # rank 0's own statistics
+    assert float(coll["model"][k].mean()) == 1.5            # the mean over the two ranks
+    assert local["epoch"] == 1 and coll["epoch"] == 2 and os.path.exists(out + ".sync")
 
 
 def test_baseline_config1_mrfa_mtia_prior_only_plumbing():
