@@ -88,6 +88,10 @@ class HotPath(nn.Module):
         # 85.9 -> 84.2 ms).  Same conditions as defer_decoder_wgrads.
         self.defer_encoder_wgrads = True       # (GraphedTrainStep switches it off with SyncBatchNorm: one stream, one enqueue order per rank)
         object.__setattr__(self, "_wdefer_enc", DeferredWgrads(fanout=int(os.environ.get("MRFA_ENC_WGRAD_FANOUT", "4") or 0), manual=True))
+        # test / diagnostics hook: a dict here makes forward() keep the keypoint tensors (`kp_s`, `jac_s`, `kp_d`, `jac_d`) and copy the
+        # gradients that arrive at them into static buffers (`dkp_s`, ...) with a kernel (no memcpy node), so that d loss / d keypoints of
+        # a hipGraph-REPLAYED step can be read (tests/test_headline_gpu.py).  None (default): nothing is recorded
+        object.__setattr__(self, "probe", None)
 
     def encode_many(self, frames):
         """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234), in the reference's order as far as
@@ -160,8 +164,26 @@ class HotPath(nn.Module):
             gen, warp_img, occ = self.decoder(kp_s["kp"], kp_d["kp"], dm, img=img_down, img_full=source)
         return gen
 
+    def _record_probe(self, kp_s, kp_d):
+        pr = self.probe
+        for tag, kp in (("s", kp_s), ("d", kp_d)):
+            for key, short in (("kp", "kp"), ("jacobian", "jac")):
+                t = kp.get(key)
+                if t is None:
+                    continue
+                pr[f"{short}_{tag}"] = t.detach()
+                if t.requires_grad:
+                    def hook(g, name=f"d{short}_{tag}"):
+                        buf = pr.get(name)
+                        if buf is None or buf.shape != g.shape:
+                            pr[name] = buf = torch.empty_like(g)
+                        torch.mul(g, 1.0, out=buf)
+                    t.register_hook(hook)
+
     def forward(self, source, driving):
         kp_s, kp_d = self.encode_pair(source, driving)
+        if self.probe is not None:
+            self._record_probe(kp_s, kp_d)
         bg_param = self.bg_predictor(source, driving) if self.bg_predictor is not None else None
         return self.decode(source, kp_s, kp_d, bg_param)
 

@@ -114,3 +114,18 @@ def bg_weights(sd_like: dict) -> dict:
         elif name.endswith("fc.bias"):
             sd[name] = torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]) + sd[name] * 0.3
     return sd
+
+
+# ---- the headline program: the MTIA-prior training step (BASELINE config 2), shared by tools/make_goldens.py:g12_chain_mtia, the CPU
+# emulator leg and the hipGraph-replay test
+def mtia_chain_weights(encoder_sd: dict, dense_motion_sd: dict, decoder_sd: dict) -> dict:
+    """{"encoder.": sd, "dense_motion.": sd, "decoder.": sd}: deterministic weights of the TokenPose_B -> DenseMotion -> RaftFlow chain"""
+    return {"encoder.": tokenpose_weights(encoder_sd, "g12/enc"), "dense_motion.": weights_for(dense_motion_sd, "g12/dm"),
+            "decoder.": weights_for(decoder_sd, "g12/rf")}
+
+
+def sample_index(numel: int, k: int = 64) -> torch.Tensor:
+    """the <= k flat positions of a tensor that the gradient goldens keep (evenly spread, first and last included)"""
+    if numel <= k:
+        return torch.arange(numel)
+    return torch.linspace(0, numel - 1, k).round().long()

@@ -773,8 +773,124 @@ def g11_prior_grads():
     print("G11 prior / chained gradient goldens:", len(out), {k: float(v[0]) for k, v in out.items() if k.endswith("_loss")})
 
 
+# ----------------------------------------------------------------------------------------------- G12 the headline program: MTIA chain
+def g12_chain_mtia():
+    """the reference's OWN `MRFA` (model.py:145-216) built with `prior_model: mtia` -- TokenPose_B encoder on source and
+    driving, DenseMotionNetwork, RaftFlow -- run forward (`MRFA.forward(x, epoch=0, is_train=False)`: the wiring of model.py:185-210
+    without the loss modules) + the surrogate objective mean|gen - driving| of SURVEY 8(d) + `.backward()` (train.py:58-64), B=2,
+    eval-mode BatchNorm (well conditioned) and train-mode (the benchmark's mode).  Stored: loss, sub-sampled output, keypoints and
+    d loss / d keypoints (retained on the encoder's outputs), every parameter's gradient norm and <= 64 evenly spread entries of every
+    parameter's gradient (cases.sample_index) -- and the same quantities from an fp64 run of the oracle, the truth that says how far the
+    fp32 reference itself is from exact arithmetic (the band the GPU is allowed)."""
+    import contextlib
+    import io
+    import modules.model as RM
+    from mrfa_amd.train import VOX1
+    old_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self          # model.py:155: `.cuda()` on the pyramid
+    try:
+        cfg = RU.convert_dict_to_attrit_dict({
+            "mtia_kp_detector": cases.tokenpose_cfg(), "dense_motion": cases.DENSE_MOTION_CFG, "raft_flow": cases.raft_cfg(256),
+            "train_params": dict(prior_model="mtia", num_epochs=100, bg_start=1000, scales=[1, 0.5, 0.25, 0.125], clip=10, lr=2.0e-4,
+                                 transform_params=dict(sigma_affine=0.05, sigma_tps=0.005, points_tps=5),
+                                 loss_weights=dict(perceptual=[0, 0, 0, 0, 0], equivariance=0, equivariance_jacobian=0))})
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = RM.MRFA(cfg)
+    finally:
+        torch.nn.Module.cuda = old_cuda
+    sds = cases.mtia_chain_weights(m.encoder.state_dict(), m.dense_motion.state_dict(), m.decoder.state_dict())
+    mods = [("encoder.", m.encoder), ("dense_motion.", m.dense_motion), ("decoder.", m.decoder)]
+    names = [pfx + n for pfx, mod in mods for n, _ in mod.named_parameters()]
+    out = {}
+    b = 2
+    kept = []
+    hook = m.encoder.register_forward_hook(lambda mod, inp, o: (kept.append(o), [v.retain_grad() for v in o.values()])[0] and None)
+    for train in (False, True):
+        sfx = "train" if train else "eval"
+        for pfx, mod in mods:
+            mod.load_state_dict(sds[pfx])
+        m.train(train)
+        m.zero_grad()
+        kept.clear()
+        src, drv = cases.images(f"g12/src_{sfx}", b, 256), cases.images(f"g12/drv_{sfx}", b, 256)
+        gen, warp_img, lv, kps, kpd = m({"source": src, "driving": drv}, epoch=0, is_train=False)
+        loss = (gen - drv).abs().mean()
+        loss.backward()
+        k_s, k_d = kept
+        out[f"{sfx}_loss"] = np.array([loss.item()], np.float64)
+        out[f"{sfx}_gen_s4"] = npy(gen[:, :, ::4, ::4])
+        for nm, d in (("s", k_s), ("d", k_d)):
+            out[f"{sfx}_kp_{nm}"], out[f"{sfx}_jac_{nm}"] = npy(d["kp"]), npy(d["jacobian"])
+            out[f"{sfx}_dkp_{nm}"], out[f"{sfx}_djac_{nm}"] = npy(d["kp"].grad), npy(d["jacobian"].grad)
+        P32 = {pfx + n: p for pfx, mod in mods for n, p in mod.named_parameters()}
+        out[f"{sfx}_pgrad_norms"] = np.array([0.0 if P32[n].grad is None else P32[n].grad.double().norm().item() for n in names], np.float64)
+        out[f"{sfx}_pgrad_samples"] = np.concatenate([
+            (np.zeros(len(cases.sample_index(P32[n].numel())), np.float32) if P32[n].grad is None
+             else npy(P32[n].grad.reshape(-1)[cases.sample_index(P32[n].numel())])) for n in names])
+        if train:
+            bufs = {pfx + n: v for pfx, mod in mods for n, v in mod.named_buffers()}
+            for n in ("encoder.pre_feature.bn1.running_mean", "encoder.pre_feature.stage3.3.fuse_layers.0.2.1.running_var",
+                      "decoder.generator.first.norm.running_var", "dense_motion.hourglass.encoder.down_blocks.0.norm.running_mean"):
+                out["train_buf_" + n] = npy(bufs[n])
+        # ---- a SECOND fp32 realisation of the unmodified reference: the same modules with ATen's native convolution kernels instead of
+        # oneDNN's (another summation order).  One fp32 run is one sample of the rounding noise (its distance from fp64 differed by up to
+        # 10x between the two backends, sub-network by sub-network): the parity gates take the larger of the two as the noise level.
+        for pfx, mod in mods:
+            mod.load_state_dict(sds[pfx])
+        m.train(train)
+        m.zero_grad()
+        kept.clear()
+        with torch.backends.mkldnn.flags(enabled=False):
+            gen2, _, _, _, _ = m({"source": src, "driving": drv}, epoch=0, is_train=False)
+            (gen2 - drv).abs().mean().backward()
+        k_s2, k_d2 = kept
+        out[f"{sfx}_gen_s4_alt"] = npy(gen2[:, :, ::4, ::4])
+        for nm, d in (("s", k_s2), ("d", k_d2)):
+            out[f"{sfx}_dkp_{nm}_alt"], out[f"{sfx}_djac_{nm}_alt"] = npy(d["kp"].grad), npy(d["jacobian"].grad)
+        out[f"{sfx}_pgrad_norms_alt"] = np.array([0.0 if P32[n].grad is None else P32[n].grad.double().norm().item() for n in names], np.float64)
+        out[f"{sfx}_pgrad_samples_alt"] = np.concatenate([
+            (np.zeros(len(cases.sample_index(P32[n].numel())), np.float32) if P32[n].grad is None
+             else npy(P32[n].grad.reshape(-1)[cases.sample_index(P32[n].numel())])) for n in names])
+        # ---- the same program through the oracle: fp32 (oracle-vs-reference delta printed) and fp64 (the truth)
+        for dt_, key in ((torch.float32, None), (torch.float64, "fp64")):
+            P = {}
+            for pfx, sd_ in sds.items():
+                P.update({pfx + k: ((v.to(dt_).clone().requires_grad_(pfx + k in names and not k.endswith("pos_embedding") or k == "pos_embedding"))
+                                    if v.is_floating_point() else v.clone()) for k, v in sd_.items()})
+            g_o, _, ks_o, kd_o, _ = O.mrfa_forward(src.to(dt_), drv.to(dt_), P, size=256, train=train, prior="mtia")
+            for d in (ks_o, kd_o):
+                for v in d.values():
+                    v.retain_grad()
+            l_o = (g_o - drv.to(dt_)).abs().mean()
+            l_o.backward()
+            gn = np.array([0.0 if P[n].grad is None else P[n].grad.double().norm().item() for n in names], np.float64)
+            if key is None:
+                delta(f"mtia chain {sfx} gen", g_o, gen)
+                delta(f"mtia chain {sfx} kp_d", kd_o["kp"], k_d["kp"])
+                rel = np.abs(gn - out[f"{sfx}_pgrad_norms"]) / np.maximum(out[f"{sfx}_pgrad_norms"], 1e-3 * out[f"{sfx}_pgrad_norms"].max())
+                print(f"   oracle(fp32)-vs-ref {sfx}: loss {l_o.item():.7f} vs {loss.item():.7f}; gradient norms median {np.median(rel):.2e} max {rel.max():.2e}")
+                continue
+            out[f"{sfx}_loss_fp64"] = np.array([l_o.item()], np.float64)
+            out[f"{sfx}_gen_s4_fp64"] = npy(g_o[:, :, ::4, ::4].float())
+            out[f"{sfx}_pgrad_norms_fp64"] = gn
+            out[f"{sfx}_pgrad_samples_fp64"] = np.concatenate([
+                (np.zeros(len(cases.sample_index(P[n].numel())), np.float64) if P[n].grad is None
+                 else P[n].grad.reshape(-1)[cases.sample_index(P[n].numel())].numpy().astype(np.float64)) for n in names])
+            for nm, d in (("s", ks_o), ("d", kd_o)):
+                out[f"{sfx}_dkp_{nm}_fp64"], out[f"{sfx}_djac_{nm}_fp64"] = d["kp"].grad.numpy(), d["jacobian"].grad.numpy()
+            rel = np.abs(out[f"{sfx}_pgrad_norms"] - gn) / np.maximum(gn, 1e-3 * gn.max())
+            print(f"   reference-vs-fp64 {sfx}: loss {loss.item():.7f} vs {l_o.item():.7f}; gradient norms median {np.median(rel):.2e} max {rel.max():.2e}; "
+                  f"gen mean {np.abs(out[f'{sfx}_gen_s4'] - out[f'{sfx}_gen_s4_fp64']).mean():.2e}")
+    hook.remove()
+    with open(os.path.join(GOLD, "chain_mtia_param_names.json"), "w") as f:
+        json.dump(names, f)
+    np.savez_compressed(os.path.join(GOLD, "chain_mtia.npz"), **out)
+    print("G12 MTIA chain goldens:", len(out), {k: float(v[0]) for k, v in out.items() if k.endswith("_loss")},
+          "bytes", os.path.getsize(os.path.join(GOLD, "chain_mtia.npz")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest", "g10_helpers", "g11_prior_grads"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest", "g10_helpers", "g11_prior_grads", "g12_chain_mtia"]
     for w in which:
         print("==", w)
         globals()[w]()

@@ -11,9 +11,11 @@ from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step  # noqa: E4
 from mrfa_amd.utils.prng import det_uniform, fill_state_dict  # noqa: E402
 
 dev = torch.device("cuda:0")
-model = HotPath(VOX1)
-for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
-    mod.load_state_dict(fill_state_dict(mod.state_dict(), tag=pfx))
+PRIOR = sys.argv[2] if len(sys.argv) > 2 else "fomm"          # python tools/profile_step.py 8 mtia [rows]
+model = HotPath(VOX1, prior=PRIOR)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+bench.init_weights(model)
 model.to(dev).train(True)
 opt = make_optimizer(model)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -33,6 +35,7 @@ agg = {}
 for ms, f, cfg, d in rows:
     a = agg.setdefault(d, [0.0, 0.0, 0, cfg])
     a[0] += ms; a[1] += f; a[2] += 1
-for d, (ms, f, n, cfg) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
-    tile = "wgrad" if cfg < 0 else f"{cfg >> 16}x{(cfg >> 4) & 0xfff}{'f' if cfg & 2 else ''}{'s' if cfg & 1 else ''}"
+NROWS = int(sys.argv[3]) if len(sys.argv) > 3 else 70
+for d, (ms, f, n, cfg) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:NROWS]:
+    tile = "wgrad" if cfg < 0 else ("halo " if cfg & (1 << 28) else "") + f"{(cfg >> 16) & 0xfff}x{(cfg >> 4) & 0xfff}{'f' if cfg & 2 else ''}{'s' if cfg & 1 else ''}{'b' if cfg & 4 else ''}"
     print(f"{ms:7.3f} ms  x{n:<2d} {f / ms / 1e9:6.1f} TF/s  {tile:10s} {d}")
