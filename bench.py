@@ -545,7 +545,13 @@ def main():
         # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
         # (mrfa_amd/graph.py): graph A = pack + fwd + bwd, one flat RCCL all-reduce when N > 1, graph B = clip + Adam
         from mrfa_amd.graph import GraphedTrainStep
-        loss = step()
+        if not fused:
+            loss = step()                             # torch.optim.Adam: its state tensors must exist before the capture
+        # FlatAdam needs no step before the capture (its state lives in the flat buffers from construction), and the capture is verified
+        # at the INITIAL weights on purpose: there two passes at the same weights agree to ~1e-3 (relative L2 per parameter group), so the
+        # replay-vs-eager check is sharp.  After one Adam step of the randomly initialised model (every weight moved by +-lr, including
+        # those whose gradient is rounding noise) two EAGER passes differ by 16-110 % per group and the check compared noise with noise:
+        # 1 of 12 runs failed it by chance (gpurun_out r4d) -- which is what round 3's per-rank retry papered over.
         ok, why = 1, None
         try:
             gstep = GraphedTrainStep(model, opt, src, drv, clip=clip, world=world, exchange=(world > 1 or a.force_exchange),

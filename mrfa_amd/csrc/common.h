@@ -37,6 +37,18 @@ int mrfa_tuning_fewout3(int set);          // mrfa_set_tuning("conv_fewout3", 0 
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M);
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M);
 
+// conv_lds.hip: the HRNet trunk's 3x3 stride-1 layers, input halo staged once in LDS, exact fp32 on v_mfma_f32_16x16x4_f32
+bool mrfa_conv_lds_eligible(const mrfa_conv_params& p);
+int mrfa_conv_lds_launch(hipStream_t st, const mrfa_conv_params& p);
+int mrfa_tuning_conv_lds(int set);         // mrfa_set_tuning("conv_lds", 0 / 1); set < 0: query
+
+// attention_mfma.hip: multi-head attention forward / backward on v_mfma_f32_16x16x4_f32 (the VALU kernels of tokenpose.hip are the fallback)
+bool mrfa_attention_mfma_ok(int d, const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const void* dqkv, int lddq);
+int mrfa_attention_fwd_mfma(hipStream_t st, const float* qkv, int ld, int B, int n, int heads, int d, float scale, float* out, int ldo, float* lse);
+int mrfa_attention_bwd_mfma(hipStream_t st, const float* qkv, int ld, const float* out, int ldo, const float* dout, int lddo, const float* lse,
+                            float* delta, int B, int n, int heads, int d, float scale, float* dqkv, int lddq);
+int mrfa_tuning_attention_mfma(int set);   // mrfa_set_tuning("attention_mfma", 0 / 1); set < 0: query
+
 // wgrad_small.hip: one wave per 32 x 32 weight block of one tap over a pixel range (small problems)
 bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M);
 int mrfa_wgrad_small_launch(hipStream_t st, const mrfa_wgrad_params& p, long long M);

@@ -499,6 +499,8 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "wgrad_halo_target_wgs")) return mrfa_tuning_wgrad_halo_target(value);
     if (!strcmp(key, "wgrad_halo_phase")) return mrfa_tuning_wgrad_halo_phase(value);
     if (!strcmp(key, "conv_fewout3")) return mrfa_tuning_fewout3(value != 0);
+    if (!strcmp(key, "conv_lds")) return mrfa_tuning_conv_lds(value != 0);
+    if (!strcmp(key, "attention_mfma")) return mrfa_tuning_attention_mfma(value != 0);
     if (!strcmp(key, "conv_small")) { const int prev = g_conv_small; g_conv_small = value != 0; return prev; }
     return -1;
 }

@@ -366,6 +366,11 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     const int KT = (Ktot + BK - 1) / BK;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
 
+    // ---- the HRNet trunk's 3x3 stride-1 layers (32..128 channels at 64^2..16^2): input halo staged once in LDS (conv_lds.hip)
+    if (!flat && mrfa_conv_lds_eligible(p) && !mrfa_conv_halo_eligible(p)) {   // (layer1's 64 -> 64 @64^2 stays on the bf16-pipe patch kernel: 29 vs 36 us)
+        g_last_tile = (16 << 16) | (16 << 4) | 16;               // bit 4: conv_lds
+        return mrfa_conv_lds_launch(st, p);
+    }
     // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {

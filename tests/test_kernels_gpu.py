@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, tag="c"):
+              stride=1, lds=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -157,6 +157,8 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     if mask and side.gpu:
         assert side.L.mrfa_conv2d_mask_supported(C.byref(p)) == 1
     side.call("mrfa_conv2d_nhwc", C.byref(p))
+    if lds and side.gpu:            # the case is meant for the LDS-staged kernel: make sure the dispatcher sent it there
+        assert side.L.mrfa_conv2d_last_config() & 16, "not dispatched to conv_lds"
     return side.done(y[:, :Cout], st.sum(0))
 
 
@@ -195,6 +197,15 @@ CONV_CASES = {
     "small_linear_576_192_affine": dict(N=1, H=1, W=276, Cin=576, Cout=192, R=1, pad=0, oaff=True),
     "small_ragged": dict(N=1, H=7, W=9, Cin=48, Cout=40, stats=True),
     "small_wide_m": dict(N=8, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False),
+    # conv_lds.hip (input halo staged once in LDS, fp32 MFMA): HRNet's 3x3 stride-1 layers at the bench batch -- one case per tile
+    # configuration, every epilogue option, the pre-activation prologue, ragged channels, a halo that needs two staging passes
+    "lds_hr32_at64": dict(N=8, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, lds=True),
+    "lds_hr64_at32_res": dict(N=8, H=32, W=32, Cin=64, Cout=64, res=True, relu=True, stats=True, lds=True),
+    "lds_hr128_at16_acc": dict(N=8, H=16, W=16, Cin=128, Cout=128, acc=True, alpha=0.5, relu=False, bias=False, lds=True),
+    "lds_layer1_two_passes_pro": dict(N=4, H=64, W=64, Cin=64, Cout=64, pro=True, stats=True, lds=True),
+    "lds_ragged_c96_c40": dict(N=2, H=16, W=32, Cin=96, Cout=40, stats=True, oaff=True, lds=True),
+    "lds_c16_out": dict(N=1, H=16, W=16, Cin=32, Cout=16, relu=False, lds=True),
+    "lds_row_segments": dict(N=1, H=8, W=64, Cin=32, Cout=128, res=True, lds=True),
     # strided gather (HRNet's downsampling layers: hr_base.py:241,253,302,305,365), even and odd input sizes
     "small_stride2_stem": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False),
     "small_stride2_fuse_odd": dict(N=1, H=13, W=17, Cin=32, Cout=128, stride=2, stats=True, relu=False, bias=False),
@@ -495,7 +506,8 @@ def dgrad_case(side, *, N=2, H=8, W=9, Cin=64, Cout=96, R=3, pad=1, tag="d"):
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(Cout=126), dict(Cout=3, Cin=64, R=7, pad=3), dict(Cout=10, Cin=35, R=7, pad=0),
-                                 dict(Cin=3, Cout=64, R=7, pad=3), dict(R=1, pad=0, Cin=98, Cout=128)])
+                                 dict(Cin=3, Cout=64, R=7, pad=3), dict(R=1, pad=0, Cin=98, Cout=128),
+                                 dict(N=4, H=32, W=32, Cin=64, Cout=64), dict(N=4, H=16, W=16, Cin=128, Cout=32)])       # (conv_lds.hip shapes)
 def test_dgrad_matches_autograd(cfg):
     tag = "dgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
     (got,) = dgrad_case(Side(True), tag=tag, **cfg)

@@ -20,7 +20,7 @@ static float* dalloc(size_t n, float v) {
 int main() {
     struct Shape { const char* name; int N, H, W, Cin, Cout, R; };
     const Shape shapes[] = {{"hr 32->32 3x3 @64", 8, 64, 64, 32, 32, 3}, {"hr 64->64 3x3 @32", 8, 32, 32, 64, 64, 3},
-                            {"hr 128->128 3x3 @16", 8, 16, 16, 128, 128, 3}, {"vit 192->576 1x1 tokens", 8, 1, 276, 192, 576, 1},
+                            {"hr 128->128 3x3 @16", 8, 16, 16, 128, 128, 3}, {"hr 64->64 3x3 @64 (layer1)", 8, 64, 64, 64, 64, 3}, {"vit 192->576 1x1 tokens", 8, 1, 276, 192, 576, 1},
                             {"vit 576->192 1x1 tokens", 8, 1, 276, 576, 192, 1}, {"vit 192->192 1x1 tokens", 8, 1, 276, 192, 192, 1},
                             {"hr 64->256 1x1 @64", 8, 64, 64, 64, 256, 1},
                             {"gen 128->64 3x3 @256", 8, 256, 256, 128, 64, 3}, {"gen 256->128 3x3 @128", 8, 128, 128, 256, 128, 3},
