@@ -247,6 +247,121 @@ def run_inference(a, emit=True):
     print(json.dumps(line), flush=True)
 
 
+def roofline_from_profile(prof, nprof, hip):
+    """`roofline` of the dominant MFMA kernel from an eager, HIP-event-timed issue of the step (Ctx.profile records): algorithmic FLOPs of
+    every conv_halo launch (forward + data gradient) over their summed launch durations, against the dense peak of the active matrix mode."""
+    roof = None
+    if not prof:
+        return roof
+    split = hip.mfma_mode() in ("bf16x6", "bf16x3", "bf16")
+    nprod = {"bf16x3": 3, "bf16": 1}.get(hip.mfma_mode(), 6)
+    # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel, bit 2 = bf16x6 split-operand kernel)
+    dom = (128 << 16) | (128 << 4) | (4 if split else 0)
+    HALO = 1 << 28                            # mrfa_conv2d_last_config bit 28: the patch-tiled 3x3 kernel (conv_halo.hip)
+    sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0 and (cfg & HALO)]
+    row_tiled = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if (cfg & ~1) == dom]
+    dom_name = "conv_halo_kernel (3x3 patch-tiled split-operand tile, all variants: fwd + dgrad launches)"
+    if not sel:                               # --mfma f32 / bf16, MRFA_CONV_HALO=0: the row-tiled 128x128 tile is the dominant kernel
+        sel, dom_name = row_tiled, None
+    allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0]
+    if sel:
+        fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
+        achieved = fl / (ms * 1e-3) / 1e12
+        traffic, tsrc = None, None
+        try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
+            if dom_name:                      # the patch-tiled kernel: round-3 PMC passes (launch-weighted mean over its variants)
+                tsrc = "profiles/r3_traffic.json"
+                with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as tf:
+                    tj = json.load(tf)["kernels"]["conv_halo_kernel"]
+            elif split:                       # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
+                tsrc = "profiles/r2_traffic.json"
+                with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as tf:
+                    tj = json.load(tf)["kernels"]["conv_bf16x6_kernel<false, true, 128, 6>"]
+            else:
+                tsrc = "profiles/r1_traffic.json"
+                with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
+                    tj = json.load(tf)
+            traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 4)
+        except Exception:
+            tsrc = None
+        # bf16x6: six bf16 MFMA products per fp32 multiply-add -> ceiling = bf16 dense peak / 6, in fp32-equivalent FLOPs
+        peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
+                "traffic_source": (f"{tsrc}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run" if tsrc else None),
+                "peak_is": (f"bf16 dense MFMA peak 2500 / {nprod} split products (fp32-equivalent FLOPs)" if split
+                            else "fp32 dense MFMA peak"),
+                "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                # measured, not nominal: what the kernel's [12 ds_read_b128 + 24 MFMA] step sustains on this part with random operand
+                # bits (power-limited; the register-only MFMA loop: 291) -- tools/ubench/mfma_lds_mix.hip, profiles/r3_mfma_lds_mix.txt
+                "sustained_ceiling_random_operands": ({"tflops": SUSTAINED_X6_TFLOPS, "frac": round(achieved / SUSTAINED_X6_TFLOPS, 4),
+                                                       "source": "profiles/r3_mfma_lds_mix.txt"} if (split and nprod == 6) else None),
+                "kernel": dom_name or ("conv_bf16x6_kernel 128x128 (fwd + dgrad launches)" if split
+                                       else "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)"),
+                "row_tiled_128x128": ({"launches_per_step": len(row_tiled) / nprof, "kernel_ms_per_step": round(sum(t for _, t in row_tiled) / nprof, 2),
+                                       "tflops": round(sum(f for f, _ in row_tiled) / max(sum(t for _, t in row_tiled), 1e-9) / 1e9, 2)}
+                                      if (dom_name and row_tiled) else None),
+                "launches_per_step": len(sel) / nprof, "avg_launch_ms": round(ms / len(sel), 4),
+                "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
+                "kernel_ms_per_step": round(ms / nprof, 2),
+                "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / nprof, 2),
+                "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
+    return roof
+
+
+def run_config4(dev, steps: int = 6, warmup: int = 2):
+    """BASELINE.json configs[3] on ONE GPU, for the record inside the default line (outside its timed region): celebvhq.yaml wiring (MTIA prior +
+    BGMotionPredictor -> bg_param), 256 x 256, bs = 16, plain-bf16 matrix products (`--mfma bf16`: operands rounded to nearest-even bf16, fp32
+    accumulate; activations are still stored as fp32 -- the bf16 STORAGE path is not built), fwd + bwd + clip + Adam as a hipGraph.
+    `roofline` = the conv_halo launches against the 2 500 TF/s dense bf16 peak.  The full line is `python bench.py --background --mfma bf16 --batch 16`."""
+    from mrfa_amd import hip
+    from mrfa_amd.engine import Ctx
+    from mrfa_amd.graph import GraphedTrainStep
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
+    from mrfa_amd.utils.prng import det_uniform
+    prev = hip.mfma_mode()
+    hip.set_mfma_mode("bf16")
+    try:
+        B = 16
+        model = HotPath(VOX1, prior="mtia", background=True)
+        init_weights(model)
+        model.to(dev).train(True)
+        opt = make_optimizer(model, lr=VOX1["train_params"]["lr"], capturable=True, fused=True, clip=VOX1["train_params"]["clip"])
+        src = det_uniform("bench4/src", (B, 3, 256, 256), 0, 1).to(dev)
+        drv = det_uniform("bench4/drv", (B, 3, 256, 256), 0, 1).to(dev)
+        g = GraphedTrainStep(model, opt, src, drv, clip=VOX1["train_params"]["clip"], world=1)
+        g.verify(loss_tol=5e-3)                        # (bf16 products amplify summation-order noise to ~1e-3 in the loss)
+        for _ in range(warmup):
+            g(src, drv)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = g(src, drv)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        loss_val = float(loss.item())
+        verify = dict(g.last_verify)
+        del g
+        for prm in model.parameters():
+            prm.grad = None
+        train_step(model, opt, src, drv, clip=VOX1["train_params"]["clip"])
+        Ctx.profile = []
+        nprof = 2
+        for _ in range(nprof):
+            train_step(model, opt, src, drv, clip=VOX1["train_params"]["clip"])
+        torch.cuda.synchronize()
+        prof, Ctx.profile = Ctx.profile, None
+        roof = roofline_from_profile(prof, nprof, hip)
+        return {"metric": "frames/sec (256x256 source+driving pair) fwd+bwd", "value": round(B / dt, 3), "unit": "pairs/s", "ms_per_step": round(1e3 * dt, 3),
+                "batch": B, "dtype": "bf16", "launch": "hipGraph", "loss": float(f"{loss_val:.6f}"), "graph_verify": verify,
+                "workload": "celebvhq.yaml (bg_start 0: BGMotionPredictor -> bg_param), MTIA prior + DenseMotion + RaftFlow, 256x256, bs=16, "
+                            "fwd+bwd+clip+Adam, plain-bf16 MFMA products on fp32-stored activations",
+                "roofline": roof}
+    finally:
+        Ctx.profile = None
+        hip.set_mfma_mode(prev)
+
+
 def spawn_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks here, the way the reference gets its ranks
     from torch.distributed.launch (run.py:50-59, train.py:39-48).  This parent NEVER touches the GPU (no HIP call, no
@@ -540,7 +655,7 @@ def main():
         loss_fn = lambda m_, s_, d_: reference_loss(m_.module if hasattr(m_, "module") else m_, full, s_, d_)
     step = lambda: train_step(model, opt, src, drv, clip=clip, loss_fn=loss_fn)
     launch = "eager"
-    gstep = None
+    gstep = gstep_info = None
     if use_graph:
         # one eager step (Adam state, scratch buffers, gather tables), then the whole step is captured into hipGraphs
         # (mrfa_amd/graph.py): graph A = pack + fwd + bwd, one flat RCCL all-reduce when N > 1, graph B = clip + Adam
@@ -561,6 +676,7 @@ def main():
             # replays must agree with each other and with eager passes, or the graph is not used.  ONE attempt: a failure fails the run (a
             # retry decided per rank would issue an extra round of collectives on that rank only and desynchronise the communicator)
             replay_noise = gstep.verify(loss_tol=ltol)
+            gstep_info = dict(gstep.last_verify)      # (a copy: the step object itself is released before the 512 x 512 leg)
         except Exception as ex:
             ok, why = 0, ex
         if world > 1:                                 # every rank must know before anybody raises (the others sit in a collective)
@@ -685,61 +801,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
         value = world * B * a.steps / dt
-        roof = None
-        if prof:
-            split = hip.mfma_mode() in ("bf16x6", "bf16x3", "bf16")
-            nprod = {"bf16x3": 3, "bf16": 1}.get(hip.mfma_mode(), 6)
-            # BM=128, BN=128, chunked (bit 0 = split-K launch of the same kernel, bit 2 = bf16x6 split-operand kernel)
-            dom = (128 << 16) | (128 << 4) | (4 if split else 0)
-            HALO = 1 << 28                            # mrfa_conv2d_last_config bit 28: the patch-tiled 3x3 kernel (conv_halo.hip)
-            sel = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0 and (cfg & HALO)]
-            row_tiled = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if (cfg & ~1) == dom]
-            dom_name = "conv_halo_kernel (3x3 patch-tiled split-operand tile, all variants: fwd + dgrad launches)"
-            if not sel:                               # --mfma f32 / bf16, MRFA_CONV_HALO=0: the row-tiled 128x128 tile is the dominant kernel
-                sel, dom_name = row_tiled, None
-            allc = [(f, e0.elapsed_time(e1)) for cfg, f, e0, e1, _ in prof if cfg >= 0]
-            if sel:
-                fl, ms = sum(f for f, _ in sel), sum(t for _, t in sel)
-                achieved = fl / (ms * 1e-3) / 1e12
-                traffic, tsrc = None, None
-                try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-                    if dom_name:                      # the patch-tiled kernel: round-3 PMC passes (launch-weighted mean over its variants)
-                        tsrc = "profiles/r3_traffic.json"
-                        with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as tf:
-                            tj = json.load(tf)["kernels"]["conv_halo_kernel"]
-                    elif split:                       # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
-                        tsrc = "profiles/r2_traffic.json"
-                        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as tf:
-                            tj = json.load(tf)["kernels"]["conv_bf16x6_kernel<false, true, 128, 6>"]
-                    else:
-                        tsrc = "profiles/r1_traffic.json"
-                        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as tf:
-                            tj = json.load(tf)
-                    traffic = round(tj["hbm_bytes_per_launch"] / 1e9, 4)
-                except Exception:
-                    tsrc = None
-                # bf16x6: six bf16 MFMA products per fp32 multiply-add -> ceiling = bf16 dense peak / 6, in fp32-equivalent FLOPs
-                peak = PEAK_BF16_MFMA_TFLOPS / nprod if split else PEAK_FP32_MFMA_TFLOPS
-                roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "GB/launch (PMC)",
-                        "traffic_source": (f"{tsrc}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run" if tsrc else None),
-                        "peak_is": (f"bf16 dense MFMA peak 2500 / {nprod} split products (fp32-equivalent FLOPs)" if split
-                                    else "fp32 dense MFMA peak"),
-                        "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                        # measured, not nominal: what the kernel's [12 ds_read_b128 + 24 MFMA] step sustains on this part with random operand
-                        # bits (power-limited; the register-only MFMA loop: 291) -- tools/ubench/mfma_lds_mix.hip, profiles/r3_mfma_lds_mix.txt
-                        "sustained_ceiling_random_operands": ({"tflops": SUSTAINED_X6_TFLOPS, "frac": round(achieved / SUSTAINED_X6_TFLOPS, 4),
-                                                               "source": "profiles/r3_mfma_lds_mix.txt"} if (split and nprod == 6) else None),
-                        "kernel": dom_name or ("conv_bf16x6_kernel 128x128 (fwd + dgrad launches)" if split
-                                               else "conv_mfma_kernel<128,128,2,4,false> (fwd + dgrad launches)"),
-                        "row_tiled_128x128": ({"launches_per_step": len(row_tiled) / nprof, "kernel_ms_per_step": round(sum(t for _, t in row_tiled) / nprof, 2),
-                                               "tflops": round(sum(f for f, _ in row_tiled) / max(sum(t for _, t in row_tiled), 1e-9) / 1e9, 2)}
-                                              if (dom_name and row_tiled) else None),
-                        "launches_per_step": len(sel) / nprof, "avg_launch_ms": round(ms / len(sel), 4),
-                        "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
-                        "kernel_ms_per_step": round(ms / nprof, 2),
-                        "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / nprof, 2),
-                        "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
+        roof = roofline_from_profile(prof, nprof, hip)
         c5 = None
         if world == 1 and not a.no_forward and not a.background and a.loss == "surrogate":
             # for the record (outside the timed region, N = 1 only): BASELINE configs[4], the 512x512 inference-only generator path at bs=4, so
@@ -755,6 +817,18 @@ def main():
                       "launch": l5["config"]["launch"], "roofline": l5["roofline"]}
             except Exception as ex:
                 c5 = {"error": repr(ex)}
+        c4 = None
+        if world == 1 and not a.no_forward and not a.background and a.loss == "surrogate" and a.prior == "mtia" and hip.mfma_mode() == "bf16x6" and launch == "hipGraph":
+            # for the record (outside the timed region, N = 1 only): BASELINE configs[3] on one GPU, so that the driver's default command carries its
+            # roofline too (VERDICT r3 'weak' 9)
+            try:
+                gstep = step = None
+                del model, opt
+                torch.cuda.empty_cache()
+                c4 = run_config4(dev)
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                c4 = {"error": repr(ex)}
         cpu = None
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the host cores are shared with N-1 busy ranks
             try:
@@ -774,11 +848,11 @@ def main():
                                     "the reference's generator losses (VGG19 perceptual pyramid on random-init weights + equivariance, 3 encoder passes)"),
                        "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "background_predictor": bool(a.background), "sync_bn": bool(a.sync_bn), "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}"),
-                       "tuning": a.tune or None,
+                       "tuning": a.tune or None, "graph_verify": gstep_info,
                        "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; train.sync_bn_buffers (explicit collective) averages the running "
                                          "buffers over the ranks before a checkpoint is written")},
             "roofline": roof, "cpu_baseline": cpu, "forward_only": fwd, "native_fp32_mfma_path": alt, "bf16x3_path": alt3,
-            "config5_512_inference": c5,
+            "config5_512_inference": c5, "config4_celebvhq_bs16_bf16": c4,
         }
     else:
         line = None

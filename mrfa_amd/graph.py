@@ -391,6 +391,9 @@ class GraphedTrainStep:
                 b.copy_(sv)
         if rng_state is not None:
             torch.cuda.set_rng_state(rng_state, dev)      # every rank / run continues from ITS generator state, not from the fixed seed
+        # for the record (bench.py prints it): the eager noise band and what was allowed, per parameter group
+        self.last_verify = {"eager_band": [float(f"{x:.3e}") for x in band], "allowed": [float(f"{x:.3e}") for x in allow],
+                            "worst_in_best_group": float(f"{worst:.3e}"), "replays": replays}
         return worst
 
     def __call__(self, source: torch.Tensor, driving: torch.Tensor) -> torch.Tensor:
