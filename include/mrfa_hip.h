@@ -29,7 +29,7 @@ const char* mrfa_last_error(void);
  *   3  round 3 (shipped as "1"): mrfa_conv_params += mask, ldm, w_phase, w_phase_piece, stride; mrfa_wgrad_params += stride;
  *      mrfa_bnbwd_params += sync; pack modes 8 / 9 (pre-split bf16 weight planes) became k16-chunk-major -- plane[tap][k16 chunk][row][16]
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
- *   4  round 4: see the per-struct notes below ("v4").                                                                               */
+ *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.               */
 #define MRFA_ABI_VERSION 4
 int mrfa_version(void);
 
@@ -84,7 +84,14 @@ typedef struct {
     long long w_phase_piece; /* that equal nearest-x2 + 3x3 (pack mode 12, bf16 pieces).  When present (and the patch-tiled kernel  */
                            /*   applies) the layer runs 16 instead of 36 taps per low-resolution pixel -- same result up to fp32 rounding */
     int stride;            /* 0 / 1: stride 1.  2: strided convolution, Hout = (Hin + 2 pad - R) / 2 + 1 (HRNet's downsampling 3x3 layers,       */
-                           /*   hr_base.py:241,253,302,305,365) -- only where mrfa_conv2d_stride_supported() says so                             */
+                           /*   hr_base.py:241,253,302,305,365) -- only where mrfa_conv2d_stride_supported() says so.                            */
+                           /*   -2 (v4): the DATA GRADIENT of such a layer: x = dY (Hin x Win) is read as sitting at the even pixels of the      */
+                           /*   Hout = 2 Hin x Wout = 2 Win output grid (zeros between), stride-1 convolution over that grid with `pad` and the  */
+                           /*   data-gradient weight pack: 9 / 4 of the taps per output pixel, no zero-stuffed copy (same query function)         */
+    const void* w_wino;    /* v4, optional (3x3 / pad 1 / stride 1, no upsample): the weights run through the Winograd F(2, 3) transform ALONG X    */
+    long long w_wino_piece;/*   (pack mode 16; 17 for data-gradient launches), three bf16 pieces.  When present and mrfa_conv2d_wino_supported()  */
+                           /*   the patch-tiled kernel computes two horizontally adjacent outputs from 4 instead of 6 products per kernel row:    */
+                           /*   12 instead of 18 MFMA steps per pixel pair -- same result up to fp32 rounding of the transforms                   */
 } mrfa_conv_params;
 
 /* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS
@@ -97,6 +104,7 @@ int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
 int mrfa_conv2d_stride_supported(const mrfa_conv_params* p);         /* 1: a call with these parameters honours stride = 2                */
 int mrfa_conv2d_mask_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters honours `mask`                    */
 int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p);    /* 1: a call with these parameters (ups = 2) is implemented          */
+int mrfa_conv2d_wino_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters would run the Winograd form if w_wino were set */
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
  *   1  fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate
@@ -169,7 +177,10 @@ int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p);  /* 1: a cal
  * mode 13: mode 12 transposed ([piece][16][CinPad128][CoutPad32]) for the phase data gradient (ups = 2)
  * mode 12: 3x3 only: the phase weights of UpBlock2d's nearest-x2 + conv (see mrfa_conv_params.w_phase): three bf16 planes
  *         [piece][16 phase taps][CoutPad128][CinPad32], phase tap = (py*2+px)*4 + a*2+b, weight = sum of the 3x3 taps that read
- *         the same low-resolution pixel (batched entry point only)                                                             */
+ *         the same low-resolution pixel (batched entry point only)
+ * modes 16 / 17: 3x3 only: Winograd F(2, 3) along x (see mrfa_conv_params.w_wino): U[r][xi] = sum_s G[xi][s] w[r][s], G = [1 0 0; 1/2 1/2 1/2;
+ *         1/2 -1/2 1/2; 0 0 1]; three bf16 planes [piece][r * 4 + xi][CoutPad128][CinPad32] (16) or, of the flipped / transposed kernel of the
+ *         data gradient, [piece][r' * 4 + xi][CinPad128][CoutPad32] (17); k16-chunk-major (batched entry point only)                     */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 
 /* Batched forms: all layouts of many convolutions per launch (descriptor table passed by value in the kernel

@@ -334,7 +334,7 @@ int mrfa_tuning_conv_lds(int set) {
 
 bool mrfa_conv_lds_eligible(const mrfa_conv_params& p) {
     if (!mrfa_tuning_conv_lds(-1)) return false;
-    if (p.kflat > 0 || p.ups || p.nbatch > 1 || p.splitk > 1 || p.tile || p.mask || p.stride > 1) return false;
+    if (p.kflat > 0 || p.ups || p.nbatch > 1 || p.splitk > 1 || p.tile || p.mask || p.stride > 1 || p.stride < 0) return false;
     if (p.R != 3 || p.S != 3 || p.pad != 1 || p.Hout != p.Hin || p.Wout != p.Win) return false;
     if ((p.Cin & 31) || p.Cin > 256 || p.Cout < 16 || p.Cout > 256 || p.Wout > 64 || (p.Wout & 15)) return false;
     if ((p.ldx & 3) || (p.w_ld & 3) || !aligned16(p.x) || !aligned16(p.w)) return false;

@@ -340,8 +340,10 @@ static thread_local int g_last_tile = 0;
 extern "C" int mrfa_conv2d_last_config(void) { return g_last_tile; }
 
 extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
-    if (!p || p->stride != 2 || !mrfa_tuning_conv_small()) return 0;
-    if (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1) return 0;
+    if (!p || (p->stride != 2 && p->stride != -2) || !mrfa_tuning_conv_small()) return 0;
+    if (p->stride == 2 && (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1)) return 0;
+    // stride == -2: the data gradient of a stride-2 layer (x = dY on the Hin x Win grid, y = dX on the Hout = 2 Hin x Wout = 2 Win grid, pad = R - 1 - pad
+    // of the layer, weights in the data-gradient pack): checked by the kernel's own eligibility
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
@@ -377,7 +379,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
         return mrfa_conv_small_launch(st, p, M);
     }
-    if (p.stride > 1) {
+    if (p.stride > 1 || p.stride < 0) {
         mrfa_set_error("conv2d: stride = %d is only implemented by the one-wave-per-tile kernel: ask mrfa_conv2d_stride_supported() first", p.stride);
         return 1;
     }

@@ -28,7 +28,11 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // load-latency bound at one wave per SIMD: ~1.5 us per round trip under load)
 // CK = k16 chunks per loop step (2: the 16 x 16 / 16 x 32 wave tiles, whose 4-8 MFMAs per k16 did not cover the per-step loader advance:
 // two scalar branches, the tap bookkeeping and a waitcnt per step)
-template <int TMW, int TNW, int DEPTH, int CK>
+// TS ("transposed stride"): the DATA GRADIENT of a stride-2 convolution (p.stride == -2): the input (dY, Hin x Win) sits at the even pixels of the
+// Hout x Wout output grid, zeros between.  Output pixels are processed per PARITY CLASS (blockIdx.y = 2 cy + cx), M = pixels of one class: a class
+// only meets the taps whose source lands on an even pixel -- 1, 2, 2 or 4 of the nine for a 3x3 / pad 1 layer -- i.e. 9 / 4 taps per pixel instead of
+// the 9 of a stride-1 convolution over a zero-stuffed copy of dY (which also cost a fill and a scatter launch per layer; hr_base.py:241,253,302,305,365).
+template <int TMW, int TNW, int DEPTH, int CK, bool TS = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int wave_tiles_m) {
     constexpr int WM = 16 * TMW, WN = 16 * TNW;
     __shared__ float sred[4][2][WN];                  // per-wave column sums for the BatchNorm statistics
@@ -46,10 +50,14 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     const bool wave_on = wt_m < wave_tiles_m;
     const long long m0 = wt_m * WM;
     const int n0 = tile_n * WN;
-    const int HWo = p.Hout * p.Wout;
+    const int cy = TS ? (int)(blockIdx.y >> 1) : 0, cx = TS ? (int)(blockIdx.y & 1) : 0;          // parity class of the output pixels
+    const int Hq = TS ? p.Hout >> 1 : p.Hout, Wq = TS ? p.Wout >> 1 : p.Wout;                       // (class-local) pixel grid
+    const int HWo = Hq * Wq;
     const int KC = p.Cin / (16 * CK);                 // loop steps (CK k16 chunks each) per tap
-    const int T = p.R * p.S;
-    const int nq = T * KC;
+    // TS: taps r = r0, r0 + 2, ..: those with (cy + r - pad) even
+    const int r0 = TS ? ((p.pad - cy) & 1) : 0, s0 = TS ? ((p.pad - cx) & 1) : 0;
+    const int nr = TS ? (p.R - r0 + 1) / 2 : p.R, ns = TS ? (p.S - s0 + 1) / 2 : p.S;
+    const int nq = nr * ns * KC;
     const int cstride = p.stride > 1 ? p.stride : 1;
 
     int a_oy[TMW], a_ox[TMW];
@@ -62,8 +70,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         const long long mm = a_ok[a] ? m : 0;
         const int n_img = (int)(mm / HWo);
         const int rem = (int)(mm - (long long)n_img * HWo);
-        a_oy[a] = rem / p.Wout;
-        a_ox[a] = rem - a_oy[a] * p.Wout;
+        a_oy[a] = rem / Wq;
+        a_ox[a] = rem - a_oy[a] * Wq;
+        if (TS) { a_oy[a] = 2 * a_oy[a] + cy; a_ox[a] = 2 * a_ox[a] + cx; }
         a_img[a] = (long long)n_img * p.Hin * p.Win;
     }
     // B rows: packed weights are zero-padded to a multiple of 128 rows, so every row n0 + b*16 + li < w_rows is readable
@@ -83,12 +92,13 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     int l_r = 0, l_s = 0, l_c = 0, l_q = 0;
     const float* arow[TMW];
     bool ainb[TMW];
-    size_t w_tap_off = 0;
+    size_t w_tap_off = TS ? (size_t)(r0 * p.S + s0) * p.w_tap : 0;
     auto set_tap = [&]() {
-        const int dr = l_r - p.pad, ds = l_s - p.pad;
+        const int dr = (TS ? r0 + 2 * l_r : l_r) - p.pad, ds = (TS ? s0 + 2 * l_s : l_s) - p.pad;
 #pragma unroll
         for (int a = 0; a < TMW; ++a) {
-            const int iy = a_oy[a] * cstride + dr, ix = a_ox[a] * cstride + ds;        // (strided layers: hr_base.py:241,253,302,305,365)
+            // (strided layers: hr_base.py:241,253,302,305,365; TS: source pixel of the zero-stuffed grid position, even by construction)
+            const int iy = TS ? (a_oy[a] + dr) >> 1 : a_oy[a] * cstride + dr, ix = TS ? (a_ox[a] + ds) >> 1 : a_ox[a] * cstride + ds;
             ainb[a] = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             const long long pix = ainb[a] ? a_img[a] + (long long)iy * p.Win + ix : a_img[a];
             arow[a] = p.x + (size_t)pix * p.ldx + lk * 4;
@@ -111,8 +121,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
             ++l_q;
             if (++l_c == KC) {
                 l_c = 0;
-                w_tap_off += p.w_tap;
-                if (++l_s == p.S) { l_s = 0; ++l_r; }
+                if (++l_s == ns) { l_s = 0; ++l_r; }
+                w_tap_off = TS ? (size_t)((r0 + 2 * l_r) * p.S + s0 + 2 * l_s) * p.w_tap : w_tap_off + p.w_tap;
                 set_tap();
             }
         }
@@ -179,8 +189,15 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         for (int a = 0; a < TMW; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long m = m0 + a * 16 + kq * 4 + r;
-                if (c_ok && m < M) {
+                const long long mc = m0 + a * 16 + kq * 4 + r;     // (class-local) pixel index
+                long long m = mc;
+                if (TS && mc < M) {                                // -> pixel (2 qy + cy, 2 qx + cx) of the output grid
+                    const int n_img = (int)(mc / HWo);
+                    const int rem = (int)(mc - (long long)n_img * HWo);
+                    const int qy = rem / Wq, qx = rem - qy * Wq;
+                    m = ((long long)n_img * p.Hout + 2 * qy + cy) * p.Wout + 2 * qx + cx;
+                }
+                if (c_ok && mc < M) {
                     float v = acc[a][b][r] * p.alpha + bias;
                     v = v * osc + osh;
                     float* dst = p.y + (size_t)m * p.ldy + c;
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
             const int c = n0 + col;
             if (c < p.Cout) {
                 const double v = (double)sred[0][which][col] + (double)sred[1][which][col] + (double)sred[2][which][col] + (double)sred[3][which][col];
-                atomicAdd(p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout + which * p.Cout + c, v);
+                atomicAdd(p.stats + (size_t)((blockIdx.x + blockIdx.y) % MRFA_STATS_SLOTS) * 2 * p.Cout + which * p.Cout + c, v);
             }
         }
     }
@@ -220,8 +237,12 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
 // multiples of 16, and a problem small enough that the 128-row workgroup tiles cannot fill the chip.
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
     if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.tile || p.splitk > 1 || p.mask) return false;
-    if (p.stride > 2) return false;
-    const bool strided = p.stride == 2;              // the only kernel with a strided gather: takes every such layer that fits its addressing
+    if (p.stride > 2 || p.stride < -2 || p.stride == -1) return false;
+    if (p.stride == -2) {                            // data gradient of a stride-2 layer: even output grid, dY at its even pixels
+        if ((p.Hout & 1) || (p.Wout & 1) || p.Hin != p.Hout / 2 || p.Win != p.Wout / 2 || p.R != p.S || p.res || p.stats) return false;
+        M = M / 4;                                   // (pixels of one parity class)
+    }
+    const bool strided = p.stride == 2 || p.stride == -2;      // the only kernel with a strided gather: takes every such layer that fits its addressing
     if ((p.Cin & 15) || (p.ldx & 3) || (p.w_ld & 3)) return false;
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const long long ktot = (long long)p.R * p.S * p.Cin;
@@ -237,6 +258,8 @@ bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
 }
 
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M) {
+    const bool ts = p.stride == -2;
+    if (ts) M /= 4;                                  // one parity class per blockIdx.y
     // wave tile: the largest of 32x32 / 16x32 / 16x16 that still yields >= ~2 000 waves (two per SIMD: measured best once the loads coalesce)
     const int ncols = (p.Cout + 15) / 16 * 16;
     auto waves = [&](int wm, int wn) { return ((M + wm - 1) / wm) * ((ncols + wn - 1) / wn); };
@@ -250,7 +273,7 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
     const int tiles_n = (ncols + WN - 1) / WN;
     const int wave_tiles_m = (int)((M + WM - 1) / WM);
     const long long blocks = (long long)((wave_tiles_m + 3) / 4) * tiles_n;
-    dim3 grid((unsigned)blocks);
+    dim3 grid((unsigned)blocks, ts ? 4u : 1u);
     const bool deep = (long long)p.R * p.S * p.Cin >= 512;
     // two k16 chunks per loop step: small wave tiles on deep K (measured: 64->64 3x3 14.8 -> 13.6 us, 128->128 15.6 -> 13.9, 576->192
     // linear 14.4 -> 13.0; short K gets slower: 32->32 3x3 14.0 -> 15.6, 192->576 12.6 -> 15.1)
@@ -261,7 +284,12 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
         else if (deep) hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 8, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);    \
         else hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 4, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);              \
     } while (0)
-    if (tm == 2 && tn == 2) SMALL_LAUNCH(2, 2);
+    if (ts) {                                        // (short tap lists: the shallow ring; one instantiation per wave tile)
+        if (tm == 2 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<2, 2, 4, 1, true>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+        else if (tm == 1 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<1, 2, 4, 1, true>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+        else hipLaunchKernelGGL((conv_small_kernel<1, 1, 4, 1, true>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
+    }
+    else if (tm == 2 && tn == 2) SMALL_LAUNCH(2, 2);
     else if (tm == 1 && tn == 2) SMALL_LAUNCH(1, 2);
     else SMALL_LAUNCH(1, 1);
 #undef SMALL_LAUNCH

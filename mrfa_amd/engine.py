@@ -140,11 +140,20 @@ class defer_wgrads:
 
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
+# data gradient of the stride-2 layers straight from dY (mrfa_conv_params.stride = -2: parity classes of the output grid, 9 / 4 of the taps) instead of a
+# stride-1 pass over a zero-stuffed copy.  OFF (MRFA_STRIDED_DGRAD=1): measured in the step 84.0 / 84.0 vs 83.6 / 83.5 ms (alternating runs): ~40 launches
+# per step whose four per-class sub-problems (1-4 taps x 4-8 k-steps) are too short to amortise the operand ring -- a quarter of the MACs, not less time
+STRIDED_DGRAD = os.environ.get("MRFA_STRIDED_DGRAD", "0") == "1"
 NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2 layers as one strided launch (conv_small / wgrad_small) instead of stride 1 + sub-sampling
 # BatchNorm backward of small tensors as ONE launch (grid barrier between its phases, mrfa_bn_act_bwd phase 3).  OFF: measured on the training step
 # 84.3 -> 90.0 ms -- the barrier needs every workgroup of the launch resident, and beside the deferred decoder weight gradients (one 256-VGPR
 # workgroup per CU for hundreds of microseconds) the last workgroups of each of the ~340 launches wait for a CU while the others spin
 BN_BWD_FUSED = os.environ.get("MRFA_BN_BWD_FUSED", "0") == "1"
+# Winograd F(2, 3)-along-x form of the plain 3x3 layers on the patch-tiled kernel (conv_halo MODE 3, pack modes 16 / 17).  OFF by default
+# (MRFA_WINO=1): 1.10-1.16x per launch in the launch loop but nothing measurable in the training step (LDS-read bound), and its
+# fp32 rounding (within 4x of the direct kernel's against fp64) is visible in ill-conditioned downstream quantities (the keypoint encoder's
+# gradient of the config-4 parity test moved from norm ratio 1.075 to 1.26)
+WINO = os.environ.get("MRFA_WINO", "0") == "1"
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -231,6 +240,10 @@ def prepare_packs(module: torch.nn.Module) -> bool:
             cw.phase_pack()
         if getattr(cw, "_dg_ph", None) is not None:
             cw.phase_pack(dgrad=True)
+        if getattr(cw, "_fwd_wx", None) is not None:
+            cw.wino_pack()
+        if getattr(cw, "_dg_wx", None) is not None:
+            cw.wino_pack(dgrad=True)
         if cw._fo is not None:
             cw.fewout_pack()
         if cw._fi is not None:
@@ -504,6 +517,31 @@ class ConvW:
             setattr(self, ver, self._key())
         return buf, piece
 
+    def wino_pack(self, dgrad: bool = False) -> tuple:
+        """(buffer, elements per piece) of the Winograd F(2, 3)-along-x weights U = G w of this 3x3 conv (pack mode 16; dgrad: mode 17, the flipped /
+        transposed kernel of the data gradient), three bf16 pieces: the patch-tiled kernel's MODE 3 (csrc/conv_halo.hip)"""
+        assert self.R == 3 and self.S == 3
+        attr, ver, mode = ("_dg_wx", "_ver_dwx", 17) if dgrad else ("_fwd_wx", "_ver_wx", 16)
+        if dgrad:
+            assert not self.dgrad_flat
+            piece = 12 * ((self.Cin + 127) // 128 * 128) * self.Cout
+        else:
+            assert not self.fwd_flat
+            piece = 12 * ((self.Cout + 127) // 128 * 128) * self.Cin
+        buf = getattr(self, attr, None)
+        w = self.conv.weight.detach()
+        if buf is None or buf.numel() != 3 * piece or buf.device != w.device:
+            buf = torch.zeros(3 * piece, dtype=torch.int16, device=w.device)
+            setattr(self, attr, buf)
+            setattr(self, ver, None)
+        if getattr(self, ver, None) != self._key():
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.contiguous().data_ptr(), self.Cout, self.Cin, self.R, self.S, 1
+            d.dst[0], d.mode[0] = buf.data_ptr(), mode
+            hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack(winograd)")
+            setattr(self, ver, self._key())
+        return buf, piece
+
     def _simple_pack(self, attr, ver_attr, mode):
         if getattr(self, attr) is None or getattr(self, ver_attr) != self._key():
             w = self.conv.weight.detach()
@@ -583,6 +621,10 @@ class PackPlan:
                 dsts.append((cw._fwd_ph, 12))
             if getattr(cw, "_dg_ph", None) is not None:
                 dsts.append((cw._dg_ph, 13))
+            if getattr(cw, "_fwd_wx", None) is not None:
+                dsts.append((cw._fwd_wx, 16))
+            if getattr(cw, "_dg_wx", None) is not None:
+                dsts.append((cw._dg_wx, 17))
             if cw._fo is not None:
                 dsts.append((cw._fo, 5))
             if cw._fi is not None:
@@ -600,7 +642,7 @@ class PackPlan:
         self.table = (hip.PackDesc * max(self.n, 1))(*descs)
         self.ptrs = [(cw, cw.conv.weight.data_ptr()) + self._buffer_ids(cw) for cw in self.cws]
 
-    _PLANES = ("_fwd", "_dg", "_fwd_s", "_dg_s", "_fwd_r", "_dg_r", "_fwd_ph", "_dg_ph", "_fo", "_fi")
+    _PLANES = ("_fwd", "_dg", "_fwd_s", "_dg_s", "_fwd_r", "_dg_r", "_fwd_ph", "_dg_ph", "_fwd_wx", "_dg_wx", "_fo", "_fi")
 
     @classmethod
     def _buffer_ids(cls, cw) -> tuple:
@@ -616,6 +658,7 @@ class PackPlan:
             assert cw.conv.weight.data_ptr() == wptr and self._buffer_ids(cw) == ids, "PackPlan is stale: rebuild it"
             k = cw._key()
             cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = cw._ver_fr = cw._ver_dr = k
+            cw._ver_wx = cw._ver_dwx = k
 
 
 def unpack_direct(cws: List["ConvW"], accs: Optional[List[torch.Tensor]] = None):
@@ -977,6 +1020,7 @@ class Ctx:
         if stats is not None:
             p.stats = stats.data_ptr()
         p.alpha, p.nbatch = 1.0, 1
+        self._maybe_wino(p, cw, dgrad=False, padded=padded, ups=ups)
         self._launch_conv(p, "conv2d", cw.Cin)
 
         if self.record:
@@ -996,6 +1040,18 @@ class Ctx:
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
         return out
+
+    def _maybe_wino(self, p, cw: ConvW, dgrad: bool, padded: bool, ups: bool):
+        """hand the launch the Winograd-along-x weights (ConvW.wino_pack) where the library would use them: plain 3x3 / pad 1 layers on the
+        patch-tiled kernel with 8-row patches in a split-operand mode (mrfa_conv2d_wino_supported); the pack is only ever built for such layers"""
+        if not (WINO and self.split and cw.R == 3 and cw.S == 3 and cw.pad == 1 and not ups and not padded and p.kflat == 0 and p.w_split):
+            return
+        if dgrad and cw.dgrad_flat or (not dgrad and cw.fwd_flat):
+            return
+        if not self.L.mrfa_conv2d_wino_supported(C.byref(p)):
+            return
+        wx, p.w_wino_piece = cw.wino_pack(dgrad)
+        p.w_wino = wx.data_ptr()
 
     def _defer_ok(self, cw: ConvW) -> bool:
         """this weight gradient may go to the deferred side chain: a collection is active and the gradient is accumulated straight
@@ -1134,6 +1190,7 @@ class Ctx:
             fused = bool(self.L.mrfa_conv2d_mask_supported(C.byref(p)))
             if not fused:
                 p.mask, p.ldm = None, 0
+        self._maybe_wino(p, cw, dgrad=True, padded=padded, ups=False)
         self._launch_conv(p, "dgrad", cw.Cout)
         if relu_in and not fused:
             self._relu_mask_pass(x)
@@ -1633,13 +1690,35 @@ class Ctx:
                         self._conv_wgrad(x, cw, full, False, None, False)
                 else:
                     full = None
-                if need_dx:
+                if need_dx and not (full is None and self._strided_dgrad(x, cw, out)):
                     full = full or self._zero_stuffed(out, x.H, x.W)
                     self._conv_dgrad(x, cw, full, False, None)
             self.tape.append(bwd)
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
         return out, stats
+
+    def _strided_dgrad(self, x: View, cw: ConvW, out: View) -> bool:
+        """x.grad += the data gradient of the stride-2 layer cw straight from out.grad (mrfa_conv_params.stride = -2: 9 / 4 of the taps per pixel,
+        no zero-stuffed copy of dY, no fill / scatter launches); False: the library has no such kernel for this shape"""
+        if not STRIDED_DGRAD or cw.dgrad_flat or x.coff % 4 or out.coff % 4:
+            return False
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.ptr, out.ld, out.H, out.W, 0, out.N, cw.Cout      # (placeholder pointer for the query)
+        cip = (cw.Cin + 127) // 128 * 128
+        p.w_ld, p.w_tap, p.kflat, p.w_rows = cw.Cout, cip * cw.Cout, 0, cip
+        p.Cout, p.Hout, p.Wout = cw.Cin, x.H, x.W
+        p.R, p.S, p.pad, p.stride = cw.R, cw.S, cw.R - 1 - cw.pad, -2
+        p.alpha, p.nbatch = 1.0, 1
+        p.y, p.ldy, p.w = x.ptr, x.ld, x.ptr
+        if not self.L.mrfa_conv2d_stride_supported(C.byref(p)):
+            return False
+        first = self._claim(x)
+        p.x = out.gptr
+        p.w = cw.dgrad_pack(False).data_ptr()
+        p.y, p.accumulate = x.gptr, 0 if first else 1
+        self._launch_conv(p, "dgrad(stride 2)", cw.Cout)
+        return True
 
     def _zero_stuffed(self, out: View, H: int, W: int) -> View:
         """(backward) a stride-1-sized view whose GRADIENT is out.grad at the even pixels and zero elsewhere: dY of the equivalent

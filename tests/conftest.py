@@ -28,3 +28,19 @@ def fresh_mode(request, monkeypatch):
         monkeypatch.setattr(engine, "FRESH_MIN_ELEMS", 0)
         monkeypatch.setattr(engine, "FRESH_NAN", True)
     return request.param
+
+
+@pytest.fixture(autouse=True)
+def _library_defaults(request):
+    """Every GPU test starts from the library's DEFAULT matrix mode (bf16x6 unless MRFA_MFMA says otherwise).  The kernel tests switch modes and
+    end with mrfa_set_mfma_mode(0); without this reset every test file that runs after tests/test_kernels_gpu.py (the parity, loss and TokenPose
+    tests) silently ran on the native fp32 pipe instead of the mode the benchmark uses -- found in round 4."""
+    if request.node.get_closest_marker("gpu") is not None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from mrfa_amd import hip
+                hip.set_mfma_mode(os.environ.get("MRFA_MFMA", hip.DEFAULT_MFMA))
+        except Exception:
+            pass
+    yield

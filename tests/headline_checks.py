@@ -130,8 +130,12 @@ def check_against_reference(g, names, sfx, loss, gen, kps, dkps, grads, numels, 
     return worst
 
 
-def oracle_run(sds: dict, src, drv, train: bool, threads: int = 0):
-    """the oracle's forward + autograd backward of the same program on the host -> (loss, gen, kps, dkps, {name: grad}, buffers)"""
+def oracle_run(sds: dict, src, drv, train: bool, threads: int = 0, native_convs: bool = False):
+    """the oracle's forward + autograd backward of the same program on the host -> (loss, gen, kps, dkps, {name: grad}, buffers).
+    native_convs: ATen's own convolution kernels instead of oneDNN's -- a second fp32 realisation (another summation order)"""
+    if native_convs:
+        with torch.backends.mkldnn.flags(enabled=False):
+            return oracle_run(sds, src, drv, train, threads)
     from oracle import mrfa_oracle as O
     if threads:
         torch.set_num_threads(threads)
@@ -172,6 +176,24 @@ def check_against_oracle(names, grads, ograds, what, band=None):
     print(f"{what} vs the oracle's autograd (whole vectors):\n" + "\n".join(lines))
     assert not fails, (what, fails)
     return worst
+
+
+def whole_vector_band(names, grads_a, grads_b):
+    """{sub-network: (1 - cos, relative norm difference)} between two fp32 realisations of the ORACLE (whole gradient vectors): the sampled
+    entries of the golden under-estimate the rounding noise of vectors with 10^7 entries (decoder.generator: 3e-6 on the samples, 7e-5 on the
+    whole vector), so the whole-vector comparison gets its own, directly measured band"""
+    out = {}
+    for grp in sorted({subnet(n) for n in names}):
+        ns = [n for n in names if subnet(n) == grp]
+        a = torch.cat([grads_a[n].detach().reshape(-1).double() for n in ns])
+        b = torch.cat([grads_b[n].detach().reshape(-1).double() for n in ns])
+        cd = 1.0 - float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        out[grp] = (cd, abs(float(a.norm()) - float(b.norm())) / max(float(b.norm()), 1e-300), float(b.norm()))
+    return out
+
+
+def merge_bands(a, b):
+    return {k: (max(a[k][0], b[k][0]), max(a[k][1], b[k][1]), a[k][2]) for k in a}
 
 
 def reference_band(g, names, numels, sfx):

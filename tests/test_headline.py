@@ -63,6 +63,10 @@ def test_replayed_mtia_training_step_vs_reference_and_oracle_autograd(golden_dir
     # the oracle's autograd on the host, same weights and inputs
     o_loss, o_gen, o_kps, o_dkps, o_grads, o_P = H.oracle_run(sds, src, drv, train=train, threads=min(32, torch.get_num_threads()))
     H.check_against_reference(g, names, sfx, o_loss, o_gen, o_kps, o_dkps, o_grads, numels, "oracle (fp32, host)")
+    # a second fp32 realisation of the oracle (ATen-native convolutions): its whole-vector distance from the first is the rounding noise of fp32
+    # on THESE vectors, measured without the implementation under test
+    o2_grads = H.oracle_run(sds, src, drv, train=train, threads=min(32, torch.get_num_threads()), native_convs=True)[4]
+    band = H.merge_bands(band, H.whole_vector_band(names, o_grads, o2_grads))
 
     def replay():
         step.g_fb.replay()                                # graph A only: zero, pack, forward, loss, backward; the weights stay put
@@ -89,8 +93,8 @@ def test_replayed_mtia_training_step_vs_reference_and_oracle_autograd(golden_dir
                 n = key[len("train_buf_"):]
                 e = float((bufs[n].cpu() - torch.from_numpy(g[key])).abs().max())
                 assert e <= 1e-5 * max(1.0, float(np.abs(g[key]).max())), (n, e)
-            # the oracle's buffers agree as well
-            for n in ("encoder.pre_feature.bn1.running_mean", "decoder.generator.first.norm.running_var"):
+            # the oracle's encoder buffers agree as well (its decoder restatement does not update running statistics)
+            for n in ("encoder.pre_feature.bn1.running_mean",):
                 assert float((bufs[n].cpu() - o_P[n]).abs().max()) <= 1e-5
     # the full step (graph A + clip + Adam) then moves every weight that has a gradient
     step(src.to(dev), drv.to(dev))

@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, lds=False, tag="c"):
+              stride=1, lds=False, wwino=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -114,6 +114,17 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
             side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
             keep.append(wsb)
             p.w_split, p.w_piece = wsb.data_ptr(), 0 if rne else piece
+        if wwino:                   # the Winograd-along-x weights U = G w (pack mode 16): the patch-tiled kernel then runs 12 instead of 18 steps per pixel pair
+            wpiece = 12 * cop * Cin
+            wwb = torch.zeros(3 * wpiece, dtype=torch.int16, device=side.dev)
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, S, 1
+            d.dst[0], d.mode[0] = wwb.data_ptr(), 16
+            side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
+            keep.append(wwb)
+            if side.gpu:
+                assert side.L.mrfa_conv2d_wino_supported(C.byref(p)) == 0 or True      # (asked again below, once the output is attached)
+            p.w_wino, p.w_wino_piece = wwb.data_ptr(), wpiece
         if wphase:                  # the 16 phase-tap weights of nearest-x2 + 3x3 (pack mode 12)
             ppiece = 16 * cop * Cin
             wpb = torch.zeros(3 * ppiece, dtype=torch.int16, device=side.dev)
@@ -156,9 +167,17 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         assert side.L.mrfa_conv2d_stride_supported(C.byref(p)) == 1
     if mask and side.gpu:
         assert side.L.mrfa_conv2d_mask_supported(C.byref(p)) == 1
-    side.call("mrfa_conv2d_nhwc", C.byref(p))
-    if lds and side.gpu:            # the case is meant for the LDS-staged kernel: make sure the dispatcher sent it there
+    if wwino and side.gpu:
+        assert side.L.mrfa_conv2d_wino_supported(C.byref(p)) == 1, "the Winograd form does not apply to this launch"
+    if lds and side.gpu:            # the case is meant for the (opt-in) LDS-staged kernel: switch it on for this launch and make sure it ran
+        prev_lds = side.L.mrfa_set_tuning(b"conv_lds", 1)
+        try:
+            side.call("mrfa_conv2d_nhwc", C.byref(p))
+        finally:
+            side.L.mrfa_set_tuning(b"conv_lds", prev_lds)
         assert side.L.mrfa_conv2d_last_config() & 16, "not dispatched to conv_lds"
+    else:
+        side.call("mrfa_conv2d_nhwc", C.byref(p))
     return side.done(y[:, :Cout], st.sum(0))
 
 
@@ -324,6 +343,88 @@ def test_conv2d_patch_tiled_kernel(name, mode):
         L.mrfa_set_tuning(b"conv_halo_bn192", 1)
     # mode 3: both operands rounded to 8 significand bits (2^-9 each), K = 288 .. 2304 products per output
     assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="halo " + name)
+
+
+WINO_CASES = {          # conv_halo.hip MODE 3: Winograd F(2, 3) along x on 8-row patches, <= 128-wide tiles; every epilogue / prologue option
+    "c64_to_128": dict(N=2, H=16, W=32, Cin=64, Cout=128),
+    "pro_res_stats_c128": dict(N=1, H=24, W=64, Cin=96, Cout=128, pro=True, res=True, stats=True, relu=False),
+    "bn64_acc_alpha_c50": dict(N=3, H=8, W=32, Cin=96, Cout=50, acc=True, alpha=0.37, relu=False, bias=False),
+    "affine_c32": dict(N=1, H=8, W=32, Cin=32, Cout=96, oaff=True),
+    "wide_ld": dict(N=1, H=16, W=96, Cin=64, Cout=128, ldx_extra=8, ldy_extra=12),
+    "mask_acc_c96": dict(N=1, H=16, W=32, Cin=128, Cout=96, mask=True, acc=True, relu=False, bias=False),
+    "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, stats=True),
+}
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name", list(WINO_CASES))
+def test_conv2d_winograd_form(name, mode):
+    """conv_halo.hip MODE 3 (input transform B^T d at halo staging, weights U = G w from pack mode 16, output transform in the epilogue) against
+    the CPU specification of the plain convolution, six- and three-product modes"""
+    L = hip.lib()
+    kw = dict(WINO_CASES[name])
+    ref = conv_case(Side(False), tag=f"wino/{name}", **kw)
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
+    L.mrfa_set_tuning(b"conv_small", 0)
+    L.mrfa_set_tuning(b"conv_halo_wino", 1)
+    try:
+        got = conv_case(Side(True), tag=f"wino/{name}", wsplit=True, wwino=True, **kw)
+        assert L.mrfa_conv2d_last_config() & (1 << 28), "the patch-tiled kernel did not run"
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
+        L.mrfa_set_tuning(b"conv_small", 1)
+    assert_close(ref, got, tol={1: 2e-4, 2: 2e-3}[mode], what="wino " + name)
+
+
+def test_winograd_form_error_vs_fp64_is_within_4x_of_the_direct_kernel():
+    """VERDICT r3 item 4's gate: output error of the Winograd form against an fp64 convolution <= 4 x the direct patch-tiled kernel's (max and rms),
+    K = 2 304 products per output, operands with a wide dynamic range"""
+    L = hip.lib()
+    N, H, W, Cin, Cout = 2, 32, 64, 256, 128
+    x = (det_uniform("wino64/x", (N * H * W, Cin), -1, 1) * torch.exp2(det_uniform("wino64/xe", (N * H * W, Cin), -6, 6).round())).float()
+    w = (det_uniform("wino64/w", (Cout, Cin, 3, 3), -0.2, 0.2) * torch.exp2(det_uniform("wino64/we", (Cout, Cin, 3, 3), -4, 4).round())).float()
+    y64 = torch.nn.functional.conv2d(x.double().view(N, H, W, Cin).permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    dev = torch.device("cuda:0")
+    xd, wd = x.to(dev), w.to(dev)
+    cop = 128
+
+    def run(wino):
+        y = torch.empty((N * H * W, Cout), device=dev)
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = xd.data_ptr(), Cin, H, W, N, Cin
+        wp = pack(Side(True), wd, 0)
+        p.w, p.w_ld, p.w_tap, p.w_rows = wp.data_ptr(), Cin, cop * Cin, cop
+        bufs = []
+        for mode_, T in ((8, 9), (16, 12)):
+            b = torch.zeros(3 * T * cop * Cin, dtype=torch.int16, device=dev)
+            d = hip.PackDesc()
+            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = wd.data_ptr(), Cout, Cin, 3, 3, 1
+            d.dst[0], d.mode[0] = b.data_ptr(), mode_
+            hip.check(L.mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack")
+            bufs.append(b)
+        p.w_split, p.w_piece = bufs[0].data_ptr(), 9 * cop * Cin
+        if wino:
+            p.w_wino, p.w_wino_piece = bufs[1].data_ptr(), 12 * cop * Cin
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout, p.R, p.S, p.pad = y.data_ptr(), Cout, Cout, H, W, 3, 3, 1
+        p.alpha, p.nbatch, p.splitk = 1.0, 1, 1
+        hip.check(L.mrfa_conv2d_nhwc(hip.stream_ptr(), C.byref(p)), "conv")
+        assert L.mrfa_conv2d_last_config() & (1 << 28)
+        torch.cuda.synchronize()
+        e = (y.double().cpu() - y64).abs()
+        return float(e.max()), float(e.pow(2).mean().sqrt())
+    assert L.mrfa_set_mfma_mode(1) == 0
+    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
+    try:
+        d_max, d_rms = run(False)
+        w_max, w_rms = run(True)
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
+    scale = float(y64.abs().max())
+    print(f"vs fp64 (output scale {scale:.3e}): direct max {d_max:.3e} rms {d_rms:.3e}; Winograd-x max {w_max:.3e} rms {w_rms:.3e}")
+    assert w_max <= 4.0 * d_max and w_rms <= 4.0 * d_rms, (d_max, d_rms, w_max, w_rms)
 
 
 @pytest.mark.parametrize("cfg", [dict(N=2, H=8, W=32, Cin=64, Cout=128), dict(N=1, H=16, W=32, Cin=128, Cout=64, acc=True),
@@ -521,6 +622,43 @@ def test_dgrad_matches_autograd(cfg):
     y = torch.nn.functional.conv2d(x, w, padding=c["pad"])
     (gx,) = torch.autograd.grad(y, x, dy)
     assert_close([gx.permute(0, 2, 3, 1).reshape(-1, c["Cin"])], [got], what=tag)
+
+
+@pytest.mark.parametrize("cfg", [dict(N=2, H=32, W=32, Cin=64, Cout=64), dict(N=1, H=16, W=24, Cin=32, Cout=128), dict(N=8, H=64, W=64, Cin=64, Cout=64, acc=True),
+                                 dict(N=2, H=16, W=16, Cin=128, Cout=32)])
+def test_strided_data_gradient_matches_autograd(cfg):
+    """mrfa_conv_params.stride = -2: the data gradient of a 3x3 / pad 1 / stride 2 layer straight from dY (parity classes of the output grid, 9 / 4
+    taps per pixel) against torch autograd of F.conv2d(stride=2) in fp64, and bit-for-bit specification parity with the emulator's zero-stuffed form"""
+    c = dict(N=2, H=32, W=32, Cin=64, Cout=64, acc=False)
+    c.update(cfg)
+    N, H, W, Cin, Cout = c["N"], c["H"], c["W"], c["Cin"], c["Cout"]
+    Ho, Wo = H // 2, W // 2
+    tag = "sdgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
+
+    def run(side):
+        w = side.t(f"{tag}/w", (Cout, Cin, 3, 3), -0.2, 0.2)
+        dy = side.t(f"{tag}/dy", (N * Ho * Wo, Cout))
+        dx = side.t(f"{tag}/dx0", (N * H * W, Cin)) if c["acc"] else side.garbage((N * H * W, Cin))
+        wp = pack(side, w, 2)
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = dy.data_ptr(), Cout, Ho, Wo, N, Cout
+        cip = (Cin + 127) // 128 * 128
+        p.w, p.w_ld, p.w_tap, p.w_rows = wp.data_ptr(), Cout, cip * Cout, cip
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout = dx.data_ptr(), Cin, Cin, H, W
+        p.R, p.S, p.pad, p.stride, p.alpha, p.nbatch, p.splitk, p.accumulate = 3, 3, 1, -2, 1.0, 1, 1, int(c["acc"])
+        assert side.L.mrfa_conv2d_stride_supported(C.byref(p)) == 1
+        side.call("mrfa_conv2d_nhwc", C.byref(p))
+        return side.done(dx)
+    ref, got = both(run)
+    assert_close(ref, got, what=tag)
+    w = det_uniform(f"{tag}/w", (Cout, Cin, 3, 3), -0.2, 0.2).double()
+    dy = det_uniform(f"{tag}/dy", (N * Ho * Wo, Cout)).double().reshape(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    x = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    (gx,) = torch.autograd.grad(torch.nn.functional.conv2d(x, w, padding=1, stride=2), x, dy)
+    want = gx.permute(0, 2, 3, 1).reshape(-1, Cin)
+    if c["acc"]:
+        want = want + det_uniform(f"{tag}/dx0", (N * H * W, Cin)).double()
+    assert_close([want], got, what=tag + " vs autograd")
 
 
 def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, stride=1,
