@@ -288,10 +288,17 @@ bool lds_config(const mrfa_conv_params& p, LdsCfg& c) {
     const int W = p.Wout, H = p.Hout;
     const long long M = (long long)p.N * H * W;
     const int ncols = (p.Cout + 15) / 16 * 16;
-    static const int cand[5][4] = {{2, 2, 4, 1}, {2, 2, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 1, 4}};     // (TM, TN, WM, WN)
+    // (TM, TN, WM, WN), in order of preference; measured per launch in the C++ loop (tools/ubench/small_kernels.cpp, MRFA_LDS_CFG sweep; conv_small: 13.9 /
+    // 13.9 / 13.5 us): 32 @64^2: (2,1,2,2) 12.3, (2,1,4,1) 12.7, (2,2,4,1) 13.8;  64 @32^2: (2,1,1,4) 11.0, (2,1,2,2) 11.3, (1,1,1,4) 12.8;  128 @16^2:
+    // (1,1,1,4) 12.9, (1,1,2,2) 13.5.  32-pixel x 16-channel wave tiles win where the row is >= 32 pixels wide: twice the workgroups of the 32 x 32 tile
+    // (two per CU: one workgroup's staging and epilogue overlap the other's k-loop) at the same weight traffic per MFMA.
+    static const int cand[6][4] = {{2, 1, 1, 4}, {2, 1, 2, 2}, {2, 1, 4, 1}, {1, 1, 1, 4}, {1, 1, 2, 2}, {2, 2, 4, 1}};
     static const int first = [] { const char* e = getenv("MRFA_LDS_CAND"); return e ? atoi(e) : 0; }();
-    for (int i = first; i < 5; ++i) {
-        const int tm = cand[i][0], tn = cand[i][1], wm = cand[i][2], wn = cand[i][3];
+    static int forced[4] = {0, 0, 0, 0};
+    static const bool has_forced = [] { const char* e = getenv("MRFA_LDS_CFG"); return e && sscanf(e, "%d,%d,%d,%d", forced, forced + 1, forced + 2, forced + 3) == 4; }();
+    for (int i = first; i < 6; ++i) {
+        const int tm = has_forced ? forced[0] : cand[i][0], tn = has_forced ? forced[1] : cand[i][1], wm = has_forced ? forced[2] : cand[i][2],
+                  wn = has_forced ? forced[3] : cand[i][3];
         const int pxt = 16 * tm;
         if (W % pxt) continue;
         const int tpr = W / pxt;                       // px-tiles per image row
@@ -301,9 +308,9 @@ bool lds_config(const mrfa_conv_params& p, LdsCfg& c) {
         else continue;
         if (H % PR) continue;
         const int wgc = wn * tn * 16;                  // output channels per workgroup
-        if (wgc >= 2 * ncols && i + 1 < 5) continue;      // half of the workgroup's channel axis (or more) would be padding
+        if (wgc >= 2 * ncols && i + 1 < 6 && !has_forced) continue;      // half of the workgroup's channel axis (or more) would be padding
         const long long waves = (M / pxt) * ((ncols + tn * 16 - 1) / (tn * 16));
-        if (waves < 900 && i + 1 < 5) continue;
+        if (waves < 900 && i + 1 < 6 && !has_forced) continue;
         // channels per staging pass: the whole Cin if the halo fits into 64 KB (two workgroups per CU), else halves / quarters
         auto bytes = [&](int cc) { return (size_t)(PR + 2) * (PWW + 2) * (cc + 4) * 4; };
         int CC = 0;                                    // (compile-time k loops exist for 32 / 64 / 128 channels per pass)
@@ -365,11 +372,17 @@ int mrfa_conv_lds_launch(hipStream_t st, const mrfa_conv_params& p) {
         else LDS_LAUNCH_K(TM_, TN_, WM_, WN_, 8);                                                                               \
     } while (0)
     const int kc = c.g.CC / 16;
-    if (c.tm == 2 && c.wm == 4) LDS_LAUNCH(2, 2, 4, 1);
-    else if (c.tm == 2) LDS_LAUNCH(2, 2, 2, 2);
-    else if (c.tn == 2) LDS_LAUNCH(1, 2, 2, 2);
-    else if (c.wm == 2) LDS_LAUNCH(1, 1, 2, 2);
-    else LDS_LAUNCH(1, 1, 1, 4);
+#define LDS_W(TM_, TN_)                                                          \
+    do {                                                                         \
+        if (c.wm == 4) LDS_LAUNCH(TM_, TN_, 4, 1);                               \
+        else if (c.wm == 2) LDS_LAUNCH(TM_, TN_, 2, 2);                          \
+        else LDS_LAUNCH(TM_, TN_, 1, 4);                                         \
+    } while (0)
+    if (c.tm == 2 && c.tn == 2) LDS_W(2, 2);
+    else if (c.tm == 2) LDS_W(2, 1);
+    else if (c.tn == 2) LDS_W(1, 2);
+    else LDS_W(1, 1);
+#undef LDS_W
 #undef LDS_LAUNCH_K
 #undef LDS_LAUNCH
     MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(lds)");
