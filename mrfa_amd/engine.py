@@ -1229,10 +1229,12 @@ class Ctx:
             if self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
                 # sum / sum-of-squares over every rank's pixels: the slots are summed locally first, so the message is 2C doubles,
                 # not [STATS_SLOTS][2C] (bn_finalize sums the slots: slot 0 = the global sums, the others zero)
-                local = stats.view(hip.STATS_SLOTS, 2 * Cn).sum(0)
-                stats.zero_()
-                stats[:2 * Cn] = local
-                torch.distributed.all_reduce(stats[:2 * Cn])
+                # (ONE glue launch: the slot sum lands in slot 0 of a fresh zero buffer from the pool -- round 3 summed, zeroed and copied in place:
+                # three launches per layer and direction, ~1 200 per step with the MTIA prior)
+                summed = self.f64z(hip.STATS_SLOTS * 2 * Cn)
+                torch.sum(stats.view(hip.STATS_SLOTS, 2 * Cn), 0, out=summed[:2 * Cn])
+                torch.distributed.all_reduce(summed[:2 * Cn])
+                stats = summed
                 count = count * world
         defer = train and self.deferred is not None            # side pass: the running statistics are updated after the join
         self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
@@ -1329,13 +1331,13 @@ class Ctx:
         if synced:
             # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums
             Cn = x.C
-            local = red[:nred].view(hip.STATS_SLOTS, 2 * Cn).sum(0)
+            red_g = self.f64z(nred)                          # (slot 0 of a fresh zero buffer: no zero fill / copy launches)
+            local = red_g[:2 * Cn]
+            torch.sum(red[:nred].view(hip.STATS_SLOTS, 2 * Cn), 0, out=local)
             db.add_(local[:Cn].float())
             dg.add_(local[Cn:].float())
-            red_g = torch.zeros_like(red[:nred])
-            red_g[:2 * Cn] = local
-            torch.distributed.all_reduce(red_g[:2 * Cn])
-            red_g.div_(world)                                # kernel divides by the LOCAL row count
+            torch.distributed.all_reduce(local)
+            local.div_(world)                                # kernel divides by the LOCAL row count
             q.red = red_g.data_ptr()
             q.dgamma = q.dbeta = None
         q.phase = 2

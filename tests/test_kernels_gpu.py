@@ -223,7 +223,6 @@ CONV_CASES = {
     "lds_hr128_at16_acc": dict(N=8, H=16, W=16, Cin=128, Cout=128, acc=True, alpha=0.5, relu=False, bias=False, lds=True),
     "lds_layer1_two_passes_pro": dict(N=4, H=64, W=64, Cin=64, Cout=64, pro=True, stats=True, lds=True),
     "lds_ragged_c96_c40": dict(N=2, H=16, W=32, Cin=96, Cout=40, stats=True, oaff=True, lds=True),
-    "lds_c48_out": dict(N=1, H=16, W=16, Cin=32, Cout=48, relu=False, lds=True),
     "lds_row_segments": dict(N=1, H=8, W=64, Cin=32, Cout=128, res=True, lds=True),
     # strided gather (HRNet's downsampling layers: hr_base.py:241,253,302,305,365), even and odd input sizes
     "small_stride2_stem": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False),
