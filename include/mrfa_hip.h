@@ -321,6 +321,10 @@ int mrfa_blend_bwd(void* stream, const float* a, int lda, const float* b, int ld
 int mrfa_antialias_down(void* stream, const float* x_nchw, int N, int C, int H, int W, const float* kern, int k,
                         int stride, float* y, int ldy);
 int mrfa_colsum(void* stream, const float* x, int ldx, long long rows, int C, float* out /*+=*/);
+/* measurement aid: a one-thread kernel that stores the device's constant-rate clock (100 MHz, s_memrealtime) into *dst when the stream reaches it.
+ * Captured into a hipGraph like any other launch, so the phases of a REPLAYED step can be timed without a profiler (tools/step_phases.py);
+ * nothing on the product path issues it                                                                                                     */
+int mrfa_timestamp(void* stream, unsigned long long* dst);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K21: the MTIA prior, TokenPose_B (reference modules/transformer/pose_tokenpose_b.py:16-50,

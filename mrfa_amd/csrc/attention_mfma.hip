@@ -65,6 +65,7 @@ __device__ __forceinline__ void stage_pair(float* da, const float* __restrict__ 
 template <int D>
 __global__ __launch_bounds__(NT) void att_fwd_mfma(const float* __restrict__ qkv, int ld, int n, int np, int heads, float scale,
                                                   float* __restrict__ out, int ldo, float* __restrict__ lse) {
+    chain_prio();
     constexpr int DP = D + 4, KS = D / 4, DT = (D + 15) / 16;
     extern __shared__ float sm[];
     float* Ks = sm;
@@ -143,6 +144,7 @@ template <int D>
 __global__ __launch_bounds__(NT) void att_bwd_q_mfma(const float* __restrict__ qkv, int ld, const float* __restrict__ o, int ldo,
                                                     const float* __restrict__ dout, int lddo, const float* __restrict__ lse, float* __restrict__ delta,
                                                     int n, int np, int heads, float scale, float* __restrict__ dqkv, int lddq) {
+    chain_prio();
     constexpr int DP = D + 4, KS = D / 4, DT = (D + 15) / 16;
     extern __shared__ float sm[];
     float* Ks = sm;
@@ -210,6 +212,7 @@ template <int D>
 __global__ __launch_bounds__(NT) void att_bwd_kv_mfma(const float* __restrict__ qkv, int ld, const float* __restrict__ dout, int lddo,
                                                      const float* __restrict__ lse, const float* __restrict__ delta, int n, int np, int heads,
                                                      float scale, float* __restrict__ dqkv, int lddq) {
+    chain_prio();
     constexpr int DP = D + 4, KS = D / 4, DT = (D + 15) / 16;
     extern __shared__ float sm[];
     float* Qs = sm;

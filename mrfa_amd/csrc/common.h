@@ -81,6 +81,15 @@ static inline int stream_grid(long long work_items, int block) {
     return (int)g;
 }
 
+// Kernels of the latency-bound chains (the keypoint encoder's ~3 500 small launches per step) raise their wave priority: in the training step they run
+// BESIDE chip-filling matrix kernels (the deferred weight gradients, one 256-VGPR workgroup per CU for hundreds of microseconds), and a chain kernel's few
+// instructions otherwise take turns with that workgroup's on the same SIMD.  s_setprio only reorders instruction issue between co-resident waves.
+__device__ __forceinline__ void chain_prio() {
+#ifndef MRFA_AB_NO_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -34,6 +34,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // the 9 of a stride-1 convolution over a zero-stuffed copy of dY (which also cost a fill and a scatter launch per layer; hr_base.py:241,253,302,305,365).
 template <int TMW, int TNW, int DEPTH, int CK, bool TS = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int wave_tiles_m) {
+    chain_prio();
     constexpr int WM = 16 * TMW, WN = 16 * TNW;
     __shared__ float sred[4][2][WN];                  // per-wave column sums for the BatchNorm statistics
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

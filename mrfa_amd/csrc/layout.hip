@@ -134,6 +134,7 @@ __global__ void copy_view_kernel(const float* __restrict__ x, int ldx, long long
 
 __global__ void copy_view_vec_kernel(const float* __restrict__ x, int ldx, int C4, float* __restrict__ y, int ldy, float mul, int acc,
                                      unsigned total4) {
+    chain_prio();
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
         const unsigned r = i / (unsigned)C4;
         const unsigned c = (i - r * (unsigned)C4) * 4u;
@@ -204,6 +205,15 @@ extern "C" int mrfa_nhwc_to_nchw(void* stream, const float* src, int lds_, float
     dim3 grid(cdiv((long long)H * W, 32), cdiv(C, 32), N);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds_, dst, C, H * W, accumulate);
     MRFA_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+__global__ void timestamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
+extern "C" int mrfa_timestamp(void* stream, unsigned long long* dst) {
+    MRFA_CHECK_ARG(dst, "timestamp: null dst");
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+    MRFA_CHECK_LAUNCH("timestamp");
     return 0;
 }
 

@@ -42,6 +42,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long c
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                    float momentum, float eps, int C, int train, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    chain_prio();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mean, invstd;
@@ -71,6 +72,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long c
 
 // ---------------------------------------------------------------------------------------------- forward apply
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params p, long long total) {
+    chain_prio();
     const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long opix = i / p.C;
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params
 // float4 form of the plain / residual case (every BatchNorm of the keypoint encoders): one thread = 4 consecutive channels of a pixel
 template <bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const mrfa_bnact_params p, long long total4, int c4) {
+    chain_prio();
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long opix = i / c4;
         const int c = (int)(i - opix * c4) * 4;
@@ -434,6 +437,7 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
 
 template <int PHASE, int MODE>
 __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
+    chain_prio();
     __shared__ float red[2][16][CH];
     __shared__ double redsum[2][CH];                         // phase 2: the MRFA_STATS_SLOTS partial sums of phase 1, added up once per workgroup
     bn_bwd_body<PHASE, MODE>(p, rows, rows_per_block, red, redsum);
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(const mrfa_bnbwd_
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                      int train, const float* __restrict__ rmean, const float* __restrict__ rvar, float eps) {
+    chain_prio();
     // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;

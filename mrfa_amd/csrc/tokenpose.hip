@@ -19,6 +19,7 @@ namespace {
 template <bool SCATTER>
 __global__ void subsample_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int H, int W, int Ho, int Wo,
                                  int C4, int s, unsigned total4) {
+    chain_prio();
     GRID_STRIDE_U(i, total4) {
         const unsigned opix = i / (unsigned)C4;
         const unsigned c = (i - opix * (unsigned)C4) * 4u;
@@ -39,6 +40,7 @@ __global__ void subsample_kernel(const float* __restrict__ src, int lds, float* 
 // ---------------------------------------------------------------------------------------------- upsample + add + act
 __global__ void ups_add_act_fwd_kernel(const float* __restrict__ lo, int ldl, int Hl, int Wl, int C4, int f, const float* __restrict__ base,
                                        int ldb, int relu, float* __restrict__ y, int ldy, unsigned total4) {
+    chain_prio();
     const int H = Hl * f, W = Wl * f;
     GRID_STRIDE_U(i, total4) {
         const unsigned pix = i / (unsigned)C4;
@@ -59,6 +61,7 @@ __global__ void ups_add_act_fwd_kernel(const float* __restrict__ lo, int ldl, in
 // one thread per low-resolution float4: walks its f x f block of the output gradient
 __global__ void ups_add_act_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dy, int lddy, int Hl, int Wl, int C4,
                                        int f, int relu, float* __restrict__ dlo, int lddl, float* dbase, int lddb, unsigned total4) {
+    chain_prio();
     const int W = Wl * f, H = Hl * f;
     GRID_STRIDE_U(i, total4) {
         const unsigned lp = i / (unsigned)C4;
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float* __restrict__ y, int ldy, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out) {
+    chain_prio();
     const int lane = threadIdx.x & 63;
     const long long r = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     if (r >= rows) return;
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int rows_per_wave) {
+    chain_prio();
     __shared__ float red[2][4][64 * 4];            // per wave partials for up to 256 channels at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long w_id = (long long)blockIdx.x * 4 + wave;
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------------- GELU (exact, erf)
 __global__ void gelu_fwd_kernel(const float* __restrict__ x, int ldx, int C4, float* __restrict__ y, int ldy, unsigned total4) {
+    chain_prio();
     GRID_STRIDE_U(i, total4) {
         const unsigned r = i / (unsigned)C4;
         const unsigned c = (i - r * (unsigned)C4) * 4u;
@@ -210,6 +216,7 @@ __global__ void gelu_fwd_kernel(const float* __restrict__ x, int ldx, int C4, fl
 
 __global__ void gelu_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy, int C4, float* __restrict__ dx,
                                 int lddx, unsigned total4) {
+    chain_prio();
     GRID_STRIDE_U(i, total4) {
         const unsigned r = i / (unsigned)C4;
         const unsigned c = (i - r * (unsigned)C4) * 4u;

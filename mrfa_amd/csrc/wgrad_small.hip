@@ -24,6 +24,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <bool SPATIAL, bool POW2>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_params p, const long long M, const int chunks_per_wave, const int nblk_ci,
                                                          const int nblk, const int pow2_w /* log2(Wout) */, const int pow2_hw) {
+    chain_prio();
     // two 32 x 32 partial buffers (plain stores: LDS float atomics cost 11 us here), filled in two rounds: 8.4 KB instead of 16.9 KB, so a
     // workgroup fits beside two resident 74 KB workgroups of the deferred wgrad_bf16x6 chain (12 KB of a CU's LDS stay free) instead of
     // waiting ~250 us for one of them to retire (measured tail of this kernel during the overlap: up to 530 us for a 15 us launch)
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) load(range + s * 16, ra[s], rb[s]);
+#ifdef MRFA_AB_NO_LOOP
+    nc = nc > 1 ? 1 : nc;
+#endif
     for (int c0 = 0; c0 < nc; c0 += 4) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -149,7 +153,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const mrfa_wgrad_param
     float* dw = p.dw + ((size_t)tap * p.Cout + co0) * p.Cin + ci0;
     for (int i = threadIdx.x; i < 32 * 32; i += 256) {
         const int r = i >> 5, c = i & 31;
+#ifdef MRFA_AB_NO_ATOMICS
+        if (co0 + r < p.Cout && ci0 + c < p.Cin) dw[(size_t)r * p.Cin + c] = p.alpha * (sacc[0][r][c] + sacc[1][r][c]);
+#else
         if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * (sacc[0][r][c] + sacc[1][r][c]));
+#endif
     }
     if (p.dbias && tap == 0 && ci0 == 0 && threadIdx.x < 32 && co0 + threadIdx.x < p.Cout) atomicAdd(p.dbias + co0 + threadIdx.x, sbias[threadIdx.x]);
 }

@@ -39,6 +39,35 @@ DIRECT_PARAM_GRADS = False
 WGRAD_STREAM = False
 
 
+class Marks:
+    """Measurement aid (tools/step_phases.py): device timestamps at named points of a step, stored by one-thread kernels (mrfa_timestamp) on
+    whatever stream reaches the point, so they are captured into the hipGraph and a REPLAYED step reports its own phase times without a profiler
+    serialising its branches.  engine.MARKS = Marks(dev) switches it on; None (default): mark() does nothing."""
+
+    def __init__(self, dev, n: int = 256):
+        self.buf = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.names: List[str] = []
+
+    def begin(self):
+        self.names = []
+
+    def read(self):
+        """[(name, microseconds since the first mark)] of the last pass"""
+        t = self.buf[:len(self.names)].cpu().tolist()
+        return [(n, (v - t[0]) / 100.0) for n, v in zip(self.names, t)]
+
+
+MARKS: Optional[Marks] = None
+
+
+def mark(name: str):
+    m = MARKS
+    if m is None or len(m.names) >= m.buf.numel():
+        return
+    hip.check(hip.lib().mrfa_timestamp(hip.stream_ptr(), m.buf.data_ptr() + 8 * len(m.names)), "timestamp")
+    m.names.append(name)
+
+
 class DeferredWgrads:
     """The weight-gradient launches of the programs recorded under `defer_wgrads(d)` (dense motion + RaftFlow: ~100 launches, 22 ms of
     kernels that fill the chip) are not issued where the backward tape reaches them but collected, and issued on ONE side stream when
@@ -61,6 +90,8 @@ class DeferredWgrads:
         # independent of each other, issued after its backward chain instead of inside it); the finals wait for all of them
         self.fanout = max(1, int(fanout))
         self.flushed = False
+        self._rr = 0
+        self._used: List["torch.cuda.Stream"] = []           # side streams that received launches since the last join
 
     def add(self, fn: Callable[[], None], final: bool = False):
         (self.finals if final else self.thunks).append(fn)
@@ -69,13 +100,48 @@ class DeferredWgrads:
         """start of a step: drop whatever an aborted previous step left behind (a backward that raised between the decoder and the join
         would otherwise have its stale weight-gradient / un-pack thunks flushed into the NEXT step's freshly zeroed .grad)"""
         if self.flushed and self.stream is not None:
-            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)      # launches already issued finish first
-        self.thunks, self.finals, self.kept, self.flushed = [], [], None, False
+            cur = torch.cuda.current_stream(self.stream.device)
+            for st in self._used:
+                cur.wait_stream(st)                          # launches already issued finish first
+        self.thunks, self.finals, self.kept, self.flushed, self._used = [], [], None, False, []
         if self in _PENDING_DEFERRED:
             _PENDING_DEFERRED.remove(self)
 
+    def _lanes(self, dev):
+        if self.stream is None or self.stream.device != dev:
+            self.stream = torch.cuda.Stream(device=dev)
+            self.fan = []
+        while len(self.fan) < self.fanout - 1:
+            self.fan.append(torch.cuda.Stream(device=dev))
+        return [self.stream] + self.fan[:self.fanout - 1]
+
+    def _deal(self, dev: torch.device):
+        """issue the collected launches on the side streams, ordered after the current stream; the streams are joined by flush()"""
+        if not self.thunks:
+            return
+        if dev.type != "cuda":
+            for fn in self.thunks:
+                fn()
+            self.thunks = []
+            return
+        cur = torch.cuda.current_stream(dev)
+        lanes = self._lanes(dev) if len(self.thunks) > self.fanout else self._lanes(dev)[:1]
+        for st in lanes:
+            st.wait_stream(cur)
+            if st not in self._used:
+                self._used.append(st)
+        for fn in self.thunks:
+            with torch.cuda.stream(lanes[self._rr % len(lanes)]):
+                fn()
+            self._rr += 1
+        # the closures own the buffers the side streams are still reading -- ALL flushes of the step (a collection can be flushed more than once:
+        # the third encoder pass of the reference objective finishes its backward before the decoder's starts) until join() / reset()
+        self.kept = (self.kept or []) + self.thunks
+        self.thunks = []
+        self.flushed = True
+
     def flush(self, dev: torch.device):
-        """issue everything collected so far on the side stream, ordered after the current stream"""
+        """issue everything collected so far on the side streams, ordered after the current stream; then the finals on the first of them, after all"""
         if not self.thunks and not self.finals:
             return
         if dev.type != "cuda":
@@ -83,40 +149,31 @@ class DeferredWgrads:
                 fn()
             self.thunks, self.finals = [], []
             return
-        if self.stream is None or self.stream.device != dev:
-            self.stream = torch.cuda.Stream(device=dev)
-            self.fan = []
-        cur = torch.cuda.current_stream(dev)
-        self.stream.wait_stream(cur)
-        if self.fanout > 1 and len(self.thunks) > self.fanout:
-            while len(self.fan) < self.fanout - 1:
-                self.fan.append(torch.cuda.Stream(device=dev))
-            lanes = [self.stream] + self.fan[:self.fanout - 1]
-            for st in lanes[1:]:
-                st.wait_stream(cur)
-            for i, fn in enumerate(self.thunks):
-                with torch.cuda.stream(lanes[i % len(lanes)]):
-                    fn()
-            for st in lanes[1:]:
+        tag = "enc wgrads" if self.manual else "dec wgrads"
+        mark(tag + ": flush")
+        self._deal(dev)
+        self._lanes(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        for st in self._used:
+            if st is not self.stream:
                 self.stream.wait_stream(st)
-        else:
-            with torch.cuda.stream(self.stream):
-                for fn in self.thunks:
-                    fn()
+        if self.stream not in self._used:
+            self._used.append(self.stream)
         with torch.cuda.stream(self.stream):
             for fn in self.finals:
                 fn()
-        # the closures own the buffers the side streams are still reading -- ALL flushes of the step (a collection can be flushed more than once:
-        # the third encoder pass of the reference objective finishes its backward before the decoder's starts) until join() / reset()
-        self.kept = (self.kept or []) + self.thunks + self.finals
-        self.thunks, self.finals = [], []
+            mark(tag + ": done")
+        self.kept = (self.kept or []) + self.finals
+        self.finals = []
         self.flushed = True
 
     def join(self, dev: torch.device):
         self.flush(dev)                                   # (no non-deferring program ran its backward: nothing overlapped, still correct)
         if self.flushed and dev.type == "cuda":
-            torch.cuda.current_stream(dev).wait_stream(self.stream)
-        self.kept, self.flushed = None, False
+            cur = torch.cuda.current_stream(dev)
+            for st in self._used:
+                cur.wait_stream(st)
+        self.kept, self.flushed, self._used = None, False, []
 
 
 WGRAD_DEFER: Optional[DeferredWgrads] = None           # programs whose forward runs under defer_wgrads(d) defer into d
@@ -597,8 +654,12 @@ class PackPlan:
     of ~180 single-layout launches; run() also marks the per-convolution caches valid, so the engine's own
     fwd_pack()/dgrad_pack() calls of the same step find nothing to do."""
 
-    def __init__(self, model: torch.nn.Module):
-        self.cws: List[ConvW] = [m._mrfa_convw for m in model.modules() if getattr(m, "_mrfa_convw", None) is not None]
+    def __init__(self, model: torch.nn.Module, only: Optional[torch.nn.Module] = None, exclude: Optional[torch.nn.Module] = None):
+        """only / exclude: a sub-module of `model` whose convolutions are the plan / are left out of it (GraphedTrainStep packs the keypoint
+        encoder's layouts first and everything else on a side stream beside the encoder's forward)"""
+        skip = {id(m) for m in exclude.modules()} if exclude is not None else set()
+        self.cws: List[ConvW] = [m._mrfa_convw for m in (only if only is not None else model).modules()
+                                 if getattr(m, "_mrfa_convw", None) is not None and id(m) not in skip]
         descs = []
         self._keep = []
         for cw in self.cws:
@@ -1958,6 +2019,7 @@ class _ProgramFn(torch.autograd.Function):
         ectx.flush_forward()
         actx.ectx, actx.seeders, actx.in_grad_fns = ectx, seeders, in_grad_fns
         actx.params, actx.n_in = params, n_in
+        actx.mname = type(module).__name__
         # return ALIASES: autograd stamps grad_fn (= this node) on the returned tensor objects, and the seeders held
         # by this node reference the program's own output tensors -- handing those out would close a reference
         # cycle through C++ (node -> seeders -> tensor -> grad_fn -> node) that no garbage collector can break
@@ -1979,10 +2041,12 @@ class _ProgramFn(torch.autograd.Function):
             for d in [d for d in _PENDING_DEFERRED if d is not ectx.wdefer]:
                 d.flush(ectx.dev)
                 _PENDING_DEFERRED.remove(d)
+        mark("backward " + actx.mname + ": start")
         for seed, g in zip(actx.seeders, gouts):
             if g is not None and seed is not None:
                 seed(g)
         ectx.run_backward()
+        mark("backward " + actx.mname + ": tape done")
         pgrads = {}
         direct_cws = [cw for cw in ectx.touched_convs if cw.dw_acc is not None and cw._direct]
         skip = ()

@@ -92,6 +92,8 @@ class HotPath(nn.Module):
         # gradients that arrive at them into static buffers (`dkp_s`, ...) with a kernel (no memcpy node), so that d loss / d keypoints of
         # a hipGraph-REPLAYED step can be read (tests/test_headline_gpu.py).  None (default): nothing is recorded
         object.__setattr__(self, "probe", None)
+        # GraphedTrainStep: the stream on which the packed weight layouts of everything but the keypoint encoder are being refreshed
+        object.__setattr__(self, "_pack_stream", None)
 
     def encode_many(self, frames):
         """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234), in the reference's order as far as
@@ -142,18 +144,33 @@ class HotPath(nn.Module):
         kp_s, kp_d = self.encode_many([source, driving])
         return kp_s, kp_d
 
+    def await_packs(self):
+        """before the first launch that reads a packed weight layout outside the keypoint encoder (GraphedTrainStep refreshes those on a side
+        stream beside the encoder's forward)"""
+        st = self._pack_stream
+        if st is not None:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+            object.__setattr__(self, "_pack_stream", None)
+
     def join(self):
         """after backward(): the side streams' backward kernels (second encoder pass, deferred weight gradients) are ordered before
         whatever the caller issues next"""
+        from . import engine
+        engine.mark("backward: main stream done")
         for st in self._sides:
+            with torch.cuda.stream(st):
+                engine.mark("backward: side stream done")
             torch.cuda.current_stream(st.device).wait_stream(st)
         if self._wdefer_dev is not None:
             self._wdefer.join(self._wdefer_dev)
+            engine.mark("joined dec wgrads")
             self._wdefer_enc.join(self._wdefer_dev)
+            engine.mark("joined enc wgrads")
 
     def decode(self, source, kp_s, kp_d, bg_param=None):
         """dense motion + refinement + generator for given keypoints (model.py:188-210)"""
         from . import engine
+        self.await_packs()
         defer = self._wdefer if (self.defer_decoder_wgrads and self.training and torch.is_grad_enabled()) else None
         if defer is not None:
             defer.reset()                  # nothing of an earlier (possibly aborted) step may reach this step's gradients
@@ -181,11 +198,17 @@ class HotPath(nn.Module):
                     t.register_hook(hook)
 
     def forward(self, source, driving):
+        from . import engine
+        engine.mark("forward: start")
         kp_s, kp_d = self.encode_pair(source, driving)
+        engine.mark("forward: keypoints")
+        self.await_packs()
         if self.probe is not None:
             self._record_probe(kp_s, kp_d)
         bg_param = self.bg_predictor(source, driving) if self.bg_predictor is not None else None
-        return self.decode(source, kp_s, kp_d, bg_param)
+        gen = self.decode(source, kp_s, kp_d, bg_param)
+        engine.mark("forward: generated")
+        return gen
 
 
 def encode_pair_eval(encoder, source, driving):
@@ -220,6 +243,7 @@ def reference_loss(model: HotPath, full_loss, source, driving) -> torch.Tensor:
         kp_s, kp_d, transformed_kp = model.encode_many([source, driving, transform.transform_frame(driving)])
     else:
         kp_s, kp_d = model.encode_pair(source, driving)
+    model.await_packs()
     bg = model.bg_predictor(source, driving) if model.bg_predictor is not None else None
     gen = model.decode(source, kp_s, kp_d, bg)
     bg_rev = model.bg_predictor(driving, source) if bg is not None else None

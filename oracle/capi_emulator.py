@@ -795,6 +795,11 @@ class Emulator:
         d.copy_(d + s if acc else s)
         return 0
 
+    def mrfa_timestamp(self, stream, dst):
+        import time
+        C.c_ulonglong.from_address(dst).value = time.perf_counter_ns() // 10          # the device clock's 100 MHz
+        return 0
+
     def mrfa_avgpool2_fwd(self, stream, x, ldx, N, H, W, Cc, y, ldy):
         v = F.avg_pool2d(nhwc(x, N, H, W, ldx, Cc).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
         nhwc(y, N, H // 2, W // 2, ldy, Cc).copy_(v)
