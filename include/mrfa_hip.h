@@ -29,8 +29,9 @@ const char* mrfa_last_error(void);
  *   3  round 3 (shipped as "1"): mrfa_conv_params += mask, ldm, w_phase, w_phase_piece, stride; mrfa_wgrad_params += stride;
  *      mrfa_bnbwd_params += sync; pack modes 8 / 9 (pre-split bf16 weight planes) became k16-chunk-major -- plane[tap][k16 chunk][row][16]
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
- *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.               */
-#define MRFA_ABI_VERSION 4
+ *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
+ *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).       */
+#define MRFA_ABI_VERSION 5
 int mrfa_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------

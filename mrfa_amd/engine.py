@@ -92,9 +92,16 @@ class DeferredWgrads:
         self.flushed = False
         self._rr = 0
         self._used: List["torch.cuda.Stream"] = []           # side streams that received launches since the last join
+        self._srcs: List["torch.cuda.Stream"] = []           # streams on which the pending launches were collected
 
     def add(self, fn: Callable[[], None], final: bool = False):
         (self.finals if final else self.thunks).append(fn)
+        if torch.cuda.is_available():
+            # the launch reads what the CURRENT stream has produced (dY of this layer): a program may run part of its backward on a branch
+            # stream (Ctx.branch), so the side streams wait for every stream that contributed, not only for the one that flushes
+            st = torch.cuda.current_stream()
+            if st not in self._srcs:
+                self._srcs.append(st)
 
     def reset(self):
         """start of a step: drop whatever an aborted previous step left behind (a backward that raised between the decoder and the join
@@ -103,7 +110,7 @@ class DeferredWgrads:
             cur = torch.cuda.current_stream(self.stream.device)
             for st in self._used:
                 cur.wait_stream(st)                          # launches already issued finish first
-        self.thunks, self.finals, self.kept, self.flushed, self._used = [], [], None, False, []
+        self.thunks, self.finals, self.kept, self.flushed, self._used, self._srcs = [], [], None, False, [], []
         if self in _PENDING_DEFERRED:
             _PENDING_DEFERRED.remove(self)
 
@@ -128,6 +135,9 @@ class DeferredWgrads:
         lanes = self._lanes(dev) if len(self.thunks) > self.fanout else self._lanes(dev)[:1]
         for st in lanes:
             st.wait_stream(cur)
+            for src in self._srcs:
+                if src != cur:
+                    st.wait_stream(src)
             if st not in self._used:
                 self._used.append(st)
         for fn in self.thunks:
@@ -154,9 +164,10 @@ class DeferredWgrads:
         self._deal(dev)
         self._lanes(dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
-        for st in self._used:
+        for st in self._used + self._srcs:
             if st is not self.stream:
                 self.stream.wait_stream(st)
+        self._srcs = []
         if self.stream not in self._used:
             self._used.append(self.stream)
         with torch.cuda.stream(self.stream):
@@ -874,6 +885,19 @@ class Ctx:
             have.append(torch.cuda.Stream(device=self.dev))
         return have[:n]
 
+    def early_branch(self, stream):
+        """`stream` if a part of this program may run on it as a branch that does NOT start from the program's own stream (the caller forked
+        it earlier and orders it before the optimizer: HotPath), else None: only while a hipGraph of a recorded (training) pass is being
+        captured on the main pass, like lanes()"""
+        if (stream is None or self.dev.type != "cuda" or not self.record or self.deferred is not None
+                or not torch.cuda.is_current_stream_capturing()):
+            return None
+        # parameter gradients must reach .grad without passing through autograd: a gradient handed back at the end of this program's backward
+        # would be consumed on the program's stream while the branch is still writing it (found by test_graphed_train_step_equals_eager[False])
+        if not DIRECT_PARAM_GRADS or self.wdefer is None:
+            return None
+        return stream
+
     def fork(self, streams):
         """the branch streams start after everything issued so far; in backward the home stream waits for them here"""
         if not streams:
@@ -902,8 +926,11 @@ class Ctx:
                     st.wait_stream(cur)
             self.tape.append(bwd)
 
-    def branch(self, stream, fn):
-        """run fn() with `stream` current (None: in line); the backward closures it records run on the same stream"""
+    def branch(self, stream, fn, keep: Optional[list] = None):
+        """run fn() with `stream` current (None: in line); the backward closures it records run on the same stream.
+        keep: a list that receives those closures -- a branch whose backward nobody joins inside the program (early_branch) reads gradient
+        buffers that were allocated on the program's own stream; the caller holds the list until it has joined the stream, so that the
+        caching allocator cannot hand those blocks to a later allocation of the same capture while the branch still reads them"""
         if stream is None:
             return fn()
         n0 = len(self.tape)
@@ -916,6 +943,8 @@ class Ctx:
                 with torch.cuda.stream(stream):
                     f()
             self.tape[i] = on_stream
+            if keep is not None:
+                keep.append(on_stream)
         return out
 
     def _chk(self, rc, what):

@@ -186,7 +186,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 4        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
+ABI_VERSION = 5        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None
 

@@ -342,7 +342,7 @@ class Emulator:
 
     # ---------------------------------------------------------------- misc
     def mrfa_version(self):
-        return 4              # MRFA_ABI_VERSION of include/mrfa_hip.h
+        return 5              # MRFA_ABI_VERSION of include/mrfa_hip.h
 
     def mrfa_last_error(self):
         return self._err

@@ -86,8 +86,13 @@ def test_graphed_train_step_equals_eager(fused):
     src, drv = _pairs(2, "g/t")
     ma, mb = _hotpath().train(), _hotpath().train()
     oa, ob = make_optimizer(ma, capturable=True), make_optimizer(mb, capturable=True, fused=fused)
+    init = copy.deepcopy(ma.state_dict())
     l0 = float(train_step(ma, oa, src, drv))
     train_step(mb, ob, src, drv)
+    # back to the INITIAL weights (the Adam state of the step stays): one Adam step at lr 2e-4 moves this randomly initialised train-mode model to
+    # a point where summation-order noise is tens of percent of the keypoint encoder's gradient, and the comparisons below then compared noise
+    # with noise (1 failure in 8 runs in round 4; bench.py's verify() had the same problem and the same fix)
+    ma.load_state_dict(init)
     mb.load_state_dict(ma.state_dict())                   # identical weights, BN buffers and Adam state from here on
     ob.load_state_dict(copy.deepcopy(oa.state_dict()))    # load_state_dict shares the tensors it is given
     step = GraphedTrainStep(mb, ob, src, drv, clip=10.0, world=1)
@@ -397,3 +402,31 @@ def test_encoder_weight_gradients_dealt_onto_side_streams_match_the_inline_order
         noise = float((a[k] - a2[k]).norm() / a[k].norm())
         onoff = float((a[k] - b[k]).norm() / a[k].norm())
         assert onoff <= 3.0 * noise + 1e-4, (k, onoff, noise)
+
+
+@pytest.mark.parametrize("early", ["0", "1"], ids=["pack-stream", "pack-stream+early-pyramid"])
+def test_pack_stream_and_early_pyramid_branch_replay_like_the_eager_step(monkeypatch, early):
+    """GraphedTrainStep refreshes the non-encoder weight layouts on a side stream beside the keypoint encoder's forward (default) and can run the
+    source image's feature pyramid -- forward and backward -- on that stream too (MRFA_EARLY_PYRAMID=1, opt-in: slower on ROCm 7.2's graph executor).
+    Both schedules must replay to the eager step's gradients: verify() at the INITIAL weights (well conditioned: the band is ~1e-2 / 2e-3 / 1e-2 of
+    the encoder / decoder / dense-motion gradient), and the stale-layout case -- weights changed between capture and replay -- must still be right,
+    i.e. the packs really run inside the graph, before their first reader."""
+    import bench
+    from mrfa_amd.graph import GraphedTrainStep
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer
+    monkeypatch.setenv("MRFA_EARLY_PYRAMID", early)
+    src, drv = _pairs(2, "g/pk")
+    m = HotPath(VOX1, prior="mtia")
+    bench.init_weights(m)
+    m.to(DEV).train(True)
+    opt = make_optimizer(m, fused=True)
+    step = GraphedTrainStep(m, opt, src, drv, clip=10.0, world=1)
+    assert step.pack_stream is not None and step.packs_rest.n > 0 and step.packs.n > 0
+    step.verify(replays=3)                                  # raises when a replay leaves the eager noise band
+    # weights changed behind the capture (a decoder and an encoder convolution scaled in place; not an optimizer step, which would move this
+    # randomly initialised model to an ill-conditioned point): graph A must re-pack them before their first reader -- verify() raises otherwise
+    with torch.no_grad():
+        for mod in (m.decoder, m.encoder):
+            w = next(p for n, p in mod.named_parameters() if p.dim() == 4 and p.shape[2] == 3 and p.shape[0] >= 32)
+            w.mul_(1.25)
+    step.verify(replays=3)
