@@ -30,8 +30,9 @@ const char* mrfa_last_error(void);
  *      mrfa_bnbwd_params += sync; pack modes 8 / 9 (pre-split bf16 weight planes) became k16-chunk-major -- plane[tap][k16 chunk][row][16]
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
  *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
- *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).       */
-#define MRFA_ABI_VERSION 5
+ *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
+ *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call).                                            */
+#define MRFA_ABI_VERSION 6
 int mrfa_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -93,6 +94,16 @@ typedef struct {
     long long w_wino_piece;/*   (pack mode 16; 17 for data-gradient launches), three bf16 pieces.  When present and mrfa_conv2d_wino_supported()  */
                            /*   the patch-tiled kernel computes two horizontally adjacent outputs from 4 instead of 6 products per kernel row:    */
                            /*   12 instead of 18 MFMA steps per pixel pair -- same result up to fp32 rounding of the transforms                   */
+    /* v6, optional, together with `stats` (fin_scale != NULL): FINISH the train-mode BatchNorm that follows this convolution as part of this call --   */
+    /* exactly what mrfa_bn_finalize(stats, fin_count, fin_gamma, fin_beta, fin_rmean, fin_rvar, fin_momentum, fin_eps, Cout, 1, fin_scale, fin_shift,   */
+    /* fin_mean, fin_invstd) would do after it (fin_rmean / fin_rvar / fin_mean / fin_invstd may be NULL).  The small-problem kernel does it in the     */
+    /* SAME launch: the last workgroup to finish (fin_counter: one zero-initialised 32-bit word per call, e.g. behind the statistics block) reduces the  */
+    /* slots -- the keypoint encoder's ~180 BatchNorm layers per pass then cost two launches each instead of three; every other kernel is followed by   */
+    /* the finalize launch inside the call                                                                                                               */
+    const float* fin_gamma; const float* fin_beta; float* fin_rmean; float* fin_rvar;
+    float fin_momentum, fin_eps; long long fin_count;
+    float* fin_scale; float* fin_shift; float* fin_mean; float* fin_invstd;
+    unsigned int* fin_counter;
 } mrfa_conv_params;
 
 /* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS

@@ -348,7 +348,24 @@ extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
     return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
 
+static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done);
+
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
+    MRFA_CHECK_ARG(pp, "conv2d: null parameter block");
+    if (pp->fin_scale) {
+        MRFA_CHECK_ARG(pp->stats && pp->fin_shift && pp->fin_gamma && pp->fin_beta && pp->fin_counter && pp->fin_count > 0,
+                       "conv2d: fin_scale needs stats, fin_shift, fin_gamma, fin_beta, fin_counter and fin_count > 0");
+        MRFA_CHECK_ARG((pp->fin_rmean == nullptr) == (pp->fin_rvar == nullptr), "conv2d: fin_rmean / fin_rvar come together");
+    }
+    bool fin_done = false;
+    const int rc = conv2d_dispatch(stream, pp, &fin_done);
+    if (rc || !pp->fin_scale || fin_done) return rc;
+    // every kernel but the one-wave-per-tile one: the finalize launch behind the convolution, inside the call
+    return mrfa_bn_finalize(stream, pp->stats, pp->fin_count, pp->fin_gamma, pp->fin_beta, pp->fin_rmean, pp->fin_rvar, pp->fin_momentum, pp->fin_eps,
+                            pp->Cout, 1, pp->fin_scale, pp->fin_shift, pp->fin_mean, pp->fin_invstd);
+}
+
+static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done) {
     const mrfa_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     MRFA_CHECK_ARG(p.x && p.w && p.y, "conv2d: null pointer");
@@ -377,6 +394,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
+        *fin_done = p.fin_scale != nullptr && p.stride != -2;    // (finished by the launch's last workgroup)
         return mrfa_conv_small_launch(st, p, M);
     }
     if (p.stride > 1 || p.stride < 0) {

@@ -229,6 +229,42 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
                 atomicAdd(p.stats + (size_t)((blockIdx.x + blockIdx.y) % MRFA_STATS_SLOTS) * 2 * p.Cout + which * p.Cout + c, v);
             }
         }
+        if (p.fin_scale) {
+            // BatchNorm finalize by the LAST workgroup of the launch (mrfa_conv_params.fin_*): every workgroup takes a ticket once its slot sums are out;
+            // whoever draws the last one reads all slots and writes what bn_finalize_kernel would have.  No release / acquire FENCES: an agent-scope
+            // fence writes back (release) or invalidates (acquire) the XCD's whole L2 -- with one per workgroup the training step went from 83 to 98 ms.
+            // None is needed: the slot sums are device-scope atomics (performed at the memory side, never left dirty in an L2), the barrier below waits
+            // for their completion (s_waitcnt vmcnt(0)) before the ticket -- also a device-scope atomic -- is drawn, and the last workgroup reads the
+            // slots with device-scope loads, which bypass the non-coherent L2s (the guide's "sc1 stores AND sc1 loads" hand-off).
+            __shared__ unsigned s_ticket;
+            __syncthreads();
+            if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (s_ticket == gridDim.x * gridDim.y - 1) {
+                const double cnt = (double)p.fin_count;
+                for (int c = threadIdx.x; c < p.Cout; c += 256) {
+                    double t1 = 0.0, t2 = 0.0;
+                    for (int s = 0; s < MRFA_STATS_SLOTS; ++s) {
+                        t1 += __hip_atomic_load(p.stats + (size_t)s * 2 * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t2 += __hip_atomic_load(p.stats + (size_t)s * 2 * p.Cout + p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const double m = t1 / cnt;
+                    double var = t2 / cnt - m * m;
+                    if (var < 0.0) var = 0.0;
+                    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)p.fin_eps));
+                    if (p.fin_rmean) {
+                        const double unb = p.fin_count > 1 ? var * cnt / (cnt - 1.0) : var;
+                        p.fin_rmean[c] = (1.f - p.fin_momentum) * p.fin_rmean[c] + p.fin_momentum * mean;
+                        p.fin_rvar[c] = (1.f - p.fin_momentum) * p.fin_rvar[c] + p.fin_momentum * (float)unb;
+                    }
+                    const float sc = p.fin_gamma[c] * invstd;
+                    p.fin_scale[c] = sc;
+                    p.fin_shift[c] = p.fin_beta[c] - mean * sc;
+                    if (p.fin_mean) p.fin_mean[c] = mean;
+                    if (p.fin_invstd) p.fin_invstd[c] = invstd;
+                }
+            }
+        }
     }
 }
 

@@ -217,6 +217,8 @@ NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2
 # 84.3 -> 90.0 ms -- the barrier needs every workgroup of the launch resident, and beside the deferred decoder weight gradients (one 256-VGPR
 # workgroup per CU for hundreds of microseconds) the last workgroups of each of the ~340 launches wait for a CU while the others spin
 BN_BWD_FUSED = os.environ.get("MRFA_BN_BWD_FUSED", "0") == "1"
+# BatchNorm finalize of the conv -> BatchNorm pairs of the keypoint encoder inside the convolution's launch (last workgroup; mrfa_conv_params.fin_*)
+BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
 # Winograd F(2, 3)-along-x form of the plain 3x3 layers on the patch-tiled kernel (conv_halo MODE 3, pack modes 16 / 17).  OFF by default
 # (MRFA_WINO=1): 1.10-1.16x per launch in the launch loop but nothing measurable in the training step (LDS-read bound), and its
 # fp32 rounding (within 4x of the direct kernel's against fp64) is visible in ill-conditioned downstream quantities (the keypoint encoder's
@@ -849,6 +851,7 @@ class Ctx:
         self.storages: List[Storage] = []            # forward activations whose gradients live in one zero arena
         self._pools = {}                 # (stream, dtype) -> ZeroPool: a chunk is zero-filled on the stream that carves it up
         self._home = hip.stream_ptr() if device.type == "cuda" else 0
+        self._fin_done = {}              # statistics buffer -> result of a BatchNorm finalize done inside the producing convolution's call
 
     # -- plumbing
     @property
@@ -1030,8 +1033,9 @@ class Ctx:
 
     # -- convolution ------------------------------------------------------------------------------------------
     def conv(self, x: View, conv: torch.nn.Conv2d, out: Optional[View] = None, *, relu=False, ups=False, pre=None,
-             stats: Optional[torch.Tensor] = None, res: Optional[View] = None, need_dx=True, use_bias=True, relu_in=False) -> View:
+             stats: Optional[torch.Tensor] = None, res: Optional[View] = None, need_dx=True, use_bias=True, relu_in=False, fin=None) -> View:
         """y = conv(pre(ups(x))) (+bias)(+res)(ReLU).  pre = (scale, shift) tensors of a pre-activation BN+ReLU.
+        fin: the BatchNorm that follows (with `stats`): finished inside the convolution call (mrfa_conv_params.fin_*, see _fin_params).
         relu_in: the caller states that x (all of its storage) holds ReLU outputs and that this conv is their only consumer: the ReLU
         backward of x's producers then rides in this conv's data gradient (mrfa_conv_params.mask) instead of a pass of its own."""
         cw = convw(conv)
@@ -1109,6 +1113,8 @@ class Ctx:
             p.res, p.ldr = res.ptr, res.ld
         if stats is not None:
             p.stats = stats.data_ptr()
+            if fin is not None:
+                self._fin_params(p, fin, stats, out.rows)
         p.alpha, p.nbatch = 1.0, 1
         self._maybe_wino(p, cw, dgrad=False, padded=padded, ups=ups)
         self._launch_conv(p, "conv2d", cw.Cin)
@@ -1312,6 +1318,14 @@ class Ctx:
 
     def _bn_finalize(self, bn, stats, count):
         Cn = bn.num_features
+        done = self._fin_done.pop(stats.data_ptr(), None) if stats is not None else None
+        if done is not None:                              # finished inside the producing convolution's call (_fin_params)
+            assert done[0] is bn and done[1] == count, "fused BatchNorm finalize: another layer / row count than the convolution was told"
+            scale, shift, mean, invstd = done[2:]
+            if self.deferred is not None:
+                self.deferred.append((bn, mean, invstd, float(count)))
+            self.nbt[bn] = self.nbt.get(bn, 0) + 1
+            return scale, shift, mean, invstd
         scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
         train = self.train
         if train and stats is not None:
@@ -1322,7 +1336,7 @@ class Ctx:
                 # (ONE glue launch: the slot sum lands in slot 0 of a fresh zero buffer from the pool -- round 3 summed, zeroed and copied in place:
                 # three launches per layer and direction, ~1 200 per step with the MTIA prior)
                 summed = self.f64z(hip.STATS_SLOTS * 2 * Cn)
-                torch.sum(stats.view(hip.STATS_SLOTS, 2 * Cn), 0, out=summed[:2 * Cn])
+                torch.sum(stats[:hip.STATS_SLOTS * 2 * Cn].view(hip.STATS_SLOTS, 2 * Cn), 0, out=summed[:2 * Cn])
                 torch.distributed.all_reduce(summed[:2 * Cn])
                 stats = summed
                 count = count * world
@@ -1352,7 +1366,27 @@ class Ctx:
         self.nbt = {}
 
     def bn_stats_buf(self, bn):
-        return self.f64z(hip.STATS_SLOTS * 2 * bn.num_features) if self.train else None
+        """[STATS_SLOTS][2C] zeroed doubles (+ one zeroed word behind them: the ticket counter of a finalize fused into the producing launch)"""
+        return self.f64z(hip.STATS_SLOTS * 2 * bn.num_features + 1) if self.train else None
+
+    def _fin_params(self, p, bn, stats, count: int):
+        """BatchNorm finalize inside the convolution launch that accumulates `stats` (mrfa_conv_params.fin_*): the small-problem kernel's last
+        workgroup does it, every other kernel is followed by the finalize launch inside the call -- bn_act() then finds the result here
+        instead of launching mrfa_bn_finalize (366 launches per training step on the keypoint encoder's forward chains)."""
+        if not self.train or stats is None:
+            return
+        if isinstance(bn, torch.nn.SyncBatchNorm) and self._sync_collective(self._sync_world(bn)):
+            return                                        # the statistics are exchanged between the convolution and the finalize
+        Cn = bn.num_features
+        scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
+        defer = self.deferred is not None                 # side pass: the running statistics are updated after the join
+        p.fin_gamma, p.fin_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+        if not defer:
+            p.fin_rmean, p.fin_rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        p.fin_momentum, p.fin_eps, p.fin_count = BN_MOMENTUM, BN_EPS, count
+        p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        p.fin_counter = stats.data_ptr() + 8 * hip.STATS_SLOTS * 2 * Cn
+        self._fin_done[stats.data_ptr()] = (bn, count, scale, shift, mean, invstd)
 
     def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None,
                sole_consumer: bool = False, res: Optional[View] = None) -> View:
@@ -1731,17 +1765,18 @@ class Ctx:
     def conv_bn_raw(self, x: View, conv, bn, need_dx=True):
         """raw = conv(x) for a conv of stride 1 or 2 that a BatchNorm follows -> (raw, batch statistics of raw)"""
         cw = convw(conv)
+        fin = bn if BN_FIN_FUSED else None
         if cw.stride == 1:
             st = self.bn_stats_buf(bn)
-            return self.conv(x, conv, stats=st, need_dx=need_dx), st
+            return self.conv(x, conv, stats=st, need_dx=need_dx, fin=fin), st
         if cw.stride == 2 and NATIVE_STRIDE and not cw.fwd_flat and conv.bias is None:
-            got = self._conv_strided(x, conv, cw, self.bn_stats_buf(bn), need_dx)
+            got = self._conv_strided(x, conv, cw, self.bn_stats_buf(bn), need_dx, fin=fin)
             if got is not None:
                 return got
         raw = self.subsample(self.conv(x, conv, need_dx=need_dx), cw.stride)
         return raw, self.bn_stats(raw, bn)
 
-    def _conv_strided(self, x: View, conv, cw: ConvW, stats, need_dx):
+    def _conv_strided(self, x: View, conv, cw: ConvW, stats, need_dx, fin=None):
         """stride-2 convolution as ONE launch with a strided gather and the BatchNorm statistics in its epilogue (hr_base.py:241,253,302,305,365)
         instead of the stride-1 convolution + sub-sampling + statistics passes: a quarter of the MACs forward and in the weight gradient.  The
         data gradient stays the stride-1 one over the zero-stuffed dY.  None: the library has no strided kernel for this shape."""
@@ -1762,6 +1797,8 @@ class Ctx:
         p.y, p.ldy = out.ptr, out.ld
         if stats is not None:
             p.stats = stats.data_ptr()
+            if fin is not None:
+                self._fin_params(p, fin, stats, out.rows)
         self._launch_conv(p, "conv2d(stride 2)", cw.Cin)
         if self.record:
             def bwd():

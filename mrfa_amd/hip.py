@@ -40,6 +40,10 @@ class ConvParams(C.Structure):
         ("w_phase", C.c_void_p), ("w_phase_piece", C.c_longlong),
         ("stride", C.c_int),
         ("w_wino", C.c_void_p), ("w_wino_piece", C.c_longlong),
+        ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_rmean", C.c_void_p), ("fin_rvar", C.c_void_p),
+        ("fin_momentum", C.c_float), ("fin_eps", C.c_float), ("fin_count", C.c_longlong),
+        ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_mean", C.c_void_p), ("fin_invstd", C.c_void_p),
+        ("fin_counter", C.c_void_p),
     ]
 
 
@@ -186,7 +190,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 5        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
+ABI_VERSION = 6        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None
 

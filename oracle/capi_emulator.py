@@ -342,7 +342,7 @@ class Emulator:
 
     # ---------------------------------------------------------------- misc
     def mrfa_version(self):
-        return 5              # MRFA_ABI_VERSION of include/mrfa_hip.h
+        return 6              # MRFA_ABI_VERSION of include/mrfa_hip.h
 
     def mrfa_last_error(self):
         return self._err
@@ -476,6 +476,10 @@ class Emulator:
                 flat = v.reshape(-1, p.Cout).double()
                 st[:p.Cout] += flat.sum(0)
                 st[p.Cout:] += (flat * flat).sum(0)
+        if p.fin_scale:              # v6: the BatchNorm that follows is finished inside the call (mrfa_conv_params.fin_*)
+            assert p.stats and p.fin_counter and p.fin_count > 0
+            return self.mrfa_bn_finalize(stream, p.stats, p.fin_count, p.fin_gamma, p.fin_beta, p.fin_rmean, p.fin_rvar, p.fin_momentum, p.fin_eps,
+                                         p.Cout, 1, p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd)
         return 0
 
     def mrfa_conv2d_wgrad_nhwc(self, stream, pref):

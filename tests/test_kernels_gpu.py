@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, lds=False, wwino=False, tag="c"):
+              stride=1, lds=False, wwino=False, fin=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -154,9 +154,21 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         rt = side.t(f"{tag}/res", (N * Ho * Wo, Cout + 4))
         keep.append(rt)
         p.res, p.ldr = rt.data_ptr(), Cout + 4
-    st = side.z((hip.STATS_SLOTS, 2 * Cout), torch.float64)          # [MRFA_STATS_SLOTS][2C], summed by the consumer
+    stbuf = side.z((hip.STATS_SLOTS * 2 * Cout + 1,), torch.float64)  # [MRFA_STATS_SLOTS][2C], summed by the consumer (+ the finalize ticket word)
+    st = stbuf[:hip.STATS_SLOTS * 2 * Cout].view(hip.STATS_SLOTS, 2 * Cout)
     if stats:
         p.stats = st.data_ptr()
+    fin_out = []
+    if fin:                         # v6: the BatchNorm that follows finished inside the call (scale, shift, mean, invstd, running statistics)
+        assert stats
+        gam, bet = side.t(f"{tag}/gamma", (Cout,), 0.5, 1.5), side.t(f"{tag}/beta", (Cout,), -0.3, 0.3)
+        rm, rv = side.t(f"{tag}/rm", (Cout,), -0.2, 0.2), side.t(f"{tag}/rv", (Cout,), 0.5, 1.5)
+        fin_out = [side.garbage((Cout,)) for _ in range(4)] + [rm, rv]
+        keep += [gam, bet]
+        p.fin_gamma, p.fin_beta, p.fin_rmean, p.fin_rvar = gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        p.fin_momentum, p.fin_eps, p.fin_count = 0.1, 1e-5, N * Ho * Wo
+        p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd = (t.data_ptr() for t in fin_out[:4])
+        p.fin_counter = stbuf.data_ptr() + 8 * hip.STATS_SLOTS * 2 * Cout
     if mask:                        # fused ReLU backward: the result is multiplied by (mask > 0) before the accumulation
         mk = side.t(f"{tag}/mask", (N * Ho * Wo, Cout + 8))
         keep.append(mk)
@@ -178,7 +190,9 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         assert side.L.mrfa_conv2d_last_config() & 16, "not dispatched to conv_lds"
     else:
         side.call("mrfa_conv2d_nhwc", C.byref(p))
-    return side.done(y[:, :Cout], st.sum(0))
+    if fin and side.gpu and fin == "small":
+        assert side.L.mrfa_conv2d_last_config() & 8, "not dispatched to the one-wave-per-tile kernel"
+    return side.done(y[:, :Cout], st.sum(0), *fin_out)
 
 
 CONV_CASES = {
@@ -225,6 +239,12 @@ CONV_CASES = {
     "lds_ragged_c96_c40": dict(N=2, H=16, W=32, Cin=96, Cout=40, stats=True, oaff=True, lds=True),
     "lds_row_segments": dict(N=1, H=8, W=64, Cin=32, Cout=128, res=True, lds=True),
     # strided gather (HRNet's downsampling layers: hr_base.py:241,253,302,305,365), even and odd input sizes
+    # v6: the BatchNorm finalize inside the call -- by the launch's last workgroup (one-wave-per-tile kernel), by a launch behind it (every other kernel)
+    "fin_small_hr32": dict(N=8, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, fin="small"),
+    "fin_small_hr128": dict(N=2, H=16, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, fin="small"),
+    "fin_flat_ragged": dict(N=1, H=7, W=9, Cin=48, Cout=40, stats=True, relu=False, fin=True),
+    "fin_small_stride2": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False, fin="small"),
+    "fin_big_tile": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, stats=True, relu=False, fin=True),
     "small_stride2_stem": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False),
     "small_stride2_fuse_odd": dict(N=1, H=13, W=17, Cin=32, Cout=128, stride=2, stats=True, relu=False, bias=False),
 }
@@ -234,6 +254,25 @@ CONV_CASES = {
 def test_conv2d(name):
     ref, got = both(lambda s: conv_case(s, tag=f"conv/{name}", **CONV_CASES[name]))
     assert_close(ref, got, what=name)
+
+
+def test_fused_finalize_sees_every_workgroups_statistics():
+    """mrfa_conv_params.fin_* on the one-wave-per-tile kernel: the launch's LAST workgroup reduces the statistics slots without a release / acquire fence
+    (device-scope atomics + device-scope loads, conv_small.hip).  A workgroup's sums missed -- or a stale L2 line read -- would show as a mean / variance
+    that disagrees with the slots as they stand after the launch: 60 launches over three shapes (512 / 32 / 256 workgroups), each checked against
+    its own slot sums in float64."""
+    side = Side(True)
+    shapes = [dict(N=8, H=64, W=64, Cin=32, Cout=32), dict(N=2, H=16, W=16, Cin=128, Cout=128), dict(N=8, H=32, W=32, Cin=64, Cout=64)]
+    for it in range(60):
+        kw = shapes[it % 3]
+        cnt, Co = kw["N"] * kw["H"] * kw["W"], kw["Cout"]
+        y, st, scale, shift, mean, invstd, rm, rv = conv_case(side, tag=f"fin/stress{it % 3}", stats=True, relu=False, bias=False, fin="small", **kw)
+        m = st[:Co] / cnt
+        var = (st[Co:] / cnt - m * m).clamp_min(0)
+        assert torch.allclose(mean, m, rtol=1e-6, atol=1e-7), (it, float((mean - m).abs().max()))
+        assert torch.allclose(invstd, 1.0 / torch.sqrt(var + 1e-5), rtol=2e-6), (it, float((invstd - 1.0 / torch.sqrt(var + 1e-5)).abs().max()))
+        # and the statistics themselves are the output's (every workgroup's atomics arrived)
+        assert torch.allclose(st[:Co], y.sum(0), rtol=1e-6, atol=1e-4)
 
 
 SPLIT_CASES = {
