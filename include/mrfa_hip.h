@@ -31,7 +31,7 @@ const char* mrfa_last_error(void);
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
  *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
  *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
- *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call).                                            */
+ *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi().                                          */
 #define MRFA_ABI_VERSION 6
 int mrfa_version(void);
 
@@ -166,6 +166,10 @@ typedef struct {
 } mrfa_wgrad_params;
 
 int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
+/* v6: n independent weight gradients (or ones that share dw / dbias, which are accumulated atomically) in as few launches as possible: the problems the
+ * one-wave-per-block kernel takes run up to 28 per launch, every other one as if mrfa_conv2d_wgrad_nhwc had been called for it (the keypoint encoder's
+ * ~415 small weight gradients per training step, issued together after its backward chains)                                                          */
+int mrfa_conv2d_wgrad_multi(void* stream, const mrfa_wgrad_params* ps, int n);
 int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p);  /* 1: a call with these parameters honours stride = 2                       */
 
 /* weight (un)packing between the reference's OIHW parameter layout and the kernel layouts.

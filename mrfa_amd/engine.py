@@ -77,7 +77,7 @@ class DeferredWgrads:
     backward() by train_step / GraphedTrainStep).  The thunks hold the activations and gradient buffers they read until join().
     Direct-gradient mode only (DIRECT_PARAM_GRADS: the un-packing into .grad is deferred with them); anything else runs in line."""
 
-    def __init__(self, fanout: int = 1, manual: bool = False):
+    def __init__(self, fanout: int = 1, manual: bool = False, batch: bool = False):
         # manual: flushed only by join() (never by the backward of the next program): the keypoint encoder's collection -- its programs run their
         # backward on several streams, and only HotPath.join() has ordered all of them before the stream the flush forks from
         self.manual = manual
@@ -90,6 +90,7 @@ class DeferredWgrads:
         # independent of each other, issued after its backward chain instead of inside it); the finals wait for all of them
         self.fanout = max(1, int(fanout))
         self.flushed = False
+        self.batch = batch                                   # plain weight-gradient launches are issued as parameter arrays (mrfa_conv2d_wgrad_multi)
         self._rr = 0
         self._used: List["torch.cuda.Stream"] = []           # side streams that received launches since the last join
         self._srcs: List["torch.cuda.Stream"] = []           # streams on which the pending launches were collected
@@ -140,7 +141,27 @@ class DeferredWgrads:
                     st.wait_stream(src)
             if st not in self._used:
                 self._used.append(st)
-        for fn in self.thunks:
+        todo = self.thunks
+        if self.batch:
+            # launches that are plain weight-gradient calls travel as ONE parameter array per side stream (mrfa_conv2d_wgrad_multi: the problems the
+            # small-problem kernel takes then run up to 28 per launch); the two-stage scratch is per stream, so it is re-pointed like launch() does
+            plain = [fn for fn in todo if getattr(fn, "params", None) is not None]
+            todo = [fn for fn in todo if getattr(fn, "params", None) is None]
+            for k, st in enumerate(lanes):
+                mine = plain[k::len(lanes)]
+                if not mine:
+                    continue
+                with torch.cuda.stream(st):
+                    sp = hip.stream_ptr()
+                    ws = Ctx._wgrad_ws.get((dev, sp))
+                    if ws is None:
+                        ws = Ctx._wgrad_ws[(dev, sp)] = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+                    arr = (hip.WgradParams * len(mine))()
+                    for i, fn in enumerate(mine):
+                        C.memmove(C.byref(arr, i * C.sizeof(hip.WgradParams)), C.byref(fn.params), C.sizeof(hip.WgradParams))
+                        arr[i].ws, arr[i].ws_bytes = ws.data_ptr(), ws.numel() * 4
+                    hip.check(hip.lib().mrfa_conv2d_wgrad_multi(sp, arr, len(mine)), "wgrad_multi(deferred)")
+        for fn in todo:
             with torch.cuda.stream(lanes[self._rr % len(lanes)]):
                 fn()
             self._rr += 1
@@ -1183,6 +1204,8 @@ class Ctx:
                 q.ws, q.ws_bytes = w2.data_ptr(), w2.numel() * 4
                 assert keep[0].st.data is not None
                 self._chk(self.L.mrfa_conv2d_wgrad_nhwc(st, C.byref(q)), "wgrad(deferred)")
+            launch.params = q                              # DeferredWgrads batches such launches (mrfa_conv2d_wgrad_multi)
+            launch.keep = keep
             self.wdefer.add(launch)
         elif prof is None and WGRAD_STREAM:
             main = torch.cuda.current_stream(self.dev)

@@ -124,6 +124,7 @@ _SIGNATURES = {
     "mrfa_get_mfma_mode": ([], C.c_int),
     "mrfa_set_tuning": ([C.c_char_p, _I], C.c_int),
     "mrfa_conv2d_wgrad_nhwc": ([_V, C.POINTER(WgradParams)], C.c_int),
+    "mrfa_conv2d_wgrad_multi": ([_V, _V, _I], C.c_int),
     "mrfa_conv_fewout_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_conv_fewout_wgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _V], C.c_int),
     "mrfa_conv_fewout_dgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),

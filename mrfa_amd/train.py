@@ -87,7 +87,8 @@ class HotPath(nn.Module):
         # their launches, the ~400 independent launches then run four abreast (measured, 5 alternating runs of 20 steps on one box:
         # 85.9 -> 84.2 ms).  Same conditions as defer_decoder_wgrads.
         self.defer_encoder_wgrads = True       # (GraphedTrainStep switches it off with SyncBatchNorm: one stream, one enqueue order per rank)
-        object.__setattr__(self, "_wdefer_enc", DeferredWgrads(fanout=int(os.environ.get("MRFA_ENC_WGRAD_FANOUT", "4") or 0), manual=True))
+        object.__setattr__(self, "_wdefer_enc", DeferredWgrads(fanout=int(os.environ.get("MRFA_ENC_WGRAD_FANOUT", "4") or 0), manual=True,
+                                                                   batch=os.environ.get("MRFA_ENC_WGRAD_MULTI", "1") != "0"))
         # test / diagnostics hook: a dict here makes forward() keep the keypoint tensors (`kp_s`, `jac_s`, `kp_d`, `jac_d`) and copy the
         # gradients that arrive at them into static buffers (`dkp_s`, ...) with a kernel (no memcpy node), so that d loss / d keypoints of
         # a hipGraph-REPLAYED step can be read (tests/test_headline_gpu.py).  None (default): nothing is recorded

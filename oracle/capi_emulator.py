@@ -1006,6 +1006,14 @@ class Emulator:
                     return rc
         return 0
 
+    def mrfa_conv2d_wgrad_multi(self, stream, ps, n):
+        """v6: n weight gradients in as few launches as possible == n calls of mrfa_conv2d_wgrad_nhwc"""
+        for i in range(n):
+            rc = self.mrfa_conv2d_wgrad_nhwc(stream, ps[i])
+            if rc:
+                return rc
+        return 0
+
     def mrfa_unpack_wgrads_multi(self, stream, descs, n):
         for i in range(n):
             d = descs[i]

@@ -700,7 +700,7 @@ def test_strided_data_gradient_matches_autograd(cfg):
 
 
 def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, stride=1,
-               tag="w"):
+               launch=True, tag="w"):
     x = side.t(f"{tag}/x", (N * H * W, (Cin + 3) // 4 * 4))
     Hv, Wv = H << ups, W << ups
     Ho, Wo = (Hv + 2 * pad - R) // stride + 1, (Wv + 2 * pad - R) // stride + 1
@@ -730,6 +730,8 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     if stride > 1:
         q.stride = stride
         assert side.L.mrfa_conv2d_wgrad_stride_supported(C.byref(q)) == 1
+    if not launch:                  # the caller issues it (test_wgrad_multi): parameter block, outputs, everything that must stay alive
+        return q, dw, db, keep + [x, dy]
     side.call("mrfa_conv2d_wgrad_nhwc", C.byref(q))
     return side.done(dw, db)
 
@@ -749,11 +751,40 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
                                  dict(N=2, H=16, W=16, Cin=32, Cout=32), dict(N=4, H=32, W=32, Cin=64, Cout=64),
                                  dict(N=2, H=16, W=16, Cin=128, Cout=128), dict(N=2, H=1, W=276, Cin=192, Cout=576, R=1, pad=0),
                                  dict(N=1, H=1, W=276, Cin=576, Cout=192, R=1, pad=0), dict(N=3, H=12, W=20, Cin=64, Cout=32),
-                                 dict(N=1, H=5, W=7, Cin=32, Cout=96)])
+                                 dict(N=1, H=5, W=7, Cin=32, Cout=96),
+                                 # its ROWS forms (16-pixel chunks inside one image row: M % 16 == 0, power-of-two grids or same-size 1x1) with 32 x 32 and
+                                 # 64 x 64 weight blocks, the strided gather among them
+                                 dict(N=8, H=1, W=276, Cin=192, Cout=576, R=1, pad=0), dict(N=8, H=1, W=276, Cin=576, Cout=192, R=1, pad=0),
+                                 dict(N=2, H=32, W=32, Cin=64, Cout=128), dict(N=2, H=16, W=32, Cin=32, Cout=64), dict(N=1, H=64, W=64, Cin=32, Cout=32),
+                                 dict(N=2, H=32, W=32, Cin=64, Cout=128, stride=2, dbias=False), dict(N=1, H=16, W=16, Cin=192, Cout=64, dbias=False)])
 def test_wgrad(cfg):
     tag = "wgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
     ref, got = both(lambda s: wgrad_case(s, tag=tag, **cfg))
     assert_close(ref, got, tol=5e-4, what=tag)
+
+
+def test_wgrad_multi():
+    """mrfa_conv2d_wgrad_multi (v6): n weight gradients in as few launches as possible == n single calls.  The list mixes the three variants of the
+    one-wave-per-block kernel (3x3 on power-of-two / other grids, same-size 1x1), a strided layer, two problems that SHARE their outputs (the two
+    encoder passes of a training step add into the same dW / dbias), more problems than one launch holds (28), and two the small kernel does not
+    take (ragged channels, a big layer): those must come out as if mrfa_conv2d_wgrad_nhwc had been called."""
+    cfgs = [dict(N=2, H=16, W=16, Cin=32, Cout=32), dict(N=3, H=12, W=20, Cin=64, Cout=32), dict(N=2, H=1, W=276, Cin=192, Cout=576, R=1, pad=0),
+            dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, dbias=False), dict(Cout=126, Cin=160), dict(N=2, H=64, W=64, Cin=256, Cout=128)]
+    cfgs += [dict(N=1, H=8, W=8, Cin=32 * (1 + i % 3), Cout=32 * (1 + i % 2)) for i in range(30)]
+
+    def run(side):
+        probs = [wgrad_case(side, tag=f"wmulti/{i}", launch=False, **c) for i, c in enumerate(cfgs)]
+        # problem 1b: a second pass over other data into the outputs of problem 0
+        q2, dw2, db2, keep2 = wgrad_case(side, tag="wmulti/0b", launch=False, **cfgs[0])
+        q2.dw, q2.dbias = probs[0][0].dw, probs[0][0].dbias
+        allq = [p[0] for p in probs] + [q2]
+        arr = (hip.WgradParams * len(allq))()
+        for i, q in enumerate(allq):
+            C.memmove(C.byref(arr, i * C.sizeof(hip.WgradParams)), C.byref(q), C.sizeof(hip.WgradParams))
+        side.call("mrfa_conv2d_wgrad_multi", arr, len(allq))
+        return side.done(*[t for p in probs for t in (p[1], p[2])])
+    ref, got = both(run)
+    assert_close(ref, got, tol=5e-4, what="wgrad_multi")
 
 
 WGRAD_HALO_CASES = [       # wgrad_halo.hip: 3x3 / pad 1, Wout % 32 == 0, Cin % 32 == 0; both block shapes, prologue, upsample, ragged Cout, tails

@@ -68,8 +68,24 @@ int main() {
             hipEventElapsedTime(&ms[which], e0, e1);
         }
         const double fl = 2.0 * M * s.Cout * (double)s.Cin * T;
-        printf("%-28s %10.2f %8.1f | %10.2f %8.1f\n", s.name, 1e3 * ms[0] / iters, fl / (ms[0] / iters) / 1e9, 1e3 * ms[1] / iters,
-               fl / (ms[1] / iters) / 1e9);
+        // throughput form: 28 copies of the problem (own dW each) per mrfa_conv2d_wgrad_multi call -- what one problem costs once launch overhead is amortised
+        float ms_multi = 0.f;
+        {
+            const int NC = 28;
+            std::vector<mrfa_wgrad_params> qs(NC, q);
+            float* dws; hipMalloc(&dws, (size_t)NC * T * s.Cout * s.Cin * 4); hipMemset(dws, 0, (size_t)NC * T * s.Cout * s.Cin * 4);
+            for (int i = 0; i < NC; ++i) qs[i].dw = dws + (size_t)i * T * s.Cout * s.Cin;
+            for (int i = 0; i < 3; ++i) mrfa_conv2d_wgrad_multi(nullptr, qs.data(), NC);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            const int it2 = iters / 10 > 0 ? iters / 10 : 1;
+            for (int i = 0; i < it2; ++i) mrfa_conv2d_wgrad_multi(nullptr, qs.data(), NC);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_multi, e0, e1);
+            ms_multi /= (float)(it2 * NC);
+            hipFree(dws);
+        }
+        printf("%-28s %10.2f %8.1f | %10.2f %8.1f | multi %6.2f us/problem %6.1f TF/s\n", s.name, 1e3 * ms[0] / iters, fl / (ms[0] / iters) / 1e9, 1e3 * ms[1] / iters,
+               fl / (ms[1] / iters) / 1e9, 1e3 * ms_multi, fl / ms_multi / 1e9);
         if (getenv("BN") && s.Cin == s.Cout) {                  // BatchNorm apply / two-phase backward on the same activation
             float *sc = dalloc(s.Cout, 1.f), *sh = dalloc(s.Cout, 1.f), *dx = dalloc(M * s.Cout, 0.f), *dg = dalloc(s.Cout, 0.f), *db = dalloc(s.Cout, 0.f);
             double* red; hipMalloc(&red, MRFA_STATS_SLOTS * 2 * s.Cout * 8); hipMemset(red, 0, MRFA_STATS_SLOTS * 2 * s.Cout * 8);
