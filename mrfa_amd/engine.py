@@ -899,9 +899,10 @@ class Ctx:
     # to another without the allocator knowing
     _lanes: dict = {}
 
-    def lanes(self, n: int):
-        """n side streams for branches of this program, or [] when branches must run in line (not capturing / CPU)"""
-        if self.dev.type != "cuda" or not BRANCH_STREAMS or self.deferred is not None or not torch.cuda.is_current_stream_capturing():
+    def lanes(self, n: int, enabled: Optional[bool] = None):
+        """n side streams for branches of this program, or [] when branches must run in line (not capturing / CPU / switched off)"""
+        on = BRANCH_STREAMS if enabled is None else enabled
+        if self.dev.type != "cuda" or not on or self.deferred is not None or not torch.cuda.is_current_stream_capturing():
             return []
         key = (self.dev, self.s)
         have = Ctx._lanes.setdefault(key, [])

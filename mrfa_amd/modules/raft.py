@@ -3,6 +3,7 @@ reference: modules/raft.py:12-311 (CorrBlock, BasicMotionEncoder, RefineFlow, Ra
 from __future__ import annotations
 
 import functools
+import os
 import math
 from typing import List
 
@@ -168,6 +169,9 @@ class _CorrVolume:
         self.dvol0 = self.dvol1 = None
 
 
+HG_LANES = os.environ.get("MRFA_HG_LANES", "0") == "1"
+
+
 class RaftFlow(nn.Module):
     """Same kwargs / state_dict / forward signature as the reference (raft.py:92-141):
     forward(kp_s, kp_d, dense_motion, img, img_full) -> (out, warp_img, occlusion_strip)."""
@@ -282,13 +286,23 @@ class RaftFlow(nn.Module):
         in_d = e.kp_gaussian(kp_d, 0.1, e.new(b, h, w, kp_d.shape[1]), pos=pos)
         if cache is not None:
             k_s, k_pool = cache["k_s"], cache["k_pool"]
+            fe_d = self.kp.run(e, in_d)
+            q_d = e.conv(fe_d, self.kp_head)
         else:
             in_s = self._source_input(e, kp_s, img, h, w)
-            k_s = e.conv(self.kp_img.run(e, in_s), self.kp_img_head)            # (B,h,w,dim)
-            k_pool = e.avgpool2(k_s)
+            # the two structure hourglasses (source keys, driving queries: raft.py:179-183) are independent chains of under-filled launches (8^2 ... 64^2
+            # grids): MRFA_HG_LANES=1 runs the source one as a parallel branch of the captured graph, forward and backward
+            lanes = e.lanes(1, HG_LANES)
+            e.fork(lanes)
+
+            def source_keys():
+                ks = e.conv(self.kp_img.run(e, in_s), self.kp_img_head)         # (B,h,w,dim)
+                return ks, e.avgpool2(ks)
+            k_s, k_pool = e.branch(lanes[0] if lanes else None, source_keys)
+            fe_d = self.kp.run(e, in_d)
+            q_d = e.conv(fe_d, self.kp_head)
+            e.join(lanes)
         in_grads = ((lambda: e.ext_grads.get(id(kp_s))), (lambda: e.ext_grads.get(id(kp_d)))) + in_grads[2:]
-        fe_d = self.kp.run(e, in_d)
-        q_d = e.conv(fe_d, self.kp_head)
         base = self.basic_res_index
         q_levels = {base: q_d}
         for i in range(base - 1, -1, -1):                                       # pooled queries == volume pooled over driving dims

@@ -1,0 +1,56 @@
+"""Split-K sweep of the row-tiled split-operand convolution on the low-resolution hourglass layers (small M, deep K):
+   python tools/sweep_splitk.py      -> us per call (incl. the split-K init / epilogue launches) for splitk = auto, 1, 2, 4, ... per shape"""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mrfa_amd import hip  # noqa: E402
+
+dev = torch.device("cuda:0")
+L = hip.lib()
+hip.set_mfma_mode("bf16x6")
+SHAPES = [("256->512 3x3 @8", 8, 8, 8, 256, 512, 0), ("1024->256 3x3 @8 ups", 8, 4, 4, 1024, 256, 1), ("512->128 3x3 @16 ups", 8, 8, 8, 512, 128, 1),
+          ("512->512 3x3 @16", 8, 16, 16, 512, 512, 0), ("256->64 3x3 @32 ups", 8, 16, 16, 256, 64, 1), ("128->256 3x3 @16", 8, 16, 16, 128, 256, 0),
+          ("128->32 3x3 @64 ups", 8, 32, 32, 128, 32, 1), ("64->128 3x3 @32", 8, 32, 32, 64, 128, 0)]
+for name, N, H, W, Cin, Cout, ups in SHAPES:
+    x = torch.randn(N * H * W, Cin, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
+    cop = (Cout + 127) // 128 * 128
+    wp = torch.zeros(9 * cop * Cin, device=dev)
+    hip.check(L.mrfa_pack_conv_weight(hip.stream_ptr(), w.data_ptr(), wp.data_ptr(), Cout, Cin, 3, 3, 0), "pack")
+    piece = 9 * cop * Cin
+    wsb = torch.zeros(3 * piece, dtype=torch.int16, device=dev)
+    d = hip.PackDesc()
+    d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, 3, 3, 1
+    d.dst[0], d.mode[0] = wsb.data_ptr(), 8
+    hip.check(L.mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack8")
+    Ho, Wo = H << ups, W << ups
+    y = torch.zeros(N * Ho * Wo, Cout, device=dev)
+    stats = torch.zeros(hip.STATS_SLOTS * 2 * Cout + 1, dtype=torch.float64, device=dev)
+    p = hip.ConvParams()
+    p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.data_ptr(), Cin, H, W, ups, N, Cin
+    p.w, p.w_ld, p.w_tap, p.kflat, p.w_rows = wp.data_ptr(), Cin, cop * Cin, 0, cop
+    p.w_split, p.w_piece = wsb.data_ptr(), piece
+    p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), Cout, Cout, Ho, Wo
+    p.R, p.S, p.pad, p.alpha, p.nbatch = 3, 3, 1, 1.0, 1
+    p.stats = stats.data_ptr()
+    fl = 2.0 * N * Ho * Wo * Cout * Cin * 9
+    res = []
+    for sk in (0, 1, 2, 4, 8, 16, 32, 64):
+        p.splitk = sk
+        for _ in range(3):
+            hip.check(L.mrfa_conv2d_nhwc(hip.stream_ptr(), C.byref(p)), "conv")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            hip.check(L.mrfa_conv2d_nhwc(hip.stream_ptr(), C.byref(p)), "conv")
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 30 * 1e3
+        res.append(f"{'auto' if sk == 0 else sk}:{us:6.1f}")
+    print(f"{name:24s} {fl / 1e9:5.2f} GF  cfg {L.mrfa_conv2d_last_config():#x}  " + "  ".join(res), flush=True)
