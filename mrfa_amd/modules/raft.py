@@ -169,6 +169,8 @@ class _CorrVolume:
         self.dvol0 = self.dvol1 = None
 
 
+# OFF by default (MRFA_HG_LANES=1): measured 83.9 / 83.0 ms with, 84.5 / 83.7 ms without (alternating runs, one box) -- but the ninth capture of one process
+# (tests/test_graph_gpu.py run as a file) died with a segmentation fault inside the HIP runtime with this branch in the graph, and not without it
 HG_LANES = os.environ.get("MRFA_HG_LANES", "0") == "1"
 
 
@@ -292,7 +294,8 @@ class RaftFlow(nn.Module):
             in_s = self._source_input(e, kp_s, img, h, w)
             # the two structure hourglasses (source keys, driving queries: raft.py:179-183) are independent chains of under-filled launches (8^2 ... 64^2
             # grids): MRFA_HG_LANES=1 runs the source one as a parallel branch of the captured graph, forward and backward
-            lanes = e.lanes(1, HG_LANES)
+            # (not with SyncBatchNorm: its collectives must be enqueued on ONE stream in ONE order on every rank)
+            lanes = e.lanes(1, HG_LANES and not any(isinstance(m_, nn.SyncBatchNorm) for m_ in self.kp_img.modules()))
             e.fork(lanes)
 
             def source_keys():
