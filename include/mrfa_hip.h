@@ -31,7 +31,7 @@ const char* mrfa_last_error(void);
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
  *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
  *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
- *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi().                                          */
+ *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect().                                          */
 #define MRFA_ABI_VERSION 6
 int mrfa_version(void);
 
@@ -297,6 +297,10 @@ int mrfa_grid_sample_bwd(void* stream, const float* in, int ldi, long long in_bs
                          const float* grid, int ldg, int N, int Ho, int Wo, const float* dout, int lddo, int mode,
                          float* din /*+= atomics, may be null*/, int lddi, long long din_bstride,
                          float* dgrid /*+= , may be null*/, int lddg);
+
+/* v6: Transform.transform_frame (model.py:44-48): bilinear F.grid_sample(frame, grid, padding_mode="reflection") with align_corners=False on NCHW frames
+ * (N,C,H,W) -> (N,C,Ho,Wo); grid (N,Ho,Wo,2) contiguous, normalised (x, y).  Forward only: nothing differentiates through the equivariance warp.   */
+int mrfa_warp_frame_reflect(void* stream, const float* in_nchw, int N, int C, int H, int W, const float* grid, int Ho, int Wo, float* out_nchw);
 
 /* K9: bilinear resize, align_corners=True (F.interpolate, raft.py:161-162,205-206,228,243,266-267,279-295,308)  */
 int mrfa_resize_bilinear_fwd(void* stream, const float* in, int ldi, int N, int Hi, int Wi, int C,

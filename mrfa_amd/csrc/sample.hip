@@ -423,7 +423,50 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     }
 }
 
+// Transform.transform_frame (model.py:44-48): F.grid_sample(frame, grid, padding_mode="reflection"), bilinear, align_corners=False, NCHW in and out, forward only
+// (the frame is data and the warp's parameters are random constants: nothing differentiates through it).  One thread per output pixel, all channels.
+__device__ __forceinline__ float reflect_coord(float v, float size) {
+    // torch's reflect_coordinates(v, -1, 2 size - 1) followed by clip_coordinates: reflection about the pixel EDGES -0.5 and size - 0.5
+    const float span = size;                        // (twice_high - twice_low) / 2
+    v = fabsf(v + 0.5f);                            // |v - min|, min = -0.5
+    const float flips = floorf(v / span);
+    const float extra = v - flips * span;           // fmodf(v, span) for v >= 0
+    v = (((int)flips) & 1) ? (span - extra - 0.5f) : (extra - 0.5f);
+    return fminf(fmaxf(v, 0.f), size - 1.f);
+}
+
+__global__ void warp_frame_reflect_kernel(const float* __restrict__ in, int C, int H, int W, const float* __restrict__ grid, int Ho, int Wo,
+                                          float* __restrict__ out, long long npix) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / ((long long)Ho * Wo);
+        const float gx = grid[2 * i], gy = grid[2 * i + 1];
+        const float x = reflect_coord(((gx + 1.f) * W - 1.f) * 0.5f, (float)W), y = reflect_coord(((gy + 1.f) * H - 1.f) * 0.5f, (float)H);
+        const float x0f = floorf(x), y0f = floorf(y);
+        const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = x - x0f, wy1 = y - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool x1ok = x1 < W, y1ok = y1 < H;                     // (after the clip x0, y0 are in range; the far neighbours may be one past the edge: weight 0)
+        const float* pin = in + n * C * (long long)H * W;
+        float* pout = out + n * C * (long long)Ho * Wo + (i - n * (long long)Ho * Wo);
+        for (int c = 0; c < C; ++c) {
+            const float* pc = pin + (long long)c * H * W;
+            float v = pc[y0 * W + x0] * wx0 * wy0;
+            if (x1ok) v += pc[y0 * W + x1] * wx1 * wy0;
+            if (y1ok) v += pc[y1 * W + x0] * wx0 * wy1;
+            if (x1ok && y1ok) v += pc[y1 * W + x1] * wx1 * wy1;
+            pout[(long long)c * Ho * Wo] = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mrfa_warp_frame_reflect(void* stream, const float* in, int N, int C, int H, int W, const float* grid, int Ho, int Wo, float* out) {
+    MRFA_CHECK_ARG(in && grid && out && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "warp_frame_reflect: bad args");
+    const long long npix = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL(warp_frame_reflect_kernel, dim3(stream_grid(npix, 256)), dim3(256), 0, (hipStream_t)stream, in, C, H, W, grid, Ho, Wo, out, npix);
+    MRFA_CHECK_LAUNCH("warp_frame_reflect");
+    return 0;
+}
 
 extern "C" int mrfa_grid_sample_fwd(void* stream, const float* in, int ldi, long long in_bstride, int in_rep, int Hi, int Wi, int C,
                                     const float* grid, int ldg, int N, int Ho, int Wo, float* out, int ldo, int mode) {

@@ -156,6 +156,7 @@ _SIGNATURES = {
     "mrfa_act_bwd": ([_V, _V, _I, _V, _I, _L, _I, _I, _V, _I, _I], C.c_int),
     "mrfa_copy_view": ([_V, _V, _I, _L, _I, _V, _I, _F, _I], C.c_int),
     "mrfa_timestamp": ([_V, _V], C.c_int),
+    "mrfa_warp_frame_reflect": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
     "mrfa_blend_fwd": ([_V, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_blend_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I, _V, _I, _V, _I], C.c_int),
     "mrfa_antialias_down": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V, _I], C.c_int),

@@ -177,8 +177,14 @@ class Transform:
     def transform_frame(self, frame):
         h, w = frame.shape[2:]
         grid = make_coordinate_grid((h, w), frame).reshape(1, h * w, 2)
-        grid = self.warp_coordinates(grid).view(self.bs, h, w, 2)
-        return F.grid_sample(frame, grid, padding_mode="reflection", align_corners=False)
+        grid = self.warp_coordinates(grid).view(self.bs, h, w, 2).contiguous().float()
+        # F.grid_sample(frame, grid, padding_mode="reflection") (model.py:48; align_corners=False) as one launch of the library
+        from . import hip
+        frame = frame.contiguous().float()
+        out = torch.empty((self.bs, frame.shape[1], h, w), dtype=torch.float32, device=frame.device)
+        hip.check(hip.lib().mrfa_warp_frame_reflect(hip.stream_ptr(), frame.data_ptr(), self.bs, frame.shape[1], h, w, grid.data_ptr(), h, w,
+                                                    out.data_ptr()), "warp_frame_reflect")
+        return out
 
     def warp_coordinates(self, coordinates):
         theta = self.theta.to(coordinates).unsqueeze(1)

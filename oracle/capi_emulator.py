@@ -715,6 +715,12 @@ class Emulator:
         nhwc(out, N, Ho, Wo, ldo, Cc).copy_(y.permute(0, 2, 3, 1))
         return 0
 
+    def mrfa_warp_frame_reflect(self, stream, inp, N, Cc, H, W, grid, Ho, Wo, out):
+        x = _flat(inp, N * Cc * H * W).view(N, Cc, H, W)
+        g = _flat(grid, N * Ho * Wo * 2).view(N, Ho, Wo, 2)
+        _flat(out, N * Cc * Ho * Wo).view(N, Cc, Ho, Wo).copy_(F.grid_sample(x, g, mode="bilinear", padding_mode="reflection", align_corners=False))
+        return 0
+
     def mrfa_grid_sample_bwd(self, stream, inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, grid, ldg, N, Ho, Wo, dout, lddo, mode, din, lddi,
                              din_bstride, dgrid, lddg):
         x, n_in = self._gs_inputs(inp, ldi, in_bstride, in_rep, Hi, Wi, Cc, N)

@@ -1012,6 +1012,22 @@ def test_grid_sample(mode, Cc, in_rep):
     assert_close(ref, got, tol=5e-4, what="grid_sample")
 
 
+def test_warp_frame_reflect():
+    """mrfa_warp_frame_reflect == F.grid_sample(frame, grid, padding_mode='reflection', align_corners=False) (Transform.transform_frame, model.py:44-48): grids far outside
+    [-1, 1] (several reflections), exactly on the edges, and a different output size"""
+    def run(side):
+        N, Cc, H, W, Ho, Wo = 2, 3, 20, 28, 16, 24
+        x = side.t("wfr/x", (N, Cc, H, W))
+        g = side.t("wfr/g", (N, Ho, Wo, 2), -3.7, 3.7)
+        g[0, 0, :6, 0] = torch.tensor([-1.0, 1.0, -1.0 - 1.0 / W, 1.0 + 1.0 / W, 0.0, 3.0], device=side.dev)
+        g[0, 0, :6, 1] = torch.tensor([1.0, -1.0, 1.0 + 1.0 / H, -1.0 - 1.0 / H, 0.0, -3.0], device=side.dev)
+        out = side.garbage((N, Cc, Ho, Wo))
+        side.call("mrfa_warp_frame_reflect", x.data_ptr(), N, Cc, H, W, g.data_ptr(), Ho, Wo, out.data_ptr())
+        return side.done(out)
+    ref, got = both(run)
+    assert_close(ref, got, tol=1e-5, what="warp_frame_reflect")
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 16, 16, 2), (64, 64, 8, 8, 1), (8, 8, 13, 5, 98), (16, 16, 64, 64, 3)])
 def test_resize(shape):
     Hi, Wi, Ho, Wo, Cc = shape
