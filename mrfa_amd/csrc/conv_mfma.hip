@@ -446,10 +446,11 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         const bool short_k_big_m = KT < 32 && M > 4096;
         const int max_split = (auto_split && !short_k_big_m) ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
         long long t = ntiles(BM, BN);
-        // (round 4 sweep, tools/sweep_splitk.py: one tile per CU without a split beats two half-K slices + init + epilogue launches -- 128 -> 32 @64^2 fused
-        // upsample 74 -> 54 us; with <= 16 tiles 256 workgroups beat 512, whose 4-step k-loops mostly add atomics -- 256 -> 512 @8^2 40 -> 32 us)
-        if (t < 256 && !(short_k_big_m && t >= 128)) {
-            int want = (int)(((t <= 16 ? 256 : 512) + t - 1) / t);
+        // (round 4, tools/sweep_splitk.py: with the split forced per launch the automatic choice is within 10 % of the best on six of eight low-resolution
+        // shapes -- 128 -> 32 @64^2 fused upsample would prefer no split (74 -> 54 us), 256 -> 512 @8^2 a quarter of the slices (40 -> 30 us).  Lowering the
+        // target here to catch those two moved OTHER layers onto the 64-row fp32 tiles through the BM loop below: +0.8 ms per step.  Left as it was.)
+        if (t < 384 && !(short_k_big_m && t >= 128)) {
+            int want = (int)((512 + t - 1) / t);
             if (auto_split) splitk = want <= max_split ? want : max_split;
             const int min_bm = (BN == 128) ? 32 : (BN == 64 ? 64 : 128);
             while (ntiles(BM, BN) * splitk < 384 && BM > min_bm) {

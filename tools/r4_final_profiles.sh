@@ -10,7 +10,7 @@ python bench.py --steps 10 --warmup 3 --prior fomm --no-cpu-baseline > $O/bench_
 python bench.py --steps 10 --warmup 3 --loss reference --no-cpu-baseline --no-forward > $O/bench_refloss.log 2>/dev/null
 python bench.py --steps 10 --warmup 3 --background --mfma bf16 --batch 16 --no-cpu-baseline --no-forward > $O/bench_config4.log 2>/dev/null
 python bench.py --size 512 --batch 4 --inference --steps 20 --warmup 3 > $O/bench_config5.log 2>/dev/null
-MRFA_SYNCBN_GRAPH=1 MRFA_SYNCBN_FORCE_COLLECTIVE=1 python bench.py --sync-bn --force-exchange --steps 5 --warmup 2 --no-cpu-baseline --no-forward --no-roofline > $O/bench_syncbn_graph_one_rank.log 2>/dev/null
+MRFA_SYNCBN_GRAPH=1 MRFA_SYNCBN_FORCE_COLLECTIVE=1 python bench.py --sync-bn --force-exchange --steps 5 --warmup 2 --no-cpu-baseline --no-forward --no-roofline > $O/bench_syncbn_graph_one_rank.log 2>$O/bench_syncbn_graph_one_rank.err
 python bench.py --force-exchange --steps 5 --warmup 2 --no-cpu-baseline --no-forward --no-roofline > $O/bench_force_exchange_one_rank.log 2>/dev/null
 [ -x tools/ubench/bin/mfma_lds_mix ] || { mkdir -p tools/ubench/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_lds_mix.hip -o tools/ubench/bin/mfma_lds_mix 2>/dev/null; }
 ./tools/ubench/bin/mfma_lds_mix 4 0 > $O/mfma_lds_mix.txt 2>/dev/null; ./tools/ubench/bin/mfma_lds_mix 4 1 >> $O/mfma_lds_mix.txt 2>/dev/null
