@@ -31,7 +31,7 @@ const char* mrfa_last_error(void);
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
  *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
  *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
- *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect().                                          */
+ *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect(); mrfa_bnbwd_params += red_world, mrfa_bn_param_grad().                                          */
 #define MRFA_ABI_VERSION 6
 int mrfa_version(void);
 
@@ -280,8 +280,13 @@ typedef struct {
     const float* res; int ldr;                   /* the forward's residual (needed for the ReLU mask)            */
     float* dres; int lddr;                       /* += gradient wrt the residual (phase 1), may be null          */
     unsigned int* sync;                          /* phase 3: one zero-initialised word (the barrier's arrival counter) */
+    int red_world;                               /* v6, phase 2: > 1 = `red` holds the sums of that many ranks (SyncBatchNorm: the caller all-reduced the
+                                                    slots between the phases): the batch means divide by red_world x the local row count.  dgamma / dbeta
+                                                    are LOCAL sums: take them from the local `red` with mrfa_bn_param_grad() before the exchange and pass NULL here */
 } mrfa_bnbwd_params;
 int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
+/* v6: dgamma[c] += sum over the slots of red[.][C + c], dbeta[c] += sum of red[.][c] (what phase 2 adds when it is given dgamma / dbeta)                  */
+int mrfa_bn_param_grad(void* stream, const double* red, int C, float* dgamma, float* dbeta);
 int mrfa_bn_act_bwd_fused_supported(const mrfa_bnbwd_params* p);     /* 1: phase = 3 is implemented for these parameters       */
 
 /* ------------------------------------------------------------------------------------------------------------

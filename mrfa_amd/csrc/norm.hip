@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
         sc = p.scale[c]; sh = p.shift[c];
         if (p.mean) { mean = p.mean[c]; invstd = p.invstd[c]; }
         if (PHASE == 2 && p.train) {
-            const double cnt = (double)rows;
+            const double cnt = (double)rows * (double)(p.red_world > 1 ? p.red_world : 1);       // (SyncBatchNorm: `red` summed over the ranks)
             double t1 = 0.0, t2 = 0.0;
             for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += p.red[(size_t)s * 2 * p.C + c]; t2 += p.red[(size_t)s * 2 * p.C + p.C + c]; }
             k1 = (float)(t1 / cnt);
@@ -274,7 +274,7 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
             invstd = *reinterpret_cast<const f32x4*>(p.invstd + c);
         }
         if (PHASE == 2 && p.train) {
-            const double cnt = (double)rows;
+            const double cnt = (double)rows * (double)(p.red_world > 1 ? p.red_world : 1);       // (SyncBatchNorm: `red` summed over the ranks)
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -474,6 +474,13 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __re
     for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += red[(size_t)s * 2 * C + c]; t2 += red[(size_t)s * 2 * C + C + c]; }
     if (dbeta) atomicAdd(dbeta + c, (float)t1);
     if (dgamma) atomicAdd(dgamma + c, (float)t2);
+}
+
+extern "C" int mrfa_bn_param_grad(void* stream, const double* red, int C, float* dgamma, float* dbeta) {
+    MRFA_CHECK_ARG(red && C > 0 && (dgamma || dbeta), "bn_param_grad: bad args");
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, red, dgamma, dbeta, C, 1, nullptr, nullptr, 0.f);
+    MRFA_CHECK_LAUNCH("bn_param_grad");
+    return 0;
 }
 
 static int pick_rows_per_block(long long rows, int chunks, int C) {

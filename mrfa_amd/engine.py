@@ -228,6 +228,7 @@ class defer_wgrads:
 
 
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
+SYNCBN_DIRECT_BYTES = int(os.environ.get("MRFA_SYNCBN_DIRECT_KIB", "128")) << 10      # statistics blocks up to this size are all-reduced whole (all slots)
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
 # data gradient of the stride-2 layers straight from dY (mrfa_conv_params.stride = -2: parity classes of the output grid, 9 / 4 of the taps) instead of a
 # stride-1 pass over a zero-stuffed copy.  OFF (MRFA_STRIDED_DGRAD=1): measured in the step 84.0 / 84.0 vs 83.6 / 83.5 ms (alternating runs): ~40 launches
@@ -1355,14 +1356,17 @@ class Ctx:
         if train and stats is not None:
             world = self._sync_world(bn)
             if self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
-                # sum / sum-of-squares over every rank's pixels: the slots are summed locally first, so the message is 2C doubles,
-                # not [STATS_SLOTS][2C] (bn_finalize sums the slots: slot 0 = the global sums, the others zero)
-                # (ONE glue launch: the slot sum lands in slot 0 of a fresh zero buffer from the pool -- round 3 summed, zeroed and copied in place:
-                # three launches per layer and direction, ~1 200 per step with the MTIA prior)
-                summed = self.f64z(hip.STATS_SLOTS * 2 * Cn)
-                torch.sum(stats[:hip.STATS_SLOTS * 2 * Cn].view(hip.STATS_SLOTS, 2 * Cn), 0, out=summed[:2 * Cn])
-                torch.distributed.all_reduce(summed[:2 * Cn])
-                stats = summed
+                # sum / sum-of-squares over every rank's pixels.  Small layers: ALL slots are all-reduced in place (<= 128 KB: the collective is latency-bound
+                # there, and nothing but the collective is launched -- round 3 summed, zeroed and copied: three glue launches per layer and direction,
+                # ~1 200 per step with the MTIA prior); wide layers: the slots are summed locally first (one launch) so that the message is 2C doubles
+                nsl = hip.STATS_SLOTS * 2 * Cn
+                if nsl * 8 <= SYNCBN_DIRECT_BYTES:
+                    torch.distributed.all_reduce(stats[:nsl])
+                else:
+                    summed = self.f64z(nsl)
+                    torch.sum(stats[:nsl].view(hip.STATS_SLOTS, 2 * Cn), 0, out=summed[:2 * Cn])
+                    torch.distributed.all_reduce(summed[:2 * Cn])
+                    stats = summed
                 count = count * world
         defer = train and self.deferred is not None            # side pass: the running statistics are updated after the join
         self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
@@ -1477,16 +1481,20 @@ class Ctx:
         q.phase = 1
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
         if synced:
-            # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums
+            # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums: taken from the local slots by one
+            # launch, then the slots are all-reduced in place and phase 2 divides by world x the local row count (mrfa_bnbwd_params.red_world).
+            # (Round 3: sum, two adds, the collective and a division = five launches per layer.)
             Cn = x.C
-            red_g = self.f64z(nred)                          # (slot 0 of a fresh zero buffer: no zero fill / copy launches)
-            local = red_g[:2 * Cn]
-            torch.sum(red[:nred].view(hip.STATS_SLOTS, 2 * Cn), 0, out=local)
-            db.add_(local[:Cn].float())
-            dg.add_(local[Cn:].float())
-            torch.distributed.all_reduce(local)
-            local.div_(world)                                # kernel divides by the LOCAL row count
-            q.red = red_g.data_ptr()
+            self._chk(self.L.mrfa_bn_param_grad(self.s, red.data_ptr(), Cn, dg.data_ptr(), db.data_ptr()), "bn_param_grad")
+            if nred * 8 <= SYNCBN_DIRECT_BYTES:
+                torch.distributed.all_reduce(red[:nred])
+            else:
+                red_g = self.f64z(nred)
+                local = red_g[:2 * Cn]
+                torch.sum(red[:nred].view(hip.STATS_SLOTS, 2 * Cn), 0, out=local)
+                torch.distributed.all_reduce(local)
+                q.red = red_g.data_ptr()
+            q.red_world = world
             q.dgamma = q.dbeta = None
         q.phase = 2
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(2)")

@@ -92,7 +92,7 @@ class BnBwdParams(C.Structure):
         ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
         ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int), ("dx_overwrite", C.c_int),
         ("res", C.c_void_p), ("ldr", C.c_int), ("dres", C.c_void_p), ("lddr", C.c_int),
-        ("sync", C.c_void_p),
+        ("sync", C.c_void_p), ("red_world", C.c_int),
     ]
 
 
@@ -156,6 +156,7 @@ _SIGNATURES = {
     "mrfa_act_bwd": ([_V, _V, _I, _V, _I, _L, _I, _I, _V, _I, _I], C.c_int),
     "mrfa_copy_view": ([_V, _V, _I, _L, _I, _V, _I, _F, _I], C.c_int),
     "mrfa_timestamp": ([_V, _V], C.c_int),
+    "mrfa_bn_param_grad": ([_V, _V, _I, _V, _V], C.c_int),
     "mrfa_warp_frame_reflect": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
     "mrfa_blend_fwd": ([_V, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_blend_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I, _V, _I, _V, _I], C.c_int),

@@ -671,7 +671,7 @@ class Emulator:
             slots[1, Cc:] += (du * xhat).reshape(-1, Cc).double().sum(0)
             return 0
         red = slots.sum(0)
-        rows = p.N * p.H * p.W
+        rows = p.N * p.H * p.W * max(int(getattr(p, "red_world", 0)), 1)      # v6: `red` summed over that many ranks (SyncBatchNorm)
         if p.train:
             k1 = (red[:Cc] / rows).float()
             k2 = (red[Cc:] / rows).float()
@@ -687,6 +687,14 @@ class Emulator:
             vec(p.dbeta, Cc).add_(red[:Cc].float())
         if p.dgamma:
             vec(p.dgamma, Cc).add_(red[Cc:].float())
+        return 0
+
+    def mrfa_bn_param_grad(self, stream, red, Cc, dgamma, dbeta):
+        r = vec(red, STATS_SLOTS * 2 * Cc, torch.float64).view(STATS_SLOTS, 2 * Cc).sum(0)
+        if dbeta:
+            vec(dbeta, Cc).add_(r[:Cc].float())
+        if dgamma:
+            vec(dgamma, Cc).add_(r[Cc:].float())
         return 0
 
     # ---------------------------------------------------------------- samplers
