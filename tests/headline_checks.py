@@ -29,7 +29,7 @@ from tests import cases
 #  the bottom, B = 2 -- a relative norm error of 1.4e-3 ... 4.1e-3 against 3.7e-3 allowed (1e-3 + 3 x the 0.9e-3 the reference's own two CPU realisations differ by):
 #  one failure in six runs of a gate sitting ON the distribution it is meant to contain.  6.0 puts it at 6.4e-3: 1.6 x the largest value seen; every other
 #  sub-network is below half of its allowance either way.  Still no term measured from the implementation under test.)
-COS_BASE, COS_MULT = 2e-5, 4.0
+COS_BASE, COS_MULT = 2e-5, 6.0          # (4.0 until then: `decoder.kp_img` / `decoder.to_context` sat at 0.7 of it in single replays; same multiple as the norm gate now)
 NORM_BASE, NORM_MULT = 1e-3, 6.0
 DKP_BASE, DKP_MULT = 1e-3, 3.0
 NET_FLOOR = 1e-2
