@@ -911,19 +911,6 @@ class Ctx:
             have.append(torch.cuda.Stream(device=self.dev))
         return have[:n]
 
-    def early_branch(self, stream):
-        """`stream` if a part of this program may run on it as a branch that does NOT start from the program's own stream (the caller forked
-        it earlier and orders it before the optimizer: HotPath), else None: only while a hipGraph of a recorded (training) pass is being
-        captured on the main pass, like lanes()"""
-        if (stream is None or self.dev.type != "cuda" or not self.record or self.deferred is not None
-                or not torch.cuda.is_current_stream_capturing()):
-            return None
-        # parameter gradients must reach .grad without passing through autograd: a gradient handed back at the end of this program's backward
-        # would be consumed on the program's stream while the branch is still writing it (found by test_graphed_train_step_equals_eager[False])
-        if not DIRECT_PARAM_GRADS or self.wdefer is None:
-            return None
-        return stream
-
     def fork(self, streams):
         """the branch streams start after everything issued so far; in backward the home stream waits for them here"""
         if not streams:
@@ -952,11 +939,8 @@ class Ctx:
                     st.wait_stream(cur)
             self.tape.append(bwd)
 
-    def branch(self, stream, fn, keep: Optional[list] = None):
-        """run fn() with `stream` current (None: in line); the backward closures it records run on the same stream.
-        keep: a list that receives those closures -- a branch whose backward nobody joins inside the program (early_branch) reads gradient
-        buffers that were allocated on the program's own stream; the caller holds the list until it has joined the stream, so that the
-        caching allocator cannot hand those blocks to a later allocation of the same capture while the branch still reads them"""
+    def branch(self, stream, fn):
+        """run fn() with `stream` current (None: in line); the backward closures it records run on the same stream"""
         if stream is None:
             return fn()
         n0 = len(self.tape)
@@ -969,8 +953,6 @@ class Ctx:
                 with torch.cuda.stream(stream):
                     f()
             self.tape[i] = on_stream
-            if keep is not None:
-                keep.append(on_stream)
         return out
 
     def _chk(self, rc, what):

@@ -242,20 +242,8 @@ class RaftFlow(nn.Module):
             assert not e.record and cache["shape"] == tuple(img_full.shape), "source cache: inference only, same source batch"
             imgf, feature = cache["imgf"], cache["feature"]
         else:
-            # The source image's feature pyramid (generator.py:34-42, ~290 GF at B = 8) depends on no keypoint.  While a training step is being
-            # captured, HotPath hands over the stream on which the weight layouts were refreshed at the very start of the step (`early`): the
-            # pyramid -- and, in backward, its data-gradient chain -- becomes a branch of the hipGraph beside the keypoint encoder's chains of
-            # small kernels, which leave most of the chip idle, instead of a stretch of the critical path after them.
-            early = e.early_branch(getattr(self, "_early_stream", None))
-
-            def pyramid():
-                x = e.from_nchw(img_full)
-                return x, gen.run_encode(e, x)
-            keep = [] if early is not None else None
-            imgf, feature = e.branch(early, pyramid, keep=keep)
-            if early is not None:
-                e.join([early])
-                object.__setattr__(self, "_early_keep", keep)        # until HotPath.join() (see Ctx.branch)
+            imgf = e.from_nchw(img_full)
+            feature = gen.run_encode(e, imgf)
         b, h, w = img.shape[0], img.shape[2], img.shape[3]
         size = self.size
         deform = e.wrap_nhwc(deformation.contiguous())                          # (B,h,w,2) normalised sampling grid

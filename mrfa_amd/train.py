@@ -95,9 +95,6 @@ class HotPath(nn.Module):
         object.__setattr__(self, "probe", None)
         # GraphedTrainStep: the stream on which the packed weight layouts of everything but the keypoint encoder are being refreshed
         object.__setattr__(self, "_pack_stream", None)
-        # ... and, once the main stream has waited for those layouts, the same stream as a branch for the part of the decoder that needs no keypoints
-        # (RaftFlow._program: the source image's feature pyramid, forward and backward); join() orders it before the optimizer
-        object.__setattr__(self, "_early", None)
 
     def encode_many(self, frames):
         """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234), in the reference's order as far as
@@ -155,24 +152,11 @@ class HotPath(nn.Module):
         if st is not None:
             torch.cuda.current_stream(st.device).wait_stream(st)
             object.__setattr__(self, "_pack_stream", None)
-            # OFF by default (MRFA_EARLY_PYRAMID=1): measured with tools/step_phases.py the step got SLOWER, 84.9 -> 90.0 ms -- the hipGraph
-            # executor maps the branches of a captured graph onto few internal streams by a static walk of the DAG, and with this extra long-lived
-            # branch the main stream's encoder pack waited 4 ms behind the pyramid and one encoder backward chain ran after the deferred weight
-            # gradients instead of beside them
-            if os.environ.get("MRFA_EARLY_PYRAMID", "0") == "1":
-                object.__setattr__(self, "_early", st)
 
     def join(self):
         """after backward(): the side streams' backward kernels (second encoder pass, deferred weight gradients) are ordered before
         whatever the caller issues next"""
         from . import engine
-        if self._early is not None:
-            with torch.cuda.stream(self._early):
-                engine.mark("backward: early branch done")
-            torch.cuda.current_stream(self._early.device).wait_stream(self._early)
-            object.__setattr__(self, "_early", None)
-            self.decoder._early_stream = None
-            object.__setattr__(self.decoder, "_early_keep", None)
         engine.mark("backward: main stream done")
         for st in self._sides:
             with torch.cuda.stream(st):
@@ -192,7 +176,6 @@ class HotPath(nn.Module):
         if defer is not None:
             defer.reset()                  # nothing of an earlier (possibly aborted) step may reach this step's gradients
             object.__setattr__(self, "_wdefer_dev", source.device)
-        self.decoder._early_stream = self._early
         with engine.defer_wgrads(defer):
             img_down = self.down(source)
             dm = self.dense_motion(source, kp_d, kp_s, bg_param=bg_param)

@@ -404,17 +404,14 @@ def test_encoder_weight_gradients_dealt_onto_side_streams_match_the_inline_order
         assert onoff <= 3.0 * noise + 1e-4, (k, onoff, noise)
 
 
-@pytest.mark.parametrize("early", ["0", "1"], ids=["pack-stream", "pack-stream+early-pyramid"])
-def test_pack_stream_and_early_pyramid_branch_replay_like_the_eager_step(monkeypatch, early):
-    """GraphedTrainStep refreshes the non-encoder weight layouts on a side stream beside the keypoint encoder's forward (default) and can run the
-    source image's feature pyramid -- forward and backward -- on that stream too (MRFA_EARLY_PYRAMID=1, opt-in: slower on ROCm 7.2's graph executor).
-    Both schedules must replay to the eager step's gradients: verify() at the INITIAL weights (well conditioned: the band is ~1e-2 / 2e-3 / 1e-2 of
+def test_pack_stream_replays_like_the_eager_step():
+    """GraphedTrainStep refreshes the non-encoder weight layouts on a side stream beside the keypoint encoder's forward.
+    The schedule must replay to the eager step's gradients: verify() at the INITIAL weights (well conditioned: the band is ~1e-2 / 2e-3 / 1e-2 of
     the encoder / decoder / dense-motion gradient), and the stale-layout case -- weights changed between capture and replay -- must still be right,
     i.e. the packs really run inside the graph, before their first reader."""
     import bench
     from mrfa_amd.graph import GraphedTrainStep
     from mrfa_amd.train import VOX1, HotPath, make_optimizer
-    monkeypatch.setenv("MRFA_EARLY_PYRAMID", early)
     src, drv = _pairs(2, "g/pk")
     m = HotPath(VOX1, prior="mtia")
     bench.init_weights(m)
