@@ -5,7 +5,7 @@ set -u; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out
 cd $R
 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; grep -E "passed|failed" $O/gputest.log | tail -1
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-/usr/bin/time -f "bench_default wall %e s" -o $O/bench_default.time python bench.py --steps 10 --warmup 3 > $O/bench_default.log 2>$O/bench_default.err
+S0=$SECONDS; python bench.py --steps 10 --warmup 3 > $O/bench_default.log 2>$O/bench_default.err; echo "python bench.py --steps 10 --warmup 3: $((SECONDS - S0)) s of wall time" > $O/bench_default.time
 python bench.py --steps 10 --warmup 3 --prior fomm --no-cpu-baseline > $O/bench_fomm.log 2>/dev/null
 python bench.py --steps 10 --warmup 3 --loss reference --no-cpu-baseline --no-forward > $O/bench_refloss.log 2>/dev/null
 python bench.py --steps 10 --warmup 3 --background --mfma bf16 --batch 16 --no-cpu-baseline --no-forward > $O/bench_config4.log 2>/dev/null
