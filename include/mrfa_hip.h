@@ -31,7 +31,7 @@ const char* mrfa_last_error(void);
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
  *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
  *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
- *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect(); mrfa_bnbwd_params += red_world, mrfa_bn_param_grad().                                          */
+ *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect(); mrfa_bnbwd_params += red_world, red_all, mrfa_bn_param_grad(); mrfa_conv_params += bst_*.                                          */
 #define MRFA_ABI_VERSION 6
 int mrfa_version(void);
 
@@ -104,6 +104,12 @@ typedef struct {
     float fin_momentum, fin_eps; long long fin_count;
     float* fin_scale; float* fin_shift; float* fin_mean; float* fin_invstd;
     unsigned int* fin_counter;
+    /* v6, optional, for DATA-GRADIENT launches that are the only writer of y = d(output of a BatchNorm + activation): the first phase of that BatchNorm's  */
+    /* backward in this launch's epilogue.  bst_x (row stride bst_ldx) = the BatchNorm's INPUT at the pixels of y; with u = x bst_scale + bst_shift and       */
+    /* du = (bst_relu && u <= 0) ? 0 : y, the launch adds sum(du) and sum(du (x - bst_mean) bst_invstd) per channel into `stats` -- laid out and consumed   */
+    /* like mrfa_bnbwd_params.red, so that mrfa_bn_act_bwd runs phase 2 only.  One launch less per layer on the keypoint encoder's backward chains.        */
+    /* Only where mrfa_conv2d_bwdstats_supported() says so (the small-problem kernel); not together with fin_*.                                               */
+    const float* bst_x; int bst_ldx; const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_invstd; int bst_relu;
 } mrfa_conv_params;
 
 /* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS
@@ -116,6 +122,7 @@ int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
 int mrfa_conv2d_stride_supported(const mrfa_conv_params* p);         /* 1: a call with these parameters honours stride = 2                */
 int mrfa_conv2d_mask_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters honours `mask`                    */
 int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p);    /* 1: a call with these parameters (ups = 2) is implemented          */
+int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p);   /* 1: a call with these parameters honours bst_*                                          */
 int mrfa_conv2d_wino_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters would run the Winograd form if w_wino were set */
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
@@ -283,6 +290,9 @@ typedef struct {
     int red_world;                               /* v6, phase 2: > 1 = `red` holds the sums of that many ranks (SyncBatchNorm: the caller all-reduced the
                                                     slots between the phases): the batch means divide by red_world x the local row count.  dgamma / dbeta
                                                     are LOCAL sums: take them from the local `red` with mrfa_bn_param_grad() before the exchange and pass NULL here */
+    int red_all;                                 /* v6, phase 2: 1 = sum ALL MRFA_STATS_SLOTS blocks of `red` (phase 1 of this entry point uses -- and phase 2 by
+                                                    default sums -- only as many as the launch geometry needs; sums accumulated by a convolution's bst_* epilogue
+                                                    are spread over all of them)                                                                              */
 } mrfa_bnbwd_params;
 int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
 /* v6: dgamma[c] += sum over the slots of red[.][C + c], dbeta[c] += sum of red[.][c] (what phase 2 adds when it is given dgamma / dbeta)                  */

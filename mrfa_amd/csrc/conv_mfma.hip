@@ -350,12 +350,23 @@ extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
 
 static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done);
 
+extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
+    if (!p || !p->stats || p->fin_scale || p->stride < 0 || p->kflat > 0) return 0;
+    static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    return small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
+}
+
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     MRFA_CHECK_ARG(pp, "conv2d: null parameter block");
     if (pp->fin_scale) {
         MRFA_CHECK_ARG(pp->stats && pp->fin_shift && pp->fin_gamma && pp->fin_beta && pp->fin_counter && pp->fin_count > 0,
                        "conv2d: fin_scale needs stats, fin_shift, fin_gamma, fin_beta, fin_counter and fin_count > 0");
         MRFA_CHECK_ARG((pp->fin_rmean == nullptr) == (pp->fin_rvar == nullptr), "conv2d: fin_rmean / fin_rvar come together");
+    }
+    if (pp->bst_x) {
+        MRFA_CHECK_ARG(pp->stats && pp->bst_scale && pp->bst_shift && pp->bst_mean && pp->bst_invstd && !pp->fin_scale,
+                       "conv2d: bst_x needs stats, bst_scale / _shift / _mean / _invstd and no fin_*");
+        MRFA_CHECK_ARG(mrfa_conv2d_bwdstats_supported(pp), "conv2d: bst_* is only implemented by the one-wave-per-tile kernel: ask mrfa_conv2d_bwdstats_supported() first");
     }
     bool fin_done = false;
     const int rc = conv2d_dispatch(stream, pp, &fin_done);

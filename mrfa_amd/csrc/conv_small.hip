@@ -181,9 +181,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         const int c = n0 + b * 16 + li;
         const bool c_ok = wave_on && c < p.Cout;
         float bias = 0.f, osc = 1.f, osh = 0.f;
+        float bsc = 0.f, bsh = 0.f, bmean = 0.f, binv = 0.f;          // bst_*: the BatchNorm whose output's gradient this launch writes
         if (c_ok) {
             if (p.bias) bias = p.bias[c];
             if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+            if (p.bst_x) { bsc = p.bst_scale[c]; bsh = p.bst_shift[c]; bmean = p.bst_mean[c]; binv = p.bst_invstd[c]; }
         }
         s1[b] = 0.f; s2[b] = 0.f;
 #pragma unroll
@@ -206,8 +208,16 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.accumulate) v += *dst;
                     *dst = v;
-                    s1[b] += v;
-                    s2[b] += v * v;
+                    if (p.bst_x) {
+                        // first phase of the BatchNorm backward (mrfa_conv_params.bst_*): v = d(act(bn(x))); through the activation, then the two sums
+                        const float xr = p.bst_x[(size_t)m * p.bst_ldx + c];
+                        const float du = (p.bst_relu && xr * bsc + bsh <= 0.f) ? 0.f : v;
+                        s1[b] += du;
+                        s2[b] += du * ((xr - bmean) * binv);
+                    } else {
+                        s1[b] += v;
+                        s2[b] += v * v;
+                    }
                 }
             }
     }

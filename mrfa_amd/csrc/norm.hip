@@ -239,7 +239,7 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
     const bool c_ok = c < p.C;                              // C % 4 == 0: all four channels valid together
     if (PHASE == 2 && (p.train || p.dbeta || p.dgamma)) {
         // thread (channel, quarter) adds every 4th of the used slots; the 4 quarters of a channel are lanes 4k..4k+3 of one wave
-        const int nslots = red_slots(gridDim.y);
+        const int nslots = p.red_all ? MRFA_STATS_SLOTS : red_slots(gridDim.y);      // (red_all: the sums came from another kernel's slot choice)
         const int q = threadIdx.x & 3, col = (threadIdx.x >> 2) & 63;
         const int cc = blockIdx.x * CH + col;
 #pragma unroll

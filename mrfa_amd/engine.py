@@ -241,6 +241,8 @@ NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2
 BN_BWD_FUSED = os.environ.get("MRFA_BN_BWD_FUSED", "0") == "1"
 # BatchNorm finalize of the conv -> BatchNorm pairs of the keypoint encoder inside the convolution's launch (last workgroup; mrfa_conv_params.fin_*)
 BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
+# first phase of the BatchNorm backward of single-consumer BatchNorm outputs inside the consumer's data-gradient launch (mrfa_conv_params.bst_*)
+BN_BWD_IN_DGRAD = os.environ.get("MRFA_BN_BWD_IN_DGRAD", "1") != "0"
 # Winograd F(2, 3)-along-x form of the plain 3x3 layers on the patch-tiled kernel (conv_halo MODE 3, pack modes 16 / 17).  OFF by default
 # (MRFA_WINO=1): 1.10-1.16x per launch in the launch loop but nothing measurable in the training step (LDS-read bound), and its
 # fp32 rounding (within 4x of the direct kernel's against fp64) is visible in ill-conditioned downstream quantities (the keypoint encoder's
@@ -365,7 +367,7 @@ def _r4(c: int) -> int:
 # ------------------------------------------------------------------------------------------------- storage / views
 class Storage:
     """[rows, ld] fp32 buffer + lazily allocated gradient buffer of the same geometry."""
-    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh", "bwd_masked")
+    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh", "bwd_masked", "bn_hint")
 
     def __init__(self, data: torch.Tensor):
         assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
@@ -384,6 +386,9 @@ class Storage:
         # applies the ReLU mask (fused into its epilogue where the library can, a masking pass of its own otherwise), so the
         # producers skip their ReLU-backward pass
         self.bwd_masked = False
+        # not None: the buffer is the output of a BatchNorm + activation with ONE consumer, a convolution (Ctx.bn_act(out_sole=True)): what that
+        # convolution's data gradient needs to accumulate the first phase of the BatchNorm's backward in its epilogue (Ctx._conv_dgrad)
+        self.bn_hint = None
 
     def grad_buf(self) -> torch.Tensor:
         if self.grad is None:
@@ -1294,6 +1299,21 @@ class Ctx:
             if not fused:
                 p.mask, p.ldm = None, 0
         self._maybe_wino(p, cw, dgrad=True, padded=padded, ups=False)
+        hint = getattr(x.st, "bn_hint", None) if (direct and BN_BWD_IN_DGRAD) else None
+        if hint is not None and hint["red"] is None and not relu_in and x.coff == 0 and x.C == x.st.ld and not padded and not cw.dgrad_flat:
+            # x is the output of a BatchNorm + activation whose ONLY consumer is this convolution (bn_act(out_sole=True)): this launch is the only writer
+            # of its gradient, so the first phase of that BatchNorm's backward -- the per-channel sums of du and du * xhat -- rides in its epilogue
+            # (mrfa_conv_params.bst_*) where the library has it; _bn_bwd then runs phase 2 only.  One launch less per layer on the encoder's backward chains.
+            bx = hint["x"]
+            red = self.f64z(hip.STATS_SLOTS * 2 * x.C + 2)
+            p.stats = red.data_ptr()
+            p.bst_x, p.bst_ldx, p.bst_relu = bx.ptr, bx.ld, int(hint["relu"])
+            p.bst_scale, p.bst_shift = hint["scale"].data_ptr(), hint["shift"].data_ptr()
+            p.bst_mean, p.bst_invstd = hint["mean"].data_ptr(), hint["invstd"].data_ptr()
+            if self.L.mrfa_conv2d_bwdstats_supported(C.byref(p)):
+                hint["red"] = red
+            else:
+                p.stats = p.bst_x = p.bst_scale = p.bst_shift = p.bst_mean = p.bst_invstd = None
         self._launch_conv(p, "dgrad", cw.Cout)
         if relu_in and not fused:
             self._relu_mask_pass(x)
@@ -1399,7 +1419,7 @@ class Ctx:
         self._fin_done[stats.data_ptr()] = (bn, count, scale, shift, mean, invstd)
 
     def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None,
-               sole_consumer: bool = False, res: Optional[View] = None) -> View:
+               sole_consumer: bool = False, res: Optional[View] = None, out_sole: bool = False) -> View:
         """out = [blend_a*occ +] act(bn(x)) [*(1-occ)], optional 2x2 avg-pool.  x = raw conv output, stats = its
         epilogue-accumulated sums (train) or None (eval)."""
         scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
@@ -1421,20 +1441,27 @@ class Ctx:
             if sole_consumer and x.coff == 0 and x.ld == x.C and x.st.grad is None and not self.in_backward:
                 x.st.grad_noinit = True               # this BN's backward is the only writer of x.grad and covers all of it
 
+            hint = None
+            if (out_sole and train and not pool and blend is None and res is None and out.coff == 0 and out.C == out.st.ld
+                    and not (isinstance(bn, torch.nn.SyncBatchNorm) and self._sync_collective(self._sync_world(bn)))):
+                # the caller states that ONE convolution consumes `out`: its data gradient may carry this BatchNorm's first backward phase (_conv_dgrad)
+                hint = out.st.bn_hint = {"x": x, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd, "relu": relu, "red": None}
+
             def bwd():
                 if not out.has_grad:
                     return
-                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res)
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res, hint=hint)
             self.tape.append(bwd)
         return out
 
-    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None):
+    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None, hint=None):
         bg = bngrad(bn)
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
         dg, db = bg.acc(self.pool32)
         nred = hip.STATS_SLOTS * 2 * x.C
-        red = self.f64z(nred + 2)                           # slotted like the statistics buffers (MRFA_STATS_SLOTS) + the fused launch's barrier word
+        pre_red = hint["red"] if hint is not None else None          # the sums of phase 1, already accumulated by the data gradient that wrote dy
+        red = pre_red if pre_red is not None else self.f64z(nred + 2)    # slotted like the statistics buffers (MRFA_STATS_SLOTS) + the fused launch's barrier word
         q = hip.BnBwdParams()
         q.x, q.ldx, q.N, q.H, q.W, q.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
         q.scale, q.shift, q.relu, q.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
@@ -1460,8 +1487,11 @@ class Ctx:
                 q.phase = 3
                 self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(fused)")
                 return
-        q.phase = 1
-        self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
+        if pre_red is None:
+            q.phase = 1
+            self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
+        else:
+            q.red_all = 1                                   # the convolution's epilogue spread its sums over all slots
         if synced:
             # SyncBN backward: the batch means of du and du*xhat are global; gamma/beta gradients stay local sums: taken from the local slots by one
             # launch, then the slots are all-reduced in place and phase 2 divides by world x the local row count (mrfa_bnbwd_params.red_world).

@@ -44,6 +44,8 @@ class ConvParams(C.Structure):
         ("fin_momentum", C.c_float), ("fin_eps", C.c_float), ("fin_count", C.c_longlong),
         ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_mean", C.c_void_p), ("fin_invstd", C.c_void_p),
         ("fin_counter", C.c_void_p),
+        ("bst_x", C.c_void_p), ("bst_ldx", C.c_int), ("bst_scale", C.c_void_p), ("bst_shift", C.c_void_p), ("bst_mean", C.c_void_p),
+        ("bst_invstd", C.c_void_p), ("bst_relu", C.c_int),
     ]
 
 
@@ -92,7 +94,7 @@ class BnBwdParams(C.Structure):
         ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
         ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int), ("dx_overwrite", C.c_int),
         ("res", C.c_void_p), ("ldr", C.c_int), ("dres", C.c_void_p), ("lddr", C.c_int),
-        ("sync", C.c_void_p), ("red_world", C.c_int),
+        ("sync", C.c_void_p), ("red_world", C.c_int), ("red_all", C.c_int),
     ]
 
 
@@ -156,6 +158,7 @@ _SIGNATURES = {
     "mrfa_act_bwd": ([_V, _V, _I, _V, _I, _L, _I, _I, _V, _I, _I], C.c_int),
     "mrfa_copy_view": ([_V, _V, _I, _L, _I, _V, _I, _F, _I], C.c_int),
     "mrfa_timestamp": ([_V, _V], C.c_int),
+    "mrfa_conv2d_bwdstats_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_bn_param_grad": ([_V, _V, _I, _V, _V], C.c_int),
     "mrfa_warp_frame_reflect": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
     "mrfa_blend_fwd": ([_V, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),

@@ -21,9 +21,11 @@ from ..util import run_block
 BN_MOMENTUM = 0.1
 
 
-def _conv_bn(e: Ctx, x: View, conv, bn, relu: bool, res: View = None, need_dx=True) -> View:
+def _conv_bn(e: Ctx, x: View, conv, bn, relu: bool, res: View = None, need_dx=True, out_sole=False) -> View:
+    """out_sole: the caller feeds the result to ONE convolution and nothing else (the first BatchNorm of a residual block): the first phase of this
+    BatchNorm's backward then rides in that convolution's data gradient (engine.Ctx.bn_act)"""
     raw, st = e.conv_bn_raw(x, conv, bn, need_dx=need_dx)
-    return e.bn_act(raw, bn, st, relu=relu, res=res, sole_consumer=True)
+    return e.bn_act(raw, bn, st, relu=relu, res=res, sole_consumer=True, out_sole=out_sole)
 
 
 def conv3x3(in_planes, out_planes, stride=1):
@@ -46,7 +48,7 @@ class BasicBlock(nn.Module):
 
     def run(self, e: Ctx, x: View) -> View:
         residual = x if self.downsample is None else _conv_bn(e, x, self.downsample[0], self.downsample[1], relu=False)
-        y = _conv_bn(e, x, self.conv1, self.bn1, relu=True)
+        y = _conv_bn(e, x, self.conv1, self.bn1, relu=True, out_sole=True)
         return _conv_bn(e, y, self.conv2, self.bn2, relu=True, res=residual)
 
     def forward(self, x):
@@ -71,8 +73,8 @@ class Bottleneck(nn.Module):
 
     def run(self, e: Ctx, x: View) -> View:
         residual = x if self.downsample is None else _conv_bn(e, x, self.downsample[0], self.downsample[1], relu=False)
-        y = _conv_bn(e, x, self.conv1, self.bn1, relu=True)
-        y = _conv_bn(e, y, self.conv2, self.bn2, relu=True)
+        y = _conv_bn(e, x, self.conv1, self.bn1, relu=True, out_sole=True)
+        y = _conv_bn(e, y, self.conv2, self.bn2, relu=True, out_sole=True)
         return _conv_bn(e, y, self.conv3, self.bn3, relu=True, res=residual)
 
     def forward(self, x):

@@ -471,7 +471,15 @@ class Emulator:
             if p.accumulate:
                 v = v + y
             y.copy_(v)
-            if p.stats:
+            if p.stats and p.bst_x:      # v6: first phase of the BatchNorm backward whose output's gradient this launch wrote (mrfa_conv_params.bst_*)
+                st = vec(p.stats, 2 * p.Cout, torch.float64)
+                xr = nhwc(p.bst_x, p.N, p.Hout, p.Wout, p.bst_ldx, p.Cout)
+                u = xr * vec(p.bst_scale, p.Cout) + vec(p.bst_shift, p.Cout)
+                du = torch.where(u > 0, v, torch.zeros_like(v)) if p.bst_relu else v
+                xhat = (xr - vec(p.bst_mean, p.Cout)) * vec(p.bst_invstd, p.Cout)
+                st[:p.Cout] += du.reshape(-1, p.Cout).double().sum(0)
+                st[p.Cout:] += (du * xhat).reshape(-1, p.Cout).double().sum(0)
+            elif p.stats:
                 st = vec(p.stats, 2 * p.Cout, torch.float64)
                 flat = v.reshape(-1, p.Cout).double()
                 st[:p.Cout] += flat.sum(0)
@@ -559,6 +567,10 @@ class Emulator:
         p = _obj(pref)
         return int(p.ups == 2 and bool(p.w_phase) and p.R == 3 and p.S == 3 and p.pad == 1 and p.Hin == 2 * p.Hout and p.Win == 2 * p.Wout
                    and p.Wout % 32 == 0 and p.Hout % 8 == 0 and p.Cin % 32 == 0 and not p.in_scale)
+
+    def mrfa_conv2d_bwdstats_supported(self, pref):
+        p = _obj(pref)
+        return 1 if (p.stats and not p.fin_scale and p.stride >= 0 and p.kflat == 0) else 0
 
     def mrfa_conv2d_wino_supported(self, pref):
         """shape rule of the Winograd-along-x form (the emulated convolution computes the same result with or without w_wino)"""

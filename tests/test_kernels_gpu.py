@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, lds=False, wwino=False, fin=False, tag="c"):
+              stride=1, lds=False, wwino=False, fin=False, bst=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -158,6 +158,15 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     st = stbuf[:hip.STATS_SLOTS * 2 * Cout].view(hip.STATS_SLOTS, 2 * Cout)
     if stats:
         p.stats = st.data_ptr()
+    if bst:                         # v6: the launch writes d(act(bn(x))) and accumulates the first phase of that BatchNorm's backward (bst_*)
+        assert stats and not fin
+        bx = side.t(f"{tag}/bst_x", (N * Ho * Wo, Cout + 4))
+        bsc, bsh = side.t(f"{tag}/bst_sc", (Cout,), 0.5, 1.5), side.t(f"{tag}/bst_sh", (Cout,), -0.3, 0.3)
+        bme, biv = side.t(f"{tag}/bst_me", (Cout,), -0.2, 0.2), side.t(f"{tag}/bst_iv", (Cout,), 0.5, 2.0)
+        keep += [bx, bsc, bsh, bme, biv]
+        p.bst_x, p.bst_ldx, p.bst_relu = bx.data_ptr(), Cout + 4, int(bst != "linear")
+        p.bst_scale, p.bst_shift, p.bst_mean, p.bst_invstd = bsc.data_ptr(), bsh.data_ptr(), bme.data_ptr(), biv.data_ptr()
+        assert side.L.mrfa_conv2d_bwdstats_supported(C.byref(p)) == 1
     fin_out = []
     if fin:                         # v6: the BatchNorm that follows finished inside the call (scale, shift, mean, invstd, running statistics)
         assert stats
@@ -239,6 +248,13 @@ CONV_CASES = {
     "lds_ragged_c96_c40": dict(N=2, H=16, W=32, Cin=96, Cout=40, stats=True, oaff=True, lds=True),
     "lds_row_segments": dict(N=1, H=8, W=64, Cin=32, Cout=128, res=True, lds=True),
     # strided gather (HRNet's downsampling layers: hr_base.py:241,253,302,305,365), even and odd input sizes
+    # v6: first phase of a BatchNorm backward in a data-gradient launch's epilogue (bst_*): ReLU and linear, accumulate, ragged tiles
+    "bst_hr32": dict(N=4, H=32, W=32, Cin=32, Cout=32, stats=True, relu=False, bias=False, bst=True),
+    "bst_hr64_acc": dict(N=2, H=16, W=16, Cin=64, Cout=64, stats=True, relu=False, bias=False, acc=True, bst=True),
+    "bst_linear_ragged": dict(N=1, H=7, W=9, Cin=64, Cout=48, stats=True, relu=False, bias=False, bst="linear"),
+    "bst_hr128": dict(N=2, H=16, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, bst=True),
+    "bst_hr64_m2048": dict(N=2, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, bst=True, ldy_extra=0),
+    "bst_1x1_256_64": dict(N=2, H=16, W=16, Cin=256, Cout=64, R=1, pad=0, stats=True, relu=False, bias=False, bst=True, ldy_extra=0),
     # v6: the BatchNorm finalize inside the call -- by the launch's last workgroup (one-wave-per-tile kernel), by a launch behind it (every other kernel)
     "fin_small_hr32": dict(N=8, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, fin="small"),
     "fin_small_hr128": dict(N=2, H=16, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, fin="small"),
