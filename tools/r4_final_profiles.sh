@@ -34,7 +34,7 @@ python tools/step_phases.py 8 mtia 20 2>/dev/null | grep -v amdgpu > $O/step_pha
 python tools/step_phases.py 8 fomm 20 2>/dev/null | grep -v amdgpu > $O/step_phases_fomm.txt
 python tools/enc_chain_probe.py mrfa_bn_act_fwd mrfa_conv2d_nhwc 2>/dev/null | grep -v amdgpu > $O/enc_chain_probe.txt
 python tools/sweep_splitk.py 2>/dev/null | grep -v amdgpu > $O/sweep_splitk.txt
-for k in "MRFA_BN_FIN_FUSED=0" "MRFA_PACK_STREAM=0" "MRFA_ENC_WGRAD_MULTI=0" "MRFA_WGRAD_SMALL_B64=0" "MRFA_HG_LANES=1" "X=0"; do echo "$k $(env $k python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-forward --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"; done > $O/switch_ablation.txt 2>&1
+for k in "MRFA_BN_FIN_FUSED=0" "MRFA_BN_BWD_IN_DGRAD=0" "MRFA_PACK_STREAM=0" "MRFA_ENC_WGRAD_MULTI=0" "MRFA_WGRAD_SMALL_B64=0" "MRFA_HG_LANES=1" "X=0"; do echo "$k $(env $k python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-forward --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"; done > $O/switch_ablation.txt 2>&1
 MRFA_WINO=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-forward > $O/bench_wino.log 2>/dev/null
 for v in 0 1; do python tools/bench_kernels.py --mfma 1 --iters 20 --only "3x3 @" --tune conv_halo_wino=$v 2>/dev/null | grep -v "hr \|ups\|@8\|@4\|->2 \|->1 "; done > $O/wino_ubench.txt
 ls $O
