@@ -33,7 +33,7 @@ for k in kernels:
 json.dump({"note": __doc__, "kernels": res}, open(out_json, "w"), indent=1)
 halo = [v for k, v in res.items() if k.startswith("conv_halo_kernel")]
 n = sum(v["dispatches"] for v in halo)
-tr = {"note": "launch-weighted mean over the conv_halo_kernel variants of the PMC passes in r3_pmc_summary.json (eager training step, B=8); bench.py reads kernels.conv_halo_kernel",
+tr = {"note": "launch-weighted mean over the conv_halo_kernel variants of the PMC passes in " + os.path.basename(out_json) + " (eager training step, B=8); bench.py reads kernels.conv_halo_kernel",
       "kernels": {"conv_halo_kernel": {"launches": n, "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in halo) / max(n, 1)}}}
 for k, v in res.items():
     tr["kernels"][k] = {"launches": v["dispatches"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
