@@ -1028,6 +1028,33 @@ def test_grid_sample(mode, Cc, in_rep):
     assert_close(ref, got, tol=5e-4, what="grid_sample")
 
 
+def test_timestamp_marks_are_ordered_on_a_stream():
+    """mrfa_timestamp (the measurement aid behind tools/step_phases.py): three marks around two launches on one stream read back non-decreasing, in units of
+    the device's 100 MHz clock, and the engine's Marks helper pairs them with their names"""
+    from mrfa_amd import engine
+    side = Side(True)
+    buf = torch.zeros(3, dtype=torch.int64, device=side.dev)
+    x = side.t("ts/x", (1 << 20, 4))
+    y = side.garbage((1 << 20, 4))
+    for k in range(3):
+        side.call("mrfa_timestamp", buf.data_ptr() + 8 * k)
+        if k < 2:
+            side.call("mrfa_copy_view", x.data_ptr(), 4, 1 << 20, 4, y.data_ptr(), 4, 1.0, 0)
+    torch.cuda.synchronize()
+    t = buf.cpu().tolist()
+    assert t[0] > 0 and t[0] <= t[1] <= t[2] and (t[2] - t[0]) < 100_000_000, t          # < 1 s between the first and the last
+    engine.MARKS = engine.Marks(side.dev, 8)
+    try:
+        engine.MARKS.begin()
+        engine.mark("a")
+        engine.mark("b")
+        torch.cuda.synchronize()
+        r = engine.MARKS.read()
+    finally:
+        engine.MARKS = None
+    assert [n for n, _ in r] == ["a", "b"] and r[0][1] == 0.0 and r[1][1] >= 0.0
+
+
 def test_warp_frame_reflect():
     """mrfa_warp_frame_reflect == F.grid_sample(frame, grid, padding_mode='reflection', align_corners=False) (Transform.transform_frame, model.py:44-48): grids far outside
     [-1, 1] (several reflections), exactly on the edges, and a different output size"""
