@@ -52,10 +52,21 @@ def make_coordinate_grid(spatial_size, type=None, like: Optional[torch.Tensor] =
     return torch.stack([xs.view(1, w).expand(h, w), ys.view(h, 1).expand(h, w)], dim=-1)
 
 
+_COORD_GRIDS: dict = {}
+
+
 def coords_grid_nhwc(h: int, w: int, like: torch.Tensor) -> torch.Tensor:
-    """(1,h,w,2) pixel-index grid (x,y): NHWC form of coords_grid, reference: modules/util.py:53-56"""
-    ys, xs = torch.meshgrid(torch.arange(h, device=like.device), torch.arange(w, device=like.device), indexing="ij")
-    return torch.stack([xs, ys], dim=-1).to(like.dtype)[None]
+    """(1,h,w,2) pixel-index grid (x,y): NHWC form of coords_grid, reference: modules/util.py:53-56.  A constant: kept per (size, device, dtype) -- RaftFlow asks
+    for seven of them per forward, five small launches each on the decoder's critical path.  Never modified by its users; grids first built while a hipGraph is
+    being captured are not kept (they live in that graph's private pool)."""
+    key = (h, w, like.device, like.dtype)
+    g = _COORD_GRIDS.get(key)
+    if g is None:
+        ys, xs = torch.meshgrid(torch.arange(h, device=like.device), torch.arange(w, device=like.device), indexing="ij")
+        g = torch.stack([xs, ys], dim=-1).to(like.dtype)[None]
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _COORD_GRIDS[key] = g
+    return g
 
 
 def kp2gaussian(kp: torch.Tensor, spatial_size, kp_variance: float) -> torch.Tensor:
