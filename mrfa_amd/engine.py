@@ -127,8 +127,12 @@ class DeferredWgrads:
         """issue the collected launches on the side streams, ordered after the current stream; the streams are joined by flush()"""
         if not self.thunks:
             return
-        if dev.type != "cuda":
-            for fn in self.thunks:
+        if dev.type != "cuda":                               # (the ABI emulator: no streams; the same marshalling as below, so that it is tested without a GPU)
+            todo = self.thunks
+            if self.batch:
+                todo = [fn for fn in self.thunks if getattr(fn, "params", None) is None]
+                self._issue_plain([fn for fn in self.thunks if getattr(fn, "params", None) is not None], dev)
+            for fn in todo:
                 fn()
             self.thunks = []
             return
@@ -152,15 +156,7 @@ class DeferredWgrads:
                 if not mine:
                     continue
                 with torch.cuda.stream(st):
-                    sp = hip.stream_ptr()
-                    ws = Ctx._wgrad_ws.get((dev, sp))
-                    if ws is None:
-                        ws = Ctx._wgrad_ws[(dev, sp)] = torch.empty(16 << 20, dtype=torch.float32, device=dev)
-                    arr = (hip.WgradParams * len(mine))()
-                    for i, fn in enumerate(mine):
-                        C.memmove(C.byref(arr, i * C.sizeof(hip.WgradParams)), C.byref(fn.params), C.sizeof(hip.WgradParams))
-                        arr[i].ws, arr[i].ws_bytes = ws.data_ptr(), ws.numel() * 4
-                    hip.check(hip.lib().mrfa_conv2d_wgrad_multi(sp, arr, len(mine)), "wgrad_multi(deferred)")
+                    self._issue_plain(mine, dev)
         for fn in todo:
             with torch.cuda.stream(lanes[self._rr % len(lanes)]):
                 fn()
@@ -171,14 +167,30 @@ class DeferredWgrads:
         self.thunks = []
         self.flushed = True
 
+    @staticmethod
+    def _issue_plain(fns, dev: torch.device):
+        """the parameter blocks of plain weight-gradient launches as ONE array on the current stream (mrfa_conv2d_wgrad_multi)"""
+        if not fns:
+            return
+        sp = hip.stream_ptr()
+        ws = Ctx._wgrad_ws.get((dev, sp))
+        if ws is None:
+            ws = Ctx._wgrad_ws[(dev, sp)] = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+        arr = (hip.WgradParams * len(fns))()
+        for i, fn in enumerate(fns):
+            C.memmove(C.byref(arr, i * C.sizeof(hip.WgradParams)), C.byref(fn.params), C.sizeof(hip.WgradParams))
+            arr[i].ws, arr[i].ws_bytes = ws.data_ptr(), ws.numel() * 4
+        hip.check(hip.lib().mrfa_conv2d_wgrad_multi(sp, arr, len(fns)), "wgrad_multi(deferred)")
+
     def flush(self, dev: torch.device):
         """issue everything collected so far on the side streams, ordered after the current stream; then the finals on the first of them, after all"""
         if not self.thunks and not self.finals:
             return
         if dev.type != "cuda":
-            for fn in self.thunks + self.finals:
+            self._deal(dev)
+            for fn in self.finals:
                 fn()
-            self.thunks, self.finals = [], []
+            self.finals = []
             return
         tag = "enc wgrads" if self.manual else "dec wgrads"
         mark(tag + ": flush")

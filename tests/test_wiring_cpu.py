@@ -467,13 +467,14 @@ def test_deferred_decoder_wgrads_equal_inline():
     from mrfa_amd.train import VOX1, HotPath, make_optimizer, train_step
     seen = {}
 
-    def run(defer):
+    def run(defer, batch=False):
         with emulated_hip():
             model = HotPath(VOX1, prior="fomm")
             for mod, tag in ((model.encoder, "kp"), (model.dense_motion, "dm"), (model.decoder, "rf")):
                 mod.load_state_dict(cases.weights_for(mod.state_dict(), tag))
             model.train(True)
             model.defer_decoder_wgrads = defer
+            model._wdefer.batch = batch                  # plain weight-gradient launches as ONE parameter array (mrfa_conv2d_wgrad_multi)
             opt = make_optimizer(model, fused=True)
             if defer:
                 orig = engine.DeferredWgrads.flush
@@ -494,6 +495,24 @@ def test_deferred_decoder_wgrads_equal_inline():
     assert l0 == l1
     assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
     assert float((w1 - w0).abs().max()) <= 1e-7
+    # the batched form (what the keypoint encoder's collection uses on the GPU): the same launches marshalled into one parameter array per flush
+    calls = {"n": 0, "problems": 0}
+    from oracle.capi_emulator import Emulator
+    orig_multi = Emulator.mrfa_conv2d_wgrad_multi
+
+    def counting(self, stream, ps, n):
+        calls["n"] += 1
+        calls["problems"] += n
+        return orig_multi(self, stream, ps, n)
+    Emulator.mrfa_conv2d_wgrad_multi = counting
+    try:
+        g2, w2, l2 = run(True, batch=True)
+    finally:
+        Emulator.mrfa_conv2d_wgrad_multi = orig_multi
+    assert calls["n"] >= 1 and calls["problems"] > 50, calls
+    assert l2 == l0
+    assert float((g2 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
+    assert float((w2 - w0).abs().max()) <= 1e-7
 
 
 def test_flat_adam_matches_torch_adam_and_clip():
