@@ -31,8 +31,12 @@ const char* mrfa_last_error(void);
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
  *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
  *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
- *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect(); mrfa_bnbwd_params += red_world, red_all, mrfa_bn_param_grad(); mrfa_conv_params += bst_*.                                          */
-#define MRFA_ABI_VERSION 6
+ *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect(); mrfa_bnbwd_params += red_world, red_all, mrfa_bn_param_grad(); mrfa_conv_params += bst_*.
+ *   7  round 5: STATISTIC GROUPS -- mrfa_conv_params / mrfa_bnact_params / mrfa_bnbwd_params += groups, mrfa_bn_finalize_groups(), mrfa_bn_param_grad_groups(),
+ *      mrfa_conv2d_groups_supported() (see "Statistic groups" below).  REMOVED (measured slower or neutral in round 4, never on by default): stride = -2 (the
+ *      strided data gradient), mrfa_bnbwd_params.phase = 3 with its `..._fused_supported` query (`sync` stays in the struct, reserved), the LDS-staged
+ *      small convolution behind mrfa_set_tuning("conv_lds").                                                                                              */
+#define MRFA_ABI_VERSION 7
 int mrfa_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -86,10 +90,8 @@ typedef struct {
     long long w_phase_piece; /* that equal nearest-x2 + 3x3 (pack mode 12, bf16 pieces).  When present (and the patch-tiled kernel  */
                            /*   applies) the layer runs 16 instead of 36 taps per low-resolution pixel -- same result up to fp32 rounding */
     int stride;            /* 0 / 1: stride 1.  2: strided convolution, Hout = (Hin + 2 pad - R) / 2 + 1 (HRNet's downsampling 3x3 layers,       */
-                           /*   hr_base.py:241,253,302,305,365) -- only where mrfa_conv2d_stride_supported() says so.                            */
-                           /*   -2 (v4): the DATA GRADIENT of such a layer: x = dY (Hin x Win) is read as sitting at the even pixels of the      */
-                           /*   Hout = 2 Hin x Wout = 2 Win output grid (zeros between), stride-1 convolution over that grid with `pad` and the  */
-                           /*   data-gradient weight pack: 9 / 4 of the taps per output pixel, no zero-stuffed copy (same query function)         */
+                           /*   hr_base.py:241,253,302,305,365) -- only where mrfa_conv2d_stride_supported() says so.  (-2, the strided data       */
+                           /*   gradient of v4-v6, is gone in v7: a stride-1 launch over the zero-stuffed dY is what callers use)                  */
     const void* w_wino;    /* v4, optional (3x3 / pad 1 / stride 1, no upsample): the weights run through the Winograd F(2, 3) transform ALONG X    */
     long long w_wino_piece;/*   (pack mode 16; 17 for data-gradient launches), three bf16 pieces.  When present and mrfa_conv2d_wino_supported()  */
                            /*   the patch-tiled kernel computes two horizontally adjacent outputs from 4 instead of 6 products per kernel row:    */
@@ -110,7 +112,22 @@ typedef struct {
     /* like mrfa_bnbwd_params.red, so that mrfa_bn_act_bwd runs phase 2 only.  One launch less per layer on the keypoint encoder's backward chains.        */
     /* Only where mrfa_conv2d_bwdstats_supported() says so (the small-problem kernel); not together with fin_*.                                               */
     const float* bst_x; int bst_ldx; const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_invstd; int bst_relu;
+    int groups;            /* v7: statistic groups of the N samples (0 / 1: one).  See "Statistic groups" below: `stats` = [groups][MRFA_STATS_SLOTS][2 Cout]    */
+                           /*   (fin_counter behind ALL of it), fin_scale / _shift / _mean / _invstd and bst_scale / _shift / _mean / _invstd = [groups][Cout],  */
+                           /*   fin_count = rows of ONE group, fin_rmean / fin_rvar updated once per group in group order.  Only where                           */
+                           /*   mrfa_conv2d_groups_supported() says so                                                                                            */
 } mrfa_conv_params;
+
+/* Statistic groups (v7).  The reference runs its keypoint encoder as separate calls on the source frames, the driving frames (and the transformed driving frames
+ * of the equivariance loss): modules/model.py:185-186,234 -- so in train mode every BatchNorm normalises each of those batches with ITS OWN batch statistics and
+ * updates its running statistics once per call, in call order.  Here the calls travel as ONE batch of N = groups x B samples (half / a third of the launches of a
+ * latency-bound chain, twice / three times the rows per launch): samples [g N / groups, (g + 1) N / groups) form statistic group g, and every train-mode BatchNorm
+ * quantity is kept per group: statistics blocks [groups][MRFA_STATS_SLOTS][2 C], scale / shift / mean / invstd [groups][C], the backward's `red`
+ * [groups][MRFA_STATS_SLOTS][2 C]; running_mean / running_var take `groups` momentum updates in group order (r <- (1 - m) r + m stat_g, g = 0, 1, ..), gamma / beta
+ * gradients are summed over the groups.  Everything without cross-sample coupling (convolutions, activations, LayerNorm, attention, weight gradients) is
+ * unchanged by construction.  Requirements: N % groups == 0 and no output tile of the launch may straddle two groups (the query functions check the kernels' tile
+ * heights: rows of one group % 128 == 0 always qualifies).  groups = 0 / 1 is the ungrouped behaviour of v6.                                                    */
+int mrfa_conv2d_groups_supported(const mrfa_conv_params* p);         /* 1: a call with these parameters honours groups > 1 for stats / fin_* / bst_*  */
 
 /* BatchNorm statistics buffers (`stats` of mrfa_conv_params, mrfa_bias_act, mrfa_bn_stats, mrfa_bn_finalize; `red` of mrfa_bnbwd_params): MRFA_STATS_SLOTS
  * consecutive blocks of 2*C doubles ([sum | sum of squares] per channel), zero-initialised by the caller.  A producing workgroup adds
@@ -254,6 +271,11 @@ int mrfa_bn_stats(void* stream, const float* x, int ldx, long long rows, int C, 
 int mrfa_bn_finalize(void* stream, const double* stats, long long count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, int C, int train,
                      float* scale, float* shift, float* mean_out, float* invstd_out);
+/* v7, train mode with statistic groups: stats [groups][MRFA_STATS_SLOTS][2C], count = rows of ONE group, outputs [groups][C]; the running statistics (may be
+ * NULL) take one momentum update per group, in group order -- what `groups` successive train-mode calls of the module do to them (model.py:185-186,234)          */
+int mrfa_bn_finalize_groups(void* stream, const double* stats, long long count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int C, int groups,
+                            float* scale, float* shift, float* mean_out, float* invstd_out);
 typedef struct {
     const float* x; int ldx; int N, H, W, C;
     const float* scale; const float* shift; int relu;
@@ -263,6 +285,7 @@ typedef struct {
     float* y; int ldy;
     const float* res; int ldr;       /* optional residual added BEFORE the activation: y = act(bn(x) + res) (HRNet
                                         BasicBlock / Bottleneck, transformer/hr_base.py:50-51,92-93); not with pool/blend */
+    int groups;                      /* v7: statistic groups (0 / 1: one): scale / shift = [groups][C], sample n uses row n / (N / groups); N % groups == 0 */
 } mrfa_bnact_params;
 int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* p);
 
@@ -279,25 +302,26 @@ typedef struct {
     float* dx; int lddx;                         /* += BN input gradient                                         */
     float* dgamma; float* dbeta;                 /* += (phase 2)                                                 */
     int train;                                   /* 0: eval-mode BN (no batch-statistics terms)                  */
-    int phase;                                   /* 1: reductions, 2: apply, 3: both in ONE launch with a grid-wide barrier
-                                                    between them (needs `sync`; only where mrfa_bn_act_bwd_fused_supported()
-                                                    says so; not with a cross-rank reduction of `red` in between)     */
+    int phase;                                   /* 1: reductions, 2: apply.  (3, both in one launch with a grid-wide barrier, is gone in v7:
+                                                    measured 6 ms slower per training step beside chip-filling kernels)                 */
     int dx_overwrite;                            /* phase 2: dx = ... instead of dx += ... (this BN is the only writer
                                                     of its input's gradient: no zero fill, no read of dx)              */
     const float* res; int ldr;                   /* the forward's residual (needed for the ReLU mask)            */
     float* dres; int lddr;                       /* += gradient wrt the residual (phase 1), may be null          */
-    unsigned int* sync;                          /* phase 3: one zero-initialised word (the barrier's arrival counter) */
+    unsigned int* sync;                          /* (reserved: the arrival counter of the removed phase 3)       */
     int red_world;                               /* v6, phase 2: > 1 = `red` holds the sums of that many ranks (SyncBatchNorm: the caller all-reduced the
                                                     slots between the phases): the batch means divide by red_world x the local row count.  dgamma / dbeta
                                                     are LOCAL sums: take them from the local `red` with mrfa_bn_param_grad() before the exchange and pass NULL here */
     int red_all;                                 /* v6, phase 2: 1 = sum ALL MRFA_STATS_SLOTS blocks of `red` (phase 1 of this entry point uses -- and phase 2 by
                                                     default sums -- only as many as the launch geometry needs; sums accumulated by a convolution's bst_* epilogue
                                                     are spread over all of them)                                                                              */
+    int groups;                                  /* v7: statistic groups (0 / 1: one): scale / shift / mean / invstd = [groups][C], red = [groups][MRFA_STATS_SLOTS][2C];
+                                                    the batch means of phase 2 are per group (count = rows / groups), dgamma / dbeta += the sums of ALL groups      */
 } mrfa_bnbwd_params;
 int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* p);
 /* v6: dgamma[c] += sum over the slots of red[.][C + c], dbeta[c] += sum of red[.][c] (what phase 2 adds when it is given dgamma / dbeta)                  */
 int mrfa_bn_param_grad(void* stream, const double* red, int C, float* dgamma, float* dbeta);
-int mrfa_bn_act_bwd_fused_supported(const mrfa_bnbwd_params* p);     /* 1: phase = 3 is implemented for these parameters       */
+int mrfa_bn_param_grad_groups(void* stream, const double* red, int C, int groups, float* dgamma, float* dbeta);     /* v7: red = [groups][MRFA_STATS_SLOTS][2C] */
 
 /* ------------------------------------------------------------------------------------------------------------
  * K10: bilinear grid_sample, zeros padding, NHWC, channel-vectorised.

@@ -304,10 +304,15 @@ int mrfa_tuning_attention_mfma(int set) {
     return prev;
 }
 
-// the MFMA kernels take the call: float4 accesses on every operand (16-byte aligned views, leading dimensions % 4 == 0)
-bool mrfa_attention_mfma_ok(int d, const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const void* dqkv, int lddq) {
+// the MFMA kernels take the call: float4 accesses on every operand (16-byte aligned views, leading dimensions % 4 == 0) and the other side's operands of a
+// head -- tokens padded to a multiple of 16, + 16 floats, + 2 np floats in the key-side backward (dout != NULL) -- within the 160 KB of LDS.  Longer token
+// lists stay on the VALU kernels of tokenpose.hip, whose LDS image is smaller (no padding): a call they can serve never fails here
+bool mrfa_attention_mfma_ok(int d, int n, const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const void* dqkv, int lddq) {
     auto ok = [](const void* p, int l) { return p == nullptr || (aligned16(p) && (l % 4) == 0); };
-    return mrfa_tuning_attention_mfma(-1) && (d == 16 || d == 24 || d == 32) && ok(qkv, ld) && ok(out, ldo) && ok(dout, lddo) && ok(dqkv, lddq);
+    const size_t np = (size_t)(n + 15) / 16 * 16;
+    const size_t lds = (2 * np * (d + 4) + 16 + (dout ? 2 * np : 0)) * sizeof(float);
+    return mrfa_tuning_attention_mfma(-1) && (d == 16 || d == 24 || d == 32) && lds <= 160 * 1024 && ok(qkv, ld) && ok(out, ldo) && ok(dout, lddo) &&
+           ok(dqkv, lddq);
 }
 
 #define ATT_MFMA_DISPATCH(KERNEL, LDS, ...)                                                                       \

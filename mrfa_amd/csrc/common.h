@@ -37,13 +37,8 @@ int mrfa_tuning_fewout3(int set);          // mrfa_set_tuning("conv_fewout3", 0 
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M);
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M);
 
-// conv_lds.hip: the HRNet trunk's 3x3 stride-1 layers, input halo staged once in LDS, exact fp32 on v_mfma_f32_16x16x4_f32
-bool mrfa_conv_lds_eligible(const mrfa_conv_params& p);
-int mrfa_conv_lds_launch(hipStream_t st, const mrfa_conv_params& p);
-int mrfa_tuning_conv_lds(int set);         // mrfa_set_tuning("conv_lds", 0 / 1); set < 0: query
-
 // attention_mfma.hip: multi-head attention forward / backward on v_mfma_f32_16x16x4_f32 (the VALU kernels of tokenpose.hip are the fallback)
-bool mrfa_attention_mfma_ok(int d, const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const void* dqkv, int lddq);
+bool mrfa_attention_mfma_ok(int d, int n, const void* qkv, int ld, const void* out, int ldo, const void* dout, int lddo, const void* dqkv, int lddq);
 int mrfa_attention_fwd_mfma(hipStream_t st, const float* qkv, int ld, int B, int n, int heads, int d, float scale, float* out, int ldo, float* lse);
 int mrfa_attention_bwd_mfma(hipStream_t st, const float* qkv, int ld, const float* out, int ldo, const float* dout, int lddo, const float* lse,
                             float* delta, int B, int n, int heads, int d, float scale, float* dqkv, int lddq);
@@ -88,6 +83,20 @@ __device__ __forceinline__ void chain_prio() {
 #ifndef MRFA_AB_NO_CHAIN_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
+}
+
+// Statistic groups (mrfa_hip.h, v7): the group of output row `row` of a launch with M = N Hout Wout rows, and the [MRFA_STATS_SLOTS][2 Cout] statistics
+// blocks of that group.  The host side guarantees that no workgroup's tile straddles two groups, so `row` is any row of the tile.
+__device__ __forceinline__ int stat_group(const mrfa_conv_params& p, long long row, long long M) {
+    return p.groups > 1 ? (int)(row / (M / p.groups)) : 0;
+}
+__device__ __forceinline__ double* stat_slot(const mrfa_conv_params& p, int group, unsigned slot) {
+    return p.stats + ((size_t)group * MRFA_STATS_SLOTS + slot % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+}
+// host side: rows of one group (0: the groups do not divide the batch)
+static inline long long group_rows(const mrfa_conv_params& p, long long M) {
+    if (p.groups <= 1) return M;
+    return (p.N % p.groups) == 0 ? M / p.groups : 0;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int kk = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
             const int cch = cb + 8 * (kk >> 2) + (kk & 3);
             if ((lane & 1) == 0 && cch < p.Cout) {
-                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                double* st = stat_slot(p, stat_group(p, (long long)n_img * p.Hout * p.Wout, (long long)p.N * p.Hout * p.Wout), blockIdx.x);   // (a patch lies in one image)
                 atomicAdd(st + cch, (double)s1[0]);
                 atomicAdd(st + p.Cout + cch, (double)s2[0]);
             }
@@ -644,7 +644,6 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "wgrad_halo_target_wgs")) return mrfa_tuning_wgrad_halo_target(value);
     if (!strcmp(key, "wgrad_halo_phase")) return mrfa_tuning_wgrad_halo_phase(value);
     if (!strcmp(key, "conv_fewout3")) return mrfa_tuning_fewout3(value != 0);
-    if (!strcmp(key, "conv_lds")) return mrfa_tuning_conv_lds(value != 0);
     if (!strcmp(key, "attention_mfma")) return mrfa_tuning_attention_mfma(value != 0);
     if (!strcmp(key, "conv_small")) { const int prev = g_conv_small; g_conv_small = value != 0; return prev; }
     return -1;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && c_ok) {
-                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                double* st = stat_slot(p, stat_group(p, m0, M), blockIdx.x);       // (statistic groups: the launcher keeps a tile inside one group)
                 atomicAdd(st + c, (double)s1);
                 atomicAdd(st + p.Cout + c, (double)s2);
             }
@@ -340,10 +340,8 @@ static thread_local int g_last_tile = 0;
 extern "C" int mrfa_conv2d_last_config(void) { return g_last_tile; }
 
 extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
-    if (!p || (p->stride != 2 && p->stride != -2) || !mrfa_tuning_conv_small()) return 0;
-    if (p->stride == 2 && (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1)) return 0;
-    // stride == -2: the data gradient of a stride-2 layer (x = dY on the Hin x Win grid, y = dX on the Hout = 2 Hin x Wout = 2 Win grid, pad = R - 1 - pad
-    // of the layer, weights in the data-gradient pack): checked by the kernel's own eligibility
+    if (!p || p->stride != 2 || !mrfa_tuning_conv_small()) return 0;
+    if (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1) return 0;
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
@@ -356,8 +354,26 @@ extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
     return small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
 
+// statistic groups: every kernel's output tile is at most 128 rows (and divides 128), the patch-tiled kernel's lies inside one image; a K split sums
+// its partial tiles in a pass whose workgroups stride over ALL rows, so grouped launches never split K (the automatic choice is switched off for them)
+extern "C" int mrfa_conv2d_groups_supported(const mrfa_conv_params* p) {
+    if (!p || p->groups <= 1) return p ? 1 : 0;
+    if (p->nbatch > 1 || p->splitk > 1) return 0;
+    const long long M = (long long)p->N * p->Hout * p->Wout;
+    const long long rows = group_rows(*p, M);
+    if (rows <= 0) return 0;
+    if ((rows % 128) == 0) return 1;
+    // shorter groups: the kernels whose tiles are smaller than 128 rows, where the dispatch would pick them
+    static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
+    if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(*p, M)) return 1;       // (its own rule: rows % 64 == 0)
+    return p->kflat == 0 && p->stride <= 1 && mrfa_conv_halo_eligible(*p) ? 1 : 0;                // (a patch lies inside one image)
+}
+
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     MRFA_CHECK_ARG(pp, "conv2d: null parameter block");
+    if (pp->groups > 1 && (pp->stats || pp->fin_scale || pp->bst_x))
+        MRFA_CHECK_ARG(mrfa_conv2d_groups_supported(pp), "conv2d: groups = %d is not implemented for these parameters (N = %d, %d x %d outputs, splitk %d): ask "
+                       "mrfa_conv2d_groups_supported() first", pp->groups, pp->N, pp->Hout, pp->Wout, pp->splitk);
     if (pp->fin_scale) {
         MRFA_CHECK_ARG(pp->stats && pp->fin_shift && pp->fin_gamma && pp->fin_beta && pp->fin_counter && pp->fin_count > 0,
                        "conv2d: fin_scale needs stats, fin_shift, fin_gamma, fin_beta, fin_counter and fin_count > 0");
@@ -372,8 +388,8 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     const int rc = conv2d_dispatch(stream, pp, &fin_done);
     if (rc || !pp->fin_scale || fin_done) return rc;
     // every kernel but the one-wave-per-tile one: the finalize launch behind the convolution, inside the call
-    return mrfa_bn_finalize(stream, pp->stats, pp->fin_count, pp->fin_gamma, pp->fin_beta, pp->fin_rmean, pp->fin_rvar, pp->fin_momentum, pp->fin_eps,
-                            pp->Cout, 1, pp->fin_scale, pp->fin_shift, pp->fin_mean, pp->fin_invstd);
+    return mrfa_bn_finalize_groups(stream, pp->stats, pp->fin_count, pp->fin_gamma, pp->fin_beta, pp->fin_rmean, pp->fin_rvar, pp->fin_momentum, pp->fin_eps,
+                                   pp->Cout, pp->groups > 1 ? pp->groups : 1, pp->fin_scale, pp->fin_shift, pp->fin_mean, pp->fin_invstd);
 }
 
 static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done) {
@@ -396,16 +412,11 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     const int KT = (Ktot + BK - 1) / BK;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
 
-    // ---- the HRNet trunk's 3x3 stride-1 layers (32..128 channels at 64^2..16^2): input halo staged once in LDS (conv_lds.hip)
-    if (!flat && mrfa_conv_lds_eligible(p) && !mrfa_conv_halo_eligible(p)) {   // (layer1's 64 -> 64 @64^2 stays on the bf16-pipe patch kernel: 29 vs 36 us)
-        g_last_tile = (16 << 16) | (16 << 4) | 16;               // bit 4: conv_lds
-        return mrfa_conv_lds_launch(st, p);
-    }
     // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
-        *fin_done = p.fin_scale != nullptr && p.stride != -2;    // (finished by the launch's last workgroup)
+        *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
         return mrfa_conv_small_launch(st, p, M);
     }
     if (p.stride > 1 || p.stride < 0) {
@@ -455,7 +466,8 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         // Short K loop over many pixels (HRNet's 32..64-channel 3x3 convs at 64^2 / 32^2): a K split would add a zero-init and
         // a reduction/epilogue pass over the whole output (2 x 20 us measured) to a 20 us kernel -- keep one launch
         const bool short_k_big_m = KT < 32 && M > 4096;
-        const int max_split = (auto_split && !short_k_big_m) ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
+        const bool grouped_stats = p.groups > 1 && p.stats;       // (the split-K epilogue pass does not keep statistic groups apart)
+        const int max_split = (auto_split && !short_k_big_m && !grouped_stats) ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
         long long t = ntiles(BM, BN);
         // (round 4, tools/sweep_splitk.py: with the split forced per launch the automatic choice is within 10 % of the best on six of eight low-resolution
         // shapes -- 128 -> 32 @64^2 fused upsample would prefer no split (74 -> 54 us), 256 -> 512 @8^2 a quarter of the slices (40 -> 30 us).  Lowering the

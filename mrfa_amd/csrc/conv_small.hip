@@ -28,11 +28,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // load-latency bound at one wave per SIMD: ~1.5 us per round trip under load)
 // CK = k16 chunks per loop step (2: the 16 x 16 / 16 x 32 wave tiles, whose 4-8 MFMAs per k16 did not cover the per-step loader advance:
 // two scalar branches, the tap bookkeeping and a waitcnt per step)
-// TS ("transposed stride"): the DATA GRADIENT of a stride-2 convolution (p.stride == -2): the input (dY, Hin x Win) sits at the even pixels of the
-// Hout x Wout output grid, zeros between.  Output pixels are processed per PARITY CLASS (blockIdx.y = 2 cy + cx), M = pixels of one class: a class
-// only meets the taps whose source lands on an even pixel -- 1, 2, 2 or 4 of the nine for a 3x3 / pad 1 layer -- i.e. 9 / 4 taps per pixel instead of
-// the 9 of a stride-1 convolution over a zero-stuffed copy of dY (which also cost a fill and a scatter launch per layer; hr_base.py:241,253,302,305,365).
-template <int TMW, int TNW, int DEPTH, int CK, bool TS = false>
+template <int TMW, int TNW, int DEPTH, int CK>
 __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int wave_tiles_m) {
     chain_prio();
     constexpr int WM = 16 * TMW, WN = 16 * TNW;
@@ -51,14 +47,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     const bool wave_on = wt_m < wave_tiles_m;
     const long long m0 = wt_m * WM;
     const int n0 = tile_n * WN;
-    const int cy = TS ? (int)(blockIdx.y >> 1) : 0, cx = TS ? (int)(blockIdx.y & 1) : 0;          // parity class of the output pixels
-    const int Hq = TS ? p.Hout >> 1 : p.Hout, Wq = TS ? p.Wout >> 1 : p.Wout;                       // (class-local) pixel grid
-    const int HWo = Hq * Wq;
+    const int Wq = p.Wout;
+    const int HWo = p.Hout * p.Wout;
     const int KC = p.Cin / (16 * CK);                 // loop steps (CK k16 chunks each) per tap
-    // TS: taps r = r0, r0 + 2, ..: those with (cy + r - pad) even
-    const int r0 = TS ? ((p.pad - cy) & 1) : 0, s0 = TS ? ((p.pad - cx) & 1) : 0;
-    const int nr = TS ? (p.R - r0 + 1) / 2 : p.R, ns = TS ? (p.S - s0 + 1) / 2 : p.S;
-    const int nq = nr * ns * KC;
+    const int ns = p.S;
+    const int nq = p.R * p.S * KC;
     const int cstride = p.stride > 1 ? p.stride : 1;
 
     int a_oy[TMW], a_ox[TMW];
@@ -73,7 +66,6 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         const int rem = (int)(mm - (long long)n_img * HWo);
         a_oy[a] = rem / Wq;
         a_ox[a] = rem - a_oy[a] * Wq;
-        if (TS) { a_oy[a] = 2 * a_oy[a] + cy; a_ox[a] = 2 * a_ox[a] + cx; }
         a_img[a] = (long long)n_img * p.Hin * p.Win;
     }
     // B rows: packed weights are zero-padded to a multiple of 128 rows, so every row n0 + b*16 + li < w_rows is readable
@@ -93,13 +85,12 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     int l_r = 0, l_s = 0, l_c = 0, l_q = 0;
     const float* arow[TMW];
     bool ainb[TMW];
-    size_t w_tap_off = TS ? (size_t)(r0 * p.S + s0) * p.w_tap : 0;
+    size_t w_tap_off = 0;
     auto set_tap = [&]() {
-        const int dr = (TS ? r0 + 2 * l_r : l_r) - p.pad, ds = (TS ? s0 + 2 * l_s : l_s) - p.pad;
+        const int dr = l_r - p.pad, ds = l_s - p.pad;
 #pragma unroll
         for (int a = 0; a < TMW; ++a) {
-            // (strided layers: hr_base.py:241,253,302,305,365; TS: source pixel of the zero-stuffed grid position, even by construction)
-            const int iy = TS ? (a_oy[a] + dr) >> 1 : a_oy[a] * cstride + dr, ix = TS ? (a_ox[a] + ds) >> 1 : a_ox[a] * cstride + ds;
+            const int iy = a_oy[a] * cstride + dr, ix = a_ox[a] * cstride + ds;          // (strided layers: hr_base.py:241,253,302,305,365)
             ainb[a] = a_ok[a] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
             const long long pix = ainb[a] ? a_img[a] + (long long)iy * p.Win + ix : a_img[a];
             arow[a] = p.x + (size_t)pix * p.ldx + lk * 4;
@@ -123,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
             if (++l_c == KC) {
                 l_c = 0;
                 if (++l_s == ns) { l_s = 0; ++l_r; }
-                w_tap_off = TS ? (size_t)((r0 + 2 * l_r) * p.S + s0 + 2 * l_s) * p.w_tap : w_tap_off + p.w_tap;
+                w_tap_off += p.w_tap;
                 set_tap();
             }
         }
@@ -175,6 +166,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
     }
 
     // ---- epilogue: C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
+    // (statistic groups: the four row tiles of a workgroup lie in one group -- the launcher checks rows per group % (4 WM) == 0)
+    const int grp = stat_group(p, (long long)(blockIdx.x / tiles_n) * 4 * WM, M);
     float s1[TNW], s2[TNW];
 #pragma unroll
     for (int b = 0; b < TNW; ++b) {
@@ -185,22 +178,15 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
         if (c_ok) {
             if (p.bias) bias = p.bias[c];
             if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
-            if (p.bst_x) { bsc = p.bst_scale[c]; bsh = p.bst_shift[c]; bmean = p.bst_mean[c]; binv = p.bst_invstd[c]; }
+            if (p.bst_x) { const int gc = grp * p.Cout + c; bsc = p.bst_scale[gc]; bsh = p.bst_shift[gc]; bmean = p.bst_mean[gc]; binv = p.bst_invstd[gc]; }
         }
         s1[b] = 0.f; s2[b] = 0.f;
 #pragma unroll
         for (int a = 0; a < TMW; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long mc = m0 + a * 16 + kq * 4 + r;     // (class-local) pixel index
-                long long m = mc;
-                if (TS && mc < M) {                                // -> pixel (2 qy + cy, 2 qx + cx) of the output grid
-                    const int n_img = (int)(mc / HWo);
-                    const int rem = (int)(mc - (long long)n_img * HWo);
-                    const int qy = rem / Wq, qx = rem - qy * Wq;
-                    m = ((long long)n_img * p.Hout + 2 * qy + cy) * p.Wout + 2 * qx + cx;
-                }
-                if (c_ok && mc < M) {
+                const long long m = m0 + a * 16 + kq * 4 + r;
+                if (c_ok && m < M) {
                     float v = acc[a][b][r] * p.alpha + bias;
                     v = v * osc + osh;
                     float* dst = p.y + (size_t)m * p.ldy + c;
@@ -236,42 +222,50 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
             const int c = n0 + col;
             if (c < p.Cout) {
                 const double v = (double)sred[0][which][col] + (double)sred[1][which][col] + (double)sred[2][which][col] + (double)sred[3][which][col];
-                atomicAdd(p.stats + (size_t)((blockIdx.x + blockIdx.y) % MRFA_STATS_SLOTS) * 2 * p.Cout + which * p.Cout + c, v);
+                atomicAdd(stat_slot(p, grp, blockIdx.x) + which * p.Cout + c, v);
             }
         }
         if (p.fin_scale) {
             // BatchNorm finalize by the LAST workgroup of the launch (mrfa_conv_params.fin_*): every workgroup takes a ticket once its slot sums are out;
             // whoever draws the last one reads all slots and writes what bn_finalize_kernel would have.  No release / acquire FENCES: an agent-scope
             // fence writes back (release) or invalidates (acquire) the XCD's whole L2 -- with one per workgroup the training step went from 83 to 98 ms.
-            // None is needed: the slot sums are device-scope atomics (performed at the memory side, never left dirty in an L2), the barrier below waits
-            // for their completion (s_waitcnt vmcnt(0)) before the ticket -- also a device-scope atomic -- is drawn, and the last workgroup reads the
-            // slots with device-scope loads, which bypass the non-coherent L2s (the guide's "sc1 stores AND sc1 loads" hand-off).
+            // None is needed: the slot sums are device-scope atomics (performed at the memory side, never left dirty in an L2), every thread that issued
+            // some WAITS FOR THEIR COMPLETION (the explicit s_waitcnt vmcnt(0) below: returnless atomics count in vmcnt, and neither the back-off barrier of
+            // gfx950 nor a relaxed ticket makes hipcc emit that wait by itself -- round 4 shipped without it) before the barrier that precedes
+            // the ticket -- also a device-scope atomic --, and the last workgroup reads the slots with device-scope loads, which bypass the non-coherent
+            // L2s (the guide's "sc1 stores AND sc1 loads" hand-off).  tests/test_wiring_cpu.py checks the compiled ISA for the wait.
             __shared__ unsigned s_ticket;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if (s_ticket == gridDim.x * gridDim.y - 1) {
+            if (s_ticket == gridDim.x - 1) {
                 const double cnt = (double)p.fin_count;
+                const int G = p.groups > 1 ? p.groups : 1;
                 for (int c = threadIdx.x; c < p.Cout; c += 256) {
-                    double t1 = 0.0, t2 = 0.0;
-                    for (int s = 0; s < MRFA_STATS_SLOTS; ++s) {
-                        t1 += __hip_atomic_load(p.stats + (size_t)s * 2 * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        t2 += __hip_atomic_load(p.stats + (size_t)s * 2 * p.Cout + p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    const double m = t1 / cnt;
-                    double var = t2 / cnt - m * m;
-                    if (var < 0.0) var = 0.0;
-                    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)p.fin_eps));
-                    if (p.fin_rmean) {
+                    float rm = p.fin_rmean ? p.fin_rmean[c] : 0.f, rv = p.fin_rmean ? p.fin_rvar[c] : 0.f;
+                    for (int g = 0; g < G; ++g) {                 // (statistic groups: one momentum update per group, in group order)
+                        const double* sg = p.stats + (size_t)g * MRFA_STATS_SLOTS * 2 * p.Cout;
+                        double t1 = 0.0, t2 = 0.0;
+                        for (int s = 0; s < MRFA_STATS_SLOTS; ++s) {
+                            t1 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            t2 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        const double m = t1 / cnt;
+                        double var = t2 / cnt - m * m;
+                        if (var < 0.0) var = 0.0;
+                        const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)p.fin_eps));
                         const double unb = p.fin_count > 1 ? var * cnt / (cnt - 1.0) : var;
-                        p.fin_rmean[c] = (1.f - p.fin_momentum) * p.fin_rmean[c] + p.fin_momentum * mean;
-                        p.fin_rvar[c] = (1.f - p.fin_momentum) * p.fin_rvar[c] + p.fin_momentum * (float)unb;
+                        rm = (1.f - p.fin_momentum) * rm + p.fin_momentum * mean;
+                        rv = (1.f - p.fin_momentum) * rv + p.fin_momentum * (float)unb;
+                        const float sc = p.fin_gamma[c] * invstd;
+                        const int gc = g * p.Cout + c;
+                        p.fin_scale[gc] = sc;
+                        p.fin_shift[gc] = p.fin_beta[c] - mean * sc;
+                        if (p.fin_mean) p.fin_mean[gc] = mean;
+                        if (p.fin_invstd) p.fin_invstd[gc] = invstd;
                     }
-                    const float sc = p.fin_gamma[c] * invstd;
-                    p.fin_scale[c] = sc;
-                    p.fin_shift[c] = p.fin_beta[c] - mean * sc;
-                    if (p.fin_mean) p.fin_mean[c] = mean;
-                    if (p.fin_invstd) p.fin_invstd[c] = invstd;
+                    if (p.fin_rmean) { p.fin_rmean[c] = rm; p.fin_rvar[c] = rv; }
                 }
             }
         }
@@ -284,12 +278,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
 // multiples of 16, and a problem small enough that the 128-row workgroup tiles cannot fill the chip.
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
     if (p.kflat > 0 || p.ups || p.in_scale || p.nbatch > 1 || p.tile || p.splitk > 1 || p.mask) return false;
-    if (p.stride > 2 || p.stride < -2 || p.stride == -1) return false;
-    if (p.stride == -2) {                            // data gradient of a stride-2 layer: even output grid, dY at its even pixels
-        if ((p.Hout & 1) || (p.Wout & 1) || p.Hin != p.Hout / 2 || p.Win != p.Wout / 2 || p.R != p.S || p.res || p.stats) return false;
-        M = M / 4;                                   // (pixels of one parity class)
-    }
-    const bool strided = p.stride == 2 || p.stride == -2;      // the only kernel with a strided gather: takes every such layer that fits its addressing
+    if (p.stride > 2 || p.stride < 0) return false;
+    if (p.groups > 1 && (group_rows(p, M) % 64) != 0) return false;      // statistic groups: a workgroup (4 waves x 16 / 32 rows) stays inside one group
+    const bool strided = p.stride == 2;              // the only kernel with a strided gather: takes every such layer that fits its addressing
     if ((p.Cin & 15) || (p.ldx & 3) || (p.w_ld & 3)) return false;
     if (!aligned16(p.x) || !aligned16(p.w)) return false;
     const long long ktot = (long long)p.R * p.S * p.Cin;
@@ -305,8 +296,6 @@ bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M) {
 }
 
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M) {
-    const bool ts = p.stride == -2;
-    if (ts) M /= 4;                                  // one parity class per blockIdx.y
     // wave tile: the largest of 32x32 / 16x32 / 16x16 that still yields >= ~2 000 waves (two per SIMD: measured best once the loads coalesce)
     const int ncols = (p.Cout + 15) / 16 * 16;
     auto waves = [&](int wm, int wn) { return ((M + wm - 1) / wm) * ((ncols + wn - 1) / wn); };
@@ -316,11 +305,12 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
     if (ncols % 32 != 0 && tn == 2 && ncols < 32) tn = 1;
     static const int force = [] { const char* e = getenv("MRFA_CS_TILE"); return e ? atoi(e) : 0; }();      // tuning: 22 / 12 / 11
     if (force == 22) { tm = 2; tn = 2; } else if (force == 12) { tm = 1; tn = 2; } else if (force == 11) { tm = 1; tn = 1; }
+    if (p.groups > 1 && tm == 2 && (group_rows(p, M) % 128) != 0) tm = 1;       // (eligibility guarantees % 64)
     const int WM = 16 * tm, WN = 16 * tn;
     const int tiles_n = (ncols + WN - 1) / WN;
     const int wave_tiles_m = (int)((M + WM - 1) / WM);
     const long long blocks = (long long)((wave_tiles_m + 3) / 4) * tiles_n;
-    dim3 grid((unsigned)blocks, ts ? 4u : 1u);
+    dim3 grid((unsigned)blocks);
     const bool deep = (long long)p.R * p.S * p.Cin >= 512;
     // two k16 chunks per loop step: small wave tiles on deep K (measured: 64->64 3x3 14.8 -> 13.6 us, 128->128 15.6 -> 13.9, 576->192
     // linear 14.4 -> 13.0; short K gets slower: 32->32 3x3 14.0 -> 15.6, 192->576 12.6 -> 15.1)
@@ -331,12 +321,7 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
         else if (deep) hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 8, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);    \
         else hipLaunchKernelGGL((conv_small_kernel<TM_, TN_, 4, 1>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);              \
     } while (0)
-    if (ts) {                                        // (short tap lists: the shallow ring; one instantiation per wave tile)
-        if (tm == 2 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<2, 2, 4, 1, true>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
-        else if (tm == 1 && tn == 2) hipLaunchKernelGGL((conv_small_kernel<1, 2, 4, 1, true>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
-        else hipLaunchKernelGGL((conv_small_kernel<1, 1, 4, 1, true>), grid, dim3(256), 0, st, p, M, tiles_n, wave_tiles_m);
-    }
-    else if (tm == 2 && tn == 2) SMALL_LAUNCH(2, 2);
+    if (tm == 2 && tn == 2) SMALL_LAUNCH(2, 2);
     else if (tm == 1 && tn == 2) SMALL_LAUNCH(1, 2);
     else SMALL_LAUNCH(1, 1);
 #undef SMALL_LAUNCH

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && c_ok) {
-                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                double* st = stat_slot(p, stat_group(p, m0, M), blockIdx.x);       // (statistic groups: the launcher keeps a tile inside one group)
                 atomicAdd(st + c, (double)s1);
                 atomicAdd(st + p.Cout + c, (double)s2);
             }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             const int kk = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
             const int cch = cb + 8 * (kk >> 2) + (kk & 3);
             if ((lane & 1) == 0 && cch < p.Cout) {
-                double* st = p.stats + (size_t)(blockIdx.x % MRFA_STATS_SLOTS) * 2 * p.Cout;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+                double* st = stat_slot(p, stat_group(p, m0, M), blockIdx.x);       // (statistic groups: the launcher keeps a tile inside one group)
                 atomicAdd(st + cch, (double)s1[0]);
                 atomicAdd(st + p.Cout + cch, (double)s2[0]);
             }

@@ -40,44 +40,51 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                   float momentum, float eps, int C, int train, float* __restrict__ scale,
+                                   float momentum, float eps, int C, int train, int groups, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     chain_prio();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float mean, invstd;
-    if (train) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += stats[(size_t)s * 2 * C + c]; t2 += stats[(size_t)s * 2 * C + C + c]; }
-        const double m = t1 / (double)count;
-        double var = t2 / (double)count - m * m;
-        if (var < 0.0) var = 0.0;
-        mean = (float)m;
-        invstd = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean) {
+    // statistic groups (train mode): one set of outputs and one momentum update of the running statistics per group, in group order --
+    // what `groups` successive calls of the module do (reference model.py:185-186,234)
+    float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        float mean, invstd;
+        if (train) {
+            const double* sg = stats + (size_t)g * MRFA_STATS_SLOTS * 2 * C;
+            double t1 = 0.0, t2 = 0.0;
+            for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += sg[(size_t)s * 2 * C + c]; t2 += sg[(size_t)s * 2 * C + C + c]; }
+            const double m = t1 / (double)count;
+            double var = t2 / (double)count - m * m;
+            if (var < 0.0) var = 0.0;
+            mean = (float)m;
+            invstd = (float)(1.0 / sqrt(var + (double)eps));
             const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            rm = (1.f - momentum) * rm + momentum * mean;
+            rv = (1.f - momentum) * rv + momentum * (float)unb;
+        } else {
+            mean = rm;
+            invstd = 1.0f / sqrtf(rv + eps);
         }
-    } else {
-        mean = rmean[c];
-        invstd = 1.0f / sqrtf(rvar[c] + eps);
+        const float sc = gamma[c] * invstd;
+        scale[g * C + c] = sc;
+        shift[g * C + c] = beta[c] - mean * sc;
+        if (mean_out) mean_out[g * C + c] = mean;
+        if (invstd_out) invstd_out[g * C + c] = invstd;
     }
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
-    if (mean_out) mean_out[c] = mean;
-    if (invstd_out) invstd_out[c] = invstd;
+    if (train && rmean) { rmean[c] = rm; rvar[c] = rv; }
 }
 
 // ---------------------------------------------------------------------------------------------- forward apply
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params p, long long total) {
     chain_prio();
     const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
+    const long long gpix = p.groups > 1 ? (long long)(p.N / p.groups) * Ho * Wo : 0;      // output pixels per statistic group
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long opix = i / p.C;
         const int c = (int)(i - opix * p.C);
-        const float sc = p.scale[c], sh = p.shift[c];
+        const int gc = gpix ? (int)(opix / gpix) * p.C + c : c;
+        const float sc = p.scale[gc], sh = p.shift[gc];
         float v;
         if (!p.pool) {
             v = p.x[(size_t)opix * p.ldx + c] * sc + sh;
@@ -110,10 +117,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const mrfa_bnact_params
 template <bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const mrfa_bnact_params p, long long total4, int c4) {
     chain_prio();
+    const long long gpix = p.groups > 1 ? (long long)(p.N / p.groups) * p.H * p.W : 0;      // pixels per statistic group
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long opix = i / c4;
         const int c = (int)(i - opix * c4) * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c), sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+        const int gc = gpix ? (int)(opix / gpix) * p.C + c : c;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + gc), sh = *reinterpret_cast<const f32x4*>(p.shift + gc);
         f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)opix * p.ldx + c) * sc + sh;
         if (RES) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)opix * p.ldr + c);
         if (p.relu) {
@@ -132,6 +141,25 @@ __device__ __forceinline__ int red_slots(unsigned row_blocks) {
     return row_blocks >= 64 ? MRFA_STATS_SLOTS : (row_blocks >= 16 ? 8 : 1);
 }
 
+// Statistic groups (mrfa_bnbwd_params.groups): the grid's y axis holds one run of `row_blocks` workgroups per group, each run covering that group's
+// rows [g cnt, (g + 1) cnt) in steps of rows_per_block.  Ungrouped: one run over all rows.
+struct GroupSpan {
+    int g;                  // this workgroup's group
+    unsigned by, row_blocks; // its index inside the group's run, workgroups per run
+    long long cnt, r0, r1;  // rows per group, this workgroup's rows
+};
+__device__ __forceinline__ GroupSpan group_span(const mrfa_bnbwd_params& p, long long rows, int rows_per_block) {
+    GroupSpan s;
+    const int G = p.groups > 1 ? p.groups : 1;
+    s.row_blocks = gridDim.y / G;
+    s.g = blockIdx.y / s.row_blocks;
+    s.by = blockIdx.y - s.g * s.row_blocks;
+    s.cnt = rows / G;
+    s.r0 = s.g * s.cnt + (long long)s.by * rows_per_block;
+    s.r1 = min((s.g + 1) * s.cnt, s.r0 + rows_per_block);
+    return s;
+}
+
 // u = x*scale+shift ; a = relu(u) ; out = pool(a) or blend(A, a, occ).  PHASE 1: per-channel sum(du), sum(du*xhat),
 // plus dA / docc of the blend.  PHASE 2: dx += gamma*invstd*(du - mean(du) - xhat*mean(du*xhat)) (train) or du*scale.
 template <int PHASE>
@@ -140,17 +168,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * CH + lane;
     const bool c_ok = c < p.C;
-    const long long r0 = (long long)blockIdx.y * rows_per_block;
-    const long long r1 = min(rows, r0 + rows_per_block);
+    const GroupSpan gs = group_span(p, rows, rows_per_block);
+    const long long r0 = gs.r0, r1 = gs.r1;
+    const int gc = gs.g * p.C + c;                           // this group's row of the [groups][C] per-channel arrays
+    double* const red_g = p.red + (size_t)gs.g * MRFA_STATS_SLOTS * 2 * p.C;
     const int Wo = p.W / 2, Ho = p.H / 2;
     float sc = 0.f, sh = 0.f, mean = 0.f, invstd = 0.f, k1 = 0.f, k2 = 0.f, gi = 0.f;
     if (c_ok) {
-        sc = p.scale[c]; sh = p.shift[c];
-        if (p.mean) { mean = p.mean[c]; invstd = p.invstd[c]; }
+        sc = p.scale[gc]; sh = p.shift[gc];
+        if (p.mean) { mean = p.mean[gc]; invstd = p.invstd[gc]; }
         if (PHASE == 2 && p.train) {
-            const double cnt = (double)rows * (double)(p.red_world > 1 ? p.red_world : 1);       // (SyncBatchNorm: `red` summed over the ranks)
+            const double cnt = (double)gs.cnt * (double)(p.red_world > 1 ? p.red_world : 1);       // (SyncBatchNorm: `red` summed over the ranks)
             double t1 = 0.0, t2 = 0.0;
-            for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += p.red[(size_t)s * 2 * p.C + c]; t2 += p.red[(size_t)s * 2 * p.C + p.C + c]; }
+            for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += red_g[(size_t)s * 2 * p.C + c]; t2 += red_g[(size_t)s * 2 * p.C + p.C + c]; }
             k1 = (float)(t1 / cnt);
             k2 = (float)(t2 / cnt);
             gi = p.gamma[c] * invstd;
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
         if (wave == 0 && c_ok) {
             double a = 0.0, b = 0.0;
             for (int w = 0; w < NW; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
-            double* rd = p.red + (size_t)((blockIdx.y + blockIdx.x) % red_slots(gridDim.y)) * 2 * p.C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+            double* rd = red_g + (size_t)((gs.by + blockIdx.x) % red_slots(gs.row_blocks)) * 2 * p.C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
             atomicAdd(rd + c, a);
             atomicAdd(rd + p.C + c, b);
         }
@@ -226,9 +256,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const mrfa_bnbwd_params
 // update (dgamma += sum du*xhat, dbeta += sum du) into the first row-block instead of a separate launch.
 // MODE 0: plain, 1: residual, 2: 2x2 pool, 3: occlusion blend -- compile-time, so that the row loop of the common (plain / residual)
 // case has no uniform branches between its loads (as run-time flags they kept hipcc from batching the x / dy / res loads of a row group)
-// COHERENT: the phase-2 part of the fused (phase 3) launch: the partial sums were written by other workgroups of the SAME launch, so they are read
-// with agent-scope atomic loads (the per-XCD L2s are not coherent for plain loads inside one kernel)
-template <int PHASE, int MODE, bool COHERENT = false>
+template <int PHASE, int MODE>
 __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long long rows, int rows_per_block, float (&red)[2][16][CH],
                                             double (&redsum)[2][CH]) {
     constexpr bool POOL = MODE == 2, BLEND = MODE == 3, RES = MODE == 1;
@@ -237,9 +265,12 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
     const int slot = wave * 4 + rsub;                       // 16 row slots per workgroup
     const int c = blockIdx.x * CH + cg * 4;
     const bool c_ok = c < p.C;                              // C % 4 == 0: all four channels valid together
+    const GroupSpan gs = group_span(p, rows, rows_per_block);
+    const int gc = gs.g * p.C + c;                          // this group's row of the [groups][C] per-channel arrays
+    double* const red_g = p.red + (size_t)gs.g * MRFA_STATS_SLOTS * 2 * p.C;
     if (PHASE == 2 && (p.train || p.dbeta || p.dgamma)) {
         // thread (channel, quarter) adds every 4th of the used slots; the 4 quarters of a channel are lanes 4k..4k+3 of one wave
-        const int nslots = p.red_all ? MRFA_STATS_SLOTS : red_slots(gridDim.y);      // (red_all: the sums came from another kernel's slot choice)
+        const int nslots = p.red_all ? MRFA_STATS_SLOTS : red_slots(gs.row_blocks);      // (red_all: the sums came from another kernel's slot choice)
         const int q = threadIdx.x & 3, col = (threadIdx.x >> 2) & 63;
         const int cc = blockIdx.x * CH + col;
 #pragma unroll
@@ -247,13 +278,7 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
             double t = 0.0;
             if (cc < p.C) {
                 for (int s = q; s < nslots; s += 4) {
-                    const double* src = p.red + (size_t)s * 2 * p.C + which * p.C + cc;
-                    if constexpr (COHERENT) {
-                        const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        t += __longlong_as_double((long long)bits);
-                    } else {
-                        t += *src;
-                    }
+                    t += red_g[(size_t)s * 2 * p.C + which * p.C + cc];
                 }
             }
             t += __shfl_xor(t, 1, 64);
@@ -262,19 +287,18 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
         }
         __syncthreads();
     }
-    const long long r0 = (long long)blockIdx.y * rows_per_block;
-    const long long r1 = min(rows, r0 + rows_per_block);
+    const long long r0 = gs.r0, r1 = gs.r1;
     const int Wo = p.W / 2, Ho = p.H / 2;
     f32x4 sc = {0, 0, 0, 0}, sh = sc, mean = sc, invstd = sc, k1 = sc, k2 = sc, gi = sc;
     if (c_ok) {
-        sc = *reinterpret_cast<const f32x4*>(p.scale + c);
-        sh = *reinterpret_cast<const f32x4*>(p.shift + c);
+        sc = *reinterpret_cast<const f32x4*>(p.scale + gc);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + gc);
         if (p.mean) {
-            mean = *reinterpret_cast<const f32x4*>(p.mean + c);
-            invstd = *reinterpret_cast<const f32x4*>(p.invstd + c);
+            mean = *reinterpret_cast<const f32x4*>(p.mean + gc);
+            invstd = *reinterpret_cast<const f32x4*>(p.invstd + gc);
         }
         if (PHASE == 2 && p.train) {
-            const double cnt = (double)rows * (double)(p.red_world > 1 ? p.red_world : 1);       // (SyncBatchNorm: `red` summed over the ranks)
+            const double cnt = (double)gs.cnt * (double)(p.red_world > 1 ? p.red_world : 1);       // (SyncBatchNorm: `red` summed over the ranks)
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -283,7 +307,7 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
                 gi[k] = g[k] * invstd[k];
             }
         }
-        if (PHASE == 2 && blockIdx.y == 0 && slot == 0) {   // parameter gradients, once per channel
+        if (PHASE == 2 && gs.by == 0 && slot == 0) {        // parameter gradients, once per channel (and statistic group: the groups' sums add up)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (p.dbeta) atomicAdd(p.dbeta + c + k, (float)redsum[0][cg * 4 + k]);         // atomic: see unpack_multi_kernel
@@ -428,7 +452,7 @@ __device__ __forceinline__ void bn_bwd_body(const mrfa_bnbwd_params& p, long lon
         if (threadIdx.x < CH && cc < p.C) {
             double a = 0.0, b = 0.0;
             for (int w = 0; w < 16; ++w) { a += red[0][w][threadIdx.x]; b += red[1][w][threadIdx.x]; }
-            double* rd = p.red + (size_t)((blockIdx.y + blockIdx.x) % red_slots(gridDim.y)) * 2 * p.C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
+            double* rd = red_g + (size_t)((gs.by + blockIdx.x) % red_slots(gs.row_blocks)) * 2 * p.C;       // see MRFA_STATS_SLOTS (mrfa_hip.h)
             atomicAdd(rd + cc, a);
             atomicAdd(rd + p.C + cc, b);
         }
@@ -443,44 +467,26 @@ __global__ __launch_bounds__(256) void bn_act_bwd_vec_kernel(const mrfa_bnbwd_pa
     bn_bwd_body<PHASE, MODE>(p, rows, rows_per_block, red, redsum);
 }
 
-// phase 3: reductions, a grid-wide barrier, apply -- ONE launch instead of two for the small tensors of the keypoint encoder, whose backward is a
-// chain of ~1 500 launches per pass at 8-13 us each (the tensor is still in L2 when the second half re-reads it).  The barrier is an arrival counter
-// (`sync`, zeroed by the caller): every workgroup of the launch must become resident, so the host only takes this path for grids of at most one
-// workgroup per CU; other kernels may hold CUs for a while (concurrent streams), they do not depend on this one, so the spinning workgroups only wait.
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(const mrfa_bnbwd_params p, long long rows, int rows_per_block) {
-    __shared__ float red[2][16][CH];
-    __shared__ double redsum[2][CH];
-    bn_bwd_body<1, MODE>(p, rows, rows_per_block, red, redsum);
-    __syncthreads();                                         // this workgroup's atomics into `red` (and its dres stores) are issued
-    if (threadIdx.x == 0) {
-        __atomic_thread_fence(__ATOMIC_RELEASE);             // ... and visible device-wide before the arrival
-        __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned total = gridDim.x * gridDim.y;
-        while (__hip_atomic_load(p.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < total) __builtin_amdgcn_s_sleep(4);
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
-    __syncthreads();
-    bn_bwd_body<2, MODE, true>(p, rows, rows_per_block, red, redsum);
-}
-
-__global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                     int train, const float* __restrict__ rmean, const float* __restrict__ rvar, float eps) {
+__global__ void bn_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int nslots) {
     chain_prio();
-    // train: red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta).  (eval handled by caller with train stats.)
+    // red[C+c] = sum(du*xhat) is d(gamma); red[c] = sum(du) is d(beta); nslots = statistic groups x MRFA_STATS_SLOTS consecutive blocks
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double t1 = 0.0, t2 = 0.0;
-    for (int s = 0; s < MRFA_STATS_SLOTS; ++s) { t1 += red[(size_t)s * 2 * C + c]; t2 += red[(size_t)s * 2 * C + C + c]; }
+    for (int s = 0; s < nslots; ++s) { t1 += red[(size_t)s * 2 * C + c]; t2 += red[(size_t)s * 2 * C + C + c]; }
     if (dbeta) atomicAdd(dbeta + c, (float)t1);
     if (dgamma) atomicAdd(dgamma + c, (float)t2);
 }
 
-extern "C" int mrfa_bn_param_grad(void* stream, const double* red, int C, float* dgamma, float* dbeta) {
-    MRFA_CHECK_ARG(red && C > 0 && (dgamma || dbeta), "bn_param_grad: bad args");
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, red, dgamma, dbeta, C, 1, nullptr, nullptr, 0.f);
+extern "C" int mrfa_bn_param_grad_groups(void* stream, const double* red, int C, int groups, float* dgamma, float* dbeta) {
+    MRFA_CHECK_ARG(red && C > 0 && groups >= 1 && (dgamma || dbeta), "bn_param_grad: bad args");
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, red, dgamma, dbeta, C, groups * MRFA_STATS_SLOTS);
     MRFA_CHECK_LAUNCH("bn_param_grad");
     return 0;
+}
+
+extern "C" int mrfa_bn_param_grad(void* stream, const double* red, int C, float* dgamma, float* dbeta) {
+    return mrfa_bn_param_grad_groups(stream, red, C, 1, dgamma, dbeta);
 }
 
 static int pick_rows_per_block(long long rows, int chunks, int C) {
@@ -515,8 +521,19 @@ extern "C" int mrfa_bn_finalize(void* stream, const double* stats, long long cou
     MRFA_CHECK_ARG(gamma && beta && scale && shift && C > 0, "bn_finalize: bad args");
     MRFA_CHECK_ARG(train ? stats != nullptr : (running_mean && running_var), "bn_finalize: missing statistics");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, C, train, scale, shift, mean_out, invstd_out);
+                       running_mean, running_var, momentum, eps, C, train, 1, scale, shift, mean_out, invstd_out);
     MRFA_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int mrfa_bn_finalize_groups(void* stream, const double* stats, long long count, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, int C, int groups,
+                                       float* scale, float* shift, float* mean_out, float* invstd_out) {
+    MRFA_CHECK_ARG(stats && gamma && beta && scale && shift && C > 0 && groups >= 1 && count > 0, "bn_finalize_groups: bad args");
+    MRFA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_groups: running_mean / running_var come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, C, 1, groups, scale, shift, mean_out, invstd_out);
+    MRFA_CHECK_LAUNCH("bn_finalize_groups");
     return 0;
 }
 
@@ -526,6 +543,7 @@ extern "C" int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* pp) {
     MRFA_CHECK_ARG(!p.pool || ((p.H % 2) == 0 && (p.W % 2) == 0), "bn_act_fwd: pool needs even H,W");
     MRFA_CHECK_ARG(!(p.pool && p.blend_a), "bn_act_fwd: pool and blend are exclusive");
     MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)), "bn_act_fwd: residual excludes pool and blend");
+    MRFA_CHECK_ARG(p.groups <= 1 || (p.N % p.groups) == 0, "bn_act_fwd: %d statistic groups do not divide N = %d", p.groups, p.N);
     const long long opix = (long long)p.N * (p.pool ? p.H / 2 : p.H) * (p.pool ? p.W / 2 : p.W);
     const long long total = opix * p.C;
     if (!p.pool && !p.blend_a && (p.C % 4) == 0 && (p.ldx % 4) == 0 && (p.ldy % 4) == 0 && aligned16(p.x) && aligned16(p.y) && aligned16(p.scale) &&
@@ -541,46 +559,25 @@ extern "C" int mrfa_bn_act_fwd(void* stream, const mrfa_bnact_params* pp) {
     return 0;
 }
 
-// the fused launch: train-mode plain / residual BatchNorm whose grid fits one workgroup per CU (all workgroups resident: the barrier needs them)
-static bool bn_bwd_fused_ok(const mrfa_bnbwd_params& p, dim3 grid) {
-    return p.train && !p.pool && !p.blend_a && (long long)grid.x * grid.y <= 256;
-}
-
-extern "C" int mrfa_bn_act_bwd_fused_supported(const mrfa_bnbwd_params* pp) {
-    if (!pp || !pp->x || !pp->dy || !pp->dx) return 0;
-    const mrfa_bnbwd_params& p = *pp;
-    const long long rows = (long long)p.N * p.H * p.W;
-    const int chunks = cdiv(p.C, CH);
-    dim3 grid(chunks, cdiv(rows, pick_rows_per_block(rows, chunks, p.C)));
-    const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && (p.lddx % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.dx) &&
-                     aligned16(p.scale) && aligned16(p.shift) && p.mean && aligned16(p.mean) && aligned16(p.invstd) && p.gamma && aligned16(p.gamma) &&
-                     (!p.res || ((p.ldr % 4 == 0) && aligned16(p.res) && (!p.dres || ((p.lddr % 4 == 0) && aligned16(p.dres)))));
-    return vec && bn_bwd_fused_ok(p, grid) ? 1 : 0;
-}
-
 extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
     const mrfa_bnbwd_params& p = *pp;
     MRFA_CHECK_ARG(p.x && p.dy && p.scale && p.shift && p.red, "bn_act_bwd: null pointer");
     MRFA_CHECK_ARG(!p.train || (p.mean && p.invstd && p.gamma), "bn_act_bwd: train mode needs mean/invstd/gamma");
     MRFA_CHECK_ARG(!(p.res && (p.pool || p.blend_a)) && !(p.dres && !p.res), "bn_act_bwd: residual excludes pool and blend");
     MRFA_CHECK_ARG(!(p.pool && p.blend_a), "bn_act_bwd: pool and blend are exclusive (one compile-time MODE per launch)");
+    const int G = p.groups > 1 ? p.groups : 1;
+    MRFA_CHECK_ARG((p.N % G) == 0, "bn_act_bwd: %d statistic groups do not divide N = %d", G, p.N);
     const long long rows = (long long)p.N * p.H * p.W;
     const int chunks = cdiv(p.C, CH);
+    // (statistic groups: the row blocks are cut per group, G runs of them along grid.y -- group_span())
     const int rpb = pick_rows_per_block(rows, chunks, p.C);
-    dim3 grid(chunks, cdiv(rows, rpb));
-    MRFA_CHECK_ARG(p.phase >= 1 && p.phase <= 3, "bn_act_bwd: phase %d", p.phase);
+    dim3 grid(chunks, G * cdiv(rows / G, rpb));
+    MRFA_CHECK_ARG(p.phase == 1 || p.phase == 2, "bn_act_bwd: phase %d", p.phase);
     const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.lddy % 4 == 0) && aligned16(p.x) && aligned16(p.dy) && aligned16(p.scale) &&
                      aligned16(p.shift) && (!p.mean || (aligned16(p.mean) && aligned16(p.invstd))) && (!p.gamma || aligned16(p.gamma)) &&
                      (p.phase == 1 || ((p.lddx % 4 == 0) && aligned16(p.dx))) &&
                      (!p.res || ((p.ldr % 4 == 0) && aligned16(p.res) && (!p.dres || ((p.lddr % 4 == 0) && aligned16(p.dres))))) &&
                      (!p.blend_a || ((p.lda % 4 == 0) && aligned16(p.blend_a) && (!p.dblend_a || ((p.ldda % 4 == 0) && aligned16(p.dblend_a)))));
-    if (p.phase == 3) {
-        MRFA_CHECK_ARG(vec && bn_bwd_fused_ok(p, grid) && p.sync && p.dx, "bn_act_bwd: phase 3 is not implemented for these parameters: ask mrfa_bn_act_bwd_fused_supported()");
-        if (p.res) hipLaunchKernelGGL((bn_act_bwd_fused_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
-        else hipLaunchKernelGGL((bn_act_bwd_fused_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
-        MRFA_CHECK_LAUNCH("bn_act_bwd(fused)");
-        return 0;
-    }
     if (vec) {
         MRFA_CHECK_ARG(p.phase == 1 || p.dx != nullptr, "bn_act_bwd: phase 2 needs dx");
         const int mode = p.pool ? 2 : (p.blend_a ? 3 : (p.res ? 1 : 0));
@@ -598,7 +595,7 @@ extern "C" int mrfa_bn_act_bwd(void* stream, const mrfa_bnbwd_params* pp) {
         hipLaunchKernelGGL((bn_act_bwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p, rows, rpb);
         if (p.dgamma || p.dbeta) {
             hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(p.C, 256)), dim3(256), 0, (hipStream_t)stream, p.red, p.dgamma, p.dbeta,
-                               p.C, p.train, nullptr, nullptr, 0.f);
+                               p.C, G * MRFA_STATS_SLOTS);
         }
     }
     MRFA_CHECK_LAUNCH("bn_act_bwd");

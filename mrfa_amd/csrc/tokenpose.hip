@@ -554,7 +554,7 @@ extern "C" int mrfa_attention_fwd(void* stream, const float* qkv, int ld, int B,
                                   float* lse) {
     MRFA_CHECK_ARG(qkv && out && lse && vec_ok(qkv, ld), "attention_fwd: null or misaligned pointer");
     if (att_check("attention_fwd", B, n, heads, d, (size_t)2 * n * (d + 4))) return 1;
-    if (mrfa_attention_mfma_ok(d, qkv, ld, out, ldo, nullptr, 0, nullptr, 0))          // the matrix-pipe kernels (attention_mfma.hip)
+    if (mrfa_attention_mfma_ok(d, n, qkv, ld, out, ldo, nullptr, 0, nullptr, 0))          // the matrix-pipe kernels (attention_mfma.hip)
         return mrfa_attention_fwd_mfma((hipStream_t)stream, qkv, ld, B, n, heads, d, scale, out, ldo, lse);
     const size_t lds = (size_t)2 * n * (d + 4) * sizeof(float);
     const dim3 grid(B * heads, cdiv(n, ATT_ROWS));
@@ -570,7 +570,7 @@ extern "C" int mrfa_attention_bwd(void* stream, const float* qkv, int ld, const 
     MRFA_CHECK_ARG(qkv && out && dout && lse && delta && dqkv && vec_ok(qkv, ld) && vec_ok(dout, lddo),
                    "attention_bwd: null or misaligned pointer");
     if (att_check("attention_bwd", B, n, heads, d, (size_t)2 * n * (d + 4) + 2 * n)) return 1;
-    if (mrfa_attention_mfma_ok(d, qkv, ld, out, ldo, dout, lddo, dqkv, lddq))
+    if (mrfa_attention_mfma_ok(d, n, qkv, ld, out, ldo, dout, lddo, dqkv, lddq))
         return mrfa_attention_bwd_mfma((hipStream_t)stream, qkv, ld, out, ldo, dout, lddo, lse, delta, B, n, heads, d, scale, dqkv, lddq);
     const dim3 grid(B * heads, cdiv(n, ATT_ROWS));
     {

@@ -242,15 +242,7 @@ class defer_wgrads:
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 SYNCBN_DIRECT_BYTES = int(os.environ.get("MRFA_SYNCBN_DIRECT_KIB", "128")) << 10      # statistics blocks up to this size are all-reduced whole (all slots)
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
-# data gradient of the stride-2 layers straight from dY (mrfa_conv_params.stride = -2: parity classes of the output grid, 9 / 4 of the taps) instead of a
-# stride-1 pass over a zero-stuffed copy.  OFF (MRFA_STRIDED_DGRAD=1): measured in the step 84.0 / 84.0 vs 83.6 / 83.5 ms (alternating runs): ~40 launches
-# per step whose four per-class sub-problems (1-4 taps x 4-8 k-steps) are too short to amortise the operand ring -- a quarter of the MACs, not less time
-STRIDED_DGRAD = os.environ.get("MRFA_STRIDED_DGRAD", "0") == "1"
 NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2 layers as one strided launch (conv_small / wgrad_small) instead of stride 1 + sub-sampling
-# BatchNorm backward of small tensors as ONE launch (grid barrier between its phases, mrfa_bn_act_bwd phase 3).  OFF: measured on the training step
-# 84.3 -> 90.0 ms -- the barrier needs every workgroup of the launch resident, and beside the deferred decoder weight gradients (one 256-VGPR
-# workgroup per CU for hundreds of microseconds) the last workgroups of each of the ~340 launches wait for a CU while the others spin
-BN_BWD_FUSED = os.environ.get("MRFA_BN_BWD_FUSED", "0") == "1"
 # BatchNorm finalize of the conv -> BatchNorm pairs of the keypoint encoder inside the convolution's launch (last workgroup; mrfa_conv_params.fin_*)
 BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
 # first phase of the BatchNorm backward of single-consumer BatchNorm outputs inside the consumer's data-gradient launch (mrfa_conv_params.bst_*)
@@ -284,6 +276,29 @@ BRANCH_STREAMS = os.environ.get("MRFA_BRANCH_STREAMS", "0") == "1"        # Ctx.
 #  * everything else it accumulates into shared parameter gradients is atomic (weight un-packing, bias / BatchNorm /
 #    LayerNorm parameter gradients).
 SIDE_PASS: Optional[list] = None
+
+
+# ---- statistic groups (include/mrfa_hip.h v7): the reference's separate encoder calls -- encoder(source), encoder(driving), encoder(transformed driving),
+# model.py:185-186,234 -- travel through ONE program as a batch of groups x B samples.  In train mode every BatchNorm keeps its quantities per group
+# (batch statistics, scale / shift, the backward's sums; `groups` momentum updates of the running statistics in group order; num_batches_tracked += groups);
+# everything else has no cross-sample coupling.  Half / a third of the launches of a latency-bound chain, twice / three times the rows per launch.
+STAT_GROUPS = 1
+
+
+class stat_groups:
+    """with stat_groups(g): programs started inside treat their batch as g statistic groups of N / g consecutive samples"""
+
+    def __init__(self, groups: int):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global STAT_GROUPS
+        self.prev, STAT_GROUPS = STAT_GROUPS, self.groups
+
+    def __exit__(self, *exc):
+        global STAT_GROUPS
+        STAT_GROUPS = self.prev
+        return False
 
 
 class side_pass:
@@ -882,6 +897,8 @@ class Ctx:
         self.bf16 = self.L.mrfa_get_mfma_mode() == 3         # plain bf16 products: the patch-tiled kernels take ONE rounded weight plane
         self.in_backward = False
         self.deferred = SIDE_PASS            # not None: this program runs on the side stream next to another pass of its module
+        self.groups = STAT_GROUPS if train else 1       # statistic groups of the batch (stat_groups); eval mode has no batch statistics
+        assert self.groups == 1 or self.deferred is None, "a side pass carries one statistic group"
         self.wdefer = WGRAD_DEFER            # not None: weight-gradient launches of this program are collected (DeferredWgrads)
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
@@ -1133,13 +1150,18 @@ class Ctx:
         p.relu = int(relu)
         if res is not None:
             p.res, p.ldr = res.ptr, res.ld
-        if stats is not None:
-            p.stats = stats.data_ptr()
-            if fin is not None:
-                self._fin_params(p, fin, stats, out.rows)
         p.alpha, p.nbatch = 1.0, 1
+        late_stats = False
+        if stats is not None:
+            p.stats, p.groups = stats.data_ptr(), self.groups
+            if self.groups > 1 and not self.L.mrfa_conv2d_groups_supported(C.byref(p)):
+                p.stats, p.groups, late_stats = None, 0, True       # (a tile would straddle two groups: one statistics pass per group behind the launch)
+            elif fin is not None:
+                self._fin_params(p, fin, stats, out.rows)
         self._maybe_wino(p, cw, dgrad=False, padded=padded, ups=ups)
         self._launch_conv(p, "conv2d", cw.Cin)
+        if late_stats:
+            self._bn_stats_into(out, stats)
 
         if self.record:
             def bwd():
@@ -1317,15 +1339,16 @@ class Ctx:
             # of its gradient, so the first phase of that BatchNorm's backward -- the per-channel sums of du and du * xhat -- rides in its epilogue
             # (mrfa_conv_params.bst_*) where the library has it; _bn_bwd then runs phase 2 only.  One launch less per layer on the encoder's backward chains.
             bx = hint["x"]
-            red = self.f64z(hip.STATS_SLOTS * 2 * x.C + 2)
-            p.stats = red.data_ptr()
+            red = self.f64z(hint["groups"] * hip.STATS_SLOTS * 2 * x.C + 2)
+            p.stats, p.groups = red.data_ptr(), hint["groups"]
             p.bst_x, p.bst_ldx, p.bst_relu = bx.ptr, bx.ld, int(hint["relu"])
             p.bst_scale, p.bst_shift = hint["scale"].data_ptr(), hint["shift"].data_ptr()
             p.bst_mean, p.bst_invstd = hint["mean"].data_ptr(), hint["invstd"].data_ptr()
-            if self.L.mrfa_conv2d_bwdstats_supported(C.byref(p)):
+            if self.L.mrfa_conv2d_bwdstats_supported(C.byref(p)) and self.L.mrfa_conv2d_groups_supported(C.byref(p)):
                 hint["red"] = red
             else:
                 p.stats = p.bst_x = p.bst_scale = p.bst_shift = p.bst_mean = p.bst_invstd = None
+                p.groups = 0
         self._launch_conv(p, "dgrad", cw.Cout)
         if relu_in and not fused:
             self._relu_mask_pass(x)
@@ -1363,36 +1386,50 @@ class Ctx:
             scale, shift, mean, invstd = done[2:]
             if self.deferred is not None:
                 self.deferred.append((bn, mean, invstd, float(count)))
-            self.nbt[bn] = self.nbt.get(bn, 0) + 1
+            self.nbt[bn] = self.nbt.get(bn, 0) + self.groups
             return scale, shift, mean, invstd
-        scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
         train = self.train
+        G = self.groups if (train and stats is not None) else 1      # statistic groups: [G][C] results, `count` = rows of the whole batch
+        scale, shift, mean, invstd = self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn)
         if train and stats is not None:
             world = self._sync_world(bn)
             if self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
-                # sum / sum-of-squares over every rank's pixels.  Small layers: ALL slots are all-reduced in place (<= 128 KB: the collective is latency-bound
+                # sum / sum-of-squares over every rank's pixels.  Small layers: ALL slots (of all statistic groups: one collective for the source and the
+                # driving pass) are all-reduced in place (<= 128 KB: the collective is latency-bound
                 # there, and nothing but the collective is launched -- round 3 summed, zeroed and copied: three glue launches per layer and direction,
                 # ~1 200 per step with the MTIA prior); wide layers: the slots are summed locally first (one launch) so that the message is 2C doubles
                 nsl = hip.STATS_SLOTS * 2 * Cn
-                if nsl * 8 <= SYNCBN_DIRECT_BYTES:
-                    torch.distributed.all_reduce(stats[:nsl])
+                if G * nsl * 8 <= SYNCBN_DIRECT_BYTES:
+                    torch.distributed.all_reduce(stats[:G * nsl])
                 else:
-                    summed = self.f64z(nsl)
-                    torch.sum(stats[:nsl].view(hip.STATS_SLOTS, 2 * Cn), 0, out=summed[:2 * Cn])
-                    torch.distributed.all_reduce(summed[:2 * Cn])
-                    stats = summed
+                    stats = self._allreduce_slot_sums(stats, G, Cn)
                 count = count * world
         defer = train and self.deferred is not None            # side pass: the running statistics are updated after the join
-        self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
-                                          bn.bias.data_ptr(), None if defer else bn.running_mean.data_ptr(),
-                                          None if defer else bn.running_var.data_ptr(),
-                                          BN_MOMENTUM, BN_EPS, Cn, int(train), scale.data_ptr(), shift.data_ptr(),
-                                          mean.data_ptr(), invstd.data_ptr()), "bn_finalize")
+        if G > 1:
+            self._chk(self.L.mrfa_bn_finalize_groups(self.s, stats.data_ptr(), count // G, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, Cn, G,
+                                                     scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()), "bn_finalize_groups")
+        else:
+            self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
+                                              bn.bias.data_ptr(), None if defer else bn.running_mean.data_ptr(),
+                                              None if defer else bn.running_var.data_ptr(),
+                                              BN_MOMENTUM, BN_EPS, Cn, int(train), scale.data_ptr(), shift.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr()), "bn_finalize")
         if defer:
             self.deferred.append((bn, mean, invstd, float(count)))
         if train:
-            self.nbt[bn] = self.nbt.get(bn, 0) + 1     # num_batches_tracked += 1, batched in flush_forward()
+            self.nbt[bn] = self.nbt.get(bn, 0) + G     # num_batches_tracked += 1 per statistic group, batched in flush_forward()
         return scale, shift, mean, invstd
+
+    def _allreduce_slot_sums(self, slots: torch.Tensor, G: int, Cn: int) -> torch.Tensor:
+        """wide layers under SyncBatchNorm: the [G][STATS_SLOTS][2C] blocks are summed over the slots locally, the [G][2C] sums are all-reduced (a message of
+        G x 2C doubles instead of 32 times that) and returned as slot 0 of a fresh zeroed [G][STATS_SLOTS][2C] block"""
+        S = hip.STATS_SLOTS
+        local = torch.sum(slots[:G * S * 2 * Cn].view(G, S, 2 * Cn), 1)
+        torch.distributed.all_reduce(local)
+        out = self.f64z(G * S * 2 * Cn)
+        out.view(G, S, 2 * Cn)[:, 0].copy_(local)
+        return out
 
     def flush_forward(self):
         """end of a program's forward: one multi-tensor launch for all BatchNorm batch counters instead of one each"""
@@ -1408,8 +1445,16 @@ class Ctx:
         self.nbt = {}
 
     def bn_stats_buf(self, bn):
-        """[STATS_SLOTS][2C] zeroed doubles (+ one zeroed word behind them: the ticket counter of a finalize fused into the producing launch)"""
-        return self.f64z(hip.STATS_SLOTS * 2 * bn.num_features + 1) if self.train else None
+        """[groups][STATS_SLOTS][2C] zeroed doubles (+ one zeroed word behind them: the ticket counter of a finalize fused into the producing launch)"""
+        return self.f64z(self.groups * hip.STATS_SLOTS * 2 * bn.num_features + 1) if self.train else None
+
+    def _bn_stats_into(self, x: View, stats: torch.Tensor):
+        """per-channel sum / sum of squares of x into `stats` by a pass of its own (one per statistic group: a group is a run of consecutive rows)"""
+        G = self.groups if self.train else 1
+        rows = x.rows // G
+        for g in range(G):
+            self._chk(self.L.mrfa_bn_stats(self.s, x.ptr + 4 * g * rows * x.ld, x.ld, rows, x.C, stats.data_ptr() + 8 * g * hip.STATS_SLOTS * 2 * x.C),
+                      "bn_stats")
 
     def _fin_params(self, p, bn, stats, count: int):
         """BatchNorm finalize inside the convolution launch that accumulates `stats` (mrfa_conv_params.fin_*): the small-problem kernel's last
@@ -1419,15 +1464,15 @@ class Ctx:
             return
         if isinstance(bn, torch.nn.SyncBatchNorm) and self._sync_collective(self._sync_world(bn)):
             return                                        # the statistics are exchanged between the convolution and the finalize
-        Cn = bn.num_features
-        scale, shift, mean, invstd = self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn)
+        Cn, G = bn.num_features, self.groups
+        scale, shift, mean, invstd = self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn)
         defer = self.deferred is not None                 # side pass: the running statistics are updated after the join
         p.fin_gamma, p.fin_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
         if not defer:
             p.fin_rmean, p.fin_rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-        p.fin_momentum, p.fin_eps, p.fin_count = BN_MOMENTUM, BN_EPS, count
+        p.fin_momentum, p.fin_eps, p.fin_count = BN_MOMENTUM, BN_EPS, count // G
         p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
-        p.fin_counter = stats.data_ptr() + 8 * hip.STATS_SLOTS * 2 * Cn
+        p.fin_counter = stats.data_ptr() + 8 * G * hip.STATS_SLOTS * 2 * Cn
         self._fin_done[stats.data_ptr()] = (bn, count, scale, shift, mean, invstd)
 
     def bn_act(self, x: View, bn, stats, *, relu=True, pool=False, blend=None, out: Optional[View] = None,
@@ -1440,6 +1485,7 @@ class Ctx:
         p = hip.BnActParams()
         p.x, p.ldx, p.N, p.H, p.W, p.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
         p.scale, p.shift, p.relu, p.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
+        p.groups = self.groups if (self.train and stats is not None) else 1
         if blend is not None:
             a, occ = blend
             p.blend_a, p.lda, p.occ, p.ldo = a.ptr, a.ld, occ.ptr, occ.ld
@@ -1457,21 +1503,24 @@ class Ctx:
             if (out_sole and train and not pool and blend is None and res is None and out.coff == 0 and out.C == out.st.ld
                     and not (isinstance(bn, torch.nn.SyncBatchNorm) and self._sync_collective(self._sync_world(bn)))):
                 # the caller states that ONE convolution consumes `out`: its data gradient may carry this BatchNorm's first backward phase (_conv_dgrad)
-                hint = out.st.bn_hint = {"x": x, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd, "relu": relu, "red": None}
+                hint = out.st.bn_hint = {"x": x, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd, "relu": relu, "red": None,
+                                         "groups": p.groups}
+
+            groups = p.groups
 
             def bwd():
                 if not out.has_grad:
                     return
-                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res, hint=hint)
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res, hint=hint, groups=groups)
             self.tape.append(bwd)
         return out
 
-    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None, hint=None):
+    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None, hint=None, groups=1):
         bg = bngrad(bn)
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
         dg, db = bg.acc(self.pool32)
-        nred = hip.STATS_SLOTS * 2 * x.C
+        nred = groups * hip.STATS_SLOTS * 2 * x.C          # (statistic groups: [groups][STATS_SLOTS][2C])
         pre_red = hint["red"] if hint is not None else None          # the sums of phase 1, already accumulated by the data gradient that wrote dy
         red = pre_red if pre_red is not None else self.f64z(nred + 2)    # slotted like the statistics buffers (MRFA_STATS_SLOTS) + the fused launch's barrier word
         q = hip.BnBwdParams()
@@ -1489,16 +1538,9 @@ class Ctx:
         q.dx_overwrite = int(self._claim(dx_view))         # before .gptr, which would zero-fill a fresh buffer
         q.dx, q.lddx = dx_view.gptr, dx_view.ld
         q.dgamma, q.dbeta = dg.data_ptr(), db.data_ptr()
-        q.train = int(train)
+        q.train, q.groups = int(train), groups
         world = self._sync_world(bn) if train else 1
         synced = train and self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm)
-        if train and not synced and BN_BWD_FUSED:
-            # small tensors (the keypoint encoder's ~170 BatchNorms per pass): reductions + grid barrier + apply in ONE launch
-            q.sync = red.data_ptr() + 8 * nred
-            if self.L.mrfa_bn_act_bwd_fused_supported(C.byref(q)):
-                q.phase = 3
-                self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(fused)")
-                return
         if pre_red is None:
             q.phase = 1
             self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(1)")
@@ -1509,15 +1551,11 @@ class Ctx:
             # launch, then the slots are all-reduced in place and phase 2 divides by world x the local row count (mrfa_bnbwd_params.red_world).
             # (Round 3: sum, two adds, the collective and a division = five launches per layer.)
             Cn = x.C
-            self._chk(self.L.mrfa_bn_param_grad(self.s, red.data_ptr(), Cn, dg.data_ptr(), db.data_ptr()), "bn_param_grad")
+            self._chk(self.L.mrfa_bn_param_grad_groups(self.s, red.data_ptr(), Cn, groups, dg.data_ptr(), db.data_ptr()), "bn_param_grad")
             if nred * 8 <= SYNCBN_DIRECT_BYTES:
                 torch.distributed.all_reduce(red[:nred])
             else:
-                red_g = self.f64z(nred)
-                local = red_g[:2 * Cn]
-                torch.sum(red[:nred].view(hip.STATS_SLOTS, 2 * Cn), 0, out=local)
-                torch.distributed.all_reduce(local)
-                q.red = red_g.data_ptr()
+                q.red = self._allreduce_slot_sums(red, groups, Cn).data_ptr()
             q.red_world = world
             q.dgamma = q.dbeta = None
         q.phase = 2
@@ -1526,6 +1564,7 @@ class Ctx:
     def prebn(self, x: View, bn, stats=None):
         """Pre-activation BN+ReLU folded into the next conv's prologue (ResBlock2d / ChannelBlock2d).  Returns the `pre`
         triple for conv(); must be called BEFORE that conv so the tape order is right (its closure runs AFTER the conv's)."""
+        assert self.groups == 1, "pre-activation BatchNorm (ResBlock2d / ChannelBlock2d) inside a program with statistic groups: not implemented"
         if self.train and stats is None:
             stats = self.f64z(hip.STATS_SLOTS * 2 * x.C)
             self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
@@ -1802,8 +1841,8 @@ class Ctx:
         not accumulate them (the stride-2 convolutions, which are sub-sampled after the conv)"""
         if not self.train:
             return None
-        stats = self.f64z(hip.STATS_SLOTS * 2 * bn.num_features)
-        self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
+        stats = self.f64z(self.groups * hip.STATS_SLOTS * 2 * bn.num_features)
+        self._bn_stats_into(x, stats)
         return stats
 
     def subsample(self, x: View, stride: int = 2, out: Optional[View] = None) -> View:
@@ -1851,11 +1890,16 @@ class Ctx:
         out = self.new(x.N, Ho, Wo, cw.Cout)
         p.w = cw.fwd_pack(False).data_ptr()
         p.y, p.ldy = out.ptr, out.ld
+        late_stats = False
         if stats is not None:
-            p.stats = stats.data_ptr()
-            if fin is not None:
+            p.stats, p.groups = stats.data_ptr(), self.groups
+            if self.groups > 1 and not self.L.mrfa_conv2d_groups_supported(C.byref(p)):
+                p.stats, p.groups, late_stats = None, 0, True
+            elif fin is not None:
                 self._fin_params(p, fin, stats, out.rows)
         self._launch_conv(p, "conv2d(stride 2)", cw.Cin)
+        if late_stats:
+            self._bn_stats_into(out, stats)
         if self.record:
             def bwd():
                 if not out.has_grad:
@@ -1875,35 +1919,13 @@ class Ctx:
                         self._conv_wgrad(x, cw, full, False, None, False)
                 else:
                     full = None
-                if need_dx and not (full is None and self._strided_dgrad(x, cw, out)):
+                if need_dx:
                     full = full or self._zero_stuffed(out, x.H, x.W)
                     self._conv_dgrad(x, cw, full, False, None)
             self.tape.append(bwd)
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
         return out, stats
-
-    def _strided_dgrad(self, x: View, cw: ConvW, out: View) -> bool:
-        """x.grad += the data gradient of the stride-2 layer cw straight from out.grad (mrfa_conv_params.stride = -2: 9 / 4 of the taps per pixel,
-        no zero-stuffed copy of dY, no fill / scatter launches); False: the library has no such kernel for this shape"""
-        if not STRIDED_DGRAD or cw.dgrad_flat or x.coff % 4 or out.coff % 4:
-            return False
-        p = hip.ConvParams()
-        p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = out.ptr, out.ld, out.H, out.W, 0, out.N, cw.Cout      # (placeholder pointer for the query)
-        cip = (cw.Cin + 127) // 128 * 128
-        p.w_ld, p.w_tap, p.kflat, p.w_rows = cw.Cout, cip * cw.Cout, 0, cip
-        p.Cout, p.Hout, p.Wout = cw.Cin, x.H, x.W
-        p.R, p.S, p.pad, p.stride = cw.R, cw.S, cw.R - 1 - cw.pad, -2
-        p.alpha, p.nbatch = 1.0, 1
-        p.y, p.ldy, p.w = x.ptr, x.ld, x.ptr
-        if not self.L.mrfa_conv2d_stride_supported(C.byref(p)):
-            return False
-        first = self._claim(x)
-        p.x = out.gptr
-        p.w = cw.dgrad_pack(False).data_ptr()
-        p.y, p.accumulate = x.gptr, 0 if first else 1
-        self._launch_conv(p, "dgrad(stride 2)", cw.Cout)
-        return True
 
     def _zero_stuffed(self, out: View, H: int, W: int) -> View:
         """(backward) a stride-1-sized view whose GRADIENT is out.grad at the even pixels and zero elsewhere: dY of the equivalent

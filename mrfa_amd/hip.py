@@ -46,6 +46,7 @@ class ConvParams(C.Structure):
         ("fin_counter", C.c_void_p),
         ("bst_x", C.c_void_p), ("bst_ldx", C.c_int), ("bst_scale", C.c_void_p), ("bst_shift", C.c_void_p), ("bst_mean", C.c_void_p),
         ("bst_invstd", C.c_void_p), ("bst_relu", C.c_int),
+        ("groups", C.c_int),
     ]
 
 
@@ -80,6 +81,7 @@ class BnActParams(C.Structure):
         ("blend_a", C.c_void_p), ("lda", C.c_int), ("occ", C.c_void_p), ("ldo", C.c_int),
         ("y", C.c_void_p), ("ldy", C.c_int),
         ("res", C.c_void_p), ("ldr", C.c_int),
+        ("groups", C.c_int),
     ]
 
 
@@ -94,7 +96,7 @@ class BnBwdParams(C.Structure):
         ("red", C.c_void_p), ("dx", C.c_void_p), ("lddx", C.c_int),
         ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("train", C.c_int), ("phase", C.c_int), ("dx_overwrite", C.c_int),
         ("res", C.c_void_p), ("ldr", C.c_int), ("dres", C.c_void_p), ("lddr", C.c_int),
-        ("sync", C.c_void_p), ("red_world", C.c_int), ("red_all", C.c_int),
+        ("sync", C.c_void_p), ("red_world", C.c_int), ("red_all", C.c_int), ("groups", C.c_int),
     ]
 
 
@@ -132,7 +134,6 @@ _SIGNATURES = {
     "mrfa_conv_fewout_dgrad": ([_V, _V, _I, _I, _I, _I, _I, _V, _V, _I, _I, _I, _I, _I, _V, _I], C.c_int),
     "mrfa_conv2d_mask_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_stride_supported": ([C.POINTER(ConvParams)], C.c_int),
-    "mrfa_bn_act_bwd_fused_supported": ([C.POINTER(BnBwdParams)], C.c_int),
     "mrfa_conv2d_wgrad_stride_supported": ([C.POINTER(WgradParams)], C.c_int),
     "mrfa_conv_fewout_dgrad_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
@@ -141,6 +142,7 @@ _SIGNATURES = {
     "mrfa_build_ktab": ([c_int_p, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_bn_stats": ([_V, _V, _I, _L, _I, _V], C.c_int),
     "mrfa_bn_finalize": ([_V, _V, _L, _V, _V, _V, _V, _F, _F, _I, _I, _V, _V, _V, _V], C.c_int),
+    "mrfa_bn_finalize_groups": ([_V, _V, _L, _V, _V, _V, _V, _F, _F, _I, _I, _V, _V, _V, _V], C.c_int),
     "mrfa_bn_act_fwd": ([_V, C.POINTER(BnActParams)], C.c_int),
     "mrfa_bn_act_bwd": ([_V, C.POINTER(BnBwdParams)], C.c_int),
     "mrfa_grid_sample_fwd": ([_V, _V, _I, _L, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _I, _I], C.c_int),
@@ -159,7 +161,9 @@ _SIGNATURES = {
     "mrfa_copy_view": ([_V, _V, _I, _L, _I, _V, _I, _F, _I], C.c_int),
     "mrfa_timestamp": ([_V, _V], C.c_int),
     "mrfa_conv2d_bwdstats_supported": ([C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_groups_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_bn_param_grad": ([_V, _V, _I, _V, _V], C.c_int),
+    "mrfa_bn_param_grad_groups": ([_V, _V, _I, _I, _V, _V], C.c_int),
     "mrfa_warp_frame_reflect": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
     "mrfa_blend_fwd": ([_V, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_blend_bwd": ([_V, _V, _I, _V, _I, _V, _I, _V, _I, _L, _I, _V, _I, _V, _I, _V, _I], C.c_int),
@@ -196,7 +200,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 6        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
+ABI_VERSION = 7        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None
 

@@ -74,6 +74,12 @@ class HotPath(nn.Module):
         # sequential order: see engine.SIDE_PASS.  mrfa_amd.graph.GraphedTrainStep switches it on for the MTIA prior.
         self.concurrent_encoder = False
         object.__setattr__(self, "_sides", [])
+        # training: the encoder calls of a step -- encoder(source), encoder(driving) (and encoder(transformed driving) under the reference objective;
+        # model.py:185-186,234) -- as ONE program over a batch of len(frames) x B samples whose BatchNorm layers keep their batch statistics per call
+        # ("statistic groups", include/mrfa_hip.h v7 / engine.stat_groups): same results as the separate calls -- per-call statistics, running buffers
+        # updated once per call in call order, num_batches_tracked += number of calls --, half / a third of the launches of the step's longest
+        # latency-bound chain, and one stream instead of two.  MRFA_BATCHED_ENCODER=0: the separate calls (concurrent_encoder then applies).
+        self.batched_encoder = os.environ.get("MRFA_BATCHED_ENCODER", "1") != "0"
         # training with direct parameter gradients: the weight-gradient kernels of dense motion + decoder (~100 launches, 22 ms, each
         # filling the chip) are collected during their backward and issued on a side stream when the backward reaches the keypoint
         # encoder, whose small kernels leave most of the GPU idle (engine.DeferredWgrads).  join() orders them before the optimizer.
@@ -115,6 +121,12 @@ class HotPath(nn.Module):
     def _encode_many(self, frames):
         from . import engine
         first = frames[0]
+        if (self.batched_encoder and self.training and len(frames) > 1 and all(f.shape == first.shape for f in frames)):
+            with engine.stat_groups(len(frames)):
+                kp = self.encoder(torch.cat(list(frames), dim=0))
+            b = first.shape[0]
+            parts = {k: v.view(len(frames), b, *v.shape[1:]).unbind(0) for k, v in kp.items()}
+            return [{k: parts[k][i] for k in kp} for i in range(len(frames))]
         if not (self.training and self.concurrent_encoder and first.is_cuda and torch.is_grad_enabled() and len(frames) > 1
                 and engine.prepare_packs(self.encoder)):
             return [self.encoder(f) for f in frames]

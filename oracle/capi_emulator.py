@@ -37,6 +37,11 @@ def vec(ptr, n, dtype=torch.float32):
     return _flat(ptr, n, dtype) if ptr else None
 
 
+def _groups(p) -> int:
+    """statistic groups of a parameter block (v7): 0 / 1 / absent = one"""
+    return max(int(getattr(p, "groups", 0) or 0), 1)
+
+
 def _obj(ref):
     return ref._obj if hasattr(ref, "_obj") else ref
 
@@ -342,7 +347,7 @@ class Emulator:
 
     # ---------------------------------------------------------------- misc
     def mrfa_version(self):
-        return 6              # MRFA_ABI_VERSION of include/mrfa_hip.h
+        return 7              # MRFA_ABI_VERSION of include/mrfa_hip.h
 
     def mrfa_last_error(self):
         return self._err
@@ -446,10 +451,6 @@ class Emulator:
                 wt = torch.as_strided(_flat(wp, (T - 1) * p.w_tap + (p.Cout - 1) * p.w_ld + p.Cin), (T, p.Cout, p.Cin),
                                       (p.w_tap, p.w_ld, 1))
                 w = wt.permute(1, 2, 0).reshape(p.Cout, p.Cin, p.R, p.S)
-            if p.stride == -2:       # data gradient of a stride-2 layer: dY at the even pixels of the output grid, zeros between
-                full = torch.zeros(x.shape[0], x.shape[1], p.Hout, p.Wout, dtype=x.dtype)
-                full[:, :, 0:2 * p.Hin:2, 0:2 * p.Win:2] = x
-                x = full
             acc = F.conv2d(x, w.contiguous(), None, padding=p.pad, stride=max(p.stride, 1)) * p.alpha
             if p.ups == 2:           # data gradient of a fused-upsample layer: the 3x3 data gradient on the high-resolution grid, 2x2 sum-pooled
                 acc = F.avg_pool2d(acc, 2) * 4.0
@@ -471,24 +472,41 @@ class Emulator:
             if p.accumulate:
                 v = v + y
             y.copy_(v)
-            if p.stats and p.bst_x:      # v6: first phase of the BatchNorm backward whose output's gradient this launch wrote (mrfa_conv_params.bst_*)
-                st = vec(p.stats, 2 * p.Cout, torch.float64)
-                xr = nhwc(p.bst_x, p.N, p.Hout, p.Wout, p.bst_ldx, p.Cout)
-                u = xr * vec(p.bst_scale, p.Cout) + vec(p.bst_shift, p.Cout)
-                du = torch.where(u > 0, v, torch.zeros_like(v)) if p.bst_relu else v
-                xhat = (xr - vec(p.bst_mean, p.Cout)) * vec(p.bst_invstd, p.Cout)
-                st[:p.Cout] += du.reshape(-1, p.Cout).double().sum(0)
-                st[p.Cout:] += (du * xhat).reshape(-1, p.Cout).double().sum(0)
-            elif p.stats:
-                st = vec(p.stats, 2 * p.Cout, torch.float64)
-                flat = v.reshape(-1, p.Cout).double()
-                st[:p.Cout] += flat.sum(0)
-                st[p.Cout:] += (flat * flat).sum(0)
+            # v7, statistic groups: samples [g N / G, (g + 1) N / G) accumulate into statistics block g, with group g's bst_* vectors
+            G = _groups(p)
+            assert p.N % G == 0 and (G == 1 or nb == 1)
+            n = p.N // G
+            for g in range(G):
+                vg = v[g * n:(g + 1) * n]
+                if p.stats and p.bst_x:  # v6: first phase of the BatchNorm backward whose output's gradient this launch wrote (mrfa_conv_params.bst_*)
+                    st = vec(p.stats + 8 * g * STATS_SLOTS * 2 * p.Cout, 2 * p.Cout, torch.float64)
+                    xr = nhwc(p.bst_x, p.N, p.Hout, p.Wout, p.bst_ldx, p.Cout)[g * n:(g + 1) * n]
+                    gv = lambda ptr: vec(ptr + 4 * g * p.Cout, p.Cout)
+                    u = xr * gv(p.bst_scale) + gv(p.bst_shift)
+                    du = torch.where(u > 0, vg, torch.zeros_like(vg)) if p.bst_relu else vg
+                    xhat = (xr - gv(p.bst_mean)) * gv(p.bst_invstd)
+                    st[:p.Cout] += du.reshape(-1, p.Cout).double().sum(0)
+                    st[p.Cout:] += (du * xhat).reshape(-1, p.Cout).double().sum(0)
+                elif p.stats:
+                    st = vec(p.stats + 8 * g * STATS_SLOTS * 2 * p.Cout, 2 * p.Cout, torch.float64)
+                    flat = vg.reshape(-1, p.Cout).double()
+                    st[:p.Cout] += flat.sum(0)
+                    st[p.Cout:] += (flat * flat).sum(0)
         if p.fin_scale:              # v6: the BatchNorm that follows is finished inside the call (mrfa_conv_params.fin_*)
             assert p.stats and p.fin_counter and p.fin_count > 0
-            return self.mrfa_bn_finalize(stream, p.stats, p.fin_count, p.fin_gamma, p.fin_beta, p.fin_rmean, p.fin_rvar, p.fin_momentum, p.fin_eps,
-                                         p.Cout, 1, p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd)
+            return self.mrfa_bn_finalize_groups(stream, p.stats, p.fin_count, p.fin_gamma, p.fin_beta, p.fin_rmean, p.fin_rvar, p.fin_momentum,
+                                                p.fin_eps, p.Cout, _groups(p), p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd)
         return 0
+
+    def mrfa_conv2d_groups_supported(self, pref):
+        """the library's rule (the emulator itself honours `groups` for every shape)"""
+        p = _obj(pref)
+        if p.groups <= 1:
+            return 1
+        rows = p.N // p.groups * p.Hout * p.Wout
+        small = (p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and p.N * p.Hout * p.Wout <= 65536 and p.Cout <= 640
+                 and p.R * p.S * p.Cin <= 1152 and 2.0 * p.N * p.Hout * p.Wout * p.Cout * p.R * p.S * p.Cin <= 1.3e9)
+        return int(p.nbatch <= 1 and p.splitk <= 1 and p.N % p.groups == 0 and (rows % 128 == 0 or (small and rows % 64 == 0)))
 
     def mrfa_conv2d_wgrad_nhwc(self, stream, pref):
         p = _obj(pref)
@@ -533,10 +551,6 @@ class Emulator:
     def mrfa_conv2d_stride_supported(self, pref):
         """shape rule of the library's one-wave-per-tile kernel (the emulator itself honours `stride` everywhere)"""
         p = _obj(pref)
-        if p.stride == -2:           # data gradient of a stride-2 layer (dY at the even pixels of the output grid)
-            return int(p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and p.ldx % 4 == 0 and p.nbatch <= 1 and p.R == p.S
-                       and p.Hout % 2 == 0 and p.Wout % 2 == 0 and p.Hin == p.Hout // 2 and p.Win == p.Wout // 2 and not p.res and not p.stats
-                       and p.N * p.Hout * p.Wout // 4 <= 65536 and p.Cout <= 640 and p.R * p.S * p.Cin <= 1152)
         return int(p.stride == 2 and p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and p.ldx % 4 == 0 and p.nbatch <= 1
                    and p.N * p.Hout * p.Wout <= 65536 and p.Cout <= 640 and p.R * p.S * p.Cin <= 1152)
 
@@ -617,10 +631,28 @@ class Emulator:
             vec(invstd_out, Cc).copy_(invstd)
         return 0
 
+    def mrfa_bn_finalize_groups(self, stream, stats, count, gamma, beta, rmean, rvar, momentum, eps, Cc, groups, scale, shift, mean_out, invstd_out):
+        """v7: `groups` train-mode finalizes, one after the other -- statistics block g -> row g of the outputs; the running statistics take the
+        groups' momentum updates in that order (what successive calls of the module do: reference model.py:185-186,234)"""
+        for g in range(groups):
+            off = 4 * g * Cc
+            rc = self.mrfa_bn_finalize(stream, stats + 8 * g * STATS_SLOTS * 2 * Cc, count, gamma, beta, rmean, rvar, momentum, eps, Cc, 1,
+                                       scale + off, shift + off, mean_out + off if mean_out else mean_out, invstd_out + off if invstd_out else invstd_out)
+            if rc:
+                return rc
+        return 0
+
+    @staticmethod
+    def _per_sample(ptr, p, Cc):
+        """(N, 1, 1, C) view of a [groups][C] per-channel array: sample n uses row n // (N / groups)  (v7, statistic groups)"""
+        G = _groups(p)
+        assert p.N % G == 0
+        return vec(ptr, G * Cc).view(G, 1, 1, 1, Cc).expand(G, p.N // G, 1, 1, Cc).reshape(p.N, 1, 1, Cc)
+
     def mrfa_bn_act_fwd(self, stream, pref):
         p = _obj(pref)
         x = nhwc(p.x, p.N, p.H, p.W, p.ldx, p.C)
-        u = x * vec(p.scale, p.C) + vec(p.shift, p.C)
+        u = x * self._per_sample(p.scale, p, p.C) + self._per_sample(p.shift, p, p.C)
         if getattr(p, "res", None):
             u = u + nhwc(p.res, p.N, p.H, p.W, p.ldr, p.C)
         if p.relu:
@@ -635,23 +667,14 @@ class Emulator:
         nhwc(p.y, p.N, Ho, Wo, p.ldy, p.C).copy_(u)
         return 0
 
-    def mrfa_bn_act_bwd_fused_supported(self, pref):
-        p = _obj(pref)
-        return int(bool(p.train) and not p.pool and not p.blend_a and p.C % 4 == 0 and p.N * p.H * p.W * p.C <= (4 << 20))
-
     def mrfa_bn_act_bwd(self, stream, pref):
         p = _obj(pref)
-        if p.phase == 3:             # both phases in one launch (the library puts a grid-wide barrier between them)
-            assert p.sync
-            p.phase = 1
-            rc = self.mrfa_bn_act_bwd(stream, pref)
-            p.phase = 2
-            rc = rc or self.mrfa_bn_act_bwd(stream, pref)
-            p.phase = 3
-            return rc
+        assert p.phase in (1, 2)
         Cc = p.C
+        G = _groups(p)               # v7, statistic groups: per-sample rows of the [G][C] arrays, per-group sums and counts
+        n = p.N // G
         x = nhwc(p.x, p.N, p.H, p.W, p.ldx, Cc)
-        sc, sh = vec(p.scale, Cc), vec(p.shift, Cc)
+        sc, sh = self._per_sample(p.scale, p, Cc), self._per_sample(p.shift, p, Cc)
         u = x * sc + sh
         if getattr(p, "res", None):
             u = u + nhwc(p.res, p.N, p.H, p.W, p.ldr, Cc)
@@ -674,19 +697,20 @@ class Emulator:
         du = torch.where(u > 0, da, torch.zeros_like(da)) if p.relu else da
         if p.phase == 1 and getattr(p, "dres", None):
             nhwc(p.dres, p.N, p.H, p.W, p.lddr, Cc).add_(du)
-        mean = vec(p.mean, Cc) if p.mean else torch.zeros(Cc)
-        invstd = vec(p.invstd, Cc) if p.invstd else torch.zeros(Cc)
+        mean = self._per_sample(p.mean, p, Cc) if p.mean else torch.zeros(Cc)
+        invstd = self._per_sample(p.invstd, p, Cc) if p.invstd else torch.zeros(Cc)
         xhat = (x - mean) * invstd
-        slots = vec(p.red, STATS_SLOTS * 2 * Cc, torch.float64).view(STATS_SLOTS, 2 * Cc)   # slotted like the statistics buffers
+        slots = vec(p.red, G * STATS_SLOTS * 2 * Cc, torch.float64).view(G, STATS_SLOTS, 2 * Cc)   # slotted like the statistics buffers, per group
         if p.phase == 1:
-            slots[1, :Cc] += du.reshape(-1, Cc).double().sum(0)          # any slot: phase 2 sums them all
-            slots[1, Cc:] += (du * xhat).reshape(-1, Cc).double().sum(0)
+            for g in range(G):
+                slots[g, 1, :Cc] += du[g * n:(g + 1) * n].reshape(-1, Cc).double().sum(0)          # any slot: phase 2 sums them all
+                slots[g, 1, Cc:] += (du * xhat)[g * n:(g + 1) * n].reshape(-1, Cc).double().sum(0)
             return 0
-        red = slots.sum(0)
-        rows = p.N * p.H * p.W * max(int(getattr(p, "red_world", 0)), 1)      # v6: `red` summed over that many ranks (SyncBatchNorm)
+        red = slots.sum(1)                                                    # [G][2C]
+        rows = n * p.H * p.W * max(int(getattr(p, "red_world", 0)), 1)        # v6: `red` summed over that many ranks (SyncBatchNorm)
         if p.train:
-            k1 = (red[:Cc] / rows).float()
-            k2 = (red[Cc:] / rows).float()
+            k1 = (red[:, :Cc] / rows).float().view(G, 1, 1, 1, Cc).expand(G, n, 1, 1, Cc).reshape(p.N, 1, 1, Cc)
+            k2 = (red[:, Cc:] / rows).float().view(G, 1, 1, 1, Cc).expand(G, n, 1, 1, Cc).reshape(p.N, 1, 1, Cc)
             dx = vec(p.gamma, Cc) * invstd * (du - k1 - xhat * k2)
         else:
             dx = du * sc
@@ -696,13 +720,16 @@ class Emulator:
         else:
             tgt.add_(dx)
         if p.dbeta:
-            vec(p.dbeta, Cc).add_(red[:Cc].float())
+            vec(p.dbeta, Cc).add_(red[:, :Cc].sum(0).float())
         if p.dgamma:
-            vec(p.dgamma, Cc).add_(red[Cc:].float())
+            vec(p.dgamma, Cc).add_(red[:, Cc:].sum(0).float())
         return 0
 
     def mrfa_bn_param_grad(self, stream, red, Cc, dgamma, dbeta):
-        r = vec(red, STATS_SLOTS * 2 * Cc, torch.float64).view(STATS_SLOTS, 2 * Cc).sum(0)
+        return self.mrfa_bn_param_grad_groups(stream, red, Cc, 1, dgamma, dbeta)
+
+    def mrfa_bn_param_grad_groups(self, stream, red, Cc, groups, dgamma, dbeta):
+        r = vec(red, groups * STATS_SLOTS * 2 * Cc, torch.float64).view(groups * STATS_SLOTS, 2 * Cc).sum(0)
         if dbeta:
             vec(dbeta, Cc).add_(r[:Cc].float())
         if dgamma:

@@ -182,7 +182,7 @@ def test_concurrent_encoder_passes_equal_sequential():
     def run(concurrent):
         for b, sv in zip(model.buffers(), saved):
             b.copy_(sv)
-        model.concurrent_encoder = concurrent
+        model.concurrent_encoder, model.batched_encoder = concurrent, False
         for p in model.parameters():
             p.grad = None
         for p in model.parameters():                       # pre-bound gradients: the direct (atomic) accumulation path
@@ -216,6 +216,55 @@ def test_concurrent_encoder_passes_equal_sequential():
             assert torch.equal(b2[n], b0[n]), n
 
 
+@pytest.mark.parametrize("nframes", [2, 3])
+def test_batched_encoder_pass_equals_separate_calls(nframes):
+    """MTIA prior, train mode: the encoder calls of a step (source, driving[, the equivariance pass]) as ONE TokenPose_B program over the concatenated
+    batch with per-call BatchNorm statistics (HotPath.batched_encoder, engine.stat_groups, include/mrfa_hip.h v7) against the separate calls of the
+    reference (model.py:185-186,234): keypoints and Jacobians, every encoder parameter gradient (inside the atomic-order band of two separate-call
+    runs), the running statistics after `nframes` momentum updates in call order, num_batches_tracked == nframes."""
+    import bench
+    from mrfa_amd.train import VOX1, HotPath
+    model = HotPath(VOX1, prior="mtia")
+    bench.init_weights(model)
+    model.to(DEV).train(True)
+    frames = [_pairs(2, f"g/bat{k}")[k % 2] * (1.0 - 0.2 * k) for k in range(nframes)]
+    ws = [(torch.rand(2, 10, 2, device=DEV), torch.rand(2, 10, 2, 2, device=DEV)) for _ in range(nframes)]
+    saved = [b.clone() for b in model.buffers()]
+
+    def run(batched):
+        for b, sv in zip(model.buffers(), saved):
+            b.copy_(sv)
+        model.concurrent_encoder, model.batched_encoder = False, batched
+        outs = model.encode_many(frames)
+        loss = sum((o["kp"] * w[0]).sum() + (o["jacobian"] * w[1]).sum() for o, w in zip(outs, ws))
+        for p in model.encoder.parameters():
+            p.grad = None
+        loss.backward()
+        model.join()
+        torch.cuda.synchronize()
+        return [(o["kp"].detach().clone(), o["jacobian"].detach().clone()) for o in outs], {n: b.clone() for n, b in model.encoder.named_buffers()}, \
+            {n: p.grad.double().clone() for n, p in model.encoder.named_parameters() if p.grad is not None}
+
+    run(False)
+    k0, b0, g0 = run(False)
+    k1, b1, g1 = run(False)
+    k2, b2, g2 = run(True)
+    for (ka, ja), (kb, jb) in zip(k0, k2):
+        assert (ka - kb).abs().max().item() <= 1e-5 and (ja - jb).abs().max().item() <= 1e-5
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert (b2[n] - b0[n]).abs().max().item() <= 1e-5 + 1e-5 * b0[n].abs().max().item(), n
+        else:
+            assert int(b2[n]) == int(b0[n]) == nframes, n
+
+    def dist(a, b):
+        return (sum(float((a[n] - b[n]).pow(2).sum()) for n in b) / sum(float(b[n].pow(2).sum()) for n in b)) ** 0.5
+    band = dist(g1, g0)
+    assert dist(g2, g0) <= 4 * band + 1e-3, (dist(g2, g0), band)
+    worst = max(float((g2[n] - g0[n]).norm() / (g0[n].norm() + 1e-3 * max(float(v.norm()) for v in g0.values()))) for n in g0)
+    assert worst <= 0.05 + 8 * band, (worst, band)
+
+
 def test_encode_many_three_passes_keep_the_sequential_batchnorm_order():
     """three TokenPose_B passes side by side (source, driving, the equivariance pass of the reference's objective): outputs and the
     BatchNorm running statistics / batch counters equal those of three sequential passes (momentum updates applied in frame order)"""
@@ -230,7 +279,7 @@ def test_encode_many_three_passes_keep_the_sequential_batchnorm_order():
     def run(concurrent):
         for b, sv in zip(model.buffers(), saved):
             b.copy_(sv)
-        model.concurrent_encoder = concurrent
+        model.concurrent_encoder, model.batched_encoder = concurrent, False
         outs = model.encode_many(frames)
         loss = sum(o["kp"].sum() + o["jacobian"].sum() for o in outs)
         for p in model.encoder.parameters():

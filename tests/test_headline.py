@@ -55,7 +55,7 @@ def test_replayed_mtia_training_step_vs_reference_and_oracle_autograd(golden_dir
     opt = make_optimizer(model, fused=True)
     step = GraphedTrainStep(model, opt, src.to(dev), drv.to(dev), clip=10.0, world=1)
     if train:
-        assert model.concurrent_encoder and model.defer_decoder_wgrads           # the benchmark's schedule, not a simplified one
+        assert model.batched_encoder and model.defer_decoder_wgrads              # the benchmark's schedule, not a simplified one
     P = {pfx + n: p for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder))
          for n, p in mod.named_parameters()}
     before = {n: p.detach().clone() for n, p in P.items()}

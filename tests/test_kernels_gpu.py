@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, lds=False, wwino=False, fin=False, bst=False, tag="c"):
+              stride=1, wwino=False, fin=False, bst=False, groups=1, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -154,15 +154,18 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         rt = side.t(f"{tag}/res", (N * Ho * Wo, Cout + 4))
         keep.append(rt)
         p.res, p.ldr = rt.data_ptr(), Cout + 4
-    stbuf = side.z((hip.STATS_SLOTS * 2 * Cout + 1,), torch.float64)  # [MRFA_STATS_SLOTS][2C], summed by the consumer (+ the finalize ticket word)
-    st = stbuf[:hip.STATS_SLOTS * 2 * Cout].view(hip.STATS_SLOTS, 2 * Cout)
+    G = groups                      # v7, statistic groups: [G][MRFA_STATS_SLOTS][2C] statistics, [G][C] per-channel vectors
+    stbuf = side.z((G * hip.STATS_SLOTS * 2 * Cout + 1,), torch.float64)  # [G][MRFA_STATS_SLOTS][2C], summed by the consumer (+ the finalize ticket word)
+    st = stbuf[:G * hip.STATS_SLOTS * 2 * Cout].view(G, hip.STATS_SLOTS, 2 * Cout)
     if stats:
-        p.stats = st.data_ptr()
+        p.stats, p.groups = st.data_ptr(), G
+        if G > 1:
+            assert side.L.mrfa_conv2d_groups_supported(C.byref(p)) == 1
     if bst:                         # v6: the launch writes d(act(bn(x))) and accumulates the first phase of that BatchNorm's backward (bst_*)
         assert stats and not fin
         bx = side.t(f"{tag}/bst_x", (N * Ho * Wo, Cout + 4))
-        bsc, bsh = side.t(f"{tag}/bst_sc", (Cout,), 0.5, 1.5), side.t(f"{tag}/bst_sh", (Cout,), -0.3, 0.3)
-        bme, biv = side.t(f"{tag}/bst_me", (Cout,), -0.2, 0.2), side.t(f"{tag}/bst_iv", (Cout,), 0.5, 2.0)
+        bsc, bsh = side.t(f"{tag}/bst_sc", (G * Cout,), 0.5, 1.5), side.t(f"{tag}/bst_sh", (G * Cout,), -0.3, 0.3)
+        bme, biv = side.t(f"{tag}/bst_me", (G * Cout,), -0.2, 0.2), side.t(f"{tag}/bst_iv", (G * Cout,), 0.5, 2.0)
         keep += [bx, bsc, bsh, bme, biv]
         p.bst_x, p.bst_ldx, p.bst_relu = bx.data_ptr(), Cout + 4, int(bst != "linear")
         p.bst_scale, p.bst_shift, p.bst_mean, p.bst_invstd = bsc.data_ptr(), bsh.data_ptr(), bme.data_ptr(), biv.data_ptr()
@@ -172,12 +175,12 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         assert stats
         gam, bet = side.t(f"{tag}/gamma", (Cout,), 0.5, 1.5), side.t(f"{tag}/beta", (Cout,), -0.3, 0.3)
         rm, rv = side.t(f"{tag}/rm", (Cout,), -0.2, 0.2), side.t(f"{tag}/rv", (Cout,), 0.5, 1.5)
-        fin_out = [side.garbage((Cout,)) for _ in range(4)] + [rm, rv]
+        fin_out = [side.garbage((G * Cout,)) for _ in range(4)] + [rm, rv]
         keep += [gam, bet]
         p.fin_gamma, p.fin_beta, p.fin_rmean, p.fin_rvar = gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr()
-        p.fin_momentum, p.fin_eps, p.fin_count = 0.1, 1e-5, N * Ho * Wo
+        p.fin_momentum, p.fin_eps, p.fin_count = 0.1, 1e-5, N * Ho * Wo // G
         p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd = (t.data_ptr() for t in fin_out[:4])
-        p.fin_counter = stbuf.data_ptr() + 8 * hip.STATS_SLOTS * 2 * Cout
+        p.fin_counter = stbuf.data_ptr() + 8 * G * hip.STATS_SLOTS * 2 * Cout
     if mask:                        # fused ReLU backward: the result is multiplied by (mask > 0) before the accumulation
         mk = side.t(f"{tag}/mask", (N * Ho * Wo, Cout + 8))
         keep.append(mk)
@@ -190,18 +193,10 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         assert side.L.mrfa_conv2d_mask_supported(C.byref(p)) == 1
     if wwino and side.gpu:
         assert side.L.mrfa_conv2d_wino_supported(C.byref(p)) == 1, "the Winograd form does not apply to this launch"
-    if lds and side.gpu:            # the case is meant for the (opt-in) LDS-staged kernel: switch it on for this launch and make sure it ran
-        prev_lds = side.L.mrfa_set_tuning(b"conv_lds", 1)
-        try:
-            side.call("mrfa_conv2d_nhwc", C.byref(p))
-        finally:
-            side.L.mrfa_set_tuning(b"conv_lds", prev_lds)
-        assert side.L.mrfa_conv2d_last_config() & 16, "not dispatched to conv_lds"
-    else:
-        side.call("mrfa_conv2d_nhwc", C.byref(p))
+    side.call("mrfa_conv2d_nhwc", C.byref(p))
     if fin and side.gpu and fin == "small":
         assert side.L.mrfa_conv2d_last_config() & 8, "not dispatched to the one-wave-per-tile kernel"
-    return side.done(y[:, :Cout], st.sum(0), *fin_out)
+    return side.done(y[:, :Cout], st.sum(1).reshape(-1), *fin_out)
 
 
 CONV_CASES = {
@@ -239,14 +234,13 @@ CONV_CASES = {
     "small_linear_576_192_affine": dict(N=1, H=1, W=276, Cin=576, Cout=192, R=1, pad=0, oaff=True),
     "small_ragged": dict(N=1, H=7, W=9, Cin=48, Cout=40, stats=True),
     "small_wide_m": dict(N=8, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False),
-    # conv_lds.hip (input halo staged once in LDS, fp32 MFMA): HRNet's 3x3 stride-1 layers at the bench batch -- one case per tile
-    # configuration, every epilogue option, the pre-activation prologue, ragged channels, a halo that needs two staging passes
-    "lds_hr32_at64": dict(N=8, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, lds=True),
-    "lds_hr64_at32_res": dict(N=8, H=32, W=32, Cin=64, Cout=64, res=True, relu=True, stats=True, lds=True),
-    "lds_hr128_at16_acc": dict(N=8, H=16, W=16, Cin=128, Cout=128, acc=True, alpha=0.5, relu=False, bias=False, lds=True),
-    "lds_layer1_two_passes_pro": dict(N=4, H=64, W=64, Cin=64, Cout=64, pro=True, stats=True, lds=True),
-    "lds_ragged_c96_c40": dict(N=2, H=16, W=32, Cin=96, Cout=40, stats=True, oaff=True, lds=True),
-    "lds_row_segments": dict(N=1, H=8, W=64, Cin=32, Cout=128, res=True, lds=True),
+    # HRNet's 3x3 stride-1 layers at the bench batch (whatever kernel the dispatch picks): every epilogue option, the pre-activation prologue, ragged channels
+    "bench_hr32_at64": dict(N=8, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False),
+    "bench_hr64_at32_res": dict(N=8, H=32, W=32, Cin=64, Cout=64, res=True, relu=True, stats=True),
+    "bench_hr128_at16_acc": dict(N=8, H=16, W=16, Cin=128, Cout=128, acc=True, alpha=0.5, relu=False, bias=False),
+    "bench_layer1_two_passes_pro": dict(N=4, H=64, W=64, Cin=64, Cout=64, pro=True, stats=True),
+    "bench_ragged_c96_c40": dict(N=2, H=16, W=32, Cin=96, Cout=40, stats=True, oaff=True),
+    "bench_row_segments": dict(N=1, H=8, W=64, Cin=32, Cout=128, res=True),
     # strided gather (HRNet's downsampling layers: hr_base.py:241,253,302,305,365), even and odd input sizes
     # v6: first phase of a BatchNorm backward in a data-gradient launch's epilogue (bst_*): ReLU and linear, accumulate, ragged tiles
     "bst_hr32": dict(N=4, H=32, W=32, Cin=32, Cout=32, stats=True, relu=False, bias=False, bst=True),
@@ -262,6 +256,19 @@ CONV_CASES = {
     "fin_small_stride2": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False, fin="small"),
     "fin_big_tile": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, stats=True, relu=False, fin=True),
     "small_stride2_stem": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False),
+    # v7: statistic groups (the source / driving / transformed-driving encoder calls as one batch): per-group statistics, finalize and bst_* on the
+    # one-wave-per-tile kernel (all three wave tiles), the patch-tiled kernel, the row tiles and a strided layer
+    "groups2_small_hr32_fin": dict(N=16, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, fin="small", groups=2),
+    "groups2_small_hr128_fin": dict(N=4, H=16, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, fin="small", groups=2),
+    "groups3_small_hr64_fin": dict(N=6, H=16, W=16, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin="small", groups=3),
+    "groups2_small_64rows": dict(N=2, H=8, W=8, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin="small", groups=2),
+    "groups2_small_stride2_fin": dict(N=4, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False, fin="small", groups=2),
+    "groups2_bst_hr32": dict(N=4, H=32, W=32, Cin=32, Cout=32, stats=True, relu=False, bias=False, bst=True, groups=2),
+    "groups3_bst_hr64_acc": dict(N=6, H=16, W=16, Cin=64, Cout=64, stats=True, relu=False, bias=False, acc=True, bst=True, groups=3),
+    "groups2_big_tile_fin": dict(N=4, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, stats=True, relu=False, fin=True, groups=2),
+    "groups2_flat_stem": dict(N=4, H=16, W=16, Cin=3, Cout=64, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "groups2_1x1_64_256": dict(N=4, H=64, W=64, Cin=64, Cout=256, R=1, pad=0, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "groups2_auto_no_splitk": dict(N=4, H=8, W=8, Cin=512, Cout=512, splitk=0, stats=True, relu=False, fin=True, groups=2),
     "small_stride2_fuse_odd": dict(N=1, H=13, W=17, Cin=32, Cout=128, stride=2, stats=True, relu=False, bias=False),
 }
 
@@ -302,6 +309,8 @@ SPLIT_CASES = {
     "bn64_c64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True),
     "bn64_c50_pro": dict(N=2, H=16, W=48, Cin=64, Cout=50, tile=(128 << 16) | 64, pro=True),
     "bn64_auto": dict(N=4, H=128, W=128, Cin=128, Cout=64, ups=0),
+    "groups2_conv1x1_fin": dict(R=1, pad=0, Cin=64, Cout=256, N=4, H=32, W=32, stats=True, relu=False, bias=False, fin=True, groups=2, tile=(128 << 16) | 128),
+    "groups2_bn64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True, groups=2),
 }
 
 
@@ -345,6 +354,9 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "phase_up_c64": dict(N=2, H=8, W=32, Cin=128, Cout=64, ups=1, stats=True, wphase=True),
     "phase_up_c256_pro_res": dict(N=1, H=16, W=32, Cin=64, Cout=256, ups=1, pro=True, res=True, relu=False, wphase=True),
     "phase_up_c130_acc": dict(N=1, H=8, W=64, Cin=32, Cout=130, ups=1, acc=True, alpha=0.5, bias=False, wphase=True),
+    # v7: statistic groups (a patch lies inside one image): layer1's 64 -> 64 @64^2 of the keypoint encoder with the finalize behind the launch
+    "groups2_layer1_fin": dict(N=4, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "groups3_c128_res": dict(N=3, H=16, W=32, Cin=32, Cout=128, res=True, stats=True, groups=3),
 }
 
 
@@ -662,7 +674,7 @@ def dgrad_case(side, *, N=2, H=8, W=9, Cin=64, Cout=96, R=3, pad=1, tag="d"):
 
 @pytest.mark.parametrize("cfg", [dict(), dict(Cout=126), dict(Cout=3, Cin=64, R=7, pad=3), dict(Cout=10, Cin=35, R=7, pad=0),
                                  dict(Cin=3, Cout=64, R=7, pad=3), dict(R=1, pad=0, Cin=98, Cout=128),
-                                 dict(N=4, H=32, W=32, Cin=64, Cout=64), dict(N=4, H=16, W=16, Cin=128, Cout=32)])       # (conv_lds.hip shapes)
+                                 dict(N=4, H=32, W=32, Cin=64, Cout=64), dict(N=4, H=16, W=16, Cin=128, Cout=32)])
 def test_dgrad_matches_autograd(cfg):
     tag = "dgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
     (got,) = dgrad_case(Side(True), tag=tag, **cfg)
@@ -676,43 +688,6 @@ def test_dgrad_matches_autograd(cfg):
     y = torch.nn.functional.conv2d(x, w, padding=c["pad"])
     (gx,) = torch.autograd.grad(y, x, dy)
     assert_close([gx.permute(0, 2, 3, 1).reshape(-1, c["Cin"])], [got], what=tag)
-
-
-@pytest.mark.parametrize("cfg", [dict(N=2, H=32, W=32, Cin=64, Cout=64), dict(N=1, H=16, W=24, Cin=32, Cout=128), dict(N=8, H=64, W=64, Cin=64, Cout=64, acc=True),
-                                 dict(N=2, H=16, W=16, Cin=128, Cout=32)])
-def test_strided_data_gradient_matches_autograd(cfg):
-    """mrfa_conv_params.stride = -2: the data gradient of a 3x3 / pad 1 / stride 2 layer straight from dY (parity classes of the output grid, 9 / 4
-    taps per pixel) against torch autograd of F.conv2d(stride=2) in fp64, and bit-for-bit specification parity with the emulator's zero-stuffed form"""
-    c = dict(N=2, H=32, W=32, Cin=64, Cout=64, acc=False)
-    c.update(cfg)
-    N, H, W, Cin, Cout = c["N"], c["H"], c["W"], c["Cin"], c["Cout"]
-    Ho, Wo = H // 2, W // 2
-    tag = "sdgrad/" + "_".join(f"{k}{v}" for k, v in cfg.items())
-
-    def run(side):
-        w = side.t(f"{tag}/w", (Cout, Cin, 3, 3), -0.2, 0.2)
-        dy = side.t(f"{tag}/dy", (N * Ho * Wo, Cout))
-        dx = side.t(f"{tag}/dx0", (N * H * W, Cin)) if c["acc"] else side.garbage((N * H * W, Cin))
-        wp = pack(side, w, 2)
-        p = hip.ConvParams()
-        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = dy.data_ptr(), Cout, Ho, Wo, N, Cout
-        cip = (Cin + 127) // 128 * 128
-        p.w, p.w_ld, p.w_tap, p.w_rows = wp.data_ptr(), Cout, cip * Cout, cip
-        p.y, p.ldy, p.Cout, p.Hout, p.Wout = dx.data_ptr(), Cin, Cin, H, W
-        p.R, p.S, p.pad, p.stride, p.alpha, p.nbatch, p.splitk, p.accumulate = 3, 3, 1, -2, 1.0, 1, 1, int(c["acc"])
-        assert side.L.mrfa_conv2d_stride_supported(C.byref(p)) == 1
-        side.call("mrfa_conv2d_nhwc", C.byref(p))
-        return side.done(dx)
-    ref, got = both(run)
-    assert_close(ref, got, what=tag)
-    w = det_uniform(f"{tag}/w", (Cout, Cin, 3, 3), -0.2, 0.2).double()
-    dy = det_uniform(f"{tag}/dy", (N * Ho * Wo, Cout)).double().reshape(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
-    x = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
-    (gx,) = torch.autograd.grad(torch.nn.functional.conv2d(x, w, padding=1, stride=2), x, dy)
-    want = gx.permute(0, 2, 3, 1).reshape(-1, Cin)
-    if c["acc"]:
-        want = want + det_uniform(f"{tag}/dx0", (N * H * W, Cin)).double()
-    assert_close([want], got, what=tag + " vs autograd")
 
 
 def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, stride=1,
@@ -1320,6 +1295,80 @@ def test_pack_and_unpack_multi():
     assert_close(ref, got, tol=1e-6, what="pack/unpack multi")
 
 
+@pytest.mark.parametrize("Cc,ld,N,G,res", [(32, 32, 4, 2, True), (64, 64, 6, 3, False), (37, 41, 4, 2, True), (132, 132, 2, 2, False)])
+def test_bn_statistic_groups(Cc, ld, N, G, res):
+    """v7, statistic groups: mrfa_bn_finalize_groups + mrfa_bn_act_fwd / mrfa_bn_act_bwd with groups = G on a batch of G x (N / G) samples
+    (1) against the CPU specification and (2) against G UNGROUPED calls of the same entry points on the G sample ranges -- outputs, dx, the
+    residual gradient, running statistics after G momentum updates in group order, gamma / beta gradients summed over the groups.
+    (32 / 64 / 132 channels: float4 kernels; 37: scalar kernels.)"""
+    H, W = 8, 8
+    rows, n = N * H * W, N // G
+
+    def tensors(side):
+        x = side.t("bng/x", (rows, ld), -2, 2)
+        for g in range(G):                                  # (different statistics per group)
+            x[g * n * H * W:(g + 1) * n * H * W] *= 1.0 + 0.5 * g
+        rs = side.t("bng/res", (rows, ld))
+        gamma, beta = side.t("bng/g", (Cc,), 0.5, 1.5), side.t("bng/b", (Cc,))
+        rm, rv = side.t("bng/rm", (Cc,)), side.t("bng/rv", (Cc,), 0.5, 1.5)
+        dy = side.t("bng/dy", (rows, ld))
+        return x, rs, gamma, beta, rm, rv, dy
+
+    def one(side, x, rs, gamma, beta, rm, rv, dy, nn, groups, dx, dres, dg, dbt, y):
+        """statistics, finalize, forward, backward of `nn` samples starting at the given tensors, as `groups` statistic groups"""
+        r = nn * H * W
+        st = side.z((groups * hip.STATS_SLOTS * 2 * Cc,), torch.float64)
+        for g in range(groups):
+            side.call("mrfa_bn_stats", x.data_ptr() + 4 * g * (r // groups) * ld, ld, r // groups, Cc, st.data_ptr() + 8 * g * hip.STATS_SLOTS * 2 * Cc)
+        sc, sh, mean, inv = (side.z((groups * Cc,)) for _ in range(4))
+        if groups > 1:
+            side.call("mrfa_bn_finalize_groups", st.data_ptr(), r // groups, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, Cc, groups,
+                      sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr())
+        else:
+            side.call("mrfa_bn_finalize", st.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, Cc, 1,
+                      sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr())
+        p = hip.BnActParams()
+        p.x, p.ldx, p.N, p.H, p.W, p.C = x.data_ptr(), ld, nn, H, W, Cc
+        p.scale, p.shift, p.relu, p.pool, p.groups = sc.data_ptr(), sh.data_ptr(), 1, 0, groups
+        if res:
+            p.res, p.ldr = rs.data_ptr(), ld
+        p.y, p.ldy = y.data_ptr(), ld
+        side.call("mrfa_bn_act_fwd", C.byref(p))
+        red = side.z((groups * hip.STATS_SLOTS * 2 * Cc,), torch.float64)
+        q = hip.BnBwdParams()
+        q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), ld, nn, H, W, Cc
+        q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), 1, 0
+        q.mean, q.invstd, q.gamma = mean.data_ptr(), inv.data_ptr(), gamma.data_ptr()
+        q.dy, q.lddy = dy.data_ptr(), ld
+        if res:
+            q.res, q.ldr, q.dres, q.lddr = rs.data_ptr(), ld, dres.data_ptr(), ld
+        q.red, q.dx, q.lddx, q.dgamma, q.dbeta, q.train, q.groups = red.data_ptr(), dx.data_ptr(), ld, dg.data_ptr(), dbt.data_ptr(), 1, groups
+        for ph in (1, 2):
+            q.phase = ph
+            side.call("mrfa_bn_act_bwd", C.byref(q))
+        return sc, sh
+
+    def run(side, grouped):
+        x, rs, gamma, beta, rm, rv, dy = tensors(side)
+        dx, dres = side.t("bng/dx0", (rows, ld)), side.t("bng/dr0", (rows, ld))
+        dg, dbt = side.z((Cc,)), side.z((Cc,))
+        y = side.garbage((rows, ld))
+        if grouped:
+            sc, sh = one(side, x, rs, gamma, beta, rm, rv, dy, N, G, dx, dres, dg, dbt, y)
+        else:
+            scs = []
+            for g in range(G):
+                sl = slice(g * n * H * W, (g + 1) * n * H * W)
+                scs.append(one(side, x[sl], rs[sl], gamma, beta, rm, rv, dy[sl], n, 1, dx[sl], dres[sl], dg, dbt, y[sl]))
+            sc, sh = torch.cat([a for a, _ in scs]), torch.cat([b for _, b in scs])
+        return side.done(y[:, :Cc], dx[:, :Cc], dres[:, :Cc], dg, dbt, rm, rv, sc, sh)
+    spec = run(Side(False), True)
+    got = run(Side(True), True)
+    sep = run(Side(True), False)
+    assert_close(spec, got, tol=5e-4, what="bn groups vs specification")
+    assert_close(sep, got, tol=5e-5, what="bn groups vs separate calls")
+
+
 # ---------------------------------------------------------------------------------------------- K21 (MTIA prior)
 @pytest.mark.parametrize("Cc,ld", [(64, 64), (37, 41)])
 def test_bn_residual(Cc, ld):
@@ -1363,55 +1412,6 @@ def test_bn_residual(Cc, ld):
         return side.done(*outs)
     ref, got = both(run)
     assert_close(ref, got, tol=5e-4, what="bn_residual")
-
-
-@pytest.mark.parametrize("Cc,N,H,W,res", [(32, 8, 64, 64, False), (64, 8, 32, 32, True), (128, 8, 16, 16, True), (96, 2, 8, 6, False)])
-def test_bn_backward_fused_launch(Cc, N, H, W, res):
-    """phase 3 of mrfa_bn_act_bwd (reductions, a grid-wide barrier, apply: ONE launch; the keypoint encoder's shapes, up to 64 workgroups)
-    against the two-launch form on the same operands, both against the CPU specification; repeated launches must not hang or differ"""
-    def run(side, fused):
-        rows = N * H * W
-        x = side.t("bnf/x", (rows, Cc), -2, 2)
-        rs = side.t("bnf/res", (rows, Cc))
-        gamma, beta = side.t("bnf/g", (Cc,), 0.5, 1.5), side.t("bnf/b", (Cc,))
-        rm, rv = side.t("bnf/rm", (Cc,)), side.t("bnf/rv", (Cc,), 0.5, 1.5)
-        st = side.z((hip.STATS_SLOTS * 2 * Cc,), torch.float64)
-        side.call("mrfa_bn_stats", x.data_ptr(), Cc, rows, Cc, st.data_ptr())
-        sc, sh, mean, inv = (side.z((Cc,)) for _ in range(4))
-        side.call("mrfa_bn_finalize", st.data_ptr(), rows, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, Cc, 1,
-                  sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr())
-        dy = side.t("bnf/dy", (rows, Cc))
-        outs = []
-        for rep in range(3 if fused else 1):
-            dx, dres = side.garbage((rows, Cc)), side.t("bnf/dr0", (rows, Cc))
-            dg, dbt = side.z((Cc,)), side.z((Cc,))
-            nred = hip.STATS_SLOTS * 2 * Cc
-            red = side.z((nred + 2,), torch.float64)
-            q = hip.BnBwdParams()
-            q.x, q.ldx, q.N, q.H, q.W, q.C = x.data_ptr(), Cc, N, H, W, Cc
-            q.scale, q.shift, q.relu, q.pool = sc.data_ptr(), sh.data_ptr(), 1, 0
-            q.mean, q.invstd, q.gamma = mean.data_ptr(), inv.data_ptr(), gamma.data_ptr()
-            q.dy, q.lddy = dy.data_ptr(), Cc
-            if res:
-                q.res, q.ldr, q.dres, q.lddr = rs.data_ptr(), Cc, dres.data_ptr(), Cc
-            q.red, q.dx, q.lddx, q.dgamma, q.dbeta, q.train, q.dx_overwrite = red.data_ptr(), dx.data_ptr(), Cc, dg.data_ptr(), dbt.data_ptr(), 1, 1
-            if fused:
-                q.sync = red.data_ptr() + 8 * nred
-                assert side.L.mrfa_bn_act_bwd_fused_supported(C.byref(q)) == 1
-                q.phase = 3
-                side.call("mrfa_bn_act_bwd", C.byref(q))
-            else:
-                for ph in (1, 2):
-                    q.phase = ph
-                    side.call("mrfa_bn_act_bwd", C.byref(q))
-            outs.append(side.done(dx, dres, dg, dbt))
-        return outs
-    ref = run(Side(False), True)[0]
-    two = run(Side(True), False)[0]
-    reps = run(Side(True), True)
-    for got in reps:
-        assert_close(ref, got, tol=5e-4, what="bn fused vs specification")
-        assert_close(two, got, tol=2e-5, what="bn fused vs two launches")
 
 
 def test_subsample_and_upsample_add():

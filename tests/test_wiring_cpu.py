@@ -670,8 +670,11 @@ with emulated_hip():
     assert all(torch.equal(b, before[n]) for n, b in m.named_buffers()), "a rank-local save must not touch the live buffers"
     dist.barrier()
     # (2) the explicit collective form: every rank calls, rank 0 writes the rank-independent file
-    save_checkpoint(out + ".coll", m, opt, epoch=2, collective=True)
-    assert (rank == 0) == os.path.exists(out + ".coll") or rank != 0
+    # (every rank hands in ITS OWN path, so that a write by a rank other than 0 cannot hide behind rank 0's file)
+    save_checkpoint(out + f".coll.rank{rank}", m, opt, epoch=2, collective=True)
+    dist.barrier()
+    assert os.path.exists(out + ".coll.rank0"), "rank 0 did not write the collective checkpoint"
+    assert not any(os.path.exists(out + f".coll.rank{r}") for r in range(1, world)), "a rank other than 0 wrote a checkpoint with collective=True"
     # (3) SyncBatchNorm models: buffers are identical by construction, no collective is issued even with collective=True
     sm = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Tiny())
     if rank == 0:                                         # only rank 0 calls: must not block
@@ -692,7 +695,8 @@ def test_save_checkpoint_is_rank_local_and_the_buffer_average_is_explicit(tmp_pa
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, out]) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    local, coll = torch.load(out + ".local"), torch.load(out + ".coll")
+    local, coll = torch.load(out + ".local"), torch.load(out + ".coll.rank0")
+    assert not os.path.exists(out + ".coll.rank1")
     k = next(k for k in local["model"] if k.endswith("running_mean"))
     assert float(local["model"][k].mean()) == 1.0           # rank 0's own statistics
     assert float(coll["model"][k].mean()) == 1.5            # the mean over the two ranks
@@ -832,3 +836,69 @@ def test_prior_stage_gradients_through_emulator(golden_dir, train, b, fresh_mode
     from tests.grad_checks import check_prior_stage_gradients
     with emulated_hip():
         check_prior_stage_gradients(golden_dir, train, b, "cpu")
+
+
+@pytest.mark.parametrize("frames", [2, 3])
+def test_statistic_groups_equal_separate_calls(frames):
+    """engine.stat_groups (include/mrfa_hip.h v7): the reference's separate encoder calls -- encoder(source), encoder(driving)[, encoder(transformed
+    driving)], model.py:185-186,234 -- as ONE program over the concatenated batch must give what the separate train-mode calls give: outputs,
+    every parameter gradient, the running statistics after `frames` momentum updates in call order, num_batches_tracked == frames.  Through the
+    HRNet trunk's BatchNorm call patterns (conv-epilogue statistics with the fused finalize, stride-2 layers, residual-closing BatchNorm, the
+    first backward phase inside the consumer's data gradient), host logic + ABI specification on CPU."""
+    from mrfa_amd import engine
+    from mrfa_amd.utils.prng import det_uniform
+    b = 2
+    xs = [det_uniform(f"sg/x{i}", (b, 3, 32, 32)) * (1.0 + 0.5 * i) + 0.1 * i for i in range(frames)]       # (different statistics per call)
+    ws = [det_uniform(f"sg/w{i}", (b, 32, 8, 8)) for i in range(frames)]
+    with emulated_hip():
+        ref = small_hrnet()
+        ref.train(True)
+        ys = [ref(x) for x in xs]
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        got = small_hrnet()
+        got.train(True)
+        with engine.stat_groups(frames):
+            y = got(torch.cat(xs, 0))
+        (y * torch.cat(ws, 0)).sum().backward()
+    for i in range(frames):
+        assert (y[i * b:(i + 1) * b] - ys[i]).abs().max().item() <= 1e-5 * max(1.0, ys[i].abs().max().item()), i
+    for (n, a), (_, c) in zip(ref.named_buffers(), got.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert (a - c).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item()), n
+        else:
+            assert int(a) == int(c) == frames, n
+    for (n, p), (_, q) in zip(ref.named_parameters(), got.named_parameters()):
+        sc = max(p.grad.abs().max().item(), 1e-6)
+        assert (p.grad - q.grad).abs().max().item() <= 1e-4 * sc + 1e-7, (n, (p.grad - q.grad).abs().max().item(), sc)
+
+
+def test_fused_finalize_waits_for_its_statistics_atomics_before_the_ticket(tmp_path):
+    """conv_small.hip hands the BatchNorm statistics to the launch's LAST workgroup without fences -- device-scope fp64 atomics into the
+    slots, a barrier, a device-scope ticket.  That is only a hand-off if every thread WAITS for its slot atomics (s_waitcnt vmcnt(0)) before the barrier;
+    neither gfx950's back-off barrier nor a relaxed ticket makes the compiler emit the wait (round 4 shipped without it).  This compiles the file to ISA
+    and checks, in every kernel that draws a ticket, that a full vmcnt wait sits between the last f64 slot atomic and the barrier before the ticket."""
+    import re
+    import shutil
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    out = tmp_path / "conv_small.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mrfa_amd", "csrc"),
+                           "--offload-device-only", "-S", os.path.join(ROOT, "mrfa_amd", "csrc", "conv_small.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    kernels = re.split(r"^(_Z\w*conv_small_kernel\w*):[^\n]*$", out.read_text(), flags=re.M)
+    checked = 0
+    for name, body in zip(kernels[1::2], kernels[2::2]):
+        lines = body.split("\n")
+        tickets = [i for i, ln in enumerate(lines) if re.search(r"global_atomic_add(_u32)?\s+v\d+, v\d+, v\d+, .*sc0", ln)]       # the returning (ticket) atomic
+        if not tickets:
+            continue
+        assert len(tickets) == 1, (name, tickets)
+        t = tickets[0]
+        atoms = [i for i in range(t) if "global_atomic_add_f64" in lines[i]]
+        assert atoms, name
+        between = lines[atoms[-1] + 1:t]
+        bar = max(i for i, ln in enumerate(between) if "s_barrier" in ln)
+        assert any(re.search(r"s_waitcnt\s+vmcnt\(0\)", ln) for ln in between[:bar]), \
+            f"{name}: no s_waitcnt vmcnt(0) between the statistics atomics and the barrier before the ticket"
+        checked += 1
+    assert checked >= 6, checked        # every instantiation of the kernel carries the epilogue
