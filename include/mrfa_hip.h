@@ -29,13 +29,14 @@ const char* mrfa_last_error(void);
  *   3  round 3 (shipped as "1"): mrfa_conv_params += mask, ldm, w_phase, w_phase_piece, stride; mrfa_wgrad_params += stride;
  *      mrfa_bnbwd_params += sync; pack modes 8 / 9 (pre-split bf16 weight planes) became k16-chunk-major -- plane[tap][k16 chunk][row][16]
  *      -- and are only meaningful together with w_rows; pack modes 12-15 added.
- *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17); mrfa_conv2d_wino_supported(); stride = -2.
+ *   4  round 4: mrfa_conv_params += w_wino, w_wino_piece (pack modes 16 / 17) with a `..._wino_supported` query; stride = -2.
  *   5  round 4: mrfa_timestamp() added (no struct changed: a version-4 client still works against this library, not the reverse).
  *   6  round 4: mrfa_conv_params += fin_* (BatchNorm finalize inside the convolution call); mrfa_conv2d_wgrad_multi(); mrfa_warp_frame_reflect(); mrfa_bnbwd_params += red_world, red_all, mrfa_bn_param_grad(); mrfa_conv_params += bst_*.
  *   7  round 5: STATISTIC GROUPS -- mrfa_conv_params / mrfa_bnact_params / mrfa_bnbwd_params += groups, mrfa_bn_finalize_groups(), mrfa_bn_param_grad_groups(),
  *      mrfa_conv2d_groups_supported() (see "Statistic groups" below).  REMOVED (measured slower or neutral in round 4, never on by default): stride = -2 (the
  *      strided data gradient), mrfa_bnbwd_params.phase = 3 with its `..._fused_supported` query (`sync` stays in the struct, reserved), the LDS-staged
- *      small convolution behind mrfa_set_tuning("conv_lds").                                                                                              */
+ *      small convolution behind mrfa_set_tuning("conv_lds"), the Winograd-along-x form (w_wino stays in the struct, reserved; pack modes 16 / 17 and its
+ *      `..._wino_supported` query are gone).                                                                                              */
 #define MRFA_ABI_VERSION 7
 int mrfa_version(void);
 
@@ -92,10 +93,8 @@ typedef struct {
     int stride;            /* 0 / 1: stride 1.  2: strided convolution, Hout = (Hin + 2 pad - R) / 2 + 1 (HRNet's downsampling 3x3 layers,       */
                            /*   hr_base.py:241,253,302,305,365) -- only where mrfa_conv2d_stride_supported() says so.  (-2, the strided data       */
                            /*   gradient of v4-v6, is gone in v7: a stride-1 launch over the zero-stuffed dY is what callers use)                  */
-    const void* w_wino;    /* v4, optional (3x3 / pad 1 / stride 1, no upsample): the weights run through the Winograd F(2, 3) transform ALONG X    */
-    long long w_wino_piece;/*   (pack mode 16; 17 for data-gradient launches), three bf16 pieces.  When present and mrfa_conv2d_wino_supported()  */
-                           /*   the patch-tiled kernel computes two horizontally adjacent outputs from 4 instead of 6 products per kernel row:    */
-                           /*   12 instead of 18 MFMA steps per pixel pair -- same result up to fp32 rounding of the transforms                   */
+    const void* w_wino;    /* (reserved: the Winograd F(2, 3)-along-x form of v4-v6 -- 1.10-1.16x per launch, nothing in the training step on a    */
+    long long w_wino_piece;/*   power-limited part -- is gone in v7; must be NULL / 0)                                                              */
     /* v6, optional, together with `stats` (fin_scale != NULL): FINISH the train-mode BatchNorm that follows this convolution as part of this call --   */
     /* exactly what mrfa_bn_finalize(stats, fin_count, fin_gamma, fin_beta, fin_rmean, fin_rvar, fin_momentum, fin_eps, Cout, 1, fin_scale, fin_shift,   */
     /* fin_mean, fin_invstd) would do after it (fin_rmean / fin_rvar / fin_mean / fin_invstd may be NULL).  The small-problem kernel does it in the     */
@@ -140,7 +139,6 @@ int mrfa_conv2d_stride_supported(const mrfa_conv_params* p);         /* 1: a cal
 int mrfa_conv2d_mask_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters honours `mask`                    */
 int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p);    /* 1: a call with these parameters (ups = 2) is implemented          */
 int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p);   /* 1: a call with these parameters honours bst_*                                          */
-int mrfa_conv2d_wino_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters would run the Winograd form if w_wino were set */
 /* Matrix-pipe selection for the 128 x 128 chunked tiles of mrfa_conv2d_nhwc and mrfa_conv2d_wgrad_nhwc (process-wide):
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands; 157 TF/s pipe)
  *   1  fp32 operands split exactly into 3 bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate
@@ -218,9 +216,7 @@ int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p);  /* 1: a cal
  * mode 12: 3x3 only: the phase weights of UpBlock2d's nearest-x2 + conv (see mrfa_conv_params.w_phase): three bf16 planes
  *         [piece][16 phase taps][CoutPad128][CinPad32], phase tap = (py*2+px)*4 + a*2+b, weight = sum of the 3x3 taps that read
  *         the same low-resolution pixel (batched entry point only)
- * modes 16 / 17: 3x3 only: Winograd F(2, 3) along x (see mrfa_conv_params.w_wino): U[r][xi] = sum_s G[xi][s] w[r][s], G = [1 0 0; 1/2 1/2 1/2;
- *         1/2 -1/2 1/2; 0 0 1]; three bf16 planes [piece][r * 4 + xi][CoutPad128][CinPad32] (16) or, of the flipped / transposed kernel of the
- *         data gradient, [piece][r' * 4 + xi][CinPad128][CoutPad32] (17); k16-chunk-major (batched entry point only)                     */
+ * (modes 16 / 17, the Winograd-along-x weights of v4-v6, are gone in v7)                                                              */
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 
 /* Batched forms: all layouts of many convolutions per launch (descriptor table passed by value in the kernel

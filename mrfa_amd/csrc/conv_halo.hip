@@ -62,25 +62,6 @@ struct Geo {
     static_assert(NU <= 4, "halo units are loaded at taps 0,2,4,6 and stored two taps later");
 };
 
-// MODE 3 ("WX"): Winograd F(2, 3) ALONG X.  Two horizontally adjacent outputs of a kernel row need 4 products instead of 6:
-//   V[xi] = B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)  of the four input pixels d0..d3 = columns 2 tx - 1 .. 2 tx + 2,
-//   M[xi] = sum over channels and kernel rows of U[r][xi] * V[r][xi]   (U = G w: pack modes 16 / 17),   y0 = M0 + M1 + M2,  y1 = M1 - M2 - M3.
-// The input transform is computed ONCE per (halo row, x-tile, channel) while the halo is staged (fp32 adds before the exact bf16 split), the
-// LDS image holds the transformed halo [half][(halo row, xi, x-tile)][16 B], a "tap" (r, xi) is again a constant fragment offset, and a wave's
-// MFMA tile is 32 x-TILES = the 64 pixels of its two patch rows: 12 instead of 18 MFMA steps per chunk and pixel, four accumulator sets (one per
-// xi) instead of two.  Same arithmetic contract as the direct form up to the fp32 rounding of the two transforms.
-template <int PR>
-struct GeoW {
-    static constexpr int NT = PR * 64;
-    static constexpr int ENT = (PR + 2) * 64;            // (halo row, xi, x-tile) entries
-    static constexpr int AHALF = ENT * 16 + 64;          // + 64 B: the k 8..15 half lands in the other bank half
-    static constexpr int APLANE = 2 * AHALF;
-    static constexpr int ABUF = 3 * APLANE;
-    static constexpr int UNITS = (PR + 2) * 16 * 4;      // (halo row, x-tile, channel quad): each loads four pixels
-    static constexpr int NU = (UNITS + NT - 1) / NT;
-    static_assert(AHALF % 128 == 64, "half-plane stride must put the k 8..15 half into the other bank half");
-};
-
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) {      // (bf16 chop of b) << 16 | (bf16 chop of a)
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
@@ -109,18 +90,15 @@ template <int PR, bool PRO, int BN, int NP, int MODE>
 __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(const mrfa_conv_params p, const int tiles_n, const int tiles_x, const int tiles_y,
                                                               const int total_tiles) {
     using G = Geo<PR>;
-    using GW = GeoW<PR>;
-    constexpr bool WX = MODE == 3;
     constexpr int BHALF = GeoB<BN>::BHALF, BPLANE = GeoB<BN>::BPLANE, BSLAB = GeoB<BN>::BSLAB;
     constexpr int NT = G::NT;
-    constexpr int AHALF_ = WX ? GW::AHALF : G::AHALF, APLANE_ = WX ? GW::APLANE : G::APLANE, ABUF_ = WX ? GW::ABUF : G::ABUF;
     constexpr int TN = BN / 64;                    // 32-column MFMA tiles per wave along N
     constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);     // bf16 pieces needed (bf16x3 drops the third; plain bf16: one rounded plane)
     constexpr int BUNITS = NPC * BN * 2;           // 16-byte units of one weight slab
     constexpr int NBU = (BUNITS + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ABUF_ + 2 * BSLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::ABUF + 2 * BSLAB];
     unsigned char* const smA = smem;
-    unsigned char* const smB = smem + 2 * ABUF_;
+    unsigned char* const smB = smem + 2 * G::ABUF;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -138,12 +116,12 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int y0 = ty * PR, x0 = tx * PW, n0 = tile_n * BN;
 
     constexpr bool PH = MODE == 1, PD = MODE == 2;
-    constexpr int KT = (PH || PD) ? 4 : (WX ? 12 : 9);         // taps (= pipeline steps) per 16-channel chunk
+    constexpr int KT = (PH || PD) ? 4 : 9;                 // taps (= pipeline steps) per 16-channel chunk
     static_assert(!(PH || PD) || G::NU <= 3, "phase form: the halo units are loaded at tap 0 and stored at taps 1..3");
     const int ph_y = PH ? (int)(blockIdx.y >> 1) : 0, ph_x = PH ? (int)(blockIdx.y & 1) : 0;
     const int ush = (PH || PD) ? 0 : p.ups;        // phase forms: the patch is ON the low-resolution grid
     const float* __restrict__ x = p.x;
-    const unsigned short* __restrict__ ws = reinterpret_cast<const unsigned short*>((PH || PD) ? p.w_phase : (WX ? p.w_wino : p.w_split)) +
+    const unsigned short* __restrict__ ws = reinterpret_cast<const unsigned short*>((PH || PD) ? p.w_phase : p.w_split) +
                                             (PH ? (size_t)(blockIdx.y * 4) * (size_t)p.w_tap : (size_t)0);
     // PD: x is the high-resolution gradient (Hin x Win = 2 Hout x 2 Wout), the halo lives on the output (low-resolution) grid
     const int Hv = PD ? p.Hout : (p.Hin << ush), Wv = PD ? p.Wout : (p.Win << ush);
@@ -178,33 +156,10 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int row = rem >> 1, half = rem & 1;
         // pre-split planes are k16-chunk-major (pack_multi.hip chunk_major()): the slab of (tap, chunk) = w_rows consecutive rows of 32 bytes,
         // ONE contiguous run (row-major planes gave 32 bytes out of every row: a quarter of each 128-byte line fetched from L2; +3-5 %)
-        b_goff[j] = pc * (int)((PH || PD) ? p.w_phase_piece : (WX ? p.w_wino_piece : p.w_piece)) + (n0 + row) * 16 + half * 8;
+        b_goff[j] = pc * (int)((PH || PD) ? p.w_phase_piece : p.w_piece) + (n0 + row) * 16 + half * 8;
         b_loff[j] = pc * BPLANE + half * BHALF + row * 16;
     }
 
-    // ---- WX: units (halo row hy, x-tile tx, channel quad): pixels x0 - 1 + 2 tx + {0, 1, 2, 3} of input row y0 - 1 + hy
-    int w_row[WX ? GW::NU : 1], w_img0 = 0, w_loff[WX ? GW::NU : 1];
-    unsigned w_inb[WX ? GW::NU : 1];
-    bool w_val[WX ? GW::NU : 1];
-    if constexpr (WX) {
-        w_img0 = n_img * p.Hin * p.Win * p.ldx + q4 * 4;                  // a valid address for out-of-image pixels (zeroed after the prologue)
-#pragma unroll
-        for (int j = 0; j < GW::NU; ++j) {
-            const int u = tid + j * NT;
-            w_val[j] = u < GW::UNITS;
-            const int t = (w_val[j] ? u : 0) >> 2;
-            const int tx = t & 15, hy = t >> 4;
-            const int iy = y0 - 1 + hy, ixb = x0 - 1 + 2 * tx;
-            const bool rok = w_val[j] && (unsigned)iy < (unsigned)Hv;
-            unsigned m = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m |= (rok && (unsigned)(ixb + k) < (unsigned)Wv) ? (1u << k) : 0u;
-            w_inb[j] = m;
-            w_row[j] = (n_img * p.Hin * p.Win + (rok ? iy : 0) * p.Win + ixb) * p.ldx + q4 * 4;
-            w_loff[j] = (q4 >> 1) * AHALF_ + ((hy * 4) * 16 + tx) * 16 + (q4 & 1) * 8;
-        }
-    }
-    f32x4 rw[WX ? 4 : 1];
     f32x4 ra[G::NU], psc, psh;
     u32x4 rb[NBU];
     const int w_tap = (int)p.w_tap;
@@ -243,43 +198,6 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * G::APLANE) = p3;
         }
     };
-    auto load_aw = [&](int j, int c) {
-        if constexpr (WX) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int off = ((w_inb[j] >> k) & 1u) ? w_row[j] + k * p.ldx : w_img0;
-                rw[k] = *reinterpret_cast<const f32x4*>(x + (size_t)off + c * 16);
-            }
-        }
-    };
-    auto store_aw = [&](int j, int buf) {
-        if constexpr (WX) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                f32x4 t = rw[k];
-                if constexpr (PRO) {
-                    t = t * psc + psh;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
-                }
-                v[k] = ((w_inb[j] >> k) & 1u) ? t : z;
-            }
-            const f32x4 tv[4] = {v[0] - v[2], v[1] + v[2], v[2] - v[1], v[1] - v[3]};          // B^T d
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) {
-                u32x2 p1, p2, p3;
-                split3(tv[xi], p1, p2, p3);
-                if (w_val[j]) {
-                    unsigned char* dst = smA + buf * ABUF_ + w_loff[j] + xi * 256;
-                    *reinterpret_cast<u32x2*>(dst) = p1;
-                    if constexpr (NPC >= 2) *reinterpret_cast<u32x2*>(dst + APLANE_) = p2;
-                    if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * APLANE_) = p3;
-                }
-            }
-        }
-    };
     auto load_b = [&](int c, int tap) {
         const unsigned short* src = PD ? ws + (size_t)((c & 3) * 4 + tap) * w_tap + (size_t)(c >> 2) * chunk_stride : ws + (size_t)tap * w_tap + (size_t)c * chunk_stride;
 #pragma unroll
@@ -291,10 +209,9 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (b_val[j]) *reinterpret_cast<u32x4*>(smB + buf * BSLAB + b_loff[j]) = rb[j];
     };
 
-    constexpr int NACC = WX ? 4 : 2;               // WX: one accumulator set per Winograd position xi (the output transform runs in the epilogue)
-    f32x16 acc[NACC][TN];
+    f32x16 acc[2][TN];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -303,34 +220,12 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int frow = lane & 31, fhalf = lane >> 5;
     const int a_frag = fhalf * G::AHALF + ((2 * wm + ph_y) * HP + frow + ph_x) * 16;      // + ((i + r) * HP + s) * 16 per (row tile, tap)
     const int b_frag = fhalf * BHALF + (wn * (TN * 32) + frow) * 16;            // + j * 512 per column tile
-    // WX: MFMA row frow = (patch row 2 wm + (frow >> 4), x-tile frow & 15); entry ((halo row) * 4 + xi) * 16 + x-tile
-    const int a_fragw = fhalf * AHALF_ + (((2 * wm + (frow >> 4)) * 4) * 16 + (frow & 15)) * 16;      // + (r * 4 + xi) * 256 per tap
 
     auto compute = [&](auto TAP, int abuf, int bbuf, int vc) {
         constexpr int tap = decltype(TAP)::value;
         // PD: source of tap (a, b) of phase (py, px) is the phase-image pixel (y + 1 - py - a, x + 1 - px - b): halo offset (2 - a, 2 - b) minus the phase
         constexpr int r = PD ? 2 - (tap >> 1) : (PH ? tap >> 1 : tap / 3), s = PD ? 2 - (tap & 1) : (PH ? tap & 1 : tap % 3);
         const unsigned char* B = smB + bbuf * BSLAB + b_frag;
-        if constexpr (WX) {
-            // tap = r * 4 + xi: ONE A fragment (32 x-tiles) per piece, accumulated into the set of its position xi
-            const unsigned char* A = smA + abuf * ABUF_ + a_fragw + tap * 256;
-            bf16x8 aw[NPC];
-#pragma unroll
-            for (int pc = 0; pc < NPC; ++pc) aw[pc] = *reinterpret_cast<const bf16x8*>(A + pc * APLANE_);
-            constexpr int PAw[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PBw[6] = {0, 2, 1, 0, 1, 0};
-            bf16x8 bw[NPC][TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pc = 0; pc < NPC; ++pc) bw[pc][j] = *reinterpret_cast<const bf16x8*>(B + pc * BPLANE + j * 512);
-#pragma unroll
-            for (int t = 6 - NP; t < 6; ++t)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[tap & 3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[PBw[t]][j], aw[PAw[t]], acc[tap & 3][j], 0, 0, 0);
-            return;
-        }
         const unsigned char* A = smA + abuf * G::ABUF + a_frag - (PD ? (((vc >> 1) & 1) * HP + (vc & 1)) * 16 : 0);
         constexpr int JG = TN == 3 ? 3 : (TN < 2 ? TN : 2);      // column tiles per pass: BN = 256 runs two passes over the same A fragments
         bf16x8 a[NPC][2];
@@ -362,17 +257,11 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- prologue: halo of chunk 0 -> A[0], slab (0, 0) -> B[0], slab (0, 1) -> registers
     load_pro(0);
-    if constexpr (WX) {
 #pragma unroll
-        for (int j = 0; j < GW::NU; ++j) { load_aw(j, 0); store_aw(j, 0); }
-        load_b(0, 0);
-    } else {
+    for (int j = 0; j < G::NU; ++j) load_a(j, 0);
+    load_b(0, 0);
 #pragma unroll
-        for (int j = 0; j < G::NU; ++j) load_a(j, 0);
-        load_b(0, 0);
-#pragma unroll
-        for (int j = 0; j < G::NU; ++j) store_a(j, 0);
-    }
+    for (int j = 0; j < G::NU; ++j) store_a(j, 0);
     store_b(0);
     load_b(0, 1);
     __syncthreads();
@@ -391,11 +280,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             store_b(ubuf ^ 1);
             if constexpr (tap + 2 < KT) load_b(c, tap + 2); else load_b(cn, tap + 2 - KT);
             if constexpr (tap == 0) load_pro(cn);      // (the stores of chunk c's halo, which used the previous pair, are all behind us)
-            if constexpr (WX) {                        // twelve steps per chunk: unit j (four pixel loads) is loaded at tap 4 j and transformed / split / stored at tap 4 j + 3
-                static_assert(!WX || GW::NU <= 3, "WX: halo units are loaded at taps 0, 4, 8");
-                if constexpr (tap % 4 == 0 && tap / 4 < GW::NU) load_aw(tap / 4, cn);
-                if constexpr (tap % 4 == 3 && tap / 4 < GW::NU) store_aw(tap / 4, abuf ^ 1);
-            } else if constexpr (PH || PD) {                  // four steps per chunk: every unit of the next halo is loaded at tap 0, unit j stored at tap 1 + j
+            if constexpr (PH || PD) {                  // four steps per chunk: every unit of the next halo is loaded at tap 0, unit j stored at tap 1 + j
                 if constexpr (tap >= 1 && tap - 1 < G::NU) store_a(tap - 1, abuf ^ 1);
                 if constexpr (tap == 0) {
 #pragma unroll
@@ -420,16 +305,6 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             step(std::integral_constant<int, 7>{});
             step(std::integral_constant<int, 8>{});
         }
-        if constexpr (KT == 12) {
-            step(std::integral_constant<int, 4>{});
-            step(std::integral_constant<int, 5>{});
-            step(std::integral_constant<int, 6>{});
-            step(std::integral_constant<int, 7>{});
-            step(std::integral_constant<int, 8>{});
-            step(std::integral_constant<int, 9>{});
-            step(std::integral_constant<int, 10>{});
-            step(std::integral_constant<int, 11>{});
-        }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -444,12 +319,10 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            // patch row; phase form: output pixel (2 pyl + ph_y, 2 (x0 + px) + ph_x).  WX: lane = (patch row 2 wm + (px >> 4), x-tile px & 15), i = the
-            // pixel of the pair: (y, x0 + 2 (px & 15) + i)
-            const int pyl = WX ? y0 + 2 * wm + (px >> 4) : y0 + 2 * wm + i;
+            // patch row; phase form: output pixel (2 pyl + ph_y, 2 (x0 + px) + ph_x)
+            const int pyl = y0 + 2 * wm + i;
             const long long m = PH ? ((long long)n_img * p.Hout + 2 * pyl + ph_y) * p.Wout + 2 * (x0 + px) + ph_x
-                                   : (WX ? ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + 2 * (px & 15) + i
-                                         : ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + px);
+                                   : ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + px;
             if (pyl < (PH ? p.Hin : p.Hout)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -462,14 +335,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         const float bias = (p.bias && c_ok) ? p.bias[c0 + e] : 0.f;
                         const float osc = (p.out_scale && c_ok) ? p.out_scale[c0 + e] : 1.f;
                         const float osh = (p.out_scale && c_ok) ? p.out_shift[c0 + e] : 0.f;
-                        float av;
-                        if constexpr (WX) {                        // output transform A^T M: y0 = M0 + M1 + M2, y1 = M1 - M2 - M3
-                            const int q = 4 * g + e;
-                            av = i == 0 ? (acc[0][j][q] + acc[1][j][q]) + acc[2][j][q] : (acc[1][j][q] - acc[2][j][q]) - acc[3][j][q];
-                        } else {
-                            av = acc[i][j][4 * g + e];
-                        }
-                        v[e] = (av * p.alpha + bias) * osc + osh;
+                        v[e] = (acc[i][j][4 * g + e] * p.alpha + bias) * osc + osh;
                     }
                     if (p.mask) {                              // fused ReLU backward of the producer of this gradient (data-gradient launches)
 #pragma unroll
@@ -557,15 +423,6 @@ int g_halo_bn64_fill = 1;
 // per CU); BN = 256 (each wave 64 pixels x 128 channels: the halo is staged once for twice the MFMAs, 18 instead of 24 fragment reads
 // per 48 MFMAs) when Cout pads to a multiple of 256 anyway and the workgroup count allows
 int g_halo_phase = 1;
-int g_halo_wino = -1;            // -1: not initialised (MRFA_CONV_HALO_WINO; default on)
-
-// the Winograd-along-x form (MODE 3) applies to a plain 3x3 launch: split-operand mode (six / three products), 8-row patches, <= 128-wide tiles
-// (four accumulator sets: 128 accumulator registers per wave at BN = 128; the 192- / 256-wide variants would need 192 / 256)
-bool halo_wino_shape(const mrfa_conv_params& p) {
-    if (g_halo_wino < 0) { const char* e = getenv("MRFA_CONV_HALO_WINO"); g_halo_wino = !(e && e[0] == '0'); }
-    const int mode = mrfa_get_mfma_mode();
-    return g_halo_wino && (mode == 1 || mode == 2) && p.ups == 0 && (p.Hout % 8) == 0 && !p.w_phase;
-}
 
 // the phase form of a fused upsample applies: pre-summed phase weights present, the LOW-resolution grid tiles into 8 x 32 patches
 bool halo_phase(const mrfa_conv_params& p) {
@@ -633,7 +490,6 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!key) return -1;
     if (!strcmp(key, "conv_halo")) { const int prev = halo_on(); g_halo_on = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_min_tiles")) { const int prev = g_halo_min_tiles; g_halo_min_tiles = value; return prev; }
-    if (!strcmp(key, "conv_halo_wino")) { const int prev = g_halo_wino < 0 ? 1 : g_halo_wino; g_halo_wino = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_phase")) { const int prev = g_halo_phase; g_halo_phase = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_bn256")) { const int prev = g_halo_bn256; g_halo_bn256 = value != 0; return prev; }
     if (!strcmp(key, "conv_halo_bn64_fill")) { const int prev = g_halo_bn64_fill; g_halo_bn64_fill = value != 0; return prev; }
@@ -663,16 +519,6 @@ static bool halo_phase_dgrad(const mrfa_conv_params& p) {
 }
 
 extern "C" int mrfa_conv2d_phase_dgrad_supported(const mrfa_conv_params* p) { return p && halo_phase_dgrad(*p) ? 1 : 0; }
-// 1: a launch with these parameters would take the Winograd-along-x form if w_wino were set (the engine asks before it builds that pack)
-extern "C" int mrfa_conv2d_wino_supported(const mrfa_conv_params* pp) {
-    if (!pp) return 0;
-    mrfa_conv_params p = *pp;
-    if (!p.w_wino) p.w_wino = p.w_split;             // (any non-null value: only the shape decides)
-    if (p.kflat > 0 || !mrfa_conv_halo_eligible(p) || !halo_wino_shape(p)) return 0;
-    int PR, BN;
-    halo_config(p, PR, BN);
-    return PR == 8 && BN <= 128 && !halo_uses_phase(p, PR, BN) ? 1 : 0;
-}
 
 extern "C" int mrfa_conv2d_mask_supported(const mrfa_conv_params* p) { return p && p->kflat == 0 && mrfa_conv_halo_eligible(*p) ? 1 : 0; }
 
@@ -701,9 +547,6 @@ int mrfa_conv_halo_launch(hipStream_t st, const mrfa_conv_params& p) {
         halo_config(p, PR, BN);
     }
     const bool phase = p.ups != 2 && halo_uses_phase(p, PR, BN);
-    // (not where the direct form picked a 192- / 256-wide tile: four accumulator sets only fit 128 columns, and narrower tiles there cost more than
-    // the 12 / 18 MFMA steps save -- measured: dgrad into 192 channels 1.108 -> 1.252 ms)
-    const bool wino = p.ups == 0 && !phase && PR == 8 && BN <= 128 && p.w_wino != nullptr && halo_wino_shape(p) && 3 * p.w_wino_piece < (1ll << 31);
     const int tiles_n = cdiv(p.Cout, BN), tiles_x = (phase ? p.Win : p.Wout) / PW, tiles_y = cdiv(phase ? p.Hin : p.Hout, PR);
     const long long total = (long long)p.N * tiles_y * tiles_x * tiles_n;
     dim3 grid((unsigned)(cdiv(total, 8) * 8), phase ? 4u : 1u);
@@ -723,17 +566,7 @@ int mrfa_conv_halo_launch(hipStream_t st, const mrfa_conv_params& p) {
         else if (BN == 256) HALO_LAUNCH(PR_, PRO_, 256, MODE_);                       \
         else HALO_LAUNCH(PR_, PRO_, 128, MODE_);                                      \
     } while (0)
-    if (wino) {
-#define WINO_LAUNCH(PRO_, BN_)                                                                                                                         \
-    do {                                                                                                                                            \
-        if (three) hipLaunchKernelGGL((conv_halo_kernel<8, PRO_, BN_, 3, 3>), grid, dim3(512), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);       \
-        else hipLaunchKernelGGL((conv_halo_kernel<8, PRO_, BN_, 6, 3>), grid, dim3(512), 0, st, p, tiles_n, tiles_x, tiles_y, (int)total);             \
-    } while (0)
-        if (BN == 64) { if (pro) WINO_LAUNCH(true, 64); else WINO_LAUNCH(false, 64); }
-        else { if (pro) WINO_LAUNCH(true, 128); else WINO_LAUNCH(false, 128); }
-#undef WINO_LAUNCH
-    }
-    else if (p.ups == 2) { if (BN == 64) HALO_LAUNCH(8, false, 64, 2); else HALO_LAUNCH(8, false, 128, 2); }
+    if (p.ups == 2) { if (BN == 64) HALO_LAUNCH(8, false, 64, 2); else HALO_LAUNCH(8, false, 128, 2); }
     else if (phase) { if (pro) HALO_BN(8, true, 1); else HALO_BN(8, false, 1); }
     else if (PR == 8 && BN == 192) HALO_LAUNCH(8, false, 192, 0);
     else if (PR == 8) { if (pro) HALO_BN(8, true, 0); else HALO_BN(8, false, 0); }

@@ -303,8 +303,6 @@ int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long 
     if (waves(32, 32) < 2048) { tm = 1; tn = 2; }
     if (tm == 1 && waves(16, 32) < 2048) { tn = 1; }
     if (ncols % 32 != 0 && tn == 2 && ncols < 32) tn = 1;
-    static const int force = [] { const char* e = getenv("MRFA_CS_TILE"); return e ? atoi(e) : 0; }();      // tuning: 22 / 12 / 11
-    if (force == 22) { tm = 2; tn = 2; } else if (force == 12) { tm = 1; tn = 2; } else if (force == 11) { tm = 1; tn = 1; }
     if (p.groups > 1 && tm == 2 && (group_rows(p, M) % 128) != 0) tm = 1;       // (eligibility guarantees % 64)
     const int WM = 16 * tm, WN = 16 * tn;
     const int tiles_n = (ncols + WN - 1) / WN;

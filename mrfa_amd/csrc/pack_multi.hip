@@ -124,44 +124,6 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackArgs a) {
             }
             continue;
         }
-        if (mode == 16 || mode == 17) {
-            // Winograd F(2, 3) along x (conv_halo.hip MODE 3): two horizontally adjacent outputs of a 3x3 row need 4 instead of 6 products when
-            // the three taps s of a kernel row r are replaced by the four "positions" xi:  U[r][xi] = sum_s G[xi][s] w[r][s],
-            // G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]  (computed in fp32, then split exactly into three bf16 pieces).  Layout: three bf16 planes
-            // [piece][r * 4 + xi][CoutPad128][CinPad32] (mode 16) or, for the data gradient, the transposed / flipped kernel w'[ci][co][r'][s'] =
-            // w[co][ci][2 - r'][2 - s'] run through the same transform: [piece][r' * 4 + xi][CinPad128][CoutPad32] (mode 17); k16-chunk-major.
-            const bool tr = mode == 17;
-            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(dst);
-            const int rowsP = tr ? rup(Cin, 128) : rup(Cout, 128), colsP = tr ? rup(Cout, 32) : rup(Cin, 32);
-            const long long piece = 12ll * rowsP * colsP;
-            const int nfast = tr ? nco : nci, nslow = tr ? nci : nco;
-            const int f0 = (threadIdx.x & 15) * 2;
-            for (int q = threadIdx.x >> 4; q < nslow * 12; q += 16) {
-                const int sl = q / 12, pt = q - sl * 12;
-                if (f0 >= nfast) continue;
-                const int r_ = pt >> 2, xi = pt & 3;
-                float v[2] = {0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (f0 + e < nfast) {
-                        const int co_l = tr ? f0 + e : sl, ci_l = tr ? sl : f0 + e;
-                        const float* wl = lds + co_l * row + ci_l * T + (tr ? (2 - r_) * 3 : r_ * 3);
-                        const float g0 = tr ? wl[2] : wl[0], g1 = wl[1], g2 = tr ? wl[0] : wl[2];        // (flipped along s for the data gradient)
-                        v[e] = xi == 0 ? g0 : (xi == 3 ? g2 : (xi == 1 ? 0.5f * (g0 + g1 + g2) : 0.5f * (g0 - g1 + g2)));
-                    }
-                }
-                const long long idx = tr ? chunk_major(pt, ci0 + sl, co0 + f0, rowsP, colsP) : chunk_major(pt, co0 + sl, ci0 + f0, rowsP, colsP);
-                float x0 = v[0], x1 = v[1];
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    const unsigned b0 = __float_as_uint(x0) & 0xffff0000u, b1 = __float_as_uint(x1) & 0xffff0000u;
-                    *reinterpret_cast<unsigned*>(d16 + pc * piece + idx) = (b0 >> 16) | b1;
-                    x0 -= __uint_as_float(b0);
-                    x1 -= __uint_as_float(b1);
-                }
-            }
-            continue;
-        }
         const bool ci_fast = mode == 0 || mode == 1 || mode == 5 || mode == 8 || mode == 14;
         const bool bf = mode == 8 || mode == 9 || mode == 14 || mode == 15;
         const bool rne1 = mode == 14 || mode == 15;               // ONE plane, round-to-nearest-even (plain bf16 mode), layout of mode 8 / 9
@@ -297,7 +259,7 @@ extern "C" int mrfa_pack_conv_weights_multi(void* stream, const mrfa_pack_desc* 
                        descs[i].ndst);
         for (int k = 0; k < descs[i].ndst; ++k) {
             const int m = descs[i].mode[k];
-            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9 || m == 14 || m == 15 || ((m == 12 || m == 13 || m == 16 || m == 17) && descs[i].R == 3 && descs[i].S == 3)),
+            MRFA_CHECK_ARG(descs[i].dst[k] && (m == 0 || m == 1 || m == 2 || m == 3 || m == 5 || m == 7 || m == 8 || m == 9 || m == 14 || m == 15 || ((m == 12 || m == 13) && descs[i].R == 3 && descs[i].S == 3)),
                            "pack_conv_weights_multi: desc %d: null dst or mode %d", i, m);
         }
     }

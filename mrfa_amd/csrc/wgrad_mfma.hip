@@ -408,7 +408,7 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     int taps_arg = taps;
     // split-operand kernel, several taps, Cin not a multiple of the tile width (64, 96, 160, 192 ...): tile the flattened [taps][Cin]
     // axis with 128-wide tiles (wgrad_split.hip "chunk-flat") when that removes >= 15 % of the padded tile work
-    static const bool cflat_on = [] { const char* e = getenv("MRFA_WGRAD_CFLAT"); return !(e && e[0] == '0'); }();
+    constexpr bool cflat_on = true;
     if (cflat_on && split_mode && taps > 1 && (p.Cin % 4) == 0) {
         // (a 64-wide tile does ~1.4x the work per column of a 128-wide one: measured 110 vs 190 TF/s)
         const double per_tap = (double)taps * tiles_n * BN * (BN == 64 ? 1.4 : 1.0), flat_w = (double)cdiv(taps * p.Cin, 128) * 128;

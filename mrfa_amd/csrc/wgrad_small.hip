@@ -261,8 +261,7 @@ __global__ __launch_bounds__(256) void wgrad_small_multi_kernel(const SmallMulti
 constexpr int SMALL_VARIANTS = 7;
 int small_problem(const mrfa_wgrad_params& p, long long M, SmallProblem* o) {
     const int T = p.R * p.S;
-    static const bool rows_on = [] { const char* e = getenv("MRFA_WGRAD_SMALL_ROWS"); return !(e && e[0] == '0'); }();
-    static const bool b64_on = [] { const char* e = getenv("MRFA_WGRAD_SMALL_B64"); return !(e && e[0] == '0'); }();
+    constexpr bool rows_on = true, b64_on = true;     // (round 4's row-walking loads and 64 x 64 weight blocks: measured faster, no switch)
     const bool spatial0 = T > 1 || p.Hin != p.Hout || p.Win != p.Wout;
     auto lg2_ = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
     const bool rows0 = rows_on && (M % 16) == 0 && (!spatial0 || (lg2_(p.Wout) >= 0 && lg2_(p.Hout) >= 0 && (p.Wout % 16) == 0));
@@ -303,7 +302,9 @@ bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M) {
     if (M > 65536 || p.Cout > 640 || p.Cin > 640) return false;
     // what the 128-wide tiles do well stays there: >= 128 x 128 weights per tap over many pixels
     if (p.stride == 2) return true;                  // (the only weight-gradient kernel with a strided gather)
-    if (p.Cout >= 128 && p.Cin >= 128 && M > 4096) return false;                  // (the only weight-gradient kernel with a strided gather)
+    // (6 144 rows: the token transformer's 192 <-> 576 linears over the 16 x 276 rows of a batched source + driving encoder pass stay here -- the 128-row
+    // tiles took 85 / 76 us for what this kernel does in ~15; round 4's limit was 4 096, one pass of 8 x 276 rows)
+    if (p.Cout >= 128 && p.Cin >= 128 && M > 6144) return false;
     if (2.0 * (double)M * p.Cout * (double)p.Cin * p.R * p.S > 1.3e9) return false;
     return true;
 }

@@ -94,7 +94,6 @@ class DeferredWgrads:
         self._rr = 0
         self._used: List["torch.cuda.Stream"] = []           # side streams that received launches since the last join
         self._srcs: List["torch.cuda.Stream"] = []           # streams on which the pending launches were collected
-
     def add(self, fn: Callable[[], None], final: bool = False):
         (self.finals if final else self.thunks).append(fn)
         if torch.cuda.is_available():
@@ -242,16 +241,10 @@ class defer_wgrads:
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 SYNCBN_DIRECT_BYTES = int(os.environ.get("MRFA_SYNCBN_DIRECT_KIB", "128")) << 10      # statistics blocks up to this size are all-reduced whole (all slots)
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
-NATIVE_STRIDE = os.environ.get("MRFA_NATIVE_STRIDE", "1") != "0"      # stride-2 layers as one strided launch (conv_small / wgrad_small) instead of stride 1 + sub-sampling
 # BatchNorm finalize of the conv -> BatchNorm pairs of the keypoint encoder inside the convolution's launch (last workgroup; mrfa_conv_params.fin_*)
 BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
 # first phase of the BatchNorm backward of single-consumer BatchNorm outputs inside the consumer's data-gradient launch (mrfa_conv_params.bst_*)
 BN_BWD_IN_DGRAD = os.environ.get("MRFA_BN_BWD_IN_DGRAD", "1") != "0"
-# Winograd F(2, 3)-along-x form of the plain 3x3 layers on the patch-tiled kernel (conv_halo MODE 3, pack modes 16 / 17).  OFF by default
-# (MRFA_WINO=1): 1.10-1.16x per launch in the launch loop but nothing measurable in the training step (LDS-read bound), and its
-# fp32 rounding (within 4x of the direct kernel's against fp64) is visible in ill-conditioned downstream quantities (the keypoint encoder's
-# gradient of the config-4 parity test moved from norm ratio 1.075 to 1.26)
-WINO = os.environ.get("MRFA_WINO", "0") == "1"
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -262,20 +255,11 @@ FRESH_MIN_ELEMS = (int(os.environ.get("MRFA_FRESH_MIN_MIB", "9")) << 20) // 4
 # as NaN instead of whatever the allocator hands out, so a kernel that READS a buffer no writer has covered -- or a first writer that
 # does not cover all of it -- shows up as a non-finite gradient instead of passing by luck
 FRESH_NAN = os.environ.get("MRFA_FRESH_NAN", "0") == "1"
-# OFF by default (MRFA_BRANCH_STREAMS=1 to try): measured on the training step, HRNet's three resolution branches side by side
-# gain 2.6 % without the pass-level concurrency (141.9 -> 138.2 ms) and nothing on top of it; RaftFlow's two structure
-# hourglasses beside the generator encoder gain nothing (122.9 vs 126.2 ms).  NESTED forks (branch streams forked from the side
-# stream of HotPath.encode_pair) crash hipStreamEndCapture on ROCm 7.2, so a side pass (Ctx.deferred) never forks.
-BRANCH_STREAMS = os.environ.get("MRFA_BRANCH_STREAMS", "0") == "1"        # Ctx.lanes(): independent branches of a program as parallel branches of the captured hipGraph
-
-
-# ---- concurrent keypoint-encoder passes (mrfa_amd.train.HotPath.encode_pair): the pass issued on the side stream
-#  * must not touch what the main-stream pass updates with plain read-modify-writes: the BatchNorm running statistics and
-#    batch counters (collected in SIDE_PASS and applied after the join, in the reference's source-then-driving order) and the
-#    gradients of the parameters used by torch glue islands (returned to autograd instead of being added in place);
-#  * everything else it accumulates into shared parameter gradients is atomic (weight un-packing, bias / BatchNorm /
-#    LayerNorm parameter gradients).
-SIDE_PASS: Optional[list] = None
+# HRNet's resolution branches (three independent chains of BasicBlocks per stage-3 module) as parallel branches of the captured hipGraph (Ctx.lanes()).
+# On since round 5: with ONE batched encoder pass (statistic groups below) the forward chain takes 8.2 instead of 10.3 ms with them (round 4, beside a
+# second encoder pass on its own stream, they lost: more than four live branches are folded together by the graph executor).  Never with
+# SyncBatchNorm collectives (every rank must enqueue them on ONE stream in ONE order): mrfa_amd.graph.GraphedTrainStep switches them off then.
+BRANCH_STREAMS = os.environ.get("MRFA_BRANCH_STREAMS", "1") != "0"        # (kept as a switch for same-box A/B runs)
 
 
 # ---- statistic groups (include/mrfa_hip.h v7): the reference's separate encoder calls -- encoder(source), encoder(driving), encoder(transformed driving),
@@ -299,42 +283,6 @@ class stat_groups:
         global STAT_GROUPS
         STAT_GROUPS = self.prev
         return False
-
-
-class side_pass:
-    """with side_pass() as deferred: ... -> list of (bn, mean, invstd, count) / (bn, None, None, passes) records"""
-
-    def __enter__(self):
-        global SIDE_PASS
-        self.prev, SIDE_PASS = SIDE_PASS, []
-        return SIDE_PASS
-
-    def __exit__(self, *exc):
-        global SIDE_PASS
-        SIDE_PASS = self.prev
-        return False
-
-
-def apply_deferred_bn(deferred: list):
-    """running_mean / running_var / num_batches_tracked updates of a side pass, on the current stream (multi-tensor launches):
-    r <- (1 - m) r + m * batch statistic, the unbiased variance recovered from the saved 1/sqrt(var + eps)"""
-    stats = [d for d in deferred if d[1] is not None]
-    if stats:
-        rms, rvs = [d[0].running_mean for d in stats], [d[0].running_var for d in stats]
-        torch._foreach_mul_(rms, 1.0 - BN_MOMENTUM)
-        torch._foreach_add_(rms, [d[1] for d in stats], alpha=BN_MOMENTUM)
-        v = torch._foreach_mul([d[2] for d in stats], [d[2] for d in stats])
-        torch._foreach_reciprocal_(v)
-        torch._foreach_add_(v, -BN_EPS)
-        torch._foreach_mul_(v, [BN_MOMENTUM * (d[3] / (d[3] - 1.0) if d[3] > 1 else 1.0) for d in stats])
-        torch._foreach_mul_(rvs, 1.0 - BN_MOMENTUM)
-        torch._foreach_add_(rvs, v)
-    counts = {}
-    for d in deferred:
-        if d[1] is None:
-            counts.setdefault(d[3], []).append(d[0].num_batches_tracked)
-    for k, ts in counts.items():
-        torch._foreach_add_(ts, k)
 
 
 def prepare_packs(module: torch.nn.Module) -> bool:
@@ -361,10 +309,6 @@ def prepare_packs(module: torch.nn.Module) -> bool:
             cw.phase_pack()
         if getattr(cw, "_dg_ph", None) is not None:
             cw.phase_pack(dgrad=True)
-        if getattr(cw, "_fwd_wx", None) is not None:
-            cw.wino_pack()
-        if getattr(cw, "_dg_wx", None) is not None:
-            cw.wino_pack(dgrad=True)
         if cw._fo is not None:
             cw.fewout_pack()
         if cw._fi is not None:
@@ -641,31 +585,6 @@ class ConvW:
             setattr(self, ver, self._key())
         return buf, piece
 
-    def wino_pack(self, dgrad: bool = False) -> tuple:
-        """(buffer, elements per piece) of the Winograd F(2, 3)-along-x weights U = G w of this 3x3 conv (pack mode 16; dgrad: mode 17, the flipped /
-        transposed kernel of the data gradient), three bf16 pieces: the patch-tiled kernel's MODE 3 (csrc/conv_halo.hip)"""
-        assert self.R == 3 and self.S == 3
-        attr, ver, mode = ("_dg_wx", "_ver_dwx", 17) if dgrad else ("_fwd_wx", "_ver_wx", 16)
-        if dgrad:
-            assert not self.dgrad_flat
-            piece = 12 * ((self.Cin + 127) // 128 * 128) * self.Cout
-        else:
-            assert not self.fwd_flat
-            piece = 12 * ((self.Cout + 127) // 128 * 128) * self.Cin
-        buf = getattr(self, attr, None)
-        w = self.conv.weight.detach()
-        if buf is None or buf.numel() != 3 * piece or buf.device != w.device:
-            buf = torch.zeros(3 * piece, dtype=torch.int16, device=w.device)
-            setattr(self, attr, buf)
-            setattr(self, ver, None)
-        if getattr(self, ver, None) != self._key():
-            d = hip.PackDesc()
-            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.contiguous().data_ptr(), self.Cout, self.Cin, self.R, self.S, 1
-            d.dst[0], d.mode[0] = buf.data_ptr(), mode
-            hip.check(hip.lib().mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack(winograd)")
-            setattr(self, ver, self._key())
-        return buf, piece
-
     def _simple_pack(self, attr, ver_attr, mode):
         if getattr(self, attr) is None or getattr(self, ver_attr) != self._key():
             w = self.conv.weight.detach()
@@ -749,10 +668,6 @@ class PackPlan:
                 dsts.append((cw._fwd_ph, 12))
             if getattr(cw, "_dg_ph", None) is not None:
                 dsts.append((cw._dg_ph, 13))
-            if getattr(cw, "_fwd_wx", None) is not None:
-                dsts.append((cw._fwd_wx, 16))
-            if getattr(cw, "_dg_wx", None) is not None:
-                dsts.append((cw._dg_wx, 17))
             if cw._fo is not None:
                 dsts.append((cw._fo, 5))
             if cw._fi is not None:
@@ -770,7 +685,7 @@ class PackPlan:
         self.table = (hip.PackDesc * max(self.n, 1))(*descs)
         self.ptrs = [(cw, cw.conv.weight.data_ptr()) + self._buffer_ids(cw) for cw in self.cws]
 
-    _PLANES = ("_fwd", "_dg", "_fwd_s", "_dg_s", "_fwd_r", "_dg_r", "_fwd_ph", "_dg_ph", "_fwd_wx", "_dg_wx", "_fo", "_fi")
+    _PLANES = ("_fwd", "_dg", "_fwd_s", "_dg_s", "_fwd_r", "_dg_r", "_fwd_ph", "_dg_ph", "_fo", "_fi")
 
     @classmethod
     def _buffer_ids(cls, cw) -> tuple:
@@ -786,7 +701,6 @@ class PackPlan:
             assert cw.conv.weight.data_ptr() == wptr and self._buffer_ids(cw) == ids, "PackPlan is stale: rebuild it"
             k = cw._key()
             cw._ver_f = cw._ver_d = cw._ver_fo = cw._ver_fi = cw._ver_fs = cw._ver_ds = cw._ver_ph = cw._ver_dph = cw._ver_fr = cw._ver_dr = k
-            cw._ver_wx = cw._ver_dwx = k
 
 
 def unpack_direct(cws: List["ConvW"], accs: Optional[List[torch.Tensor]] = None):
@@ -896,9 +810,7 @@ class Ctx:
         self.split = self.L.mrfa_get_mfma_mode() in (1, 2)   # bf16x6 / bf16x3 kernels: also hand over pre-split weights
         self.bf16 = self.L.mrfa_get_mfma_mode() == 3         # plain bf16 products: the patch-tiled kernels take ONE rounded weight plane
         self.in_backward = False
-        self.deferred = SIDE_PASS            # not None: this program runs on the side stream next to another pass of its module
         self.groups = STAT_GROUPS if train else 1       # statistic groups of the batch (stat_groups); eval mode has no batch statistics
-        assert self.groups == 1 or self.deferred is None, "a side pass carries one statistic group"
         self.wdefer = WGRAD_DEFER            # not None: weight-gradient launches of this program are collected (DeferredWgrads)
         self.touched_convs: List[ConvW] = []
         self.touched_bns: List[BNGrad] = []
@@ -937,7 +849,7 @@ class Ctx:
     def lanes(self, n: int, enabled: Optional[bool] = None):
         """n side streams for branches of this program, or [] when branches must run in line (not capturing / CPU / switched off)"""
         on = BRANCH_STREAMS if enabled is None else enabled
-        if self.dev.type != "cuda" or not on or self.deferred is not None or not torch.cuda.is_current_stream_capturing():
+        if self.dev.type != "cuda" or not on or not torch.cuda.is_current_stream_capturing():
             return []
         key = (self.dev, self.s)
         have = Ctx._lanes.setdefault(key, [])
@@ -1158,7 +1070,6 @@ class Ctx:
                 p.stats, p.groups, late_stats = None, 0, True       # (a tile would straddle two groups: one statistics pass per group behind the launch)
             elif fin is not None:
                 self._fin_params(p, fin, stats, out.rows)
-        self._maybe_wino(p, cw, dgrad=False, padded=padded, ups=ups)
         self._launch_conv(p, "conv2d", cw.Cin)
         if late_stats:
             self._bn_stats_into(out, stats)
@@ -1180,18 +1091,6 @@ class Ctx:
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
         return out
-
-    def _maybe_wino(self, p, cw: ConvW, dgrad: bool, padded: bool, ups: bool):
-        """hand the launch the Winograd-along-x weights (ConvW.wino_pack) where the library would use them: plain 3x3 / pad 1 layers on the
-        patch-tiled kernel with 8-row patches in a split-operand mode (mrfa_conv2d_wino_supported); the pack is only ever built for such layers"""
-        if not (WINO and self.split and cw.R == 3 and cw.S == 3 and cw.pad == 1 and not ups and not padded and p.kflat == 0 and p.w_split):
-            return
-        if dgrad and cw.dgrad_flat or (not dgrad and cw.fwd_flat):
-            return
-        if not self.L.mrfa_conv2d_wino_supported(C.byref(p)):
-            return
-        wx, p.w_wino_piece = cw.wino_pack(dgrad)
-        p.w_wino = wx.data_ptr()
 
     def _defer_ok(self, cw: ConvW) -> bool:
         """this weight gradient may go to the deferred side chain: a collection is active and the gradient is accumulated straight
@@ -1332,7 +1231,6 @@ class Ctx:
             fused = bool(self.L.mrfa_conv2d_mask_supported(C.byref(p)))
             if not fused:
                 p.mask, p.ldm = None, 0
-        self._maybe_wino(p, cw, dgrad=True, padded=padded, ups=False)
         hint = getattr(x.st, "bn_hint", None) if (direct and BN_BWD_IN_DGRAD) else None
         if hint is not None and hint["red"] is None and not relu_in and x.coff == 0 and x.C == x.st.ld and not padded and not cw.dgrad_flat:
             # x is the output of a BatchNorm + activation whose ONLY consumer is this convolution (bn_act(out_sole=True)): this launch is the only writer
@@ -1384,8 +1282,6 @@ class Ctx:
         if done is not None:                              # finished inside the producing convolution's call (_fin_params)
             assert done[0] is bn and done[1] == count, "fused BatchNorm finalize: another layer / row count than the convolution was told"
             scale, shift, mean, invstd = done[2:]
-            if self.deferred is not None:
-                self.deferred.append((bn, mean, invstd, float(count)))
             self.nbt[bn] = self.nbt.get(bn, 0) + self.groups
             return scale, shift, mean, invstd
         train = self.train
@@ -1404,19 +1300,15 @@ class Ctx:
                 else:
                     stats = self._allreduce_slot_sums(stats, G, Cn)
                 count = count * world
-        defer = train and self.deferred is not None            # side pass: the running statistics are updated after the join
         if G > 1:
             self._chk(self.L.mrfa_bn_finalize_groups(self.s, stats.data_ptr(), count // G, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), BN_MOMENTUM, BN_EPS, Cn, G,
                                                      scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()), "bn_finalize_groups")
         else:
             self._chk(self.L.mrfa_bn_finalize(self.s, stats.data_ptr() if stats is not None else None, count, bn.weight.data_ptr(),
-                                              bn.bias.data_ptr(), None if defer else bn.running_mean.data_ptr(),
-                                              None if defer else bn.running_var.data_ptr(),
+                                              bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                               BN_MOMENTUM, BN_EPS, Cn, int(train), scale.data_ptr(), shift.data_ptr(),
                                               mean.data_ptr(), invstd.data_ptr()), "bn_finalize")
-        if defer:
-            self.deferred.append((bn, mean, invstd, float(count)))
         if train:
             self.nbt[bn] = self.nbt.get(bn, 0) + G     # num_batches_tracked += 1 per statistic group, batched in flush_forward()
         return scale, shift, mean, invstd
@@ -1433,10 +1325,6 @@ class Ctx:
 
     def flush_forward(self):
         """end of a program's forward: one multi-tensor launch for all BatchNorm batch counters instead of one each"""
-        if self.deferred is not None:
-            self.deferred.extend((bn, None, None, k) for bn, k in self.nbt.items())
-            self.nbt = {}
-            return
         by_count = {}
         for bn, k in self.nbt.items():
             by_count.setdefault(k, []).append(bn.num_batches_tracked)
@@ -1466,10 +1354,8 @@ class Ctx:
             return                                        # the statistics are exchanged between the convolution and the finalize
         Cn, G = bn.num_features, self.groups
         scale, shift, mean, invstd = self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn)
-        defer = self.deferred is not None                 # side pass: the running statistics are updated after the join
         p.fin_gamma, p.fin_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
-        if not defer:
-            p.fin_rmean, p.fin_rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        p.fin_rmean, p.fin_rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
         p.fin_momentum, p.fin_eps, p.fin_count = BN_MOMENTUM, BN_EPS, count // G
         p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
         p.fin_counter = stats.data_ptr() + 8 * G * hip.STATS_SLOTS * 2 * Cn
@@ -1864,7 +1750,7 @@ class Ctx:
         if cw.stride == 1:
             st = self.bn_stats_buf(bn)
             return self.conv(x, conv, stats=st, need_dx=need_dx, fin=fin), st
-        if cw.stride == 2 and NATIVE_STRIDE and not cw.fwd_flat and conv.bias is None:
+        if cw.stride == 2 and not cw.fwd_flat and conv.bias is None:
             got = self._conv_strided(x, conv, cw, self.bn_stats_buf(bn), need_dx, fin=fin)
             if got is not None:
                 return got
@@ -2172,13 +2058,6 @@ class _ProgramFn(torch.autograd.Function):
     @staticmethod
     def backward(actx, *gouts):
         ectx = actx.ectx
-        if ectx.deferred is not None and ectx.dev.type == "cuda":
-            # side pass: the incoming gradients were allocated on the main stream; tell the caching allocator that this stream reads
-            # them (eager launches only matter: a captured graph owns static memory)
-            cur = torch.cuda.current_stream(ectx.dev)
-            for g in gouts:
-                if g is not None and g.is_cuda:
-                    g.record_stream(cur)
         if _PENDING_DEFERRED and any(d is not ectx.wdefer for d in _PENDING_DEFERRED):
             # the backward pass has left the programs deferring into another collection: their weight gradients start now, beside this
             # program's backward (this program's own collection, if it has one, waits for HotPath.join())
@@ -2223,9 +2102,9 @@ class _ProgramFn(torch.autograd.Function):
         for p in actx.params:                      # parameters touched by torch glue islands
             g = ectx.ext_grads.get(id(p))
             if g is not None:
-                if _direct_ok(p) and ectx.deferred is None:
+                if _direct_ok(p):
                     p.grad.add_(g)
-                else:                              # side pass: autograd's AccumulateGrad orders the add after both streams
+                else:
                     pgrads[id(p)] = g
         in_grads = [fn() if (fn is not None and need) else None
                     for fn, need in zip(actx.in_grad_fns, actx.needs_input_grad[4:4 + actx.n_in])]

@@ -178,7 +178,7 @@ class GraphedTrainStep:
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, source: torch.Tensor, driving: torch.Tensor,
                  clip: float = 10.0, world: int = 1, exchange: Optional[bool] = None, overlap_wgrad: bool = False,
-                 concurrent_encoder: Optional[bool] = None, loss_fn=None, overlap_exchange: Optional[bool] = None,
+                 loss_fn=None, overlap_exchange: Optional[bool] = None,
                  defer_wgrads: Optional[bool] = None):
         """loss_fn(model, source, driving) -> scalar loss; None = the surrogate mean|model(source, driving) - driving|.
         overlap_exchange: cut graph A at the encoder boundary and overlap the all-reduce with the encoder's backward (surrogate-loss step
@@ -191,21 +191,12 @@ class GraphedTrainStep:
         self.model, self.opt, self.clip, self.world = model, optimizer, clip, world
         self.loss_fn = loss_fn
         syncbn_collectives = any(isinstance(m, nn.SyncBatchNorm) for m in model.modules()) and (world > 1 or engine.SYNCBN_FORCE)
-        if concurrent_encoder and syncbn_collectives:
-            raise ValueError("GraphedTrainStep(concurrent_encoder=True) with SyncBatchNorm: the side-stream encoder pass would interleave its "
-                             "statistics collectives with the main stream's in a hardware-decided order, different on every rank "
-                             "(communicator deadlock); leave concurrent_encoder=None / False")
-        if concurrent_encoder is None:               # pays for TokenPose_B (2 x ~2 000 small launches); KPDetector is 2 x ~150
-            concurrent_encoder = getattr(model, "prior", "") == "mtia" and os.environ.get("MRFA_CONCURRENT_ENCODER", "1") == "1"
-            if syncbn_collectives:
-                # SyncBatchNorm's statistics collectives are captured into the graph (RCCL ops are capturable): every rank must enqueue them in
-                # ONE order on the communicator, so the two encoder passes stay on one stream (the side-stream pass would interleave its
-                # collectives with the main stream's in an order the hardware, not the program, decides)
-                concurrent_encoder = False
-                if hasattr(model, "defer_encoder_wgrads"):
-                    model.defer_encoder_wgrads = False     # (measured on one rank with the forced collective: 113 -> 123 ms with the fan-out)
-        if hasattr(model, "concurrent_encoder"):
-            model.concurrent_encoder = bool(concurrent_encoder)
+        # SyncBatchNorm's statistics collectives are captured into the graph (RCCL ops are capturable): every rank must enqueue them in ONE order on
+        # the communicator, i.e. on one stream: no branch lanes inside the encoder program (engine.Ctx.lanes), and the encoder's weight gradients stay in
+        # line (measured on one rank with the forced collective: 113 -> 123 ms with the fan-out)
+        self.no_lanes = syncbn_collectives
+        if syncbn_collectives and hasattr(model, "defer_encoder_wgrads"):
+            model.defer_encoder_wgrads = False
         self.exchange = (world > 1) if exchange is None else exchange      # all-reduce between the graphs
         if overlap_exchange is None:
             env = os.environ.get("MRFA_OVERLAP_EXCHANGE", "0")     # "force": cut the graph even without an exchange (timing the cut alone)
@@ -321,11 +312,15 @@ class GraphedTrainStep:
 
     def _head(self):
         """forward + loss + backward: all of it, or (overlapped exchange) down to the keypoint encoder's outputs"""
-        if self.split is not None:
-            return self.split.head(self.src, self.drv)
-        loss, gen = self._loss()
-        loss.backward()
-        return loss, gen
+        lanes, engine.BRANCH_STREAMS = engine.BRANCH_STREAMS, engine.BRANCH_STREAMS and not self.no_lanes
+        try:
+            if self.split is not None:
+                return self.split.head(self.src, self.drv)
+            loss, gen = self._loss()
+            loss.backward()
+            return loss, gen
+        finally:
+            engine.BRANCH_STREAMS = lanes
 
     def _tail(self):
         if self.split is not None:

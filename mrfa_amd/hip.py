@@ -122,7 +122,6 @@ _SIGNATURES = {
     "mrfa_last_error": ([], C.c_char_p),
     "mrfa_conv2d_nhwc": ([_V, C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_phase_dgrad_supported": ([C.POINTER(ConvParams)], C.c_int),
-    "mrfa_conv2d_wino_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_last_config": ([], C.c_int),
     "mrfa_set_mfma_mode": ([_I], C.c_int),
     "mrfa_get_mfma_mode": ([], C.c_int),

@@ -3,7 +3,6 @@ reference: modules/raft.py:12-311 (CorrBlock, BasicMotionEncoder, RefineFlow, Ra
 from __future__ import annotations
 
 import functools
-import os
 import math
 from typing import List
 
@@ -169,11 +168,6 @@ class _CorrVolume:
         self.dvol0 = self.dvol1 = None
 
 
-# OFF by default (MRFA_HG_LANES=1): measured 83.9 / 83.0 ms with, 84.5 / 83.7 ms without (alternating runs, one box) -- but the ninth capture of one process
-# (tests/test_graph_gpu.py run as a file) died with a segmentation fault inside the HIP runtime with this branch in the graph, and not without it
-HG_LANES = os.environ.get("MRFA_HG_LANES", "0") == "1"
-
-
 class RaftFlow(nn.Module):
     """Same kwargs / state_dict / forward signature as the reference (raft.py:92-141):
     forward(kp_s, kp_d, dense_motion, img, img_full) -> (out, warp_img, occlusion_strip)."""
@@ -280,19 +274,12 @@ class RaftFlow(nn.Module):
             q_d = e.conv(fe_d, self.kp_head)
         else:
             in_s = self._source_input(e, kp_s, img, h, w)
-            # the two structure hourglasses (source keys, driving queries: raft.py:179-183) are independent chains of under-filled launches (8^2 ... 64^2
-            # grids): MRFA_HG_LANES=1 runs the source one as a parallel branch of the captured graph, forward and backward
-            # (not with SyncBatchNorm: its collectives must be enqueued on ONE stream in ONE order on every rank)
-            lanes = e.lanes(1, HG_LANES and not any(isinstance(m_, nn.SyncBatchNorm) for m_ in self.kp_img.modules()))
-            e.fork(lanes)
-
-            def source_keys():
-                ks = e.conv(self.kp_img.run(e, in_s), self.kp_img_head)         # (B,h,w,dim)
-                return ks, e.avgpool2(ks)
-            k_s, k_pool = e.branch(lanes[0] if lanes else None, source_keys)
+            # (round 4 ran the source hourglass as a parallel branch of the captured graph: 0.6 ms, and the ninth capture of one process died inside
+            # the HIP runtime with that branch in the graph -- removed in round 5)
+            k_s = e.conv(self.kp_img.run(e, in_s), self.kp_img_head)            # (B,h,w,dim)
+            k_pool = e.avgpool2(k_s)
             fe_d = self.kp.run(e, in_d)
             q_d = e.conv(fe_d, self.kp_head)
-            e.join(lanes)
         in_grads = ((lambda: e.ext_grads.get(id(kp_s))), (lambda: e.ext_grads.get(id(kp_d)))) + in_grads[2:]
         base = self.basic_res_index
         q_levels = {base: q_d}

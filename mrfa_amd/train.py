@@ -68,18 +68,14 @@ class HotPath(nn.Module):
         self.dense_motion = DenseMotionNetwork(**cfg["dense_motion"])
         self.decoder = RaftFlow(**cfg["raft_flow"])
         self.down = AntiAliasInterpolation2d(3, 0.25)
-        # training on a GPU: issue the driving-frame encoder pass on a second HIP stream next to the source-frame pass.  The
-        # two passes are independent chains of small, latency-bound kernels (TokenPose_B: ~2 000 launches each, 12 us
-        # average); side by side they take 39 ms instead of 58 ms (tools/graph_two_encoders.py).  Same results as the
-        # sequential order: see engine.SIDE_PASS.  mrfa_amd.graph.GraphedTrainStep switches it on for the MTIA prior.
-        self.concurrent_encoder = False
-        object.__setattr__(self, "_sides", [])
         # training: the encoder calls of a step -- encoder(source), encoder(driving) (and encoder(transformed driving) under the reference objective;
         # model.py:185-186,234) -- as ONE program over a batch of len(frames) x B samples whose BatchNorm layers keep their batch statistics per call
-        # ("statistic groups", include/mrfa_hip.h v7 / engine.stat_groups): same results as the separate calls -- per-call statistics, running buffers
-        # updated once per call in call order, num_batches_tracked += number of calls --, half / a third of the launches of the step's longest
-        # latency-bound chain, and one stream instead of two.  MRFA_BATCHED_ENCODER=0: the separate calls (concurrent_encoder then applies).
-        self.batched_encoder = os.environ.get("MRFA_BATCHED_ENCODER", "1") != "0"
+        # ("statistic groups", include/mrfa_hip.h v7 / engine.stat_groups): the results of the separate calls -- per-call statistics, running buffers
+        # updated once per call in call order, num_batches_tracked += number of calls -- from half / a third of the launches (2 483 instead of 3 573 per
+        # step), on one stream.  Rounds 1-4 ran the calls as separate programs on concurrent streams; measured against that on one box (round 5, B = 8):
+        # surrogate step 84.7-85.6 vs 83.8-84.2 ms, reference objective (three calls) 120.6 vs 124.8 ms, SyncBatchNorm (one stream by necessity) 95.1 vs
+        # 104.0 ms.  Default for the MTIA prior (TokenPose_B: ~1 000 launches per call and direction); KPDetector's ~150-launch calls stay separate.
+        self.batched_encoder = prior == "mtia"
         # training with direct parameter gradients: the weight-gradient kernels of dense motion + decoder (~100 launches, 22 ms, each
         # filling the chip) are collected during their backward and issued on a side stream when the backward reaches the keypoint
         # encoder, whose small kernels leave most of the GPU idle (engine.DeferredWgrads).  join() orders them before the optimizer.
@@ -88,13 +84,13 @@ class HotPath(nn.Module):
         from .engine import DeferredWgrads
         object.__setattr__(self, "_wdefer", DeferredWgrads())
         object.__setattr__(self, "_wdefer_dev", None)
-        # the keypoint encoder's own weight gradients (2 x ~200 small launches inside its backward chain): collected and dealt onto
-        # MRFA_ENC_WGRAD_FANOUT (default 4; 0 / 1 = in line) side streams after the chain: the two concurrent backward chains lose a fifth of
-        # their launches, the ~400 independent launches then run four abreast (measured, 5 alternating runs of 20 steps on one box:
+        # the keypoint encoder's own weight gradients (~200 small launches inside its backward chain): collected and dealt onto
+        # MRFA_ENC_WGRAD_FANOUT (default 4; 0 / 1 = in line) side streams after the chain: the backward chain loses a fifth of
+        # its launches, the independent launches then run four abreast as multi-problem launches (round 3, 5 alternating runs of 20 steps on one box:
         # 85.9 -> 84.2 ms).  Same conditions as defer_decoder_wgrads.
         self.defer_encoder_wgrads = True       # (GraphedTrainStep switches it off with SyncBatchNorm: one stream, one enqueue order per rank)
         object.__setattr__(self, "_wdefer_enc", DeferredWgrads(fanout=int(os.environ.get("MRFA_ENC_WGRAD_FANOUT", "4") or 0), manual=True,
-                                                                   batch=os.environ.get("MRFA_ENC_WGRAD_MULTI", "1") != "0"))
+                                                                   batch=True))
         # test / diagnostics hook: a dict here makes forward() keep the keypoint tensors (`kp_s`, `jac_s`, `kp_d`, `jac_d`) and copy the
         # gradients that arrive at them into static buffers (`dkp_s`, ...) with a kernel (no memcpy node), so that d loss / d keypoints of
         # a hipGraph-REPLAYED step can be read (tests/test_headline_gpu.py).  None (default): nothing is recorded
@@ -103,52 +99,23 @@ class HotPath(nn.Module):
         object.__setattr__(self, "_pack_stream", None)
 
     def encode_many(self, frames):
-        """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234), in the reference's order as far as
-        the BatchNorm running statistics are concerned; on a GPU in training mode with `concurrent_encoder`, frame 0 runs on the
-        current stream and every further frame on its own side stream"""
+        """[encoder(f) for f in frames] (reference model.py:185-186 and the third pass of :234): in training with `batched_encoder`, one program over
+        the concatenated batch with one BatchNorm statistic group per frame (engine.stat_groups)"""
         from . import engine
         first = frames[0]
         enc_defer = None
-        # (every deferring pass owns its accumulators: engine._ProgramFn.backward detaches them from the ConvW objects when the pass's backward ends.
-        # With accumulators shared between the passes the three-pass schedule of the reference objective failed GraphedTrainStep.verify().)
         if (self.defer_decoder_wgrads and self.defer_encoder_wgrads and self._wdefer_enc.fanout > 1 and self.training and torch.is_grad_enabled()
                 and first.is_cuda and len(frames) >= 2):
             enc_defer = self._wdefer_enc
             enc_defer.reset()
         with engine.defer_wgrads(enc_defer):
-            return self._encode_many(frames)
-
-    def _encode_many(self, frames):
-        from . import engine
-        first = frames[0]
-        if (self.batched_encoder and self.training and len(frames) > 1 and all(f.shape == first.shape for f in frames)):
+            if not (self.batched_encoder and self.training and len(frames) > 1 and all(f.shape == first.shape for f in frames)):
+                return [self.encoder(f) for f in frames]
             with engine.stat_groups(len(frames)):
                 kp = self.encoder(torch.cat(list(frames), dim=0))
             b = first.shape[0]
             parts = {k: v.view(len(frames), b, *v.shape[1:]).unbind(0) for k, v in kp.items()}
             return [{k: parts[k][i] for k in kp} for i in range(len(frames))]
-        if not (self.training and self.concurrent_encoder and first.is_cuda and torch.is_grad_enabled() and len(frames) > 1
-                and engine.prepare_packs(self.encoder)):
-            return [self.encoder(f) for f in frames]
-        main = torch.cuda.current_stream(first.device)
-        sides = self._sides
-        while len(sides) < len(frames) - 1:
-            sides.append(torch.cuda.Stream(device=first.device))
-        outs, deferred = [None] * len(frames), []
-        for i, f in enumerate(frames[1:], start=1):
-            side = sides[i - 1]
-            side.wait_stream(main)
-            with torch.cuda.stream(side), engine.side_pass() as d:
-                f.record_stream(side)
-                outs[i] = self.encoder(f)
-            deferred.append(d)
-        outs[0] = self.encoder(first)
-        for i in range(1, len(frames)):
-            main.wait_stream(sides[i - 1])
-            for t in outs[i].values():
-                t.record_stream(main)
-            engine.apply_deferred_bn(deferred[i - 1])   # running-statistics updates in frame order, after frame 0's
-        return outs
 
     def encode_pair(self, source, driving):
         """(kp_source, kp_driving) = (encoder(source), encoder(driving)), reference model.py:185-186"""
@@ -166,14 +133,9 @@ class HotPath(nn.Module):
             object.__setattr__(self, "_pack_stream", None)
 
     def join(self):
-        """after backward(): the side streams' backward kernels (second encoder pass, deferred weight gradients) are ordered before
-        whatever the caller issues next"""
+        """after backward(): the side streams' kernels (the deferred weight gradients) are ordered before whatever the caller issues next"""
         from . import engine
         engine.mark("backward: main stream done")
-        for st in self._sides:
-            with torch.cuda.stream(st):
-                engine.mark("backward: side stream done")
-            torch.cuda.current_stream(st.device).wait_stream(st)
         if self._wdefer_dev is not None:
             self._wdefer.join(self._wdefer_dev)
             engine.mark("joined dec wgrads")

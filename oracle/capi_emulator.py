@@ -586,12 +586,6 @@ class Emulator:
         p = _obj(pref)
         return 1 if (p.stats and not p.fin_scale and p.stride >= 0 and p.kflat == 0) else 0
 
-    def mrfa_conv2d_wino_supported(self, pref):
-        """shape rule of the Winograd-along-x form (the emulated convolution computes the same result with or without w_wino)"""
-        p = _obj(pref)
-        return int(p.kflat == 0 and p.ups == 0 and p.R == 3 and p.S == 3 and p.pad == 1 and p.Wout % 32 == 0 and p.Hout % 8 == 0
-                   and p.Cin % 32 == 0 and p.Cout >= 32 and bool(p.w_split) and not p.w_phase and p.Hout == p.Hin and p.Wout == p.Win)
-
     def mrfa_conv_fewout_dgrad_supported(self, Cin, Cout, R, pad, W, lddx):
         return int(R == 3 and pad == 1 and Cout in (1, 2) and Cin in (64, 128, 256) and lddx % 4 == 0 and W >= 4)
 
@@ -1025,30 +1019,6 @@ class Emulator:
                     nn_ = 16 * cop * cip
                     out = torch.frombuffer((C.c_short * (3 * nn_)).from_address(d.dst[k]), dtype=torch.int16).view(3, nn_)
                     r_ = self._chunk_major(full.reshape(-1), 16, cop, cip)
-                    for pc in range(3):
-                        bits = r_.view(torch.int32) & -65536
-                        out[pc] = (bits >> 16).to(torch.int16)
-                        r_ = r_ - bits.view(torch.float32)
-                    continue
-                if d.mode[k] in (16, 17):            # Winograd F(2, 3) along x: U[r][xi] = sum_s G[xi][s] w[r][s] (17: of the flipped / transposed kernel)
-                    assert d.R == 3 and d.S == 3
-                    tr = d.mode[k] == 17
-                    cop, cip = ((d.Cin + 127) // 128 * 128, (d.Cout + 31) // 32 * 32) if tr else ((d.Cout + 127) // 128 * 128, (d.Cin + 31) // 32 * 32)
-                    w = _flat(d.src, d.Cout * d.Cin * 9).view(d.Cout, d.Cin, 3, 3)
-                    if tr:
-                        w = w.flip(2, 3)
-                    full = torch.zeros(12, cop, cip, dtype=torch.float32)
-                    for r in range(3):
-                        g0, g1, g2 = w[:, :, r, 0], w[:, :, r, 1], w[:, :, r, 2]
-                        us = (g0, 0.5 * ((g0 + g1) + g2), 0.5 * ((g0 - g1) + g2), g2)             # the kernel's fp32 evaluation order
-                        for xi in range(4):
-                            if tr:
-                                full[r * 4 + xi, :d.Cin, :d.Cout] = us[xi].t()
-                            else:
-                                full[r * 4 + xi, :d.Cout, :d.Cin] = us[xi]
-                    nn_ = 12 * cop * cip
-                    out = torch.frombuffer((C.c_short * (3 * nn_)).from_address(d.dst[k]), dtype=torch.int16).view(3, nn_)
-                    r_ = self._chunk_major(full.reshape(-1), 12, cop, cip)
                     for pc in range(3):
                         bits = r_.view(torch.int32) & -65536
                         out[pc] = (bits >> 16).to(torch.int16)

@@ -166,56 +166,6 @@ def test_graphed_train_step_equals_eager(fused):
     assert losses[-1] < l0, (l0, losses)
 
 
-def test_concurrent_encoder_passes_equal_sequential():
-    """MTIA prior: the driving-frame TokenPose_B pass on a side stream (HotPath.encode_pair) gives the results of the
-    sequential order -- loss, parameter gradients (within the atomic-order noise band of two sequential runs) and the
-    BatchNorm running statistics / batch counters (source update first, driving update second)."""
-    import bench
-    from mrfa_amd import engine
-    from mrfa_amd.train import VOX1, HotPath, l1_loss
-    model = HotPath(VOX1, prior="mtia")
-    bench.init_weights(model)
-    model.to(DEV).train(True)
-    src, drv = _pairs(2, "g/conc")
-    saved = [b.clone() for b in model.buffers()]
-
-    def run(concurrent):
-        for b, sv in zip(model.buffers(), saved):
-            b.copy_(sv)
-        model.concurrent_encoder, model.batched_encoder = concurrent, False
-        for p in model.parameters():
-            p.grad = None
-        for p in model.parameters():                       # pre-bound gradients: the direct (atomic) accumulation path
-            if p.requires_grad:
-                p.grad = torch.zeros_like(p)
-        with engine.direct_param_grads():
-            loss = l1_loss(model(src, drv), drv)
-            loss.backward()
-        model.join()
-        torch.cuda.synchronize()
-        return float(loss), {n: p.grad.double().clone() for n, p in model.named_parameters() if p.grad is not None}, \
-            {n: b.clone() for n, b in model.named_buffers()}
-
-    run(False)                                             # builds packs / gather tables (a first pass never forks)
-    l0, g0, b0 = run(False)
-    l1, g1, b1 = run(False)
-    l2, g2, b2 = run(True)
-    assert len(model._sides) == 1, "the concurrent path did not run"
-    assert abs(l2 - l0) <= 1e-5 * max(1.0, abs(l0))
-    for grp in ("encoder.", "dense_motion.", "decoder."):
-        names = [n for n in g0 if n.startswith(grp)]
-
-        def dist(a, b):
-            return (sum(float((a[n] - b[n]).pow(2).sum()) for n in names) / sum(float(b[n].pow(2).sum()) for n in names)) ** 0.5
-        band = dist(g1, g0)
-        assert dist(g2, g0) <= 4 * band + 0.02, (grp, dist(g2, g0), band)
-    for n in b0:
-        if b0[n].dtype.is_floating_point:
-            assert (b2[n] - b0[n]).abs().max().item() <= 1e-5 + 1e-5 * b0[n].abs().max().item(), n
-        else:
-            assert torch.equal(b2[n], b0[n]), n
-
-
 @pytest.mark.parametrize("nframes", [2, 3])
 def test_batched_encoder_pass_equals_separate_calls(nframes):
     """MTIA prior, train mode: the encoder calls of a step (source, driving[, the equivariance pass]) as ONE TokenPose_B program over the concatenated
@@ -234,7 +184,7 @@ def test_batched_encoder_pass_equals_separate_calls(nframes):
     def run(batched):
         for b, sv in zip(model.buffers(), saved):
             b.copy_(sv)
-        model.concurrent_encoder, model.batched_encoder = False, batched
+        model.batched_encoder = batched
         outs = model.encode_many(frames)
         loss = sum((o["kp"] * w[0]).sum() + (o["jacobian"] * w[1]).sum() for o, w in zip(outs, ws))
         for p in model.encoder.parameters():
@@ -265,51 +215,10 @@ def test_batched_encoder_pass_equals_separate_calls(nframes):
     assert worst <= 0.05 + 8 * band, (worst, band)
 
 
-def test_encode_many_three_passes_keep_the_sequential_batchnorm_order():
-    """three TokenPose_B passes side by side (source, driving, the equivariance pass of the reference's objective): outputs and the
-    BatchNorm running statistics / batch counters equal those of three sequential passes (momentum updates applied in frame order)"""
-    import bench
-    from mrfa_amd.train import VOX1, HotPath
-    model = HotPath(VOX1, prior="mtia")
-    bench.init_weights(model)
-    model.to(DEV).train(True)
-    frames = [_pairs(2, f"g/em{k}")[0] for k in range(3)]
-    saved = [b.clone() for b in model.buffers()]
-
-    def run(concurrent):
-        for b, sv in zip(model.buffers(), saved):
-            b.copy_(sv)
-        model.concurrent_encoder, model.batched_encoder = concurrent, False
-        outs = model.encode_many(frames)
-        loss = sum(o["kp"].sum() + o["jacobian"].sum() for o in outs)
-        for p in model.encoder.parameters():
-            p.grad = None
-        loss.backward()
-        model.join()
-        torch.cuda.synchronize()
-        return [o["kp"].detach().clone() for o in outs], {n: b.clone() for n, b in model.encoder.named_buffers()}, \
-            {n: p.grad.double().clone() for n, p in model.encoder.named_parameters() if p.grad is not None}
-
-    run(False)                                              # builds the packs: a first pass never forks
-    k0, b0, g0 = run(False)
-    k1, b1, g1 = run(True)
-    assert len(model._sides) == 2
-    for a, b in zip(k0, k1):
-        assert (a - b).abs().max().item() <= 1e-5
-    for n in b0:
-        if b0[n].dtype.is_floating_point:
-            assert (b1[n] - b0[n]).abs().max().item() <= 1e-5 + 1e-5 * b0[n].abs().max().item(), n
-        else:
-            assert int(b1[n]) == int(b0[n]) == 3, n         # three forward passes counted
-    num = sum(float((g1[n] - g0[n]).pow(2).sum()) for n in g0) ** 0.5
-    den = sum(float(g0[n].pow(2).sum()) for n in g0) ** 0.5
-    assert num / den <= 0.05, num / den
-
-
 def test_overlapped_exchange_graph_step_equals_the_single_graph_step():
     """Data-parallel schedule of GraphedTrainStep (graph A cut at the keypoint encoder, async RCCL all-reduce of the decoder /
     dense-motion gradient ranges beside the encoder's backward graph, encoder range after it) on a ONE-rank RCCL group, MTIA prior
-    with the side-stream encoder pass: verify() accepts the two-graph replay against eager passes, the gradient ranges cover the flat
+    with the batched encoder pass: verify() accepts the two-graph replay against eager passes, the gradient ranges cover the flat
     buffer exactly once, and the replayed steps train like the un-split, exchange-free graph step (same first loss; the later ones
     are a chaotic trajectory at random initialisation and are only required to get below the first)."""
     import os
@@ -338,7 +247,7 @@ def test_overlapped_exchange_graph_step_equals_the_single_graph_step():
             torch.cuda.synchronize()
             return step, losses, opt.flat_w.clone()
         s1, l1, w1 = run(True)
-        assert s1.split is not None and s1.g_tail is not None and len(s1.model._sides) == 1
+        assert s1.split is not None and s1.g_tail is not None and s1.model.batched_encoder
         covered = sorted(s1.head_ranges + s1.tail_ranges)
         assert covered[0][0] == 0 and covered[-1][1] == s1.grads.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
         n_enc = sum((p.numel() + 3) // 4 * 4 for p in s1.model.encoder.parameters() if p.requires_grad)
@@ -415,7 +324,7 @@ def test_sync_batchnorm_collectives_are_captured_into_the_graph(monkeypatch):
 
 
 def test_encoder_weight_gradients_dealt_onto_side_streams_match_the_inline_order():
-    """HotPath._wdefer_enc (the keypoint encoder's ~400 weight-gradient launches collected during its two concurrent backward passes and dealt onto
+    """HotPath._wdefer_enc (the keypoint encoder's ~200 weight-gradient launches collected during its backward chain and dealt onto
     four side streams afterwards, their un-packing last): one eager forward + backward with the fan-out on and off; a randomly initialised
     train-mode model amplifies summation-order noise to percents of the encoder's gradient, so the yardstick is the distance of two runs with the
     fan-out OFF -- the on/off distance of every sub-network must stay within 3 x that noise."""
@@ -429,7 +338,7 @@ def test_encoder_weight_gradients_dealt_onto_side_streams_match_the_inline_order
         m = HotPath(VOX1, prior="mtia")
         bench.init_weights(m)
         m.to(DEV).train(True)
-        m.concurrent_encoder, m.defer_decoder_wgrads = True, True
+        m.defer_decoder_wgrads = True
         m._wdefer_enc.fanout = fanout
         make_optimizer(m, fused=True)                         # flat gradient buffers: the direct-gradient mode the deferral needs
         for p in m.parameters():

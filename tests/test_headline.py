@@ -1,5 +1,5 @@
-"""The headline program of the benchmark -- the hipGraph-REPLAYED MTIA-prior training step (BASELINE config 2: TokenPose_B x 2 on two
-concurrent streams, DenseMotion, RaftFlow, surrogate L1 loss, backward with deferred weight gradients) -- held to the reference's own
+"""The headline program of the benchmark -- the hipGraph-REPLAYED MTIA-prior training step (BASELINE config 2: ONE batched TokenPose_B pass over source + driving (per-call BatchNorm statistics),
+DenseMotion, RaftFlow, surrogate L1 loss, backward with deferred weight gradients) -- held to the reference's own
 `MRFA(prior_model='mtia')` (tests/golden/chain_mtia.npz, tools/make_goldens.py:g12_chain_mtia: model.py:185-210, train.py:58-64) and to
 the oracle's autograd.  VERDICT r3 item 2: what meets the reference here is the replayed graph, not an eager twin of it.
 
@@ -34,7 +34,7 @@ def test_oracle_autograd_of_the_mtia_chain_vs_reference_golden(golden_dir):
 @pytest.mark.gpu
 @pytest.mark.parametrize("train", [False, True], ids=["eval_bn", "train_bn"])
 def test_replayed_mtia_training_step_vs_reference_and_oracle_autograd(golden_dir, train):
-    """HotPath(VOX1, prior='mtia') from known weights at B=2 -> GraphedTrainStep (FlatAdam, concurrent encoder passes, deferred weight
+    """HotPath(VOX1, prior='mtia') from known weights at B=2 -> GraphedTrainStep (FlatAdam, the batched encoder pass with HRNet branch lanes, deferred weight
     gradients: everything the benchmark's step uses) -> ONE replay of graph A -> loss, generated frames, keypoints, d loss / d keypoints,
     per-sub-network gradient vectors (direction + length), BatchNorm running buffers: against the reference's MRFA golden and against the
     oracle's autograd run here on the host.  Then a second replay must reproduce the first inside the same gates (replays are the

@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, wwino=False, fin=False, bst=False, groups=1, tag="c"):
+              stride=1, fin=False, bst=False, groups=1, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -114,17 +114,6 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
             side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
             keep.append(wsb)
             p.w_split, p.w_piece = wsb.data_ptr(), 0 if rne else piece
-        if wwino:                   # the Winograd-along-x weights U = G w (pack mode 16): the patch-tiled kernel then runs 12 instead of 18 steps per pixel pair
-            wpiece = 12 * cop * Cin
-            wwb = torch.zeros(3 * wpiece, dtype=torch.int16, device=side.dev)
-            d = hip.PackDesc()
-            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = w.data_ptr(), Cout, Cin, R, S, 1
-            d.dst[0], d.mode[0] = wwb.data_ptr(), 16
-            side.call("mrfa_pack_conv_weights_multi", C.pointer(d), 1)
-            keep.append(wwb)
-            if side.gpu:
-                assert side.L.mrfa_conv2d_wino_supported(C.byref(p)) == 0 or True      # (asked again below, once the output is attached)
-            p.w_wino, p.w_wino_piece = wwb.data_ptr(), wpiece
         if wphase:                  # the 16 phase-tap weights of nearest-x2 + 3x3 (pack mode 12)
             ppiece = 16 * cop * Cin
             wpb = torch.zeros(3 * ppiece, dtype=torch.int16, device=side.dev)
@@ -191,8 +180,6 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         assert side.L.mrfa_conv2d_stride_supported(C.byref(p)) == 1
     if mask and side.gpu:
         assert side.L.mrfa_conv2d_mask_supported(C.byref(p)) == 1
-    if wwino and side.gpu:
-        assert side.L.mrfa_conv2d_wino_supported(C.byref(p)) == 1, "the Winograd form does not apply to this launch"
     side.call("mrfa_conv2d_nhwc", C.byref(p))
     if fin and side.gpu and fin == "small":
         assert side.L.mrfa_conv2d_last_config() & 8, "not dispatched to the one-wave-per-tile kernel"
@@ -409,88 +396,6 @@ def test_conv2d_patch_tiled_kernel(name, mode):
         L.mrfa_set_tuning(b"conv_halo_bn192", 1)
     # mode 3: both operands rounded to 8 significand bits (2^-9 each), K = 288 .. 2304 products per output
     assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="halo " + name)
-
-
-WINO_CASES = {          # conv_halo.hip MODE 3: Winograd F(2, 3) along x on 8-row patches, <= 128-wide tiles; every epilogue / prologue option
-    "c64_to_128": dict(N=2, H=16, W=32, Cin=64, Cout=128),
-    "pro_res_stats_c128": dict(N=1, H=24, W=64, Cin=96, Cout=128, pro=True, res=True, stats=True, relu=False),
-    "bn64_acc_alpha_c50": dict(N=3, H=8, W=32, Cin=96, Cout=50, acc=True, alpha=0.37, relu=False, bias=False),
-    "affine_c32": dict(N=1, H=8, W=32, Cin=32, Cout=96, oaff=True),
-    "wide_ld": dict(N=1, H=16, W=96, Cin=64, Cout=128, ldx_extra=8, ldy_extra=12),
-    "mask_acc_c96": dict(N=1, H=16, W=32, Cin=128, Cout=96, mask=True, acc=True, relu=False, bias=False),
-    "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128, stats=True),
-}
-
-
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("name", list(WINO_CASES))
-def test_conv2d_winograd_form(name, mode):
-    """conv_halo.hip MODE 3 (input transform B^T d at halo staging, weights U = G w from pack mode 16, output transform in the epilogue) against
-    the CPU specification of the plain convolution, six- and three-product modes"""
-    L = hip.lib()
-    kw = dict(WINO_CASES[name])
-    ref = conv_case(Side(False), tag=f"wino/{name}", **kw)
-    assert L.mrfa_set_mfma_mode(mode) == 0
-    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
-    L.mrfa_set_tuning(b"conv_small", 0)
-    L.mrfa_set_tuning(b"conv_halo_wino", 1)
-    try:
-        got = conv_case(Side(True), tag=f"wino/{name}", wsplit=True, wwino=True, **kw)
-        assert L.mrfa_conv2d_last_config() & (1 << 28), "the patch-tiled kernel did not run"
-    finally:
-        L.mrfa_set_mfma_mode(0)
-        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
-        L.mrfa_set_tuning(b"conv_small", 1)
-    assert_close(ref, got, tol={1: 2e-4, 2: 2e-3}[mode], what="wino " + name)
-
-
-def test_winograd_form_error_vs_fp64_is_within_4x_of_the_direct_kernel():
-    """VERDICT r3 item 4's gate: output error of the Winograd form against an fp64 convolution <= 4 x the direct patch-tiled kernel's (max and rms),
-    K = 2 304 products per output, operands with a wide dynamic range"""
-    L = hip.lib()
-    N, H, W, Cin, Cout = 2, 32, 64, 256, 128
-    x = (det_uniform("wino64/x", (N * H * W, Cin), -1, 1) * torch.exp2(det_uniform("wino64/xe", (N * H * W, Cin), -6, 6).round())).float()
-    w = (det_uniform("wino64/w", (Cout, Cin, 3, 3), -0.2, 0.2) * torch.exp2(det_uniform("wino64/we", (Cout, Cin, 3, 3), -4, 4).round())).float()
-    y64 = torch.nn.functional.conv2d(x.double().view(N, H, W, Cin).permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
-    dev = torch.device("cuda:0")
-    xd, wd = x.to(dev), w.to(dev)
-    cop = 128
-
-    def run(wino):
-        y = torch.empty((N * H * W, Cout), device=dev)
-        p = hip.ConvParams()
-        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = xd.data_ptr(), Cin, H, W, N, Cin
-        wp = pack(Side(True), wd, 0)
-        p.w, p.w_ld, p.w_tap, p.w_rows = wp.data_ptr(), Cin, cop * Cin, cop
-        bufs = []
-        for mode_, T in ((8, 9), (16, 12)):
-            b = torch.zeros(3 * T * cop * Cin, dtype=torch.int16, device=dev)
-            d = hip.PackDesc()
-            d.src, d.Cout, d.Cin, d.R, d.S, d.ndst = wd.data_ptr(), Cout, Cin, 3, 3, 1
-            d.dst[0], d.mode[0] = b.data_ptr(), mode_
-            hip.check(L.mrfa_pack_conv_weights_multi(hip.stream_ptr(), C.pointer(d), 1), "pack")
-            bufs.append(b)
-        p.w_split, p.w_piece = bufs[0].data_ptr(), 9 * cop * Cin
-        if wino:
-            p.w_wino, p.w_wino_piece = bufs[1].data_ptr(), 12 * cop * Cin
-        p.y, p.ldy, p.Cout, p.Hout, p.Wout, p.R, p.S, p.pad = y.data_ptr(), Cout, Cout, H, W, 3, 3, 1
-        p.alpha, p.nbatch, p.splitk = 1.0, 1, 1
-        hip.check(L.mrfa_conv2d_nhwc(hip.stream_ptr(), C.byref(p)), "conv")
-        assert L.mrfa_conv2d_last_config() & (1 << 28)
-        torch.cuda.synchronize()
-        e = (y.double().cpu() - y64).abs()
-        return float(e.max()), float(e.pow(2).mean().sqrt())
-    assert L.mrfa_set_mfma_mode(1) == 0
-    prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
-    try:
-        d_max, d_rms = run(False)
-        w_max, w_rms = run(True)
-    finally:
-        L.mrfa_set_mfma_mode(0)
-        L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
-    scale = float(y64.abs().max())
-    print(f"vs fp64 (output scale {scale:.3e}): direct max {d_max:.3e} rms {d_rms:.3e}; Winograd-x max {w_max:.3e} rms {w_rms:.3e}")
-    assert w_max <= 4.0 * d_max and w_rms <= 4.0 * d_rms, (d_max, d_rms, w_max, w_rms)
 
 
 @pytest.mark.parametrize("cfg", [dict(N=2, H=8, W=32, Cin=64, Cout=128), dict(N=1, H=16, W=32, Cin=128, Cout=64, acc=True),

@@ -138,51 +138,6 @@ def test_full_pipeline_vs_oracle_fresh_inputs():
     _cmp(warp, owarp.numpy(), what="warp_img")
 
 
-def test_winograd_form_in_the_pipeline_vs_oracle_and_the_direct_form(monkeypatch):
-    """The opt-in Winograd F(2, 3)-along-x form (engine.WINO / MRFA_WINO=1: conv_halo MODE 3 with pack modes 16 / 17 on every eligible plain 3x3
-    layer, forward AND data gradient) through the whole KPDetector -> DenseMotion -> RaftFlow pipeline at 256^2, B=2, eval mode: output against
-    the CPU oracle inside the standing gates (max 1e-3, mean 1e-4), and the parameter gradients against the direct form's (cos >= 0.9999 per
-    sub-network, norms within 1e-3)."""
-    from mrfa_amd import engine
-    from mrfa_amd.train import VOX1, HotPath, l1_loss
-    b, size = 2, 256
-    src, drv = cases.images("wino/src", b, size), cases.images("wino/drv", b, size)
-    model = HotPath(VOX1, prior="fomm")
-    sds = {}
-    for n, m in (("kp", model.encoder), ("dm", model.dense_motion), ("rf", model.decoder)):
-        sds[n] = cases.weights_for(m.state_dict(), n)
-        m.load_state_dict(sds[n])
-    model.to(DEV).eval()
-
-    def run(wino):
-        monkeypatch.setattr(engine, "WINO", wino)
-        for p_ in model.parameters():
-            p_.grad = None
-        gen = model(src.to(DEV), drv.to(DEV))
-        l1_loss(gen, drv.to(DEV)).backward()
-        model.join()
-        torch.cuda.synchronize()
-        g = {grp: torch.cat([p_.grad.reshape(-1).double() for p_ in getattr(model, grp).parameters() if p_.grad is not None])
-             for grp in ("encoder", "dense_motion", "decoder")}
-        return gen.detach(), g
-    gen_d, g_d = run(False)
-    gen_w, g_w = run(True)
-    assert any(getattr(m._mrfa_convw, "_fwd_wx", None) is not None for m in model.modules() if getattr(m, "_mrfa_convw", None) is not None), \
-        "no layer took the Winograd form"
-    with torch.no_grad():
-        P = {"encoder." + k: v for k, v in sds["kp"].items()}
-        P.update({"dense_motion." + k: v for k, v in sds["dm"].items()})
-        P.update({"decoder." + k: v for k, v in sds["rf"].items()})
-        ogen = O.mrfa_forward(src, drv, P, size=size, train=False, prior="fomm")[0]
-    _cmp(gen_w, ogen.numpy(), what="out (Winograd form)")
-    d = (gen_w - gen_d).abs()
-    print(f"Winograd vs direct form: output max {d.max().item():.2e} mean {d.mean().item():.2e}; " + ", ".join(
-        f"{k}: cos {float(torch.dot(g_w[k], g_d[k]) / (g_w[k].norm() * g_d[k].norm())):.6f} norm ratio {float(g_w[k].norm() / g_d[k].norm()):.5f}" for k in g_d))
-    for k in g_d:
-        cos = float(torch.dot(g_w[k], g_d[k]) / (g_w[k].norm() * g_d[k].norm()))
-        assert cos >= 0.9999 and abs(float(g_w[k].norm() / g_d[k].norm()) - 1.0) <= 1e-3, (k, cos)
-
-
 def test_batch_independence_at_bench_size():
     """Size-independent property at the bench configuration (B=8, 256^2): in eval mode every pair is independent, so
     the B=8 result must equal the per-pair B=1 results (catches any cross-sample indexing bug in the big-tile paths)."""
