@@ -362,7 +362,7 @@ def run_config4(dev, steps: int = 6, warmup: int = 2):
         hip.set_mfma_mode(prev)
 
 
-def spawn_ranks(n: int, argv) -> int:
+def spawn_ranks(n: int, argv, script: str = None, need_gpus: bool = True) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks here, the way the reference gets its ranks
     from torch.distributed.launch (run.py:50-59, train.py:39-48).  This parent NEVER touches the GPU (no HIP call, no
     torch.cuda.is_available(), no device_count(): the GPUs are counted from the KFD sysfs topology, visible_gpus()) -- each rank is a fresh child process with RANK / LOCAL_RANK / WORLD_SIZE /
@@ -370,8 +370,7 @@ def spawn_ranks(n: int, argv) -> int:
     (SIGTERM, SIGKILL after KILL_GRACE_S) and the exit code is non-zero: a run that silently used fewer ranks than asked cannot happen."""
     import socket
     import subprocess
-    dry = "--dry" in argv
-    if not dry:
+    if need_gpus:           # (False: tests/bench_dry_run.py, the CPU rehearsal of this launcher)
         have = visible_gpus()
         if have is not None and have < n:
             print(f"[bench] --gpus {n}: only {have} GPU(s) visible on this node", file=sys.stderr)
@@ -383,7 +382,7 @@ def spawn_ranks(n: int, argv) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     alive = set(range(n))
     deadline = None                                   # set when a rank failed: the others get SIGTERM, then SIGKILL after the grace period
@@ -437,90 +436,9 @@ def visible_gpus():
     return nodes
 
 
-DRY_CFG = dict(   # --dry only: the VOX1 wiring at 64 x 64 with shallow hourglasses, small enough for the CPU emulator
-    fomm_kp_detector=dict(block_expansion=8, num_kp=10, num_channels=3, max_features=32, num_blocks=3, temperature=0.1,
-                          scale_factor=0.25, estimate_jacobian=True, estimate_occlusion=False),
-    dense_motion=dict(block_expansion=8, max_features=32, num_blocks=3, scale_factor=0.25, num_kp=10, num_channels=3,
-                      estimate_occlusion_map=True),
-    raft_flow=dict(prior_only=False, num_kp=10, dim=256, size=64,
-                   generator=dict(num_channels=3, block_expansion=64, max_features=512, num_up_blocks=5),
-                   driving_encoder=dict(in_features=10, block_expansion=8, max_features=32, num_blocks=3),
-                   source_encoder=dict(in_features=13, block_expansion=8, max_features=32, num_blocks=3)),
-    train_params=dict(lr=2.0e-4, clip=10.0, prior_model="fomm"))
-
-
-def run_dry(a):
-    """`--dry`: the launcher / rendezvous / exchange / timing / reporting control flow of the data-parallel bench WITHOUT a GPU -- gloo
-    instead of RCCL, CPU tensors, the HIP library replaced by the C-ABI emulator (tests/emu.py -> oracle/capi_emulator.py: test
-    infrastructure, which is why this leg is labelled `"dry": true` and its `value` is not a measurement).  The step is the schedule
-    GraphedTrainStep replays (train.train_step_overlapped: flat gradient buffer, all-reduce ranges, 1/world folded into FlatAdam),
-    issued eagerly on a 64 x 64 miniature of the VOX1 wiring.  Used by tests/test_bench_launcher.py."""
-    import torch.distributed as dist
-    from tests.emu import emulated_hip
-    from mrfa_amd.train import HotPath, make_optimizer, sync_bn_buffers, train_step_overlapped
-    from mrfa_amd.utils.prng import det_uniform, fill_state_dict
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    torch.set_num_threads(2)
-    if rank == a.dry_fail_rank:
-        sys.exit(7)
-    if world_env > 1:
-        dist.init_process_group(backend="gloo", init_method="env://")
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world != a.gpus:
-        raise SystemExit(f"[bench] --gpus {a.gpus} but the process group has {world} rank(s)")
-    with emulated_hip():
-        model = HotPath(DRY_CFG, prior="fomm")
-        for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
-            mod.load_state_dict(fill_state_dict(mod.state_dict(), tag=pfx))
-        model.train(True)
-        opt = make_optimizer(model, fused=True)
-        B = a.batch
-        src = det_uniform(f"bench/src/r{rank}", (B, 3, 64, 64), 0, 1)
-        drv = det_uniform(f"bench/drv/r{rank}", (B, 3, 64, 64), 0, 1)
-        step = lambda: train_step_overlapped(model, opt, src, drv, world=world)
-        for _ in range(a.warmup):
-            loss = step()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            loss = step()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64)
-        wsum = opt.flat_w.double().sum().reshape(1)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            ws = [torch.zeros_like(wsum) for _ in range(world)]
-            dist.all_gather(ws, wsum)
-            replicas_equal = all(bool(torch.equal(w, ws[0])) for w in ws)
-            sync_bn_buffers(model)                         # what every rank calls before rank 0 writes a checkpoint: running statistics averaged over the ranks
-            bsum = torch.cat([b.double().flatten() for n_, b in model.named_buffers() if n_.endswith(("running_mean", "running_var"))]).sum().reshape(1)
-            bs = [torch.zeros_like(bsum) for _ in range(world)]
-            dist.all_gather(bs, bsum)
-            buffers_equal = all(bool(torch.equal(b, bs[0])) for b in bs)
-        else:
-            replicas_equal = buffers_equal = True
-        dt = float(tmax.item())
-    line = {"metric": "frames/sec (256x256 source+driving pair) fwd+bwd", "value": None, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "dry": True,
-            "config": {"workload": "DRY RUN (no GPU): 64x64 miniature of the vox1 wiring on CPU through the C-ABI emulator, gloo; checks the "
-                                   "launcher, the rendezvous, the flat gradient exchange and the reporting -- not a measurement",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "launch": "dry", "loss": float(f"{float(loss):.6f}"),
-                       "replicas_equal_after_steps": replicas_equal, "bn_buffers_equal_after_sync": buffers_equal,
-                       "dry_pairs_per_s": round(world * B * a.steps / dt, 3)},
-            "roofline": None, "cpu_baseline": None}
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-
-
-def main():
+def main(rank_body=None, script=None, argv=None, child_argv=None):
+    """rank_body / script: tests/bench_dry_run.py re-uses this launcher (argument parsing, rank spawning, WORLD_SIZE checks) with a CPU rank
+    body of its own -- the benchmark itself never reaches test infrastructure except in the `cpu_baseline` leg"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -555,28 +473,22 @@ def main():
     ap.add_argument("--allow-eager-fallback", action="store_true",
                     help="N = 1 only: if the hipGraph capture or its verification fails, time eager launches instead of exiting non-zero "
                          "(the line then says config.launch = eager)")
-    ap.add_argument("--dry", action="store_true",
-                    help="no GPU: run the multi-rank control flow (launcher, rendezvous, flat gradient exchange, timing, reporting) on CPU "
-                         "with gloo and the C-ABI emulator on a 64x64 miniature; the line carries \"dry\": true and no value")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="mrfa_set_tuning knob (kernel selection only, never results), repeatable: A/B runs on one box, e.g. --tune conv_halo=0")
-    ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # launcher test: this rank exits 7 before the rendezvous
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
     # ---- ranks.  Under torch.distributed.run (the driver's N > 1 command) WORLD_SIZE is set and must equal --gpus; a bare
     # `python bench.py --gpus N` starts its N ranks itself, BEFORE anything in this process touches the GPU.
     if "WORLD_SIZE" not in os.environ:
         if a.gpus > 1:
-            sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+            sys.exit(spawn_ranks(a.gpus, child_argv if child_argv is not None else (sys.argv[1:] if argv is None else argv), script=script, need_gpus=rank_body is None))
     elif int(os.environ["WORLD_SIZE"]) != a.gpus:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
               f"(python bench.py --gpus N, or torch.distributed.run --nproc-per-node N bench.py --gpus N)", file=sys.stderr)
         sys.exit(2)
-    if a.dry:
-        if a.batch is None:
-            a.batch = 1
-        return run_dry(a)
+    if rank_body is not None:
+        return rank_body(a)
     if a.batch is None:
         a.batch = 4 if a.inference else 8
     if a.inference:
