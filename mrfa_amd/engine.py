@@ -239,6 +239,13 @@ class defer_wgrads:
 
 
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
+SYNCBN_COLLECTIVES = 0          # statistics all-reduces issued by this process so far (bench.py --sync-bn reports the number per step)
+
+
+def _syncbn_all_reduce(t: torch.Tensor):
+    global SYNCBN_COLLECTIVES
+    SYNCBN_COLLECTIVES += 1
+    torch.distributed.all_reduce(t)
 SYNCBN_DIRECT_BYTES = int(os.environ.get("MRFA_SYNCBN_DIRECT_KIB", "128")) << 10      # statistics blocks up to this size are all-reduced whole (all slots)
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
 # BatchNorm finalize of the conv -> BatchNorm pairs of the keypoint encoder inside the convolution's launch (last workgroup; mrfa_conv_params.fin_*)
@@ -1296,7 +1303,7 @@ class Ctx:
                 # ~1 200 per step with the MTIA prior); wide layers: the slots are summed locally first (one launch) so that the message is 2C doubles
                 nsl = hip.STATS_SLOTS * 2 * Cn
                 if G * nsl * 8 <= SYNCBN_DIRECT_BYTES:
-                    torch.distributed.all_reduce(stats[:G * nsl])
+                    _syncbn_all_reduce(stats[:G * nsl])
                 else:
                     stats = self._allreduce_slot_sums(stats, G, Cn)
                 count = count * world
@@ -1318,7 +1325,7 @@ class Ctx:
         G x 2C doubles instead of 32 times that) and returned as slot 0 of a fresh zeroed [G][STATS_SLOTS][2C] block"""
         S = hip.STATS_SLOTS
         local = torch.sum(slots[:G * S * 2 * Cn].view(G, S, 2 * Cn), 1)
-        torch.distributed.all_reduce(local)
+        _syncbn_all_reduce(local)
         out = self.f64z(G * S * 2 * Cn)
         out.view(G, S, 2 * Cn)[:, 0].copy_(local)
         return out
@@ -1439,7 +1446,7 @@ class Ctx:
             Cn = x.C
             self._chk(self.L.mrfa_bn_param_grad_groups(self.s, red.data_ptr(), Cn, groups, dg.data_ptr(), db.data_ptr()), "bn_param_grad")
             if nred * 8 <= SYNCBN_DIRECT_BYTES:
-                torch.distributed.all_reduce(red[:nred])
+                _syncbn_all_reduce(red[:nred])
             else:
                 q.red = self._allreduce_slot_sums(red, groups, Cn).data_ptr()
             q.red_world = world

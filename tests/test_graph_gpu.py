@@ -385,3 +385,50 @@ def test_pack_stream_replays_like_the_eager_step():
             w = next(p for n, p in mod.named_parameters() if p.dim() == 4 and p.shape[2] == 3 and p.shape[0] >= 32)
             w.mul_(1.25)
     step.verify(replays=3)
+
+
+@pytest.mark.parametrize("frames,b", [(2, 2), (3, 2), (2, 8)])
+def test_statistic_groups_on_the_gpu_equal_separate_calls_sharply(frames, b):
+    """The batched pass against the separate calls where summation-order noise is small enough to see a SYSTEMATIC error: the HRNet trunk with one
+    block per branch (tests/test_wiring_cpu.small_hrnet: every BatchNorm call pattern of the encoder -- conv-epilogue statistics with the fused finalize,
+    stride-2 layers, residual-closing BatchNorm, the first backward phase inside the consumer's data gradient, the per-group statistics pass behind
+    launches whose tiles would straddle two groups) on 32 x 32 and 64 x 64 inputs.  Outputs to 1e-5, running statistics to 1e-6, EVERY parameter gradient
+    to 2e-4 of its scale (the random-init TokenPose_B of test_batched_encoder_pass_equals_separate_calls amplifies noise to percents and can only bound)."""
+    from mrfa_amd import engine
+    from mrfa_amd.utils.prng import det_uniform
+    from tests.test_wiring_cpu import small_hrnet
+    size = 32 if b == 2 else 64
+    xs = [(det_uniform(f"sgg/x{i}", (b, 3, size, size)) * (1.0 + 0.5 * i) + 0.1 * i).to(DEV) for i in range(frames)]
+    ws = [det_uniform(f"sgg/w{i}", (b, 32, size // 4, size // 4)).to(DEV) for i in range(frames)]
+
+    def run(batched):
+        m = small_hrnet().to(DEV)
+        m.train(True)
+        if batched:
+            with engine.stat_groups(frames):
+                y = m(torch.cat(xs, 0))
+            (y * torch.cat(ws, 0)).sum().backward()
+            ys = list(y.detach().split(b))
+        else:
+            ys = [m(x) for x in xs]
+            sum((yy * w).sum() for yy, w in zip(ys, ws)).backward()
+            ys = [yy.detach() for yy in ys]
+        torch.cuda.synchronize()
+        return ys, {n: p.grad.double().clone() for n, p in m.named_parameters()}, {n: v.clone() for n, v in m.named_buffers()}
+    y0, g0, b0 = run(False)
+    y0b, g0b, _ = run(False)
+    y1, g1, b1 = run(True)
+    for a, c in zip(y0, y1):
+        assert (a - c).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert (b0[n] - b1[n]).abs().max().item() <= 1e-6 * max(1.0, b0[n].abs().max().item()), n
+        else:
+            assert int(b0[n]) == int(b1[n]) == frames, n
+    worst, noise = 0.0, 0.0
+    for n in g0:
+        sc = max(g0[n].abs().max().item(), 1e-6)
+        worst = max(worst, (g0[n] - g1[n]).abs().max().item() / sc)
+        noise = max(noise, (g0[n] - g0b[n]).abs().max().item() / sc)
+    print(f"batched vs separate calls: worst per-parameter gradient error {worst:.2e} of the parameter's scale (two separate-call runs: {noise:.2e})")
+    assert worst <= 2e-4 + 4 * noise, (worst, noise)
