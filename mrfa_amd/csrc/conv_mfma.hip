@@ -77,6 +77,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
         const int rem = (int)(mm - (long long)n_img * HWo);
         a_oy[j] = rem / p.Wout;
         a_ox[j] = rem - a_oy[j] * p.Wout;
+        if (FLAT && p.stride == 2) { a_oy[j] *= 2; a_ox[j] *= 2; }       // strided gather (flat-K launches only: HRNet's 3 -> 64 stem, hr_base.py:302)
         a_base[j] = n_img * p.Hin * p.Win;
     }
     bool b_ok[RB];
@@ -340,8 +341,10 @@ static thread_local int g_last_tile = 0;
 extern "C" int mrfa_conv2d_last_config(void) { return g_last_tile; }
 
 extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
-    if (!p || p->stride != 2 || !mrfa_tuning_conv_small()) return 0;
+    if (!p || p->stride != 2) return 0;
     if (p->Hout != (p->Hin + 2 * p->pad - p->R) / 2 + 1 || p->Wout != (p->Win + 2 * p->pad - p->S) / 2 + 1) return 0;
+    if (p->kflat > 0) return (!p->ups && p->nbatch <= 1 && p->splitk <= 1 && p->ktab) ? 1 : 0;      // flat-K gather of the fp32 tile kernel
+    if (!mrfa_tuning_conv_small()) return 0;
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
@@ -419,8 +422,8 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
         return mrfa_conv_small_launch(st, p, M);
     }
-    if (p.stride > 1 || p.stride < 0) {
-        mrfa_set_error("conv2d: stride = %d is only implemented by the one-wave-per-tile kernel: ask mrfa_conv2d_stride_supported() first", p.stride);
+    if (p.stride < 0 || p.stride > 2 || (p.stride == 2 && !(flat && !p.ups && p.nbatch <= 1))) {
+        mrfa_set_error("conv2d: stride = %d is only implemented by the one-wave-per-tile kernel and by flat-K launches: ask mrfa_conv2d_stride_supported() first", p.stride);
         return 1;
     }
     if (p.mask && !(!flat && mrfa_conv_halo_eligible(p))) {

@@ -345,7 +345,7 @@ def _r4(c: int) -> int:
 # ------------------------------------------------------------------------------------------------- storage / views
 class Storage:
     """[rows, ld] fp32 buffer + lazily allocated gradient buffer of the same geometry."""
-    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh", "bwd_masked", "bn_hint")
+    __slots__ = ("data", "grad", "rows", "ld", "grad_noinit", "fresh", "bwd_masked", "bn_hint", "seq", "plan")
 
     def __init__(self, data: torch.Tensor):
         assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
@@ -367,6 +367,10 @@ class Storage:
         # not None: the buffer is the output of a BatchNorm + activation with ONE consumer, a convolution (Ctx.bn_act(out_sole=True)): what that
         # convolution's data gradient needs to accumulate the first phase of the BatchNorm's backward in its epilogue (Ctx._conv_dgrad)
         self.bn_hint = None
+        # position of this buffer among its program's forward activations and that program's zero plan (Ctx.zero_plan): a gradient buffer that had to be
+        # zero-filled on first touch is remembered there, and the next run of the same program zero-fills all such buffers in ONE multi-tensor launch
+        self.seq = -1
+        self.plan = None
 
     def grad_buf(self) -> torch.Tensor:
         if self.grad is None:
@@ -374,6 +378,8 @@ class Storage:
         elif self.fresh:
             self.grad.zero_()
             self.fresh = False
+            if self.plan is not None and self.seq >= 0:
+                self.plan.add(self.seq)
         return self.grad
 
 
@@ -827,6 +833,10 @@ class Ctx:
         self._pools = {}                 # (stream, dtype) -> ZeroPool: a chunk is zero-filled on the stream that carves it up
         self._home = hip.stream_ptr() if device.type == "cuda" else 0
         self._fin_done = {}              # statistics buffer -> result of a BatchNorm finalize done inside the producing convolution's call
+        # set of forward-activation indices whose (large, lazily initialised) gradient buffer needed a zero fill on first touch the last time this program
+        # ran (run_program keeps one per module and input shapes: the programs are static): run_backward() zero-fills them in one multi-tensor launch
+        # instead of ~100 fill launches scattered over the backward chains (tools/trace_fills.py: 121 fills per step, ~10 us each on the critical path)
+        self.zero_plan: Optional[set] = None
 
     # -- plumbing
     @property
@@ -937,14 +947,18 @@ class Ctx:
             ld = (C_ + 31) // 32 * 32
             v = View(Storage(torch.zeros((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_, 0, True)
             if self.record and not self.in_backward:
-                self.storages.append(v.st)
+                self._register(v.st)
             return v
         ld = _r4(C_) if ld is None else ld
         alloc = torch.zeros if zero else torch.empty
         v = View(Storage(alloc((N * H * W, ld), dtype=torch.float32, device=self.dev)), N, H, W, C_)
         if self.record and not self.in_backward:
-            self.storages.append(v.st)
+            self._register(v.st)
         return v
+
+    def _register(self, st: "Storage"):
+        st.seq, st.plan = len(self.storages), self.zero_plan
+        self.storages.append(st)
 
     def wrap_nhwc(self, t: torch.Tensor) -> View:
         """Zero-copy view of a contiguous (N,H,W,C) fp32 tensor."""
@@ -1757,7 +1771,7 @@ class Ctx:
         if cw.stride == 1:
             st = self.bn_stats_buf(bn)
             return self.conv(x, conv, stats=st, need_dx=need_dx, fin=fin), st
-        if cw.stride == 2 and not cw.fwd_flat and conv.bias is None:
+        if cw.stride == 2 and conv.bias is None:
             got = self._conv_strided(x, conv, cw, self.bn_stats_buf(bn), need_dx, fin=fin)
             if got is not None:
                 return got
@@ -1772,10 +1786,14 @@ class Ctx:
         cop = (cw.Cout + 127) // 128 * 128
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, 0, x.N, cw.Cin
-        p.w_ld, p.w_tap, p.kflat, p.w_rows = cw.Cin, cop * cw.Cin, 0, cop
+        if cw.fwd_flat:                                # few input channels (the 3 -> 64 stem, hr_base.py:302): the fp32 tile kernel's flat-K gather, strided
+            p.w_ld, p.w_tap, p.kflat, p.w_rows = (cw.T * cw.Cin + 31) // 32 * 32, 0, cw.T * cw.Cin, cop
+            p.ktab = cw.ktab_fwd().data_ptr()
+        else:
+            p.w_ld, p.w_tap, p.kflat, p.w_rows = cw.Cin, cop * cw.Cin, 0, cop
         p.Cout, p.Hout, p.Wout = cw.Cout, Ho, Wo
         p.R, p.S, p.pad, p.stride = cw.R, cw.S, cw.pad, 2
-        p.alpha, p.nbatch = 1.0, 1
+        p.alpha, p.nbatch, p.splitk = 1.0, 1, 1
         p.y, p.ldy = x.ptr, _r4(cw.Cout)              # (placeholders of the right alignment for the query)
         p.w = x.ptr
         if not self.L.mrfa_conv2d_stride_supported(C.byref(p)):
@@ -1935,7 +1953,10 @@ class Ctx:
         p.R, p.S, p.pad = 1, 1, 0
         p.alpha, p.accumulate = alpha, int(accumulate)
         p.nbatch, p.x_bs, p.w_bs, p.y_bs = nbatch, a_bs, b_bs, c_bs
-        p.splitk = 1
+        # accumulating launches with few row tiles and a long K (dq of the pooled correlation levels: 64 ... 1 024 query rows x 4 096 keys per sample) let
+        # the library split K over workgroups (atomics onto the existing gradient: no init / epilogue pass): 16-128 workgroups looping 128 k-steps each took
+        # 190 us per launch for 1 GFLOP (5.6 TF/s, tools/profile_step.py)
+        p.splitk = 0 if accumulate else 1
         self._launch_conv(p, "gemm_nt")
 
     def gemm_tn_acc(self, a_ptr, lda, b_ptr, ldb, c_ptr, M, Nn, K, alpha, nbatch, a_bs, b_bs, c_bs):
@@ -2002,6 +2023,12 @@ class Ctx:
                 if FRESH_NAN:
                     st.grad.fill_(float("nan"))
                 st.fresh = True
+        if self.zero_plan:
+            pre = [st for st in self.storages if st.fresh and st.seq in self.zero_plan]
+            if pre:
+                torch._foreach_zero_([st.grad for st in pre])
+                for st in pre:
+                    st.fresh = False
         todo = [st for st in self.storages if st.grad is None]
         total = sum(st.data.numel() for st in todo)
         if total:
@@ -2052,6 +2079,9 @@ class _ProgramFn(torch.autograd.Function):
         # parameters' requires_grad even under torch.no_grad()): no tape, no retained activations for inference
         need = want_grad and any(actx.needs_input_grad[4:])
         ectx = Ctx(dev, train=module.training, record=need)
+        if need and dev.type == "cuda":
+            plans = module.__dict__.setdefault("_mrfa_zero_plans", {})
+            ectx.zero_plan = plans.setdefault((getattr(program, "__name__", repr(program)), module.training, STAT_GROUPS, tuple(tuple(t.shape) for t in inputs)), set())
         outs, seeders, in_grad_fns = program(ectx, *inputs)
         ectx.flush_forward()
         actx.ectx, actx.seeders, actx.in_grad_fns = ectx, seeders, in_grad_fns

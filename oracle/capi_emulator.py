@@ -551,6 +551,8 @@ class Emulator:
     def mrfa_conv2d_stride_supported(self, pref):
         """shape rule of the library's one-wave-per-tile kernel (the emulator itself honours `stride` everywhere)"""
         p = _obj(pref)
+        if p.stride == 2 and p.kflat > 0:        # flat-K launches: the fp32 tile kernel's strided gather
+            return int(not p.ups and p.nbatch <= 1 and p.splitk <= 1 and bool(p.ktab))
         return int(p.stride == 2 and p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and p.ldx % 4 == 0 and p.nbatch <= 1
                    and p.N * p.Hout * p.Wout <= 65536 and p.Cout <= 640 and p.R * p.S * p.Cin <= 1152)
 

@@ -243,6 +243,9 @@ CONV_CASES = {
     "fin_small_stride2": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False, fin="small"),
     "fin_big_tile": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, stats=True, relu=False, fin=True),
     "small_stride2_stem": dict(N=2, H=32, W=32, Cin=64, Cout=64, stride=2, stats=True, relu=False, bias=False),
+    # the fp32 tile kernel's flat-K gather with stride 2 (HRNet's 3 -> 64 stem convolution, hr_base.py:302), statistic groups, finalize behind the launch
+    "flat_stride2_stem_c3": dict(N=4, H=32, W=32, Cin=3, Cout=64, stride=2, stats=True, relu=False, bias=False, fin=True, groups=2, ldx_extra=1),
+    "flat_stride2_odd_c13": dict(N=1, H=13, W=17, Cin=13, Cout=40, stride=2, relu=True),
     # v7: statistic groups (the source / driving / transformed-driving encoder calls as one batch): per-group statistics, finalize and bst_* on the
     # one-wave-per-tile kernel (all three wave tiles), the patch-tiled kernel, the row tiles and a strided layer
     "groups2_small_hr32_fin": dict(N=16, H=64, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, fin="small", groups=2),
@@ -549,6 +552,35 @@ def test_gemm_nt_batched():
     a = det_uniform("g/a", (3, 100, 64)).double()
     b = det_uniform("g/b", (3, 72, 64)).double()
     assert_close([torch.einsum("bik,bjk->bij", a, b).reshape(300, 72) * 0.0625], got, what="gemm_nt vs einsum")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gemm_nt_batched_accumulating_split_k(mode):
+    """the correlation volume's dq of the pooled levels (raft.py:185 backward: 64 query rows x 4 096 keys x 256 channels per sample): a batched NT GEMM
+    that ACCUMULATES into the existing gradient and lets the library split its long K over workgroups (splitk = 0: atomics, no init / epilogue pass)"""
+    def run(side):
+        B, M, Nn, K = 4, 64, 256, 4096
+        a = side.t("gs/a", (B * M, K))
+        bm = side.t("gs/b", (B * Nn, K), -0.1, 0.1)
+        c = side.t("gs/c0", (B * M, Nn))
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = a.data_ptr(), K, 1, M, 1, K
+        p.w, p.w_ld, p.w_rows = bm.data_ptr(), K, Nn
+        p.y, p.ldy, p.Cout, p.Hout, p.Wout = c.data_ptr(), Nn, Nn, 1, M
+        p.R, p.S, p.pad, p.alpha, p.accumulate = 1, 1, 0, 0.0625, 1
+        p.nbatch, p.x_bs, p.w_bs, p.y_bs, p.splitk = B, M * K, Nn * K, M * Nn, 0
+        side.call("mrfa_conv2d_nhwc", C.byref(p))
+        if side.gpu:
+            assert side.L.mrfa_conv2d_last_config() & 1, "the launch did not split K"
+        return side.done(c)
+    L = hip.lib()
+    ref = run(Side(False))
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    try:
+        got = run(Side(True))
+    finally:
+        L.mrfa_set_mfma_mode(0)
+    assert_close(ref, got, what="gemm_nt accumulate split-K")
 
 
 def dgrad_case(side, *, N=2, H=8, W=9, Cin=64, Cout=96, R=3, pad=1, tag="d"):
