@@ -393,7 +393,15 @@ def test_statistic_groups_on_the_gpu_equal_separate_calls_sharply(frames, b):
     block per branch (tests/test_wiring_cpu.small_hrnet: every BatchNorm call pattern of the encoder -- conv-epilogue statistics with the fused finalize,
     stride-2 layers, residual-closing BatchNorm, the first backward phase inside the consumer's data gradient, the per-group statistics pass behind
     launches whose tiles would straddle two groups) on 32 x 32 and 64 x 64 inputs.  Outputs to 1e-5, running statistics to 1e-6, EVERY parameter gradient
-    to 2e-4 of its scale (the random-init TokenPose_B of test_batched_encoder_pass_equals_separate_calls amplifies noise to percents and can only bound)."""
+    to 2e-4 of its scale on 32 x 32 (the random-init TokenPose_B of test_batched_encoder_pass_equals_separate_calls amplifies noise to percents and can
+    only bound).
+
+    At 8 x 64 x 64 the trunk itself is ill-conditioned -- the CPU fp32 oracle sits 5.7e-3 from its own fp64 run in layer1.3.bn3.bias, a handful
+    of ReLU decisions on nearly-dead channels -- and the two forms take different kernels where a launch is small (the separate call of 8 samples splits
+    K, the batch of 16 does not), so those decisions need not coincide.  There the gate is the fp64 oracle (oracle/tokenpose_oracle.hrnet, autograd, run
+    here on the host): the batched pass may be no further from it than 2e-4 + 2 x what the SEPARATE calls are (measured: both 1.4e-2 .. 1.6e-2, two
+    separate-call runs of one process 2e-6 or 1.4e-2 apart depending on the box).  This case is a bound; the sharp statements are the 32 x 32 cases above,
+    the forward outputs and running statistics of every case, and the grouped kernel cases of tests/test_kernels_gpu.py at these shapes."""
     from mrfa_amd import engine
     from mrfa_amd.utils.prng import det_uniform
     from tests.test_wiring_cpu import small_hrnet
@@ -425,10 +433,22 @@ def test_statistic_groups_on_the_gpu_equal_separate_calls_sharply(frames, b):
             assert (b0[n] - b1[n]).abs().max().item() <= 1e-6 * max(1.0, b0[n].abs().max().item()), n
         else:
             assert int(b0[n]) == int(b1[n]) == frames, n
-    worst, noise = 0.0, 0.0
+    errs, noise = [], 0.0
     for n in g0:
         sc = max(g0[n].abs().max().item(), 1e-6)
-        worst = max(worst, (g0[n] - g1[n]).abs().max().item() / sc)
+        errs.append((g0[n] - g1[n]).abs().max().item() / sc)
         noise = max(noise, (g0[n] - g0b[n]).abs().max().item() / sc)
-    print(f"batched vs separate calls: worst per-parameter gradient error {worst:.2e} of the parameter's scale (two separate-call runs: {noise:.2e})")
-    assert worst <= 2e-4 + 4 * noise, (worst, noise)
+    worst, median = max(errs), sorted(errs)[len(errs) // 2]
+    print(f"batched vs separate calls: worst per-parameter gradient error {worst:.2e} of the parameter's scale, median {median:.2e} "
+          f"(two separate-call runs: {noise:.2e})")
+    if size == 32:
+        assert worst <= 2e-4 + 4 * noise, (worst, noise)
+        return
+    from oracle import tokenpose_oracle as TO
+    P = {"h." + k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+         for k, v in small_hrnet().state_dict().items()}
+    sum((TO.hrnet(x.cpu().double(), P, "h", True) * w.cpu().double()).sum() for x, w in zip(xs, ws)).backward()
+    far = lambda g: max((g[n].cpu() - P["h." + n].grad).abs().max().item() / max(P["h." + n].grad.abs().max().item(), 1e-6) for n in g)
+    sep, bat = far(g0), far(g1)
+    print(f"distance from the fp64 oracle: separate calls {sep:.2e}, batched pass {bat:.2e}")
+    assert bat <= 2e-4 + 2.0 * sep, (bat, sep)
