@@ -36,8 +36,10 @@ const char* mrfa_last_error(void);
  *      mrfa_conv2d_groups_supported() (see "Statistic groups" below).  REMOVED (measured slower or neutral in round 4, never on by default): stride = -2 (the
  *      strided data gradient), mrfa_bnbwd_params.phase = 3 with its `..._fused_supported` query (`sync` stays in the struct, reserved), the LDS-staged
  *      small convolution behind mrfa_set_tuning("conv_lds"), the Winograd-along-x form (w_wino stays in the struct, reserved; pack modes 16 / 17 and its
- *      `..._wino_supported` query are gone).                                                                                              */
-#define MRFA_ABI_VERSION 7
+ *      `..._wino_supported` query are gone).
+ *   8  round 5: mrfa_conv_params += sk_ticket, y_zero (a K split that finishes inside its launch: no init pass, no epilogue pass) with the query
+ *      mrfa_conv2d_split_k().                                                                                                              */
+#define MRFA_ABI_VERSION 8
 int mrfa_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -115,7 +117,18 @@ typedef struct {
                            /*   (fin_counter behind ALL of it), fin_scale / _shift / _mean / _invstd and bst_scale / _shift / _mean / _invstd = [groups][Cout],  */
                            /*   fin_count = rows of ONE group, fin_rmean / fin_rvar updated once per group in group order.  Only where                           */
                            /*   mrfa_conv2d_groups_supported() says so                                                                                            */
+    /* v8, optional: a K SPLIT THAT FINISHES INSIDE ITS LAUNCH.  The low-resolution layers (4^2 .. 32^2: too few output tiles to fill 256 CUs) split K over       */
+    /* gridDim.z and add partial tiles into y with device-scope atomics; through v7 that cost a pass before (y = bias) and a pass behind (affine / residual / */
+    /* ReLU / statistics) the launch -- 107 launches per training step on the serial low-resolution chains.  sk_ticket: ZEROED 32-bit words, one per output  */
+    /* tile (at least ceil(N Hout Wout / 32) ceil(Cout / 32) max(nbatch, 1) of them cover every tile shape), fresh for every call: each workgroup takes a    */
+    /* ticket of its tile once its atomics have completed, and the one that draws the last re-reads the summed tile (device-scope loads), adds the bias,     */
+    /* applies out_scale / res / relu, stores it and accumulates `stats` (one statistic group per tile: groups > 1 is honoured).  y_zero = 1: the caller      */
+    /* states that y already holds zeros (e.g. a slice of a zero-filled arena): the init pass is dropped as well (with a bias: only together with            */
+    /* sk_ticket).  Ignored by launches that do not split (mrfa_conv2d_split_k() tells) and with accumulate = 1.                                              */
+    unsigned int* sk_ticket;
+    int y_zero;
 } mrfa_conv_params;
+int mrfa_conv2d_split_k(const mrfa_conv_params* p);                  /* K slices a call with these parameters would use (1: no split; y / sk_ticket may be NULL) */
 
 /* Statistic groups (v7).  The reference runs its keypoint encoder as separate calls on the source frames, the driving frames (and the transformed driving frames
  * of the equivariance loss): modules/model.py:185-186,234 -- so in train mode every BatchNorm normalises each of those batches with ITS OWN batch statistics and

@@ -99,6 +99,20 @@ static inline long long group_rows(const mrfa_conv_params& p, long long M) {
     return (p.N % p.groups) == 0 ? M / p.groups : 0;
 }
 
+// A K split that finishes inside its launch (mrfa_conv_params.sk_ticket, v8): called by EVERY thread of a workgroup behind its split-K atomics; true in the
+// workgroup that drew the tile's last ticket -- all `nsplit` partial tiles are then summed in y.  The hand-off is the one of conv_small.hip's fused BatchNorm
+// finalize (no fences: an agent-scope release / acquire writes back / invalidates a whole L2): the partial sums are device-scope atomics, performed at the
+// memory side; every thread waits for the completion of its own (s_waitcnt vmcnt(0): returnless atomics count there) before the barrier that precedes the
+// ticket, itself a device-scope atomic; the last workgroup then reads y with device-scope loads, which bypass the non-coherent per-XCD L2s.
+__device__ __forceinline__ bool splitk_last_arriver(unsigned* ticket, unsigned nsplit) {
+    __shared__ unsigned s_sk_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_sk_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_sk_ticket == nsplit - 1;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

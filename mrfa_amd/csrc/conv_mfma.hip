@@ -228,12 +228,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
     // ------------------------------------------------------------------ epilogue
     const int half = lane >> 5;
     const bool splitk = p.splitk > 1;
+    if (splitk) {
+        // partial tile: device-scope atomics into y (zeros, or the bias written by the init pass)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < p.Cout && m < M) atomicAdd(y + (size_t)m * p.ldy + c, acc[i][j][r] * p.alpha);
+                }
+        }
+        // v8: the workgroup that completes the tile applies the epilogue itself (otherwise splitk_epilogue_kernel does, in a pass of its own)
+        if (!p.sk_ticket || !splitk_last_arriver(p.sk_ticket + (size_t)bz * total_tiles + lin, gridDim.z)) return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int c = n0 + (wn * TN + j) * 32 + (lane & 31);
         const bool c_ok = c < p.Cout;
         float bias = 0.f, osc = 1.f, osh = 0.f;
-        if (c_ok && !splitk) {
+        if (c_ok) {
             if (p.bias) bias = p.bias[c];
             if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
         }
@@ -244,24 +260,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
             for (int r = 0; r < 16; ++r) {
                 const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (c_ok && m < M) {
-                    float v = acc[i][j][r] * p.alpha;
                     float* dst = y + (size_t)m * p.ldy + c;
-                    if (splitk) {
-                        atomicAdd(dst, v);
-                    } else {
-                        v += bias;
-                        v = v * osc + osh;
-                        if (p.res) v += p.res[(size_t)m * p.ldr + c];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
-                        s1 += v;
-                        s2 += v * v;
-                    }
+                    float v = splitk ? __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[i][j][r] * p.alpha;
+                    v += bias;
+                    v = v * osc + osh;
+                    if (p.res) v += p.res[(size_t)m * p.ldr + c];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.accumulate && !splitk) v += *dst;
+                    *dst = v;
+                    s1 += v;
+                    s2 += v * v;
                 }
             }
         }
-        if (p.stats && !splitk) {
+        if (p.stats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && c_ok) {
@@ -349,7 +361,7 @@ extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
     return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
 
-static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done);
+static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done, int* dry_split = nullptr);
 
 extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
     if (!p || !p->stats || p->fin_scale || p->stride < 0 || p->kflat > 0) return 0;
@@ -370,6 +382,15 @@ extern "C" int mrfa_conv2d_groups_supported(const mrfa_conv_params* p) {
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(*p, M)) return 1;       // (its own rule: rows % 64 == 0)
     return p->kflat == 0 && p->stride <= 1 && mrfa_conv_halo_eligible(*p) ? 1 : 0;                // (a patch lies inside one image)
+}
+
+// v8: the K slices conv2d_dispatch would use for these parameters (the dispatch itself, stopped before its first launch)
+extern "C" int mrfa_conv2d_split_k(const mrfa_conv_params* p) {
+    if (!p) return 1;
+    if (p->splitk > 1) return p->splitk;
+    int k = 1;
+    bool fin_done = false;
+    return conv2d_dispatch(nullptr, p, &fin_done, &k) ? 1 : k;
 }
 
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
@@ -395,10 +416,10 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
                                    pp->Cout, pp->groups > 1 ? pp->groups : 1, pp->fin_scale, pp->fin_shift, pp->fin_mean, pp->fin_invstd);
 }
 
-static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done) {
+static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done, int* dry_split) {
     const mrfa_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
-    MRFA_CHECK_ARG(p.x && p.w && p.y, "conv2d: null pointer");
+    MRFA_CHECK_ARG(p.x && p.w && (p.y || dry_split), "conv2d: null pointer");
     MRFA_CHECK_ARG(p.N > 0 && p.Cin > 0 && p.Cout > 0 && p.Hout > 0 && p.Wout > 0, "conv2d: bad sizes");
     MRFA_CHECK_ARG(p.R >= 1 && p.S >= 1 && p.R <= 15 && p.S <= 15, "conv2d: kernel size %dx%d unsupported", p.R, p.S);
     MRFA_CHECK_ARG((p.w_ld % 4) == 0 && aligned16(p.w), "conv2d: packed weight must be 16-B aligned, w_ld %% 4 == 0");
@@ -418,6 +439,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {
+        if (dry_split) { *dry_split = 1; return 0; }
         g_last_tile = (16 << 16) | (16 << 4) | 8;                // bit 3: conv_small
         *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
         return mrfa_conv_small_launch(st, p, M);
@@ -437,6 +459,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     }
     // ---- 3x3 stride-1 layers with 32-aligned rows in split-operand mode: patch-tiled kernel, input halo split once per chunk (conv_halo.hip)
     if (!flat && mrfa_conv_halo_eligible(p)) {
+        if (dry_split) { *dry_split = 1; return 0; }
         g_last_tile = (128 << 16) | ((p.Cout <= 64 ? 64 : 128) << 4) | 4 | (1 << 28);       // bit 28: conv_halo
         return mrfa_conv_halo_launch(st, p);
     }
@@ -469,7 +492,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         // Short K loop over many pixels (HRNet's 32..64-channel 3x3 convs at 64^2 / 32^2): a K split would add a zero-init and
         // a reduction/epilogue pass over the whole output (2 x 20 us measured) to a 20 us kernel -- keep one launch
         const bool short_k_big_m = KT < 32 && M > 4096;
-        const bool grouped_stats = p.groups > 1 && p.stats;       // (the split-K epilogue pass does not keep statistic groups apart)
+        const bool grouped_stats = p.groups > 1 && p.stats && !(p.sk_ticket && !p.accumulate);       // (the split-K epilogue PASS does not keep statistic groups apart; the fused one does)
         const int max_split = (auto_split && !short_k_big_m && !grouped_stats) ? (KT / 2 > 0 ? KT / 2 : 1) : 1;
         long long t = ntiles(BM, BN);
         // (round 4, tools/sweep_splitk.py: with the split forced per launch the automatic choice is within 10 % of the best on six of eight low-resolution
@@ -495,23 +518,31 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         BM = p.tile >> 16; BN = p.tile & 0x7fff; w8 = (p.tile & 0x8000) != 0;
         if (p.splitk >= 1) splitk = p.splitk;
     }
+    if (dry_split) { *dry_split = splitk; return 0; }
+    // v8: with sk_ticket the tile's last workgroup applies bias / affine / residual / ReLU / statistics (no epilogue pass); with y_zero the output already holds
+    // zeros (no init pass: the bias then comes with the fused epilogue)
+    const bool fused = splitk > 1 && p.sk_ticket && !p.accumulate;
+    mrfa_conv_params pk = p;                                 // what the kernels see
     if (splitk > 1) {
-        if (!p.accumulate) {
+        const bool init = !p.accumulate && !(p.y_zero && (fused || !p.bias));
+        if (init) {
             const long long rows = M * nb;
             MRFA_CHECK_ARG(nb == 1 || p.y_bs == (long long)M * p.ldy, "conv2d: split-K batched output must be dense");
             hipLaunchKernelGGL(splitk_init_kernel, dim3(stream_grid(rows * p.Cout, 256)), dim3(256), 0, st, p.y, p.ldy, rows,
                                p.Cout, p.bias);
             MRFA_CHECK_LAUNCH("splitk_init");
+            pk.bias = nullptr;                               // (written by the init pass)
         }
+        if (!fused) pk.sk_ticket = nullptr;
     }
     g_last_tile = (BM << 16) | (BN << 4) | ((flat ? 1 : 0) << 1) | (splitk > 1 ? 1 : 0);
     int rc = 1;
-#define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, p, KT, M, splitk)
+#define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, pk, KT, M, splitk)
     if (!p.tile && BM == 128 && BN == 128 && !flat) w8 = true;      // 8 waves: 4 waves/SIMD hide the load/barrier phases (+4..13 %)
     if (g_mfma_mode >= 1 && BM == 128 && (BN == 128 || BN == 64) && !flat) {
         g_last_tile |= 4;                                            // bit 2: split-operand kernel
-        rc = mrfa_conv_split_launch(st, p, KT, M, splitk, BN);
-    } else if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, p, KT, M, splitk);
+        rc = mrfa_conv_split_launch(st, pk, KT, M, splitk, BN);
+    } else if (w8 && BM == 128 && BN == 128) rc = launch_cfg<128, 128, 2, 4>(st, pk, KT, M, splitk);
     else CFG(128, 128, 2, 2);
     else CFG(128, 96, 4, 1);
     else CFG(128, 64, 2, 2);
@@ -522,7 +553,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     else { mrfa_set_error("conv2d: no tile config %dx%d", BM, BN); return 1; }
 #undef CFG
     if (rc) return rc;
-    if (splitk > 1 && (p.relu || p.stats || p.out_scale || p.res)) {
+    if (splitk > 1 && !fused && (p.relu || p.stats || p.out_scale || p.res)) {
         MRFA_CHECK_ARG(!p.accumulate, "conv2d: split-K with accumulate cannot apply an epilogue");
         const long long rows = M * nb;
         dim3 grid(cdiv(p.Cout, 64), (unsigned)(rows < 256 ? rows : 256));

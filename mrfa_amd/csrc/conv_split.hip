@@ -305,12 +305,28 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
     // ------------------------------------------------------------------ epilogue of the split-K launches (as conv_mfma.hip)
     const int half = lane >> 5;
     const bool splitk = p.splitk > 1;
+    if (splitk) {
+        // partial tile: device-scope atomics into y (zeros, or the bias written by the init pass)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < p.Cout && m < M) atomicAdd(y + (size_t)m * p.ldy + c, acc[i][j][r] * p.alpha);
+                }
+        }
+        // v8: the workgroup that completes the tile applies the epilogue itself (otherwise splitk_epilogue_kernel does, in a pass of its own)
+        if (!p.sk_ticket || !splitk_last_arriver(p.sk_ticket + (size_t)bz * total_tiles + lin, gridDim.z)) return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int c = n0 + (wn * TN + j) * 32 + (lane & 31);
         const bool c_ok = c < p.Cout;
         float bias = 0.f, osc = 1.f, osh = 0.f;
-        if (c_ok && !splitk) {
+        if (c_ok) {
             if (p.bias) bias = p.bias[c];
             if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
         }
@@ -321,24 +337,20 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             for (int r = 0; r < 16; ++r) {
                 const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (c_ok && m < M) {
-                    float v = acc[i][j][r] * p.alpha;
                     float* dst = y + (size_t)m * p.ldy + c;
-                    if (splitk) {
-                        atomicAdd(dst, v);
-                    } else {
-                        v += bias;
-                        v = v * osc + osh;
-                        if (p.res) v += p.res[(size_t)m * p.ldr + c];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
-                        s1 += v;
-                        s2 += v * v;
-                    }
+                    float v = splitk ? __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[i][j][r] * p.alpha;
+                    v += bias;
+                    v = v * osc + osh;
+                    if (p.res) v += p.res[(size_t)m * p.ldr + c];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.accumulate && !splitk) v += *dst;
+                    *dst = v;
+                    s1 += v;
+                    s2 += v * v;
                 }
             }
         }
-        if (p.stats && !splitk) {
+        if (p.stats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && c_ok) {

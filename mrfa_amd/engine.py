@@ -252,6 +252,7 @@ PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward 
 BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
 # first phase of the BatchNorm backward of single-consumer BatchNorm outputs inside the consumer's data-gradient launch (mrfa_conv_params.bst_*)
 BN_BWD_IN_DGRAD = os.environ.get("MRFA_BN_BWD_IN_DGRAD", "1") != "0"
+FUSED_SPLITK = os.environ.get("MRFA_FUSED_SPLITK", "1") != "0"        # K splits that finish inside their launch (Ctx._conv_out; kept for same-box A/B runs)
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -1018,12 +1019,12 @@ class Ctx:
         assert x.C == cw.Cin, (x.C, cw.Cin)
         Hv, Wv = (x.H * 2, x.W * 2) if ups else (x.H, x.W)
         Ho, Wo = Hv + 2 * cw.pad - cw.R + 1, Wv + 2 * cw.pad - cw.S + 1
-        out = out or self.new(x.N, Ho, Wo, cw.Cout)
-        assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cw.Cout)
+        assert out is None or (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cw.Cout)
         bias = conv.bias if use_bias else None
         direct = (cw.fewout and not ups and pre is None and res is None and stats is None and not relu
                   and x.ld % 4 == 0 and x.coff % 4 == 0)
         if direct:
+            out = out or self.new(x.N, Ho, Wo, cw.Cout)
             self._chk(self.L.mrfa_conv_fewout_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, cw.Cin, cw.fewout_pack().data_ptr(),
                                                   bias.data_ptr() if bias is not None else None, out.ptr, out.ld, cw.Cout, cw.R, cw.pad, 0),
                       "conv_fewout_fwd")
@@ -1075,7 +1076,7 @@ class Ctx:
                     wph, p.w_phase_piece = cw.phase_pack()
                     p.w_phase = wph.data_ptr()
         p.w_rows = cop
-        p.y, p.ldy, p.Cout, p.Hout, p.Wout = out.ptr, out.ld, cw.Cout, Ho, Wo
+        p.Cout, p.Hout, p.Wout = cw.Cout, Ho, Wo
         p.R, p.S, p.pad = cw.R, cw.S, cw.pad
         if pre is not None:
             p.in_scale, p.in_shift, p.in_relu = pre[0].data_ptr(), pre[1].data_ptr(), 1
@@ -1087,6 +1088,8 @@ class Ctx:
         late_stats = False
         if stats is not None:
             p.stats, p.groups = stats.data_ptr(), self.groups
+        out = self._conv_out(p, out, x.N, Ho, Wo, cw.Cout)
+        if stats is not None:
             if self.groups > 1 and not self.L.mrfa_conv2d_groups_supported(C.byref(p)):
                 p.stats, p.groups, late_stats = None, 0, True       # (a tile would straddle two groups: one statistics pass per group behind the launch)
             elif fin is not None:
@@ -1111,6 +1114,28 @@ class Ctx:
             self.tape.append(bwd)
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
+        return out
+
+    def _conv_out(self, p, out: Optional[View], N, Ho, Wo, Cout) -> View:
+        """the output of a forward convolution whose parameter block is complete but for y.  Launches that split K (the low-resolution levels: too few output
+        tiles for 256 CUs) finish inside the launch (mrfa_conv_params.sk_ticket, v8): their tickets and -- when the output is ours to allocate -- the output
+        itself come from the zero-filled arena, so that neither the y = bias pass before nor the affine / residual / ReLU / statistics pass behind such a launch
+        exists (107 launches per training step on the serial low-resolution chains of the hourglasses and the generator's bottleneck)."""
+        rows = N * Ho * Wo
+        if FUSED_SPLITK and rows <= 32768:
+            nt = ((rows + 31) // 32) * ((Cout + 31) // 32)
+            p.sk_ticket = self.pool32.take(nt).data_ptr()
+            if self.L.mrfa_conv2d_split_k(C.byref(p)) > 1:
+                if out is None:
+                    ld = _r4(Cout)
+                    out = View(Storage(self.pool32.take(rows * ld).view(rows, ld)), N, Ho, Wo, Cout)
+                    if self.record and not self.in_backward:
+                        self._register(out.st)
+                    p.y_zero = 1
+            else:
+                p.sk_ticket = None
+        out = out or self.new(N, Ho, Wo, Cout)
+        p.y, p.ldy = out.ptr, out.ld
         return out
 
     def _defer_ok(self, cw: ConvW) -> bool:

@@ -47,6 +47,7 @@ class ConvParams(C.Structure):
         ("bst_x", C.c_void_p), ("bst_ldx", C.c_int), ("bst_scale", C.c_void_p), ("bst_shift", C.c_void_p), ("bst_mean", C.c_void_p),
         ("bst_invstd", C.c_void_p), ("bst_relu", C.c_int),
         ("groups", C.c_int),
+        ("sk_ticket", C.c_void_p), ("y_zero", C.c_int),
     ]
 
 
@@ -161,6 +162,7 @@ _SIGNATURES = {
     "mrfa_timestamp": ([_V, _V], C.c_int),
     "mrfa_conv2d_bwdstats_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_groups_supported": ([C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_split_k": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_bn_param_grad": ([_V, _V, _I, _V, _V], C.c_int),
     "mrfa_bn_param_grad_groups": ([_V, _V, _I, _I, _V, _V], C.c_int),
     "mrfa_warp_frame_reflect": ([_V, _V, _I, _I, _I, _I, _V, _I, _I, _V], C.c_int),
@@ -199,7 +201,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 7        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
+ABI_VERSION = 8        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None
 

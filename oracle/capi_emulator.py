@@ -347,7 +347,7 @@ class Emulator:
 
     # ---------------------------------------------------------------- misc
     def mrfa_version(self):
-        return 7              # MRFA_ABI_VERSION of include/mrfa_hip.h
+        return 8              # MRFA_ABI_VERSION of include/mrfa_hip.h
 
     def mrfa_last_error(self):
         return self._err
@@ -457,8 +457,15 @@ class Emulator:
             assert acc.shape[2] == p.Hout and acc.shape[3] == p.Wout, (acc.shape, p.Hout, p.Wout)
             v = acc.permute(0, 2, 3, 1)
             y = nhwc(yp, p.N, p.Hout, p.Wout, p.ldy, p.Cout)
-            if p.splitk > 1 and False:
-                pass
+            if b == 0 and not p.accumulate and self.mrfa_conv2d_split_k(pref) > 1:
+                # v8: what a caller promises to a launch that splits K
+                if p.y_zero:
+                    assert float(y.abs().max()) == 0.0, "y_zero = 1 but y does not hold zeros"
+                if p.sk_ticket:
+                    nt = -(-p.N * p.Hout * p.Wout // 32) * -(-p.Cout // 32) * nb
+                    tk = vec(p.sk_ticket, nt, torch.int32)
+                    assert int(tk.abs().max()) == 0, "sk_ticket words must be zero on entry (fresh per call)"
+                    tk.fill_(2)                      # (the library leaves the tickets it drew in them)
             if p.bias:
                 v = v + vec(p.bias, p.Cout)
             if p.out_scale:
@@ -497,6 +504,19 @@ class Emulator:
             return self.mrfa_bn_finalize_groups(stream, p.stats, p.fin_count, p.fin_gamma, p.fin_beta, p.fin_rmean, p.fin_rvar, p.fin_momentum,
                                                 p.fin_eps, p.Cout, _groups(p), p.fin_scale, p.fin_shift, p.fin_mean, p.fin_invstd)
         return 0
+
+    def mrfa_conv2d_split_k(self, pref):
+        """v8.  The emulator never splits anything; it ANSWERS like a library that splits K on launches with few output tiles, so that callers' handling of
+        sk_ticket / y_zero runs on the CPU too (mrfa_conv2d_nhwc below checks their promises)"""
+        p = _obj(pref)
+        if p.splitk > 1:
+            return p.splitk
+        M = p.N * p.Hout * p.Wout
+        K = p.kflat if p.kflat > 0 else p.R * p.S * p.Cin
+        small = (p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and M <= 65536 and p.Cout <= 640
+                 and K <= 1152 and 2.0 * M * p.Cout * K <= 1.3e9)
+        tiles = -(-M // 128) * -(-p.Cout // 128) * max(p.nbatch, 1)
+        return 2 if (p.splitk == 0 and not small and tiles < 384 and K >= 128 and p.stride <= 1) else 1
 
     def mrfa_conv2d_groups_supported(self, pref):
         """the library's rule (the emulator itself honours `groups` for every shape)"""

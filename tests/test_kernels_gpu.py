@@ -82,7 +82,7 @@ def ktab(side, Cc, R, S, pad):
 
 def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, bias=True, relu=True, res=False,
               stats=False, acc=False, alpha=1.0, tile=0, splitk=1, oaff=False, ldx_extra=0, ldy_extra=4, wsplit=False, wphase=False, mask=False,
-              stride=1, fin=False, bst=False, groups=1, tag="c"):
+              stride=1, fin=False, bst=False, groups=1, fused=False, tag="c"):
     S = R
     x = side.t(f"{tag}/x", (N * H * W, Cin + ldx_extra))
     w = side.t(f"{tag}/w", (Cout, Cin, R, S), -0.2, 0.2)
@@ -90,7 +90,7 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     Hv, Wv = H << ups, W << ups
     Ho, Wo = (Hv + 2 * pad - R) // stride + 1, (Wv + 2 * pad - S) // stride + 1
     ldy = (Cout + 3) // 4 * 4 + ldy_extra
-    y = side.t(f"{tag}/y0", (N * Ho * Wo, ldy)) if acc else side.garbage((N * Ho * Wo, ldy))
+    y = side.t(f"{tag}/y0", (N * Ho * Wo, ldy)) if acc else (side.z((N * Ho * Wo, ldy)) if fused == "zero" else side.garbage((N * Ho * Wo, ldy)))
     p = hip.ConvParams()
     p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.data_ptr(), x.shape[1], H, W, ups, N, Cin
     cop = (Cout + 127) // 128 * 128
@@ -175,6 +175,11 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         keep.append(mk)
         p.mask, p.ldm = mk.data_ptr(), Cout + 8
     p.alpha, p.accumulate, p.nbatch, p.splitk, p.tile = alpha, int(acc), 1, splitk, tile
+    if fused:                       # v8: a K split that finishes inside its launch ("zero": the output is handed over zero-filled, no init pass either)
+        tk = side.z((-(-N * Ho * Wo // 32) * -(-Cout // 32),), torch.int32)
+        keep.append(tk)
+        p.sk_ticket, p.y_zero = tk.data_ptr(), int(fused == "zero")
+        assert side.L.mrfa_conv2d_split_k(C.byref(p)) > 1, "the case is meant to split K"
     if stride > 1:
         p.stride = stride
         assert side.L.mrfa_conv2d_stride_supported(C.byref(p)) == 1
@@ -213,6 +218,13 @@ CONV_CASES = {
     "splitk4_relu_stats": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True),
     "splitk_auto_small": dict(N=1, H=2, W=2, Cin=512, Cout=512, splitk=0, stats=True, relu=False),
     "splitk3_accumulate": dict(N=1, H=4, W=4, Cin=128, Cout=64, splitk=3, acc=True, relu=False, bias=False),
+    # v8: the split finishes inside the launch (sk_ticket; "zero": zero-filled output, no init pass): every epilogue option, ragged tiles, statistic groups
+    "fused_splitk4_relu_stats": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, fused="zero"),
+    "fused_splitk_auto_res_stats": dict(N=1, H=2, W=2, Cin=512, Cout=512, splitk=0, stats=True, res=True, fused="zero"),
+    "fused_splitk3_ticket_only_affine": dict(N=1, H=5, W=7, Cin=128, Cout=96, splitk=3, oaff=True, fused="ticket"),
+    "fused_splitk_plain_nobias": dict(N=2, H=4, W=4, Cin=256, Cout=130, splitk=5, relu=False, bias=False, fused="zero"),
+    "fused_splitk_fp32_tile": dict(N=1, H=6, W=6, Cin=128, Cout=64, splitk=4, tile=(64 << 16) | 64, stats=True, res=True, fused="zero"),
+    "fused_splitk_groups2_fin": dict(N=4, H=8, W=8, Cin=512, Cout=512, splitk=0, stats=True, relu=False, fin=True, groups=2, fused="zero"),
     # conv_small.hip (one wave per 16..32-row tile, no LDS): the MTIA prior's shapes, every epilogue option, ragged M / Cout
     "small_hr32_stats": dict(N=2, H=16, W=16, Cin=32, Cout=32, stats=True, relu=False, bias=False),
     "small_hr64_res": dict(N=2, H=8, W=8, Cin=64, Cout=64, res=True, relu=True),
@@ -294,6 +306,8 @@ SPLIT_CASES = {
     "ups_res_stats": dict(ups=1, H=6, W=5, Cin=128, Cout=256, res=True, stats=True, relu=False, tile=(128 << 16) | 128),
     "conv1x1_affine": dict(R=1, pad=0, Cin=256, Cout=128, oaff=True, N=4, H=16, W=16, tile=(128 << 16) | 128),
     "splitk4": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, tile=(128 << 16) | 128),
+    "fused_splitk4": dict(N=1, H=4, W=4, Cin=256, Cout=128, splitk=4, stats=True, res=True, tile=(128 << 16) | 128, fused="zero"),
+    "fused_splitk6_bn64_ticket": dict(N=2, H=8, W=8, Cin=256, Cout=50, splitk=6, oaff=True, tile=(128 << 16) | 64, fused="ticket"),
     "accumulate_alpha": dict(acc=True, alpha=0.37, relu=False, bias=False, Cin=64, Cout=128, tile=(128 << 16) | 128),
     "auto_256_to_128": dict(N=4, H=128, W=128, Cin=256, Cout=128),
     "bn64_c64": dict(N=2, H=32, W=32, Cin=128, Cout=64, tile=(128 << 16) | 64, res=True, stats=True),
