@@ -113,6 +113,50 @@ __device__ __forceinline__ bool splitk_last_arriver(unsigned* ticket, unsigned n
     return s_sk_ticket == nsplit - 1;
 }
 
+// BatchNorm finalize by the LAST workgroup of a launch that accumulates the statistics (mrfa_conv_params.fin_*): called by EVERY thread of each of the
+// `participants` workgroups that added into p.stats, behind those atomics; whoever draws the last ticket reads all slots and writes what bn_finalize_kernel
+// would have.  No release / acquire FENCES: an agent-scope fence writes back (release) or invalidates (acquire) the XCD's whole L2 -- with one per workgroup
+// the training step went from 83 to 98 ms.  None is needed: the slot sums are device-scope atomics (performed at the memory side, never left dirty in an L2),
+// every thread that issued some WAITS FOR THEIR COMPLETION (the explicit s_waitcnt vmcnt(0): returnless atomics count in vmcnt, and neither the back-off barrier
+// of gfx950 nor a relaxed ticket makes hipcc emit that wait by itself -- round 4 shipped without it) before the barrier that precedes the ticket --
+// also a device-scope atomic --, and the last workgroup reads the slots with device-scope loads, which bypass the non-coherent L2s (the guide's "sc1 stores AND
+// sc1 loads" hand-off).  tests/test_wiring_cpu.py checks the compiled ISA of every kernel that calls this for the wait.
+__device__ __forceinline__ void fused_bn_finalize(const mrfa_conv_params& p, unsigned participants) {
+    __shared__ unsigned s_fin_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_fin_ticket = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_fin_ticket != participants - 1) return;
+    const double cnt = (double)p.fin_count;
+    const int G = p.groups > 1 ? p.groups : 1;
+    for (int c = threadIdx.x; c < p.Cout; c += blockDim.x) {
+        float rm = p.fin_rmean ? p.fin_rmean[c] : 0.f, rv = p.fin_rmean ? p.fin_rvar[c] : 0.f;
+        for (int g = 0; g < G; ++g) {                 // (statistic groups: one momentum update per group, in group order)
+            const double* sg = p.stats + (size_t)g * MRFA_STATS_SLOTS * 2 * p.Cout;
+            double t1 = 0.0, t2 = 0.0;
+            for (int s = 0; s < MRFA_STATS_SLOTS; ++s) {
+                t1 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t2 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const double m = t1 / cnt;
+            double var = t2 / cnt - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)p.fin_eps));
+            const double unb = p.fin_count > 1 ? var * cnt / (cnt - 1.0) : var;
+            rm = (1.f - p.fin_momentum) * rm + p.fin_momentum * mean;
+            rv = (1.f - p.fin_momentum) * rv + p.fin_momentum * (float)unb;
+            const float sc = p.fin_gamma[c] * invstd;
+            const int gc = g * p.Cout + c;
+            p.fin_scale[gc] = sc;
+            p.fin_shift[gc] = p.fin_beta[c] - mean * sc;
+            if (p.fin_mean) p.fin_mean[gc] = mean;
+            if (p.fin_invstd) p.fin_invstd[gc] = invstd;
+        }
+        if (p.fin_rmean) { p.fin_rmean[c] = rm; p.fin_rvar[c] = rv; }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -408,6 +408,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
+    if (p.fin_scale) fused_bn_finalize(p, (unsigned)total_tiles * gridDim.y);      // (every workgroup with a tile reaches this point with all of its threads)
 }
 
 int g_halo_on = -1;              // -1: not initialised (MRFA_CONV_HALO)

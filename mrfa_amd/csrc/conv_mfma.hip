@@ -283,6 +283,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_mfma_kernel(const
             }
         }
     }
+    if (p.fin_scale) fused_bn_finalize(p, (unsigned)total_tiles);      // (without a split: every workgroup with a tile; with one: the tile's last arriver)
 }
 
 // y = bias (or 0) broadcast: initialises the output of a split-K launch
@@ -460,6 +461,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     // ---- 3x3 stride-1 layers with 32-aligned rows in split-operand mode: patch-tiled kernel, input halo split once per chunk (conv_halo.hip)
     if (!flat && mrfa_conv_halo_eligible(p)) {
         if (dry_split) { *dry_split = 1; return 0; }
+        *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup, common.h: fused_bn_finalize)
         g_last_tile = (128 << 16) | ((p.Cout <= 64 ? 64 : 128) << 4) | 4 | (1 << 28);       // bit 28: conv_halo
         return mrfa_conv_halo_launch(st, p);
     }
@@ -535,6 +537,9 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         }
         if (!fused) pk.sk_ticket = nullptr;
     }
+    // the BatchNorm that follows (fin_*): finished by the launch's last workgroup, except behind a K split with an epilogue pass and in batched launches
+    if (p.fin_scale && nb == 1 && (splitk == 1 || fused)) *fin_done = true;
+    else pk.fin_scale = nullptr;
     g_last_tile = (BM << 16) | (BN << 4) | ((flat ? 1 : 0) << 1) | (splitk > 1 ? 1 : 0);
     int rc = 1;
 #define CFG(bm, bn, wm, wn) if (BM == bm && BN == bn) rc = launch_cfg<bm, bn, wm, wn>(st, pk, KT, M, splitk)

@@ -225,50 +225,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
                 atomicAdd(stat_slot(p, grp, blockIdx.x) + which * p.Cout + c, v);
             }
         }
-        if (p.fin_scale) {
-            // BatchNorm finalize by the LAST workgroup of the launch (mrfa_conv_params.fin_*): every workgroup takes a ticket once its slot sums are out;
-            // whoever draws the last one reads all slots and writes what bn_finalize_kernel would have.  No release / acquire FENCES: an agent-scope
-            // fence writes back (release) or invalidates (acquire) the XCD's whole L2 -- with one per workgroup the training step went from 83 to 98 ms.
-            // None is needed: the slot sums are device-scope atomics (performed at the memory side, never left dirty in an L2), every thread that issued
-            // some WAITS FOR THEIR COMPLETION (the explicit s_waitcnt vmcnt(0) below: returnless atomics count in vmcnt, and neither the back-off barrier of
-            // gfx950 nor a relaxed ticket makes hipcc emit that wait by itself -- round 4 shipped without it) before the barrier that precedes
-            // the ticket -- also a device-scope atomic --, and the last workgroup reads the slots with device-scope loads, which bypass the non-coherent
-            // L2s (the guide's "sc1 stores AND sc1 loads" hand-off).  tests/test_wiring_cpu.py checks the compiled ISA for the wait.
-            __shared__ unsigned s_ticket;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (s_ticket == gridDim.x - 1) {
-                const double cnt = (double)p.fin_count;
-                const int G = p.groups > 1 ? p.groups : 1;
-                for (int c = threadIdx.x; c < p.Cout; c += 256) {
-                    float rm = p.fin_rmean ? p.fin_rmean[c] : 0.f, rv = p.fin_rmean ? p.fin_rvar[c] : 0.f;
-                    for (int g = 0; g < G; ++g) {                 // (statistic groups: one momentum update per group, in group order)
-                        const double* sg = p.stats + (size_t)g * MRFA_STATS_SLOTS * 2 * p.Cout;
-                        double t1 = 0.0, t2 = 0.0;
-                        for (int s = 0; s < MRFA_STATS_SLOTS; ++s) {
-                            t1 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            t2 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        const double m = t1 / cnt;
-                        double var = t2 / cnt - m * m;
-                        if (var < 0.0) var = 0.0;
-                        const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)p.fin_eps));
-                        const double unb = p.fin_count > 1 ? var * cnt / (cnt - 1.0) : var;
-                        rm = (1.f - p.fin_momentum) * rm + p.fin_momentum * mean;
-                        rv = (1.f - p.fin_momentum) * rv + p.fin_momentum * (float)unb;
-                        const float sc = p.fin_gamma[c] * invstd;
-                        const int gc = g * p.Cout + c;
-                        p.fin_scale[gc] = sc;
-                        p.fin_shift[gc] = p.fin_beta[c] - mean * sc;
-                        if (p.fin_mean) p.fin_mean[gc] = mean;
-                        if (p.fin_invstd) p.fin_invstd[gc] = invstd;
-                    }
-                    if (p.fin_rmean) { p.fin_rmean[c] = rm; p.fin_rvar[c] = rv; }
-                }
-            }
-        }
+        if (p.fin_scale) fused_bn_finalize(p, gridDim.x);       // (common.h: the launch's last workgroup finishes the BatchNorm that follows)
     }
 }
 

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             }
         }
     }
+        if (p.fin_scale) fused_bn_finalize(p, (unsigned)total_tiles);      // (a K split that finishes inside the launch: one last-arriving workgroup per tile gets here)
         return;
     } else {
     // ------------------------------------------------------------------ epilogue
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             }
         }
     }
+    if (p.fin_scale) fused_bn_finalize(p, (unsigned)total_tiles);
     }
 }
 

@@ -1390,6 +1390,11 @@ class Ctx:
             self._chk(self.L.mrfa_bn_stats(self.s, x.ptr + 4 * g * rows * x.ld, x.ld, rows, x.C, stats.data_ptr() + 8 * g * hip.STATS_SLOTS * 2 * x.C),
                       "bn_stats")
 
+    @staticmethod
+    def fin(bn):
+        """the `fin=` argument of conv() for a convolution whose statistics `bn` consumes (None: the finalize stays a launch of its own)"""
+        return bn if BN_FIN_FUSED else None
+
     def _fin_params(self, p, bn, stats, count: int):
         """BatchNorm finalize inside the convolution launch that accumulates `stats` (mrfa_conv_params.fin_*): the small-problem kernel's last
         workgroup does it, every other kernel is followed by the finalize launch inside the call -- bn_act() then finds the result here

@@ -57,7 +57,7 @@ class OcclusionAwareGenerator(nn.Module):
         for i in range(n_up):
             if cat_bufs is not None:
                 st = e.bn_stats_buf(self.resblock[i].norm1)
-                out = self.channel_block[i].run(e, out, out_stats=st)
+                out = self.channel_block[i].run(e, out, out_stats=st, out_fin=e.fin(self.resblock[i].norm1))
                 out = self.resblock[i].run(e, out, x_stats=st)
             else:
                 out = self.resblock[i].run(e, out)

@@ -146,7 +146,7 @@ class DownBlock2d(_Block):
 
     def run(self, e: Ctx, x: View, out: Optional[View] = None, need_dx=True) -> View:
         st = e.bn_stats_buf(self.norm)
-        raw = e.conv(x, self.conv, stats=st, need_dx=need_dx)
+        raw = e.conv(x, self.conv, stats=st, need_dx=need_dx, fin=e.fin(self.norm))
         return e.bn_act(raw, self.norm, st, relu=True, pool=True, out=out, sole_consumer=True)
 
 
@@ -161,7 +161,7 @@ class UpBlock2d(_Block):
 
     def run(self, e: Ctx, x: View, out: Optional[View] = None, blend=None) -> View:
         st = e.bn_stats_buf(self.norm)
-        raw = e.conv(x, self.conv, stats=st, ups=True)
+        raw = e.conv(x, self.conv, stats=st, ups=True, fin=e.fin(self.norm))
         return e.bn_act(raw, self.norm, st, relu=True, blend=blend, out=out, sole_consumer=True)
 
 
@@ -176,7 +176,7 @@ class SameBlock2d(_Block):
 
     def run(self, e: Ctx, x: View, out: Optional[View] = None, need_dx=True) -> View:
         st = e.bn_stats_buf(self.norm)
-        raw = e.conv(x, self.conv, stats=st, need_dx=need_dx)
+        raw = e.conv(x, self.conv, stats=st, need_dx=need_dx, fin=e.fin(self.norm))
         return e.bn_act(raw, self.norm, st, relu=True, out=out, sole_consumer=True)
 
 
@@ -193,7 +193,7 @@ class ResBlock2d(_Block):
     def run(self, e: Ctx, x: View, out: Optional[View] = None, x_stats=None) -> View:
         pre1 = e.prebn(x, self.norm1, x_stats)
         st2 = e.bn_stats_buf(self.norm2)
-        y1 = e.conv(x, self.conv1, pre=pre1, stats=st2)
+        y1 = e.conv(x, self.conv1, pre=pre1, stats=st2, fin=e.fin(self.norm2))
         pre2 = e.prebn(y1, self.norm2, st2)
         return e.conv(y1, self.conv2, out=out, pre=pre2, res=x)
 
@@ -206,9 +206,9 @@ class ChannelBlock2d(_Block):
         self.conv1 = nn.Conv2d(in_features, in_features // 2, kernel_size=kernel_size, padding=padding)
         self.norm1 = BatchNorm2d(in_features, affine=True)
 
-    def run(self, e: Ctx, x: View, out: Optional[View] = None, out_stats=None) -> View:
+    def run(self, e: Ctx, x: View, out: Optional[View] = None, out_stats=None, out_fin=None) -> View:
         pre = e.prebn(x, self.norm1)
-        return e.conv(x, self.conv1, out=out, pre=pre, stats=out_stats)
+        return e.conv(x, self.conv1, out=out, pre=pre, stats=out_stats, fin=out_fin)
 
 
 class Encoder(nn.Module):

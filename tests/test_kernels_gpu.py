@@ -224,6 +224,8 @@ CONV_CASES = {
     "fused_splitk3_ticket_only_affine": dict(N=1, H=5, W=7, Cin=128, Cout=96, splitk=3, oaff=True, fused="ticket"),
     "fused_splitk_plain_nobias": dict(N=2, H=4, W=4, Cin=256, Cout=130, splitk=5, relu=False, bias=False, fused="zero"),
     "fused_splitk_fp32_tile": dict(N=1, H=6, W=6, Cin=128, Cout=64, splitk=4, tile=(64 << 16) | 64, stats=True, res=True, fused="zero"),
+    "fused_splitk_fin": dict(N=2, H=8, W=8, Cin=512, Cout=256, splitk=0, stats=True, relu=False, fin=True, fused="zero"),
+    "tile_fin_nosplit": dict(N=4, H=32, W=32, Cin=128, Cout=96, R=1, pad=0, tile=(128 << 16) | 96, stats=True, relu=False, fin=True),
     "fused_splitk_groups2_fin": dict(N=4, H=8, W=8, Cin=512, Cout=512, splitk=0, stats=True, relu=False, fin=True, groups=2, fused="zero"),
     # conv_small.hip (one wave per 16..32-row tile, no LDS): the MTIA prior's shapes, every epilogue option, ragged M / Cout
     "small_hr32_stats": dict(N=2, H=16, W=16, Cin=32, Cout=32, stats=True, relu=False, bias=False),
@@ -360,6 +362,8 @@ HALO_CASES = {          # conv_halo.hip: 3x3 / pad 1 / stride 1, Wout % 32 == 0;
     "phase_up_c130_acc": dict(N=1, H=8, W=64, Cin=32, Cout=130, ups=1, acc=True, alpha=0.5, bias=False, wphase=True),
     # v7: statistic groups (a patch lies inside one image): layer1's 64 -> 64 @64^2 of the keypoint encoder with the finalize behind the launch
     "groups2_layer1_fin": dict(N=4, H=32, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "decoder_down_fin": dict(N=2, H=32, W=32, Cin=64, Cout=128, stats=True, relu=False, fin=True),          # (the finalize by the launch's last workgroup)
+    "decoder_ups_fin_c192": dict(N=1, H=16, W=16, Cin=128, Cout=192, ups=1, stats=True, relu=False, fin=True),
     "groups3_c128_res": dict(N=3, H=16, W=32, Cin=32, Cout=128, res=True, stats=True, groups=3),
 }
 

@@ -872,33 +872,33 @@ def test_statistic_groups_equal_separate_calls(frames):
         assert (p.grad - q.grad).abs().max().item() <= 1e-4 * sc + 1e-7, (n, (p.grad - q.grad).abs().max().item(), sc)
 
 
-def test_fused_finalize_waits_for_its_statistics_atomics_before_the_ticket(tmp_path):
-    """conv_small.hip hands the BatchNorm statistics to the launch's LAST workgroup without fences -- device-scope fp64 atomics into the
-    slots, a barrier, a device-scope ticket.  That is only a hand-off if every thread WAITS for its slot atomics (s_waitcnt vmcnt(0)) before the barrier;
-    neither gfx950's back-off barrier nor a relaxed ticket makes the compiler emit the wait (round 4 shipped without it).  This compiles the file to ISA
-    and checks, in every kernel that draws a ticket, that a full vmcnt wait sits between the last f64 slot atomic and the barrier before the ticket."""
+@pytest.mark.parametrize("src,kernel,least", [("conv_small", "conv_small_kernel", 6), ("conv_mfma", "conv_mfma_kernel", 8), ("conv_split", "conv_bf16x6_kernel", 8),
+                                              ("conv_halo", "conv_halo_kernel", 20)])
+def test_fused_finalize_waits_for_its_statistics_atomics_before_the_ticket(tmp_path, src, kernel, least):
+    """the fence-free hand-offs to a launch's LAST workgroup (common.h: fused_bn_finalize -- the BatchNorm statistics, device-scope fp64
+    atomics into the slots -- and splitk_last_arriver -- the partial tiles of a K split, device-scope fp32 atomics into y): a barrier, then a device-scope
+    ticket.  That is only a hand-off if every thread WAITS for its atomics (s_waitcnt vmcnt(0)) before the barrier; neither gfx950's back-off barrier nor a
+    relaxed ticket makes the compiler emit the wait (round 4 shipped conv_small.hip without it).  This compiles each file that draws tickets to ISA and checks, in
+    every kernel and for every ticket, that a full vmcnt wait sits between the last floating-point atomic before it and the barrier before the ticket."""
     import re
     import shutil
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which(hipcc)):
         pytest.skip("no hipcc")
-    out = tmp_path / "conv_small.s"
+    out = tmp_path / (src + ".s")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mrfa_amd", "csrc"),
-                           "--offload-device-only", "-S", os.path.join(ROOT, "mrfa_amd", "csrc", "conv_small.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
-    kernels = re.split(r"^(_Z\w*conv_small_kernel\w*):[^\n]*$", out.read_text(), flags=re.M)
+                           "--offload-device-only", "-S", os.path.join(ROOT, "mrfa_amd", "csrc", src + ".hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    kernels = re.split(r"^(_Z\w*" + kernel + r"\w*):[^\n]*$", out.read_text(), flags=re.M)
     checked = 0
     for name, body in zip(kernels[1::2], kernels[2::2]):
         lines = body.split("\n")
-        tickets = [i for i, ln in enumerate(lines) if re.search(r"global_atomic_add(_u32)?\s+v\d+, v\d+, v\d+, .*sc0", ln)]       # the returning (ticket) atomic
-        if not tickets:
-            continue
-        assert len(tickets) == 1, (name, tickets)
-        t = tickets[0]
-        atoms = [i for i in range(t) if "global_atomic_add_f64" in lines[i]]
-        assert atoms, name
-        between = lines[atoms[-1] + 1:t]
-        bar = max(i for i, ln in enumerate(between) if "s_barrier" in ln)
-        assert any(re.search(r"s_waitcnt\s+vmcnt\(0\)", ln) for ln in between[:bar]), \
-            f"{name}: no s_waitcnt vmcnt(0) between the statistics atomics and the barrier before the ticket"
-        checked += 1
-    assert checked >= 6, checked        # every instantiation of the kernel carries the epilogue
+        tickets = [i for i, ln in enumerate(lines) if re.search(r"global_atomic_add(_u32)?\s+v\d+, v\d+, v\d+, .*sc0", ln)]       # the returning (ticket) atomics
+        for t in tickets:
+            atoms = [i for i in range(t) if re.search(r"global_atomic_add_f(64|32)", lines[i])]
+            assert atoms, name
+            between = lines[atoms[-1] + 1:t]
+            bar = max(i for i, ln in enumerate(between) if "s_barrier" in ln)
+            assert any(re.search(r"s_waitcnt\s+vmcnt\(0\)", ln) for ln in between[:bar]), \
+                f"{name}: no s_waitcnt vmcnt(0) between the atomics and the barrier before the ticket at line {t}"
+            checked += 1
+    assert checked >= least, checked        # every instantiation of the kernel carries the epilogue
