@@ -38,7 +38,7 @@ const char* mrfa_last_error(void);
  *      small convolution behind mrfa_set_tuning("conv_lds"), the Winograd-along-x form (w_wino stays in the struct, reserved; pack modes 16 / 17 and its
  *      `..._wino_supported` query are gone).
  *   8  round 5: mrfa_conv_params += sk_ticket, y_zero (a K split that finishes inside its launch: no init pass, no epilogue pass) with the query
- *      mrfa_conv2d_split_k().                                                                                                              */
+ *      mrfa_conv2d_split_k(); mrfa_layernorm_bwd += scratch.                                                                                                           */
 #define MRFA_ABI_VERSION 8
 int mrfa_version(void);
 
@@ -413,8 +413,12 @@ int mrfa_upsample_add_act_bwd(void* stream, const float* y, int ldy, const float
  * [rows] are saved for the backward                                                                               */
 int mrfa_layernorm_fwd(void* stream, const float* x, int ldx, long long rows, int C, const float* gamma, const float* beta, float eps,
                        float* y, int ldy, float* mean, float* rstd);
+/* scratch (v8; may be NULL): MRFA_LN_SLOTS * 2 * C + 1 ZEROED floats, fresh per call -- the workgroups' parameter-gradient partials meet in MRFA_LN_SLOTS slotted
+ * blocks instead of in dgamma / dbeta themselves (hundreds of workgroups adding into the same 2 C words serialise at the memory side) and the launch's last
+ * workgroup (ticket: the word behind the slots) adds their sum to dgamma / dbeta -- nothing else may write those while the launch runs                       */
+#define MRFA_LN_SLOTS 16
 int mrfa_layernorm_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, const float* gamma,
-                       const float* mean, const float* rstd, float* dx /*+=*/, int lddx, float* dgamma /*+=*/, float* dbeta /*+=*/);
+                       const float* mean, const float* rstd, float* dx /*+=*/, int lddx, float* dgamma /*+=*/, float* dbeta /*+=*/, float* scratch);
 /* exact (erf) GELU, nn.GELU() at tokenpose_base.py:51                                                             */
 int mrfa_gelu_fwd(void* stream, const float* x, int ldx, long long rows, int C, float* y, int ldy);
 int mrfa_gelu_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, float* dx /*+=*/, int lddx);

@@ -138,52 +138,78 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx += rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma ; dgamma += sum_r dy*xhat ; dbeta += sum_r dy
+// KMAX = 64-channel chunks a lane holds (4: C <= 256, the token transformer's 192; 16: C <= 1024); RU = rows of a wave whose loads are issued together (the
+// loop was one row at a time: eight dependent load -> shuffle-reduce -> store round trips per wave, 59 us per launch over 4 416 x 192 in the training step).
+// Parameter gradients: waves -> LDS -> per workgroup ONE atomic per channel, into slot (workgroup % LN_SLOTS) of `scratch` [LN_SLOTS][2][C] (138-276
+// workgroups adding into the same 2 C words serialise at the memory side); the launch's last workgroup (ticket word behind the slots; the hand-off of
+// common.h: fused_bn_finalize) sums the slots and adds them to dgamma / dbeta.  scratch == NULL: the atomics go to dgamma / dbeta directly.
+constexpr int LN_SLOTS = MRFA_LN_SLOTS;
+template <int KMAX, int RU>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                            long long rows, int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int rows_per_wave) {
+                                                           float* __restrict__ dbeta, int rows_per_wave, float* __restrict__ scratch) {
     chain_prio();
     __shared__ float red[2][4][64 * 4];            // per wave partials for up to 256 channels at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long w_id = (long long)blockIdx.x * 4 + wave;
     const long long r0 = w_id * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
-    float pg[LN_MAXK], pb[LN_MAXK];
+    float pg[KMAX], pb[KMAX], gm[KMAX];
 #pragma unroll
-    for (int k = 0; k < LN_MAXK; ++k) pg[k] = pb[k] = 0.f;
-    for (long long r = r0; r < r1; ++r) {
-        const float m = mean[r], rs = rstd[r];
-        float xh[LN_MAXK], g[LN_MAXK];
-        float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < KMAX; ++k) {
+        pg[k] = pb[k] = 0.f;
+        gm[k] = (k * 64 + lane) < C ? gamma[k * 64 + lane] : 0.f;
+    }
+    for (long long rb = r0; rb < r1; rb += RU) {
+        float xv[RU][KMAX], dv[RU][KMAX], ov[RU][KMAX], m[RU], rs[RU];
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
-            const int c = k * 64 + lane;
-            if (c < C) {
-                const float d = dy[(size_t)r * lddy + c];
-                xh[k] = (x[(size_t)r * ldx + c] - m) * rs;
-                g[k] = d * gamma[c];
-                pg[k] += d * xh[k];
-                pb[k] += d;
-                s1 += g[k];
-                s2 += g[k] * xh[k];
-            } else {
-                xh[k] = g[k] = 0.f;
+        for (int u = 0; u < RU; ++u) {
+            const long long r = min(rb + u, r1 - 1);                      // (past the end: a re-read of the last row, never stored)
+            m[u] = mean[r];
+            rs[u] = rstd[r];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = k * 64 + lane;
+                const bool ok = c < C;
+                xv[u][k] = ok ? x[(size_t)r * ldx + c] : 0.f;
+                dv[u][k] = ok ? dy[(size_t)r * lddy + c] : 0.f;
+                ov[u][k] = ok ? dx[(size_t)r * lddx + c] : 0.f;
             }
         }
-        const float k1 = wave_sum(s1) / (float)C, k2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
-            const int c = k * 64 + lane;
-            if (c < C) dx[(size_t)r * lddx + c] += rs * (g[k] - k1 - xh[k] * k2);
+        for (int u = 0; u < RU; ++u) {
+            const bool live = rb + u < r1;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const float xh = (xv[u][k] - m[u]) * rs[u];
+                const float g = dv[u][k] * gm[k];
+                if (live) { pg[k] += dv[u][k] * xh; pb[k] += dv[u][k]; }
+                s1 += g;
+                s2 += g * xh;
+                xv[u][k] = xh;
+                dv[u][k] = g;
+            }
+            const float k1 = wave_sum(s1) / (float)C, k2 = wave_sum(s2) / (float)C;
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int c = k * 64 + lane;
+                    if (c < C) dx[(size_t)(rb + u) * lddx + c] = ov[u][k] + rs[u] * (dv[u][k] - k1 - xv[u][k] * k2);
+                }
+            }
         }
     }
     // parameter gradients: waves of the block -> LDS -> one atomic per channel per block, 256 channels per round
+    float* ag = scratch ? scratch + (size_t)(blockIdx.x % LN_SLOTS) * 2 * C : dgamma;
+    float* ab = scratch ? ag + C : dbeta;
     for (int k0 = 0; k0 * 64 < C; k0 += 4) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int k = 0; k < LN_MAXK; ++k)
+            for (int k = 0; k < KMAX; ++k)
                 if (k == k0 + kk) { a = pg[k]; b = pb[k]; }
             red[0][wave][kk * 64 + lane] = a;
             red[1][wave][kk * 64 + lane] = b;
@@ -194,10 +220,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { a += red[0][w][threadIdx.x]; b += red[1][w][threadIdx.x]; }
-            if (dgamma) atomicAdd(dgamma + c, a);
-            if (dbeta) atomicAdd(dbeta + c, b);
+            if (ag) atomicAdd(ag + c, a);
+            if (ab) atomicAdd(ab + c, b);
         }
         __syncthreads();
+    }
+    if (scratch) {
+        __shared__ unsigned s_ticket;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(scratch + (size_t)LN_SLOTS * 2 * C), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket == gridDim.x - 1) {
+            for (int c = threadIdx.x; c < 2 * C; c += 256) {
+                float t = 0.f;
+                for (int sl = 0; sl < LN_SLOTS; ++sl) t += __hip_atomic_load(scratch + (size_t)sl * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float* dst = c < C ? dgamma : dbeta;
+                if (dst) dst[c < C ? c : c - C] += t;
+            }
+        }
     }
 }
 
@@ -496,11 +538,17 @@ extern "C" int mrfa_layernorm_fwd(void* stream, const float* x, int ldx, long lo
 }
 
 extern "C" int mrfa_layernorm_bwd(void* stream, const float* x, int ldx, const float* dy, int lddy, long long rows, int C, const float* gamma,
-                                  const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta) {
+                                  const float* mean, const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, float* scratch) {
     MRFA_CHECK_ARG(x && dy && gamma && mean && rstd && dx && rows > 0 && C > 0 && C <= 64 * LN_MAXK, "layernorm_bwd: bad args (C <= 1024)");
-    const int rpw = rows >= 4096 ? 8 : 2;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4 * rpw)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, rows, C, gamma, mean,
-                       rstd, dx, lddx, dgamma, dbeta, rpw);
+    // rows per wave: with the slotted parameter-gradient partials more workgroups cost no more atomic contention
+    const int rpw = scratch ? (rows >= 2048 ? 4 : 2) : (rows >= 4096 ? 8 : 2);
+    const dim3 grid(cdiv(rows, 4 * rpw));
+    if (C <= 256)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, rows, C, gamma, mean, rstd, dx, lddx, dgamma,
+                           dbeta, rpw, scratch);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, rows, C, gamma, mean, rstd, dx, lddx, dgamma,
+                           dbeta, rpw, scratch);
     MRFA_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }

@@ -1904,8 +1904,9 @@ class Ctx:
                 if bg not in self.touched_bns:
                     self.touched_bns.append(bg)
                 dg, db = bg.acc(self.pool32)
+                scr = self.pool32.take(hip.LN_SLOTS * 2 * x.C + 1)          # slotted partials of the parameter gradients + the ticket word
                 self._chk(self.L.mrfa_layernorm_bwd(self.s, x.ptr, x.ld, out.gptr, out.ld, x.rows, x.C, ln.weight.data_ptr(), mean.data_ptr(),
-                                                    rstd.data_ptr(), x.gptr, x.ld, dg.data_ptr(), db.data_ptr()), "layernorm_bwd")
+                                                    rstd.data_ptr(), x.gptr, x.ld, dg.data_ptr(), db.data_ptr(), scr.data_ptr()), "layernorm_bwd")
             self.tape.append(bwd)
         return out
 

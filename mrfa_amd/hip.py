@@ -175,7 +175,7 @@ _SIGNATURES = {
     "mrfa_upsample_add_act_fwd": ([_V, _V, _I, _I, _I, _I, _I, _I, _V, _I, _I, _V, _I], C.c_int),
     "mrfa_upsample_add_act_bwd": ([_V, _V, _I, _V, _I, _I, _I, _I, _I, _I, _I, _V, _I, _V, _I], C.c_int),
     "mrfa_layernorm_fwd": ([_V, _V, _I, _L, _I, _V, _V, _F, _V, _I, _V, _V], C.c_int),
-    "mrfa_layernorm_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _V, _V, _V, _I, _V, _V], C.c_int),
+    "mrfa_layernorm_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _V, _V, _V, _I, _V, _V, _V], C.c_int),
     "mrfa_gelu_fwd": ([_V, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_gelu_bwd": ([_V, _V, _I, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_attention_fwd": ([_V, _V, _I, _I, _I, _I, _I, _F, _V, _I, _V], C.c_int),
@@ -201,6 +201,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+LN_SLOTS = 16          # MRFA_LN_SLOTS
 ABI_VERSION = 8        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None

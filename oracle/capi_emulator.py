@@ -294,7 +294,11 @@ class Emulator:
         vec(rstd, rows).copy_(r)
         return 0
 
-    def mrfa_layernorm_bwd(self, stream, x, ldx, dy, lddy, rows, Cc, gamma, mean, rstd, dx, lddx, dgamma, dbeta):
+    def mrfa_layernorm_bwd(self, stream, x, ldx, dy, lddy, rows, Cc, gamma, mean, rstd, dx, lddx, dgamma, dbeta, scratch=None):
+        if scratch:                  # v8: the caller's promise -- zeroed, fresh per call (the library leaves its partial sums and the ticket count in it)
+            sc = vec(scratch, 16 * 2 * Cc + 1)
+            assert float(sc.abs().max()) == 0.0, "layernorm_bwd: scratch must be zeroed"
+            sc.fill_(1.0)
         xh = (mat(x, rows, ldx, Cc) - vec(mean, rows)[:, None]) * vec(rstd, rows)[:, None]
         d = mat(dy, rows, lddy, Cc)
         g = d * vec(gamma, Cc)

@@ -1395,8 +1395,9 @@ def test_subsample_and_upsample_add():
     assert_close(ref, got, tol=1e-6, what="subsample/upsample_add")
 
 
-@pytest.mark.parametrize("rows,Cc,ld", [(2208, 192, 192), (37, 70, 72), (5000, 512, 512)])
-def test_layernorm(rows, Cc, ld):
+@pytest.mark.parametrize("slotted", [False, True])
+@pytest.mark.parametrize("rows,Cc,ld", [(2208, 192, 192), (4416, 192, 192), (37, 70, 72), (5000, 512, 512), (1026, 256, 260)])
+def test_layernorm(rows, Cc, ld, slotted):
     def run(side):
         x = side.t("ln/x", (rows, ld), -2, 2)
         gamma, beta = side.t("ln/g", (Cc,), 0.5, 1.5), side.t("ln/b", (Cc,))
@@ -1406,9 +1407,10 @@ def test_layernorm(rows, Cc, ld):
                   rstd.data_ptr())
         dy = side.t("ln/dy", (rows, ld))
         dx = side.t("ln/dx0", (rows, ld))
-        dg, db = side.z((Cc,)), side.z((Cc,))
+        dg, db = side.t("ln/dg0", (Cc,)), side.t("ln/db0", (Cc,))             # (accumulated into)
+        scr = side.z((hip.LN_SLOTS * 2 * Cc + 1,)) if slotted else None    # v8: slotted parameter-gradient partials, summed by the launch's last workgroup
         side.call("mrfa_layernorm_bwd", x.data_ptr(), ld, dy.data_ptr(), ld, rows, Cc, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                  dx.data_ptr(), ld, dg.data_ptr(), db.data_ptr())
+                  dx.data_ptr(), ld, dg.data_ptr(), db.data_ptr(), scr.data_ptr() if slotted else None)
         return side.done(y[:, :Cc], mean, rstd, dx[:, :Cc], dg, db)
     ref, got = both(run)
     assert_close(ref, got, tol=2e-4, what="layernorm")
