@@ -101,3 +101,45 @@ def test_replayed_mtia_training_step_vs_reference_and_oracle_autograd(golden_dir
     torch.cuda.synchronize()
     moved = sum(int(not torch.equal(P[n].detach(), before[n])) for n in names if o_grads[n].abs().max() > 0)
     assert moved >= 0.99 * sum(int(o_grads[n].abs().max() > 0) for n in names)
+
+
+@pytest.mark.gpu
+def test_replayed_step_at_the_bench_batch_vs_oracle_autograd(golden_dir):
+    """the headline parity ran at B = 2, the benchmark runs B = 8.  The same program at the BENCH batch -- HotPath(VOX1, prior='mtia'),
+    8 source + 8 driving frames (one batched encoder pass of 16 with two statistic groups), train-mode BatchNorm, GraphedTrainStep -- one replay of graph A
+    against the oracle's fp32 autograd of that batch on the host: loss, generated frames, keypoints, every sub-network's whole gradient vector (direction and
+    length).  The reference itself cannot travel and an fp64 run of this batch needs 54 GB, so there is no golden at B = 8: the band per sub-network is the
+    larger of the B = 2 band (reference fp32 vs fp64 + Monte-Carlo arithmetic, tests/golden/chain_mtia*.npz) and the distance between two fp32 realisations of
+    the oracle AT B = 8 (oneDNN / ATen-native convolutions), neither of which contains the implementation under test."""
+    from mrfa_amd.graph import GraphedTrainStep
+    from mrfa_amd.train import VOX1, HotPath, make_optimizer
+    dev = torch.device("cuda", 0)
+    B = 8
+    g, names = H.load_golden(golden_dir)
+    model = HotPath(VOX1, prior="mtia")
+    sds = cases.mtia_chain_weights(model.encoder.state_dict(), model.dense_motion.state_dict(), model.decoder.state_dict())
+    numels = _numels(sds)
+    for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder)):
+        mod.load_state_dict(sds[pfx])
+    model.to(dev).train(True)
+    model.probe = {}
+    src, drv = cases.images("g13/src_train", B, 256), cases.images("g13/drv_train", B, 256)
+    step = GraphedTrainStep(model, make_optimizer(model, fused=True), src.to(dev), drv.to(dev), clip=10.0, world=1)
+    assert model.batched_encoder and model.defer_decoder_wgrads
+    P = {pfx + n: p for pfx, mod in (("encoder.", model.encoder), ("dense_motion.", model.dense_motion), ("decoder.", model.decoder))
+         for n, p in mod.named_parameters()}
+    thr = min(32, torch.get_num_threads())
+    o_loss, o_gen, o_kps, _, o_grads, _ = H.oracle_run(sds, src, drv, train=True, threads=thr)
+    o2_grads = H.oracle_run(sds, src, drv, train=True, threads=thr, native_convs=True)[4]
+    band = H.merge_bands(H.reference_band(g, names, numels, "train"), H.whole_vector_band(names, o_grads, o2_grads))
+    for k in range(2):
+        step.g_fb.replay()
+        torch.cuda.synchronize()
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in P.items()}
+        worst = H.check_against_oracle(names, grads, {n: o_grads[n] for n in names}, f"hipGraph replay {k} (B = {B}, train)", band)
+        assert abs(float(step.loss) - o_loss) <= 2e-5, (float(step.loss), o_loss)
+        assert float((step.gen.detach().cpu() - o_gen).abs().mean()) <= 1e-4
+        for kk in ("kp_s", "jac_s", "kp_d", "jac_d"):
+            e = float((model.probe[kk].detach().cpu() - o_kps[kk]).abs().max())
+            assert e <= 2e-4 * max(1.0, float(o_kps[kk].abs().max())), (kk, e)
+        print(f"B = {B} replay {k}: loss {float(step.loss):.7f} (oracle {o_loss:.7f}); worst measured / allowed = {worst:.2f}")
