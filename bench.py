@@ -292,9 +292,9 @@ def roofline_from_profile(prof, nprof, hip):
         achieved = fl / (ms * 1e-3) / 1e12
         traffic, tsrc = None, None
         try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-            if dom_name:                      # the patch-tiled kernel: round-4 PMC passes (launch-weighted mean over its variants)
-                tsrc = "profiles/r4_traffic.json"
-                with open(os.path.join(ROOT, "profiles", "r4_traffic.json")) as tf:
+            if dom_name:                      # the patch-tiled kernel: the latest round's PMC passes (launch-weighted mean over its variants)
+                tsrc = next(f"profiles/r{r}_traffic.json" for r in (5, 4) if os.path.exists(os.path.join(ROOT, "profiles", f"r{r}_traffic.json")))
+                with open(os.path.join(ROOT, tsrc)) as tf:
                     tj = json.load(tf)["kernels"]["conv_halo_kernel"]
             elif split:                       # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
                 tsrc = "profiles/r2_traffic.json"
