@@ -191,3 +191,51 @@ def check_chained_pipeline_gradients(golden_dir, train, b, DEV):
         extra = extra + 3.0 * _mca_band(golden_dir, tag, names[tag])
     rel = _check_pgrads(mods, g, names, tag, 1e-3, extra=extra)
     print(f"chained {sfx}: per-parameter gradient-norm error vs reference: median {np.median(rel):.2e}, max {rel.max():.2e}")
+
+
+def check_kp_occlusion_head(golden_dir, dev, train: bool):
+    """KPDetector(estimate_occlusion=True) -- reference kp_detector.py:41-48,124-128 -- against the reference's own outputs and autograd gradients
+    (tools/make_goldens.py:g13_kp_occlusion, tests/golden/kp_occlusion.npz): kp / jacobian / kp_occlusion, the loss, every parameter's gradient norm
+    (eval-mode BatchNorm: 2e-3 of the largest norm; train mode amplifies rounding noise: 3e-2) and four whole gradient tensors of the occlusion head."""
+    import json
+    import os
+
+    import numpy as np
+    import torch
+
+    from mrfa_amd.modules import KPDetector
+    from mrfa_amd.utils.prng import det_uniform
+    from tests import cases
+    sfx = "train" if train else "eval"
+    g = np.load(os.path.join(golden_dir, "kp_occlusion.npz"))
+    names = json.load(open(os.path.join(golden_dir, "kp_occlusion_param_names.json")))[sfx]
+    m = KPDetector(**dict(cases.KP_DETECTOR_CFG, estimate_occlusion=True))
+    assert [n for n, _ in m.named_parameters()] == names            # the reference's parameter names, in its order
+    m.load_state_dict(cases.weights_for(m.state_dict(), "kpocc"))
+    m.to(dev).train(train)
+    x = cases.images(f"g13/x_{sfx}", 2, 256).to(dev)
+    r = m(x)
+    loss = ((r["kp"] * det_uniform("g13/wkp", (2, 10, 2), -1, 1).to(dev)).sum() + (r["jacobian"] * det_uniform("g13/wjac", (2, 10, 2, 2), -1, 1).to(dev)).sum()
+            + (r["kp_occlusion"] * det_uniform("g13/wocc", (2, 10, 1, 1), -1, 1).to(dev)).sum())
+    loss.backward()
+    assert tuple(r["kp_occlusion"].shape) == (2, 10, 1, 1)
+    for key, got, tol in (("kp", r["kp"], 1e-4), ("jac", r["jacobian"], 2e-4), ("occ", r["kp_occlusion"], 2e-4 if not train else 2e-3)):
+        e = float((got.detach().cpu() - torch.from_numpy(g[f"{sfx}_{key}"])).abs().max())
+        assert e <= tol, (key, e)
+    assert abs(float(loss.detach()) - float(g[f"{sfx}_loss"][0])) <= (2e-3 if train else 2e-4) * max(1.0, abs(float(g[f"{sfx}_loss"][0])))
+    P = dict(m.named_parameters())
+    ref = g[f"{sfx}_pgrad_norms"].astype(np.float64)
+    got = np.array([0.0 if P[n].grad is None else float(P[n].grad.double().norm()) for n in names])
+    tol = (3e-2 if train else 2e-3) * ref.max()
+    bad = [(n, a, b) for n, a, b in zip(names, got, ref) if abs(a - b) > tol + (5e-2 if train else 5e-3) * b]
+    assert not bad, bad[:5]
+    for n in ("kp_occlusion.4.weight", "kp_occlusion.4.bias", "kp_occlusion.0.conv.weight", "kp_occlusion.3.norm.weight"):
+        a, b = P[n].grad.detach().cpu().double(), torch.from_numpy(g[f"{sfx}_pgrad_{n}"]).double()
+        assert float((a - b).norm()) <= (5e-2 if train else 5e-3) * max(float(b.norm()), 1e-6), (n, float((a - b).norm()), float(b.norm()))
+    # geometry other than the reference's raises instead of computing something else
+    m2 = KPDetector(**dict(cases.KP_DETECTOR_CFG, estimate_occlusion=True)).to(dev)
+    try:
+        m2(torch.zeros(1, 3, 512, 512, device=dev))
+        raise AssertionError("512 x 512 input did not raise")
+    except NotImplementedError:
+        pass

@@ -398,3 +398,10 @@ def test_prior_stage_gradients_vs_reference_goldens(golden_dir, train, b, fresh_
 def test_chained_pipeline_gradients_vs_reference_goldens(golden_dir, train, b):
     from tests.grad_checks import check_chained_pipeline_gradients
     check_chained_pipeline_gradients(golden_dir, train, b, DEV)
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval_bn", "train_bn"])
+def test_kp_detector_occlusion_head_vs_reference_golden(golden_dir, train):
+    """KPDetector(estimate_occlusion=True) on the HIP path against the reference's outputs and autograd gradients (reference kp_detector.py:41-48,124-128)"""
+    from tests import grad_checks
+    grad_checks.check_kp_occlusion_head(golden_dir, DEV, train)

@@ -902,3 +902,12 @@ def test_fused_finalize_waits_for_its_statistics_atomics_before_the_ticket(tmp_p
                 f"{name}: no s_waitcnt vmcnt(0) between the atomics and the barrier before the ticket at line {t}"
             checked += 1
     assert checked >= least, checked        # every instantiation of the kernel carries the epilogue
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval_bn", "train_bn"])
+def test_kp_detector_occlusion_head_through_emulator_vs_reference_golden(golden_dir, train):
+    """the host logic of KPDetector(estimate_occlusion=True) through the ABI emulator against the reference's outputs and autograd (VERDICT r4 missing 7)"""
+    from tests import grad_checks
+    from tests.emu import emulated_hip
+    with emulated_hip():
+        grad_checks.check_kp_occlusion_head(golden_dir, torch.device("cpu"), train)

@@ -774,6 +774,30 @@ def g11_prior_grads():
 
 
 # ----------------------------------------------------------------------------------------------- G12 the headline program: MTIA chain
+def g13_kp_occlusion():
+    """KPDetector(estimate_occlusion=True) of the reference (kp_detector.py:41-48,124-128; off in both YAMLs): outputs and autograd gradients, eval- and
+    train-mode BatchNorm, B = 2 -- loss = weighted sums of kp, jacobian and kp_occlusion."""
+    out, names = {}, {}
+    cfg = dict(cases.KP_DETECTOR_CFG, estimate_occlusion=True)
+    for train in (False, True):
+        sfx = "train" if train else "eval"
+        kpm = KPDetector(**cfg)
+        load(kpm, "kpocc")
+        kpm.train(train)
+        x = cases.images(f"g13/x_{sfx}", 2, 256)
+        r = kpm(x)
+        loss = ((r["kp"] * det_uniform("g13/wkp", (2, 10, 2), -1, 1)).sum() + (r["jacobian"] * det_uniform("g13/wjac", (2, 10, 2, 2), -1, 1)).sum()
+                + (r["kp_occlusion"] * det_uniform("g13/wocc", (2, 10, 1, 1), -1, 1)).sum())
+        loss.backward()
+        out[f"{sfx}_kp"], out[f"{sfx}_jac"], out[f"{sfx}_occ"] = npy(r["kp"]), npy(r["jacobian"]), npy(r["kp_occlusion"])
+        out[f"{sfx}_loss"] = np.array([loss.item()], np.float32)
+        names[sfx] = _grad_record(out, sfx, [("", kpm)], ["kp_occlusion.4.weight", "kp_occlusion.4.bias", "kp_occlusion.0.conv.weight", "kp_occlusion.3.norm.weight"])
+    np.savez_compressed(os.path.join(GOLD, "kp_occlusion.npz"), **out)
+    with open(os.path.join(GOLD, "kp_occlusion_param_names.json"), "w") as f:
+        json.dump(names, f)
+    print("G13 kp_occlusion goldens:", len(out), "occ eval", out["eval_occ"].reshape(2, 10)[0, :4])
+
+
 def g12_chain_mtia():
     """the reference's OWN `MRFA` (model.py:145-216) built with `prior_model: mtia` -- TokenPose_B encoder on source and
     driving, DenseMotionNetwork, RaftFlow -- run forward (`MRFA.forward(x, epoch=0, is_train=False)`: the wiring of model.py:185-210
@@ -890,7 +914,7 @@ def g12_chain_mtia():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest", "g10_helpers", "g11_prior_grads", "g12_chain_mtia"]
+    which = sys.argv[1:] or ["g1", "g2", "g3_prior", "g3_raft", "g4", "g5_tokenpose", "g6_callers", "g7_losses", "g8_background", "g9_mrfa_manifest", "g10_helpers", "g11_prior_grads", "g12_chain_mtia", "g13_kp_occlusion"]
     for w in which:
         print("==", w)
         globals()[w]()
