@@ -38,6 +38,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from typing import Optional
 
 import torch
@@ -247,6 +248,12 @@ class GraphedTrainStep:
         else:
             self.packs = engine.PackPlan(model)
             self.packs_rest = None
+        if syncbn_collectives or world > 1:
+            # RCCL work objects of the eager warm pass are still on ProcessGroupNCCL's watchdog list for up to one of its 100 ms polling periods; a capture that
+            # starts meanwhile was seen to die in that thread (hipErrorCapturedEvent from an event query: 1 capture in 5 with the SyncBatchNorm collectives
+            # captured, MRFA_SYNCBN_GRAPH=1; 0 in 16 with this pause): let the list drain first.  (The default exchange is issued BETWEEN the graphs, never captured.)
+            torch.cuda.synchronize()
+            time.sleep(0.5)
         self.g_fb = torch.cuda.CUDAGraph()
         GraphedTrainStep._captures += 1
         engine.CAPTURE_KEY = GraphedTrainStep._captures
