@@ -911,3 +911,14 @@ def test_kp_detector_occlusion_head_through_emulator_vs_reference_golden(golden_
     from tests.emu import emulated_hip
     with emulated_hip():
         grad_checks.check_kp_occlusion_head(golden_dir, torch.device("cpu"), train)
+
+
+def test_binding_constants_mirror_the_header():
+    """the ctypes binding's copies of the header's layout constants (slot counts of the statistics / LayerNorm scratch buffers, ABI version)"""
+    import re
+    from mrfa_amd import hip
+    h = open(os.path.join(ROOT, "include", "mrfa_hip.h")).read()
+    const = lambda name: int(re.search(r"#define\s+" + name + r"\s+(\d+)", h).group(1))
+    assert hip.ABI_VERSION == const("MRFA_ABI_VERSION")
+    assert hip.STATS_SLOTS == const("MRFA_STATS_SLOTS")
+    assert hip.LN_SLOTS == const("MRFA_LN_SLOTS")
