@@ -233,12 +233,13 @@ int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p);  /* 1: a cal
 int mrfa_pack_conv_weight(void* stream, const float* src, float* dst, int Cout, int Cin, int R, int S, int mode);
 
 /* Batched forms: all layouts of many convolutions per launch (descriptor table passed by value in the kernel
- * arguments, MRFA_PACK_MAX_DESCS per launch), used once per training step for all ~90 convolutions of the path.
+ * arguments, MRFA_PACK_MAX_DESCS per launch: 240 since round 5 (a 16 KB argument block; 48 before) because a launch lasts as long as one workgroup's tile
+ * whatever the number of tiles), used once per training step for all convolutions of the path (~600 descriptors with the MTIA prior).
  * mrfa_pack_conv_weights_multi: for every desc, src (OIHW) -> dst[k] in layout mode[k] (0,1,2,3,5,7 as above).  Padding
  *   elements of the destinations are NOT written: allocate those buffers zero-filled.
  * mrfa_unpack_wgrads_multi: for every desc, dst (OIHW gradient) += src (accumulator, [tap][Cout][Cin], or
  *   [Cout][tap][Cin] when fewout != 0)  -- modes 4 / 6 above.                                                         */
-#define MRFA_PACK_MAX_DESCS 48
+#define MRFA_PACK_MAX_DESCS 240
 typedef struct {
     const float* src;
     float* dst[3];
