@@ -38,7 +38,7 @@ const char* mrfa_last_error(void);
  *      small convolution behind mrfa_set_tuning("conv_lds"), the Winograd-along-x form (w_wino stays in the struct, reserved; pack modes 16 / 17 and its
  *      `..._wino_supported` query are gone).
  *   8  round 5: mrfa_conv_params += sk_ticket, y_zero (a K split that finishes inside its launch: no init pass, no epilogue pass) with the query
- *      mrfa_conv2d_split_k(); mrfa_layernorm_bwd += scratch.                                                                                                           */
+ *      mrfa_conv2d_split_k(); mrfa_layernorm_bwd += scratch; mrfa_resize_sum_multi() / _bwd(); MRFA_PACK_MAX_DESCS 48 -> 240.                                                                                                           */
 #define MRFA_ABI_VERSION 8
 int mrfa_version(void);
 
@@ -356,6 +356,22 @@ int mrfa_resize_bilinear_fwd(void* stream, const float* in, int ldi, int N, int 
                              float* out, int ldo, int Ho, int Wo, float scale_mul, int accumulate);
 int mrfa_resize_bilinear_bwd(void* stream, const float* dout, int lddo, int N, int Hi, int Wi, int C,
                              float* din /*+=*/, int lddi, int Ho, int Wo, float scale_mul);
+
+/* v8: many "dst (=|+=) sum_k mul_k resize(src_k)" records in ONE launch (table by value in the kernel arguments) -- the flow / occlusion re-composition between two
+ * refinement levels and the running-flow updates (raft.py:258-262,276-295): ~16 copies / resizes of 1- and 2-channel maps per level, each a launch of its own on a
+ * chain where nothing else runs.  One thread per dst element, the terms in table order: the arithmetic and the order of the mrfa_copy_view / mrfa_resize_bilinear_*
+ * launches a record replaces.  mrfa_resize_sum_multi: dst (N, Hd, Wd, C) = an output, term k = an input (N, Hs, Ws, C) resized (align_corners=True) to Hd x Wd,
+ * overwrite = 1: the first term overwrites dst.  mrfa_resize_sum_multi_bwd: dst = the gradient of an INPUT of size Hd x Wd, term k = the gradient of an output of size
+ * Hs x Ws >= Hd x Wd it was resized to (the adjoint, gather form; same size: a copy); always accumulates.  Records of one call must not overlap in what they write. */
+#define MRFA_RESIZE_SUM_MAX 48
+#define MRFA_RESIZE_SUM_TERMS 4
+typedef struct {
+    float* dst; int ldd, N, Hd, Wd, C;
+    int nterm, overwrite;
+    struct { const float* src; int lds, Hs, Ws; float mul; } term[MRFA_RESIZE_SUM_TERMS];
+} mrfa_resize_sum_desc;
+int mrfa_resize_sum_multi(void* stream, const mrfa_resize_sum_desc* descs, int n);
+int mrfa_resize_sum_multi_bwd(void* stream, const mrfa_resize_sum_desc* descs, int n);
 
 /* K11/K13: correlation-pyramid window lookup (CorrBlock, raft.py:12-48).  vol0: (N*Q, Hs*Ws) rows, one source map
  * per query pixel; vol1: the 2x2 source-pooled level (N*Q, Hs/2*Ws/2).  coords (N,h1,w1,2) pixel (x,y) already

@@ -358,6 +358,85 @@ __global__ void resize_bwd_gather_kernel(const float* __restrict__ dout, int ldd
     }
 }
 
+// ---------------------------------------------------------------------------------------------- sums of resizes, many per launch (v8)
+// The flow / occlusion re-composition between two refinement levels (raft.py:276-295) and the update of the running flow (raft.py:258-262) are ~16 copies and
+// resizes of 1- and 2-channel maps per level, each a launch of its own on a chain where nothing else runs (~170 launches per step in both directions, 5-18 us
+// each).  Here ONE launch evaluates a table of "dst (=|+=) sum_k mul_k resize(src_k)" records, one thread per dst element, the terms in table order -- the
+// arithmetic (and its order) of the launches it replaces.  Forward: dst = an output, src_k = inputs at any size.  Backward: dst = an input's gradient,
+// src_k = output gradients at sizes >= dst's (the gather form of resize_bwd_gather_kernel; identity where the sizes agree).
+struct ResizeSumArgs {
+    int n;
+    int prefix[MRFA_RESIZE_SUM_MAX + 1];               // first 256-element block of record i
+    mrfa_resize_sum_desc d[MRFA_RESIZE_SUM_MAX];
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void resize_sum_multi_kernel(const ResizeSumArgs a) {
+    int lo = 0, hi = a.n;                              // largest i with prefix[i] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)blockIdx.x >= a.prefix[mid]) lo = mid; else hi = mid;
+    }
+    const mrfa_resize_sum_desc& d = a.d[lo];
+    const long long i = (long long)((int)blockIdx.x - a.prefix[lo]) * 256 + threadIdx.x;
+    const long long total = (long long)d.N * d.Hd * d.Wd * d.C;
+    if (i >= total) return;
+    const long long pix = i / d.C;
+    const int c = (int)(i - pix * d.C);
+    const int px = (int)(pix % d.Wd);
+    const long long t = pix / d.Wd;
+    const int py = (int)(t % d.Hd);
+    const long long n = t / d.Hd;
+    float* dst = d.dst + (size_t)pix * d.ldd + c;
+    float v = d.overwrite ? 0.f : *dst;
+    bool first = d.overwrite != 0;
+    for (int k = 0; k < d.nterm; ++k) {
+        const float* __restrict__ src = d.term[k].src;
+        const int lds = d.term[k].lds, Hs = d.term[k].Hs, Ws = d.term[k].Ws;
+        const float mul = d.term[k].mul;
+        float r;
+        if (Hs == d.Hd && Ws == d.Wd) {
+            r = src[(size_t)pix * lds + c] * mul;                                   // same size: a copy (mrfa_copy_view)
+        } else if (!BWD) {
+            int x0, x1, y0, y1;
+            float fx, fy;
+            resize_src(px, Ws, d.Wd, x0, x1, fx);
+            resize_src(py, Hs, d.Hd, y0, y1, fy);
+            const float* b = src + (size_t)n * Hs * Ws * lds + c;
+            const float top = b[((size_t)y0 * Ws + x0) * lds] * (1.f - fx) + b[((size_t)y0 * Ws + x1) * lds] * fx;
+            const float bot = b[((size_t)y1 * Ws + x0) * lds] * (1.f - fx) + b[((size_t)y1 * Ws + x1) * lds] * fx;
+            r = (top * (1.f - fy) + bot * fy) * mul;                                // (resize_fwd_kernel)
+        } else {
+            // gather form of the up-sampling backward (resize_bwd_gather_kernel): dst = an input pixel (py, px) of a Hd x Wd map that was resized to Hs x Ws
+            const int Hi = d.Hd, Wi = d.Wd, Ho = Hs, Wo = Ws;
+            const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+            int oy_lo = sy > 0.f ? (int)floorf((float)(py - 1) / sy) - 1 : 0, oy_hi = sy > 0.f ? (int)ceilf((float)(py + 1) / sy) + 1 : Ho - 1;
+            int ox_lo = sx > 0.f ? (int)floorf((float)(px - 1) / sx) - 1 : 0, ox_hi = sx > 0.f ? (int)ceilf((float)(px + 1) / sx) + 1 : Wo - 1;
+            oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1); ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+            const float* g = src + (size_t)n * Ho * Wo * lds + c;
+            float acc = 0.f;
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                int y0, y1; float fy;
+                resize_src(oy, Hi, Ho, y0, y1, fy);
+                const float wy = (y0 == py ? 1.f - fy : 0.f) + (y1 == py ? fy : 0.f);
+                if (wy == 0.f) continue;
+                float row = 0.f;
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    int x0, x1; float fx;
+                    resize_src(ox, Wi, Wo, x0, x1, fx);
+                    const float wx = (x0 == px ? 1.f - fx : 0.f) + (x1 == px ? fx : 0.f);
+                    if (wx != 0.f) row += wx * g[((size_t)oy * Wo + ox) * lds];
+                }
+                acc += wy * row;
+            }
+            r = acc * mul;
+        }
+        v = first ? r : v + r;
+        first = false;
+    }
+    *dst = v;
+}
+
 // ---------------------------------------------------------------------------------------------- correlation window lookup
 // One wave per query pixel.  Lane e < (2r+1)^2 owns window element (a,b) = (e / (2r+1), e % (2r+1)) sampled at
 // (x + a - r, y + b - r) on its level's source map; all 49 lanes share the fractional offsets, so the wave touches an
@@ -538,6 +617,41 @@ extern "C" int mrfa_resize_bilinear_bwd(void* stream, const float* dout, int ldd
                        lddi, Ho, Wo, scale_mul, total);
     MRFA_CHECK_LAUNCH("resize_bwd");
     return 0;
+}
+
+static int resize_sum_launch(void* stream, const mrfa_resize_sum_desc* descs, int n, bool bwd, const char* what) {
+    MRFA_CHECK_ARG(n >= 0 && (n == 0 || descs), "%s: bad args", what);
+    for (int base = 0; base < n; base += MRFA_RESIZE_SUM_MAX) {
+        ResizeSumArgs a;
+        a.n = n - base < MRFA_RESIZE_SUM_MAX ? n - base : MRFA_RESIZE_SUM_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const mrfa_resize_sum_desc& d = descs[base + i];
+            MRFA_CHECK_ARG(d.dst && d.N > 0 && d.Hd > 0 && d.Wd > 0 && d.C > 0 && d.nterm >= 1 && d.nterm <= MRFA_RESIZE_SUM_TERMS, "%s: record %d: bad sizes / term count", what, base + i);
+            for (int k = 0; k < d.nterm; ++k) {
+                MRFA_CHECK_ARG(d.term[k].src && d.term[k].Hs > 0 && d.term[k].Ws > 0, "%s: record %d term %d: null source / bad size", what, base + i, k);
+                if (bwd) MRFA_CHECK_ARG(d.term[k].Hs >= d.Hd && d.term[k].Ws >= d.Wd, "%s: record %d term %d: the backward takes up-sampling (or same-size) terms only", what, base + i, k);
+            }
+            a.d[i] = d;
+            a.prefix[i] = blocks;
+            const long long total = (long long)d.N * d.Hd * d.Wd * d.C;
+            MRFA_CHECK_ARG(total < (1ll << 31) - 256 && blocks + (total + 255) / 256 < (1ll << 30), "%s: record %d too large", what, base + i);
+            blocks += (int)((total + 255) / 256);
+        }
+        a.prefix[a.n] = blocks;
+        if (bwd) hipLaunchKernelGGL((resize_sum_multi_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((resize_sum_multi_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        MRFA_CHECK_LAUNCH(what);
+    }
+    return 0;
+}
+
+extern "C" int mrfa_resize_sum_multi(void* stream, const mrfa_resize_sum_desc* descs, int n) {
+    return resize_sum_launch(stream, descs, n, false, "resize_sum_multi");
+}
+
+extern "C" int mrfa_resize_sum_multi_bwd(void* stream, const mrfa_resize_sum_desc* descs, int n) {
+    return resize_sum_launch(stream, descs, n, true, "resize_sum_multi_bwd");
 }
 
 extern "C" int mrfa_corr_lookup_fwd(void* stream, const float* vol0, const float* vol1, int Hs, int Ws, const float* coords, int ldc,

@@ -11,6 +11,7 @@ No CPU path exists here: every op goes through libmrfa_hip.so (mrfa_amd.hip.lib(
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import ctypes as C
@@ -252,6 +253,7 @@ PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward 
 BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
 # first phase of the BatchNorm backward of single-consumer BatchNorm outputs inside the consumer's data-gradient launch (mrfa_conv_params.bst_*)
 BN_BWD_IN_DGRAD = os.environ.get("MRFA_BN_BWD_IN_DGRAD", "1") != "0"
+FUSED_RESIZES = os.environ.get("MRFA_FUSED_RESIZES", "1") != "0"      # copies / resizes issued inside Ctx.fused_resizes() travel as ONE launch per direction (kept for same-box A/B runs)
 FUSED_SPLITK = os.environ.get("MRFA_FUSED_SPLITK", "1") != "0"        # K splits that finish inside their launch (Ctx._conv_out; kept for same-box A/B runs)
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
@@ -838,6 +840,7 @@ class Ctx:
         # ran (run_program keeps one per module and input shapes: the programs are static): run_backward() zero-fills them in one multi-tensor launch
         # instead of ~100 fill launches scattered over the backward chains (tools/trace_fills.py: 121 fills per step, ~10 us each on the critical path)
         self.zero_plan: Optional[set] = None
+        self._rs = None                    # fused_resizes(): the copies / resizes recorded for one launch
 
     # -- plumbing
     @property
@@ -1541,6 +1544,8 @@ class Ctx:
 
     def resize(self, x: View, Ho: int, Wo: int, mul: float = 1.0, out: Optional[View] = None, acc: bool = False) -> View:
         out = out or self.new(x.N, Ho, Wo, x.C, pad32=x.zpad)
+        if self._rs is not None:
+            return self._rs_record(x, out, mul, acc)
         self._chk(self.L.mrfa_resize_bilinear_fwd(self.s, x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld, Ho, Wo, mul, int(acc)),
                   "resize_fwd")
         if self.record:
@@ -1551,6 +1556,78 @@ class Ctx:
                           "resize_bwd")
             self.tape.append(bwd)
         return out
+
+    # -- many copies / resizes in one launch (mrfa_resize_sum_multi, v8) ------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def fused_resizes(self):
+        """the copy() / resize() calls issued inside are INDEPENDENT of each other except for accumulation chains into one output (out = resize(a);
+        resize(b, out=out, acc=True); ...): they are recorded and issued as ONE launch when the block ends (one thread per output element evaluates its chain
+        in call order: the arithmetic of the separate launches), and their backward passes as ONE launch grouped by input (down-sampling terms keep
+        their scatter launches).  RaftFlow's running-flow updates and its flow / occlusion re-composition between two refinement levels (raft.py:258-262,
+        276-295) are ~16 launches over 1- and 2-channel maps per level on a chain where nothing else runs."""
+        if not FUSED_RESIZES or self._rs is not None:
+            yield
+            return
+        self._rs = []
+        try:
+            yield
+        finally:
+            ops, self._rs = self._rs, None
+        if ops:
+            self._rs_flush(ops)
+
+    @staticmethod
+    def _rs_key(v: View):
+        return (id(v.st), v.coff, v.C)
+
+    def _rs_record(self, x: View, out: View, mul: float, acc: bool) -> View:
+        assert (x.N, x.C) == (out.N, out.C)
+        if any(self._rs_key(x) == self._rs_key(o) for _, o, _, _ in self._rs):
+            ops, self._rs = self._rs, []                      # reads what an earlier call of the block writes: that part goes first
+            self._rs_flush(ops)
+        self._rs.append((x, out, float(mul), bool(acc)))
+        return out
+
+    def _rs_launch(self, recs, bwd: bool):
+        """recs: [(dst view, is gradient, overwrite, [(src view, is gradient, mul)])] -> launches of <= 4 terms per record (a longer chain continues in the next launch)"""
+        T = hip.RESIZE_SUM_TERMS
+        while recs:
+            descs, rest = [], []
+            for dst, dgrad, ow, terms in recs:
+                d = hip.ResizeSumDesc()
+                d.dst, d.ldd, d.N, d.Hd, d.Wd, d.C = (dst.gptr if dgrad else dst.ptr), dst.ld, dst.N, dst.H, dst.W, dst.C
+                d.nterm, d.overwrite = min(len(terms), T), int(ow)
+                for k, (src, sgrad, mul) in enumerate(terms[:T]):
+                    d.term[k].src, d.term[k].lds, d.term[k].Hs, d.term[k].Ws, d.term[k].mul = (src.gptr if sgrad else src.ptr), src.ld, src.H, src.W, mul
+                descs.append(d)
+                if len(terms) > T:
+                    rest.append((dst, dgrad, False, terms[T:]))
+            table = (hip.ResizeSumDesc * len(descs))(*descs)
+            fn = self.L.mrfa_resize_sum_multi_bwd if bwd else self.L.mrfa_resize_sum_multi
+            self._chk(fn(self.s, table, len(descs)), "resize_sum_multi" + ("_bwd" if bwd else ""))
+            recs = rest
+
+    def _rs_flush(self, ops):
+        groups = {}
+        for x, out, mul, acc in ops:                          # by output, in call order
+            g = groups.setdefault(self._rs_key(out), [out, not acc, []])
+            g[2].append((x, False, mul))
+        self._rs_launch([(out, False, ow, terms) for out, ow, terms in groups.values()], bwd=False)
+        if not self.record:
+            return
+
+        def bwd():
+            by_in = {}
+            for x, out, mul, acc in reversed(ops):            # the order the separate backward closures ran in
+                if not out.has_grad:
+                    continue
+                if out.H >= x.H and out.W >= x.W:
+                    by_in.setdefault(self._rs_key(x), [x, []])[1].append((out, True, mul))
+                else:                                         # down-sampling: the scatter form, a launch of its own
+                    self._chk(self.L.mrfa_resize_bilinear_bwd(self.s, out.gptr, out.ld, x.N, x.H, x.W, x.C, x.gptr, x.ld, out.H, out.W, mul), "resize_bwd")
+            if by_in:
+                self._rs_launch([(x, True, False, terms) for x, terms in by_in.values()], bwd=True)
+        self.tape.append(bwd)
 
     def corr_lookup(self, vol0: torch.Tensor, vol1: torch.Tensor, dvols, Hs: int, Ws: int, coords: View, radius: int = 3,
                     out: Optional[View] = None) -> View:
@@ -1700,6 +1777,8 @@ class Ctx:
     def copy(self, x: View, out: Optional[View] = None, mul: float = 1.0, acc: bool = False) -> View:
         """out (=|+=) mul * x"""
         out = out or self.new(x.N, x.H, x.W, x.C)
+        if self._rs is not None:
+            return self._rs_record(x, out, mul, acc)
         self._chk(self.L.mrfa_copy_view(self.s, x.ptr, x.ld, x.rows, x.C, out.ptr, out.ld, mul, int(acc)), "copy_view")
         if self.record:
             def bwd():

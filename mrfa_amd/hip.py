@@ -71,6 +71,16 @@ class PackDesc(C.Structure):
                 ("Cout", C.c_int), ("Cin", C.c_int), ("R", C.c_int), ("S", C.c_int)]
 
 
+class ResizeSumTerm(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("lds", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int), ("mul", C.c_float)]
+
+
+class ResizeSumDesc(C.Structure):
+    """mrfa_resize_sum_desc: dst (=|+=) sum_k mul_k resize(src_k)"""
+    _fields_ = [("dst", C.c_void_p), ("ldd", C.c_int), ("N", C.c_int), ("Hd", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
+                ("nterm", C.c_int), ("overwrite", C.c_int), ("term", ResizeSumTerm * 4)]
+
+
 class UnpackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("T", C.c_int), ("fewout", C.c_int)]
 
@@ -149,6 +159,8 @@ _SIGNATURES = {
     "mrfa_grid_sample_bwd": ([_V, _V, _I, _L, _I, _I, _I, _I, _V, _I, _I, _I, _I, _V, _I, _I, _V, _I, _L, _V, _I], C.c_int),
     "mrfa_resize_bilinear_fwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _F, _I], C.c_int),
     "mrfa_resize_bilinear_bwd": ([_V, _V, _I, _I, _I, _I, _I, _V, _I, _I, _I, _F], C.c_int),
+    "mrfa_resize_sum_multi": ([_V, C.POINTER(ResizeSumDesc), _I], C.c_int),
+    "mrfa_resize_sum_multi_bwd": ([_V, C.POINTER(ResizeSumDesc), _I], C.c_int),
     "mrfa_corr_lookup_fwd": ([_V, _V, _V, _I, _I, _V, _I, _L, _I, _V, _I], C.c_int),
     "mrfa_corr_lookup_bwd": ([_V, _V, _V, _I, _I, _V, _I, _L, _I, _V, _I, _V, _V, _V, _I], C.c_int),
     "mrfa_nchw_to_nhwc": ([_V, _V, _V, _I, _I, _I, _I, _I, _I], C.c_int),
@@ -202,6 +214,7 @@ _SIGNATURES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 LN_SLOTS = 16          # MRFA_LN_SLOTS
+RESIZE_SUM_TERMS = 4   # MRFA_RESIZE_SUM_TERMS
 ABI_VERSION = 8        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None

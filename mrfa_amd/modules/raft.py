@@ -292,8 +292,9 @@ class RaftFlow(nn.Module):
         init_flow = e.copy(deform, mul=(h - 1) / 2.0)
         init_flow.tensor().add_((h - 1) / 2.0 - ident_h)
         r0 = size // 32
-        flow = e.resize(init_flow, r0, r0, mul=1.0 / 8.0)
-        occ = e.resize(prior_occ, r0, r0)
+        with e.fused_resizes():
+            flow = e.resize(init_flow, r0, r0, mul=1.0 / 8.0)
+            occ = e.resize(prior_occ, r0, r0)
 
         # decode concat buffers [blend | coarse warp]
         lv_c = gen.level_channels()
@@ -320,34 +321,40 @@ class RaftFlow(nn.Module):
             ctx = e.grid_sample(f, flow, 1)
             ctx = e.conv(ctx, self.to_context[i], relu=True)
             d_flow = self.refine.run(e, inp, ctx, ctx_relu=True)
-            flow_w = e.copy(flow)
-            e.copy(d_flow.slice(0, 2), out=flow_w, acc=True)
-            occ_new = e.copy(occ)
-            e.copy(d_flow.slice(2, 3), out=occ_new, acc=True)
+            # the running-flow / occlusion updates (raft.py:258-262), the coarse grid of this level and the re-composition for the next one (raft.py:276-295):
+            # ~16 copies / resizes of 1- and 2-channel maps, independent of each other -> ONE launch (engine.Ctx.fused_resizes), their backward another
+            grid_c = None
+            with e.fused_resizes():
+                flow_w = e.copy(flow)
+                e.copy(d_flow.slice(0, 2), out=flow_w, acc=True)
+                occ_new = e.copy(occ)
+                e.copy(d_flow.slice(2, 3), out=occ_new, acc=True)
+                if i < gen.num_up_blocks:
+                    grid_c = e.resize(deform, r, r) if i != base else deform
+                if i < self.num_iter - 1:                                           # raft.py:276-295
+                    r2 = r * 2
+                    sc = 2 ** (base - i) / 2.0
+                    nflow = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
+                    e.resize(init_flow, r2, r2, mul=1.0 / sc, out=nflow, acc=True)
+                    nocc = e.resize(d_flow.slice(2, 3), r2, r2)
+                    e.resize(prior_occ, r2, r2, out=nocc, acc=True)
+                    if i == 0:
+                        d_f_pre = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
+                        d_occ_pre = e.resize(d_flow.slice(2, 3), r2, r2)
+                    else:
+                        e.resize(d_f_pre, r2, r2, mul=2.0, out=nflow, acc=True)
+                        e.resize(d_occ_pre, r2, r2, out=nocc, acc=True)
+                        nd = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
+                        e.resize(d_f_pre, r2, r2, mul=2.0, out=nd, acc=True)
+                        no = e.resize(d_flow.slice(2, 3), r2, r2)
+                        e.resize(d_occ_pre, r2, r2, out=no, acc=True)
+                        d_f_pre, d_occ_pre = nd, no
             out_warp_f.append(e.grid_sample(f, flow_w, 1))
             out_occ.append(e.act(occ_new, 2))
             # coarse (prior-motion) warp straight into its decode concat slot (raft.py:265-272); level 5's is never read
             if i < gen.num_up_blocks:
-                grid_c = e.resize(deform, r, r) if i != base else deform
                 e.grid_sample(f, grid_c, 0, out=cats[i].slice(lv_c[i], 2 * lv_c[i]))
-            if i < self.num_iter - 1:                                           # raft.py:276-295
-                r2 = r * 2
-                sc = 2 ** (base - i) / 2.0
-                nflow = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
-                e.resize(init_flow, r2, r2, mul=1.0 / sc, out=nflow, acc=True)
-                nocc = e.resize(d_flow.slice(2, 3), r2, r2)
-                e.resize(prior_occ, r2, r2, out=nocc, acc=True)
-                if i == 0:
-                    d_f_pre = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
-                    d_occ_pre = e.resize(d_flow.slice(2, 3), r2, r2)
-                else:
-                    e.resize(d_f_pre, r2, r2, mul=2.0, out=nflow, acc=True)
-                    e.resize(d_occ_pre, r2, r2, out=nocc, acc=True)
-                    nd = e.resize(d_flow.slice(0, 2), r2, r2, mul=2.0)
-                    e.resize(d_f_pre, r2, r2, mul=2.0, out=nd, acc=True)
-                    no = e.resize(d_flow.slice(2, 3), r2, r2)
-                    e.resize(d_occ_pre, r2, r2, out=no, acc=True)
-                    d_f_pre, d_occ_pre = nd, no
+            if i < self.num_iter - 1:
                 flow, occ = nflow, nocc
         # NB: the image is warped with the last level's INPUT flow, not flow_w (raft.py:302)
         warp_img = e.grid_sample(imgf, flow, 1, need_din=False)

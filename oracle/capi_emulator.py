@@ -811,6 +811,42 @@ class Emulator:
         o.copy_(o + y if acc else y)
         return 0
 
+    def mrfa_resize_sum_multi(self, stream, descs, n):
+        """v8: dst (=|+=) sum_k mul_k resize(src_k), records in table order, terms in record order"""
+        for i in range(n):
+            d = descs[i]
+            o = nhwc(d.dst, d.N, d.Hd, d.Wd, d.ldd, d.C)
+            v = None if d.overwrite else o.clone()
+            for k in range(d.nterm):
+                t = d.term[k]
+                x = nhwc(t.src, d.N, t.Hs, t.Ws, t.lds, d.C)
+                if (t.Hs, t.Ws) != (d.Hd, d.Wd):
+                    x = F.interpolate(x.permute(0, 3, 1, 2), size=(d.Hd, d.Wd), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+                r = x * t.mul
+                v = r if v is None else v + r
+            o.copy_(v)
+        return 0
+
+    def mrfa_resize_sum_multi_bwd(self, stream, descs, n):
+        """v8: dst (the gradient of an input, Hd x Wd) += sum_k mul_k adjoint-resize(src_k = the gradient of an output of size Hs x Ws >= Hd x Wd)"""
+        for i in range(n):
+            d = descs[i]
+            o = nhwc(d.dst, d.N, d.Hd, d.Wd, d.ldd, d.C)
+            v = o.clone()
+            for k in range(d.nterm):
+                t = d.term[k]
+                assert t.Hs >= d.Hd and t.Ws >= d.Wd, "resize_sum_multi_bwd: up-sampling (or same-size) terms only"
+                g = nhwc(t.src, d.N, t.Hs, t.Ws, t.lds, d.C)
+                if (t.Hs, t.Ws) != (d.Hd, d.Wd):
+                    with torch.enable_grad():
+                        xl = torch.zeros(d.N, d.C, d.Hd, d.Wd, requires_grad=True)
+                        y = F.interpolate(xl, size=(t.Hs, t.Ws), mode="bilinear", align_corners=True)
+                        (gx,) = torch.autograd.grad(y, xl, g.permute(0, 3, 1, 2).contiguous())
+                    g = gx.permute(0, 2, 3, 1)
+                v = v + g * t.mul
+            o.copy_(v)
+        return 0
+
     def mrfa_resize_bilinear_bwd(self, stream, dout, lddo, N, Hi, Wi, Cc, din, lddi, Ho, Wo, mul):
         with torch.enable_grad():
             xl = torch.zeros(N, Cc, Hi, Wi, requires_grad=True)

@@ -1021,6 +1021,68 @@ def test_resize(shape):
     assert_close(ref, got, what="resize")
 
 
+def test_resize_sum_multi():
+    """v8: many "dst (=|+=) sum_k mul_k resize(src_k)" records in one launch (mrfa_resize_sum_multi / _bwd) against the ABI emulator AND against the separate
+    mrfa_copy_view / mrfa_resize_bilinear_* launches they replace (same arithmetic, same order: equal to a few ulp -- the compiler contracts multiply-adds
+    differently in the two forms): up- and down-sampling, same-size terms, three-term chains, overwriting and accumulating records, channel slices."""
+    N = 2
+
+    def build(side):
+        def rec(dst, ldd, Hd, Wd, Cc, ow, terms):
+            d = hip.ResizeSumDesc()
+            d.dst, d.ldd, d.N, d.Hd, d.Wd, d.C, d.nterm, d.overwrite = dst, ldd, N, Hd, Wd, Cc, len(terms), ow
+            for k, (src, lds, Hs, Ws, mul) in enumerate(terms):
+                d.term[k].src, d.term[k].lds, d.term[k].Hs, d.term[k].Ws, d.term[k].mul = src, lds, Hs, Ws, mul
+            return d
+        a = side.t("rsm/a", (N * 8 * 8, 4))              # 3 channels of 4: slices [0:2] and [2:3]
+        b = side.t("rsm/b", (N * 16 * 16, 2))
+        c = side.t("rsm/c", (N * 8 * 8, 2))
+        o1 = side.garbage((N * 16 * 16, 2))              # = 2 up(a[0:2]) + 0.5 b + 2 up(c)         (three-term chain, overwrite)
+        o2 = side.t("rsm/o2", (N * 16 * 16, 4))          # [..., 1:2] += up(a[2:3])                  (accumulate into a channel slice)
+        o3 = side.garbage((N * 4 * 4, 2))                # = down(b) / 8                             (down-sampling)
+        o4 = side.garbage((N * 8 * 8, 2))                # = c + a[0:2]                              (same-size chain)
+        fw = [rec(o1.data_ptr(), 2, 16, 16, 2, 1, [(a.data_ptr(), 4, 8, 8, 2.0), (b.data_ptr(), 2, 16, 16, 0.5), (c.data_ptr(), 2, 8, 8, 2.0)]),
+              rec(o2.data_ptr() + 4, 4, 16, 16, 1, 0, [(a.data_ptr() + 8, 4, 8, 8, 1.0)]),
+              rec(o3.data_ptr(), 2, 4, 4, 2, 1, [(b.data_ptr(), 2, 16, 16, 0.125)]),
+              rec(o4.data_ptr(), 2, 8, 8, 2, 1, [(c.data_ptr(), 2, 8, 8, 1.0), (a.data_ptr(), 4, 8, 8, 1.0)])]
+        return (a, b, c, o1, o2, o3, o4), fw, rec
+
+    def run(side):
+        (a, b, c, o1, o2, o3, o4), fw, rec = build(side)
+        side.call("mrfa_resize_sum_multi", (hip.ResizeSumDesc * len(fw))(*fw), len(fw))
+        # backward: gradients of a[0:2] (from o1 (x2, up-sampled) and o4 (same size)), a[2:3] (from o2), c (from o1 and o4)
+        g1, g2, g4 = side.t("rsm/g1", (N * 16 * 16, 2)), side.t("rsm/g2", (N * 16 * 16, 4)), side.t("rsm/g4", (N * 8 * 8, 2))
+        da, dc = side.t("rsm/da0", (N * 8 * 8, 4)), side.t("rsm/dc0", (N * 8 * 8, 2))
+        bw = [rec(da.data_ptr(), 4, 8, 8, 2, 0, [(g4.data_ptr(), 2, 8, 8, 1.0), (g1.data_ptr(), 2, 16, 16, 2.0)]),
+              rec(da.data_ptr() + 8, 4, 8, 8, 1, 0, [(g2.data_ptr() + 4, 4, 16, 16, 1.0)]),
+              rec(dc.data_ptr(), 2, 8, 8, 2, 0, [(g4.data_ptr(), 2, 8, 8, 1.0), (g1.data_ptr(), 2, 16, 16, 2.0)])]
+        side.call("mrfa_resize_sum_multi_bwd", (hip.ResizeSumDesc * len(bw))(*bw), len(bw))
+        return side.done(o1, o2, o3, o4, da[:, :3], dc)
+
+    def run_separately(side):
+        (a, b, c, o1, o2, o3, o4), _, _ = build(side)
+        side.call("mrfa_resize_bilinear_fwd", a.data_ptr(), 4, N, 8, 8, 2, o1.data_ptr(), 2, 16, 16, 2.0, 0)
+        side.call("mrfa_copy_view", b.data_ptr(), 2, N * 256, 2, o1.data_ptr(), 2, 0.5, 1)
+        side.call("mrfa_resize_bilinear_fwd", c.data_ptr(), 2, N, 8, 8, 2, o1.data_ptr(), 2, 16, 16, 2.0, 1)
+        side.call("mrfa_resize_bilinear_fwd", a.data_ptr() + 8, 4, N, 8, 8, 1, o2.data_ptr() + 4, 4, 16, 16, 1.0, 1)
+        side.call("mrfa_resize_bilinear_fwd", b.data_ptr(), 2, N, 16, 16, 2, o3.data_ptr(), 2, 4, 4, 0.125, 0)
+        side.call("mrfa_copy_view", c.data_ptr(), 2, N * 64, 2, o4.data_ptr(), 2, 1.0, 0)
+        side.call("mrfa_copy_view", a.data_ptr(), 4, N * 64, 2, o4.data_ptr(), 2, 1.0, 1)
+        g1, g2, g4 = side.t("rsm/g1", (N * 16 * 16, 2)), side.t("rsm/g2", (N * 16 * 16, 4)), side.t("rsm/g4", (N * 8 * 8, 2))
+        da, dc = side.t("rsm/da0", (N * 8 * 8, 4)), side.t("rsm/dc0", (N * 8 * 8, 2))
+        side.call("mrfa_copy_view", g4.data_ptr(), 2, N * 64, 2, da.data_ptr(), 4, 1.0, 1)
+        side.call("mrfa_resize_bilinear_bwd", g1.data_ptr(), 2, N, 8, 8, 2, da.data_ptr(), 4, 16, 16, 2.0)
+        side.call("mrfa_resize_bilinear_bwd", g2.data_ptr() + 4, 4, N, 8, 8, 1, da.data_ptr() + 8, 4, 16, 16, 1.0)
+        side.call("mrfa_copy_view", g4.data_ptr(), 2, N * 64, 2, dc.data_ptr(), 2, 1.0, 1)
+        side.call("mrfa_resize_bilinear_bwd", g1.data_ptr(), 2, N, 8, 8, 2, dc.data_ptr(), 2, 16, 16, 2.0)
+        return side.done(o1, o2, o3, o4, da[:, :3], dc)
+    ref, got = both(run)
+    assert_close(ref, got, tol=1e-5, what="resize_sum_multi")
+    sep = run_separately(Side(True))
+    for k, (x, y) in enumerate(zip(sep, got)):
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(x.abs().max())), (k, float((x - y).abs().max()))
+
+
 def test_corr_lookup():
     def run(side):
         Q, Hs, Ws = 50, 16, 16

@@ -922,3 +922,4 @@ def test_binding_constants_mirror_the_header():
     assert hip.ABI_VERSION == const("MRFA_ABI_VERSION")
     assert hip.STATS_SLOTS == const("MRFA_STATS_SLOTS")
     assert hip.LN_SLOTS == const("MRFA_LN_SLOTS")
+    assert hip.RESIZE_SUM_TERMS == const("MRFA_RESIZE_SUM_TERMS")
