@@ -1580,12 +1580,12 @@ class Ctx:
     def _rs_key(v: View):
         return (id(v.st), v.coff, v.C)
 
-    def _rs_record(self, x: View, out: View, mul: float, acc: bool) -> View:
+    def _rs_record(self, x: View, out: View, mul: float, acc: bool, nograd: bool = False) -> View:
         assert (x.N, x.C) == (out.N, out.C)
-        if any(self._rs_key(x) == self._rs_key(o) for _, o, _, _ in self._rs):
+        if any(self._rs_key(x) == self._rs_key(o) for _, o, _, _, _ in self._rs):
             ops, self._rs = self._rs, []                      # reads what an earlier call of the block writes: that part goes first
             self._rs_flush(ops)
-        self._rs.append((x, out, float(mul), bool(acc)))
+        self._rs.append((x, out, float(mul), bool(acc), bool(nograd)))
         return out
 
     def _rs_launch(self, recs, bwd: bool):
@@ -1609,7 +1609,7 @@ class Ctx:
 
     def _rs_flush(self, ops):
         groups = {}
-        for x, out, mul, acc in ops:                          # by output, in call order
+        for x, out, mul, acc, _ in ops:                       # by output, in call order
             g = groups.setdefault(self._rs_key(out), [out, not acc, []])
             g[2].append((x, False, mul))
         self._rs_launch([(out, False, ow, terms) for out, ow, terms in groups.values()], bwd=False)
@@ -1618,8 +1618,8 @@ class Ctx:
 
         def bwd():
             by_in = {}
-            for x, out, mul, acc in reversed(ops):            # the order the separate backward closures ran in
-                if not out.has_grad:
+            for x, out, mul, acc, nograd in reversed(ops):    # the order the separate backward closures ran in
+                if nograd or not out.has_grad:
                     continue
                 if out.H >= x.H and out.W >= x.W:
                     by_in.setdefault(self._rs_key(x), [x, []])[1].append((out, True, mul))
@@ -1774,13 +1774,13 @@ class Ctx:
         return kp, jac
 
     # -- elementwise ------------------------------------------------------------------------------------------
-    def copy(self, x: View, out: Optional[View] = None, mul: float = 1.0, acc: bool = False) -> View:
-        """out (=|+=) mul * x"""
+    def copy(self, x: View, out: Optional[View] = None, mul: float = 1.0, acc: bool = False, nograd: bool = False) -> View:
+        """out (=|+=) mul * x.  nograd: x is a constant (a coordinate grid): nothing goes on the tape for it"""
         out = out or self.new(x.N, x.H, x.W, x.C)
         if self._rs is not None:
-            return self._rs_record(x, out, mul, acc)
+            return self._rs_record(x, out, mul, acc, nograd)
         self._chk(self.L.mrfa_copy_view(self.s, x.ptr, x.ld, x.rows, x.C, out.ptr, out.ld, mul, int(acc)), "copy_view")
-        if self.record:
+        if self.record and not nograd:
             def bwd():
                 if not out.has_grad:
                     return

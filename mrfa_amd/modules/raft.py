@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..engine import Ctx, View, run_program
+from ..engine import Ctx, Storage, View, run_program
 from .generator import OcclusionAwareGenerator
 from .util import _FN, Hourglass, batch_bilinear_sampler, bilinear_sampler, coords_grid, coords_grid_nhwc, kp2gaussian  # noqa: F401
 
@@ -168,6 +168,21 @@ class _CorrVolume:
         self.dvol0 = self.dvol1 = None
 
 
+_GRID_CONSTS: dict = {}
+
+
+def _grid_const(e: Ctx, n: int, h: int, w: int, scale: float, offset: float, like: torch.Tensor) -> View:
+    """(n, h, w, 2) constant `scale * (x, y) pixel grid + offset` as an engine View (kept per key; built outside hipGraph captures, like coords_grid_nhwc's grids):
+    the coordinate terms of RaftFlow enter the fused copies as constants instead of through ATen multiply / add launches"""
+    key = (n, h, w, float(scale), float(offset), like.device)
+    t = _GRID_CONSTS.get(key)
+    if t is None:
+        t = (coords_grid_nhwc(h, w, like) * scale + offset).expand(n, h, w, 2).contiguous().view(n * h * w, 2)
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _GRID_CONSTS[key] = t
+    return View(Storage(t), n, h, w, 2)
+
+
 class RaftFlow(nn.Module):
     """Same kwargs / state_dict / forward signature as the reference (raft.py:92-141):
     forward(kp_s, kp_d, dense_motion, img, img_full) -> (out, warp_img, occlusion_strip)."""
@@ -288,9 +303,9 @@ class RaftFlow(nn.Module):
         vols = {i: _CorrVolume(e, q_levels[i], k_s, k_pool, self.scale) for i in range(base + 1)}
 
         # ---- prior initialisation (raft.py:189-206)
-        ident_h = coords_grid_nhwc(h, w, img_full)
-        init_flow = e.copy(deform, mul=(h - 1) / 2.0)
-        init_flow.tensor().add_((h - 1) / 2.0 - ident_h)
+        with e.fused_resizes():                                                 # init_flow = (h-1)/2 (deform + 1) - identity grid, one launch
+            init_flow = e.copy(deform, mul=(h - 1) / 2.0)
+            e.copy(_grid_const(e, b, h, w, -1.0, (h - 1) / 2.0, img_full), out=init_flow, acc=True, nograd=True)
         r0 = size // 32
         with e.fused_resizes():
             flow = e.resize(init_flow, r0, r0, mul=1.0 / 8.0)
@@ -311,8 +326,9 @@ class RaftFlow(nn.Module):
             else:
                 cscale, vol, rq = 1.0, vols[base], h
                 flow_q = e.resize(flow, h, w, mul=0.5 ** (i - base)) if i > base else flow
-            coords = e.copy(flow_q, mul=cscale)
-            coords.tensor().add_(coords_grid_nhwc(rq, rq, img_full) * cscale)
+            with e.fused_resizes():                                             # coords = cscale (flow + identity grid), one launch
+                coords = e.copy(flow_q, mul=cscale)
+                e.copy(_grid_const(e, b, rq, rq, cscale, 0.0, img_full), out=coords, acc=True, nograd=True)
             cfeat = e.corr_lookup(vol.vol0, vol.vol1, vol.dvols, h, w, coords)
             if i > base:
                 cfeat = e.resize(cfeat, r, r)
