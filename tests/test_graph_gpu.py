@@ -239,11 +239,12 @@ def test_overlapped_exchange_graph_step_equals_the_single_graph_step():
             model = HotPath(VOX1, prior="mtia")
             bench.init_weights(model)
             model.to(DEV).train(True)
-            opt = make_optimizer(model, fused=True)
-            train_step(model, opt, src, drv)                 # optimizer state exists before capture
+            opt = make_optimizer(model, fused=True)          # (FlatAdam: no eager step before the capture -- the first replay starts from the INITIAL weights
+            #                                                  in both runs, so its loss is comparable to 1e-4; after one Adam step of the randomly initialised
+            #                                                  model it is already a chaotic quantity: 0.3508 vs 0.3444 was seen between the two runs)
             step = GraphedTrainStep(model, opt, src, drv, world=1, exchange=exchange, overlap_exchange=exchange)
             step.verify()
-            losses = [float(step(src, drv)) for _ in range(3)]
+            losses = [float(step(src, drv)) for _ in range(8)]         # (from the initial weights: the first Adam steps of a random model may go up before they go down)
             torch.cuda.synchronize()
             return step, losses, opt.flat_w.clone()
         s1, l1, w1 = run(True)
@@ -254,10 +255,10 @@ def test_overlapped_exchange_graph_step_equals_the_single_graph_step():
         assert sum(hi - lo for lo, hi in s1.tail_ranges) == n_enc
         s0, l0, w0 = run(False)
         assert s0.split is None
-        # the first replayed step starts from (nearly) the same weights in both runs; later steps of a randomly initialised train-mode
+        # the first replayed step starts from the same weights in both runs; later steps of a randomly initialised train-mode
         # model are a chaotic trajectory (step-2 losses of two IDENTICAL runs were seen at 0.444 and 0.471), so they are only required
         # to train, not to coincide
-        assert abs(l1[0] - l0[0]) <= 5e-3 * max(1.0, abs(l0[0])), (l1, l0)
+        assert abs(l1[0] - l0[0]) <= 2e-4 * max(1.0, abs(l0[0])), (l1, l0)
         # (seen once: 0.346, 0.282, 0.406 -- the third step of a B=2 run bounced; the best later loss is the robust statement)
         assert min(l1[1:]) < l1[0] and min(l0[1:]) < l0[0], (l1, l0)
         assert torch.isfinite(w1).all() and float((w1 - w0).abs().max()) <= 50 * 2e-4      # a handful of Adam steps of lr 2e-4
