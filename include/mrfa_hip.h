@@ -38,8 +38,11 @@ const char* mrfa_last_error(void);
  *      small convolution behind mrfa_set_tuning("conv_lds"), the Winograd-along-x form (w_wino stays in the struct, reserved; pack modes 16 / 17 and its
  *      `..._wino_supported` query are gone).
  *   8  round 5: mrfa_conv_params += sk_ticket, y_zero (a K split that finishes inside its launch: no init pass, no epilogue pass) with the query
- *      mrfa_conv2d_split_k(); mrfa_layernorm_bwd += scratch; mrfa_resize_sum_multi() / _bwd(); MRFA_PACK_MAX_DESCS 48 -> 240.                                                                                                           */
-#define MRFA_ABI_VERSION 8
+ *      mrfa_conv2d_split_k(); mrfa_layernorm_bwd += scratch; mrfa_resize_sum_multi() / _bwd(); MRFA_PACK_MAX_DESCS 48 -> 240.
+ *   9  round 6: mrfa_conv_params.fin_counter points to MRFA_FIN_WORDS zeroed words (was: one); new kernel family behind mrfa_conv2d_nhwc for the keypoint
+ *      encoder's <= 128-channel 3x3 layers (conv_lean.hip; mrfa_conv2d_last_config() bit 27; it honours in_scale / in_shift, stats / fin_* / bst_* / groups),
+ *      tuning keys "conv_lean", "conv_lean_min_wgs", "conv_lean_geo".                                                                                      */
+#define MRFA_ABI_VERSION 9
 int mrfa_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -147,6 +150,9 @@ int mrfa_conv2d_groups_supported(const mrfa_conv_params* p);         /* 1: a cal
  * performed at the memory side at ~20-40 ns each (the per-XCD L2s are not coherent), so 256-512 workgroups adding into the same
  * 2*C words cost 5-21 us per launch on the MTIA prior's 0.6-GFLOP layers (tools/ubench/small_kernels.cpp) -- more than the layer. */
 #define MRFA_STATS_SLOTS 32
+/* v9: mrfa_conv_params.fin_counter = MRFA_FIN_WORDS zeroed 32-bit words per call (one through v8): the kernels that know their workgroups' indices draw the
+ * finalize tickets from eight of them -- 256-512 returning atomics on ONE word cost 3.3 us per launch -- and only the shards' last arrivers from word 0   */
+#define MRFA_FIN_WORDS 16
 int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* p);
 int mrfa_conv2d_stride_supported(const mrfa_conv_params* p);         /* 1: a call with these parameters honours stride = 2                */
 int mrfa_conv2d_mask_supported(const mrfa_conv_params* p);           /* 1: a call with these parameters honours `mask`                    */

@@ -33,6 +33,14 @@ bool mrfa_fewout3_wgrad(hipStream_t st, const float* x, int ldx, int N, int H, i
                         float* dw, float* dbias, int* rc);
 int mrfa_tuning_fewout3(int set);          // mrfa_set_tuning("conv_fewout3", 0 / 1)
 
+// conv_lean.hip: the keypoint encoder's small-channel 3x3 layers (<= 128 channels, ~1 GFLOP): four-wave patches, the halo of all input channels split once
+// into LDS, weight fragments straight from the pre-split planes in global memory, split-operand arithmetic
+bool mrfa_conv_lean_eligible(const mrfa_conv_params& p);
+int mrfa_conv_lean_launch(hipStream_t st, const mrfa_conv_params& p);
+int mrfa_tuning_conv_lean(int set);        // mrfa_set_tuning("conv_lean", 0 / 1); set < 0: query
+int mrfa_tuning_conv_lean_min(int set);    // mrfa_set_tuning("conv_lean_min_wgs", n)
+int mrfa_tuning_conv_lean_geo(int set);    // mrfa_set_tuning("conv_lean_geo", i): only geometry i of conv_lean.hip's table (-1: by workgroup count)
+
 // conv_small.hip: one wave per 16..32-row output tile, operands straight from L1/L2 into v_mfma_f32_16x16x4_f32 (small problems)
 bool mrfa_conv_small_eligible(const mrfa_conv_params& p, long long M);
 int mrfa_conv_small_launch(hipStream_t st, const mrfa_conv_params& p, long long M);
@@ -121,24 +129,61 @@ __device__ __forceinline__ bool splitk_last_arriver(unsigned* ticket, unsigned n
 // of gfx950 nor a relaxed ticket makes hipcc emit that wait by itself -- round 4 shipped without it) before the barrier that precedes the ticket --
 // also a device-scope atomic --, and the last workgroup reads the slots with device-scope loads, which bypass the non-coherent L2s (the guide's "sc1 stores AND
 // sc1 loads" hand-off).  tests/test_wiring_cpu.py checks the compiled ISA of every kernel that calls this for the wait.
-__device__ __forceinline__ void fused_bn_finalize(const mrfa_conv_params& p, unsigned participants) {
+//
+// Round 6 (measured on conv_lean.hip, 32 -> 32 @64^2 over 16 frames: 20.4 us with the finalize, 13.2 us without): what the 7 us were made of, and what replaced it.
+//  * 256-512 workgroups drawing tickets from ONE word = that many returning atomics serialised on one address (~12 ns each: the guide's fan-in row, 3.3 us).
+//    With a dense participant index `idx` the tickets are SHARDED: workgroup idx draws from word 1 + idx % 8, the last arriver of a shard draws from word 0,
+//    and the last of those finalizes (fin_counter = MRFA_FIN_WORDS zeroed words).  idx < 0: the single-word form (K splits: the participants are the tiles'
+//    last arrivers, nobody knows their indices).
+//  * the last workgroup summed the 2 x 32 slot words of a channel as a chain of 64 dependent loads; they are now issued 32 at a time (one memory round trip
+//    per batch), and with `scratch` (>= groups x 2 Cout doubles of LDS the caller no longer needs) every (group, statistic, channel) sum has its own thread.
+__device__ __forceinline__ bool fin_last_arriver(unsigned* counter, unsigned participants, int idx) {
     __shared__ unsigned s_fin_ticket;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_fin_ticket = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (idx < 0) {
+            s_fin_ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == participants - 1;
+        } else {
+            const unsigned nsh = participants < 8u ? participants : 8u, sh = (unsigned)idx % nsh;
+            const unsigned mine = participants / nsh + (sh < participants % nsh ? 1u : 0u);
+            unsigned last = 0;
+            if (__hip_atomic_fetch_add(counter + 1 + sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1)
+                last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1;
+            s_fin_ticket = last;
+        }
+    }
     __syncthreads();
-    if (s_fin_ticket != participants - 1) return;
+    return s_fin_ticket != 0;
+}
+
+// sum of the MRFA_STATS_SLOTS slot words of one statistic of one channel: device-scope loads, all in flight together
+__device__ __forceinline__ double fin_slot_sum(const double* first, size_t stride) {
+    double v[MRFA_STATS_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MRFA_STATS_SLOTS; ++s) v[s] = __hip_atomic_load(first + (size_t)s * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double t = 0.0;
+#pragma unroll
+    for (int s = 0; s < MRFA_STATS_SLOTS; ++s) t += v[s];
+    return t;
+}
+
+__device__ __forceinline__ void fused_bn_finalize(const mrfa_conv_params& p, unsigned participants, int idx = -1, double* scratch = nullptr, int scratch_n = 0) {
+    if (!fin_last_arriver(p.fin_counter, participants, idx)) return;
     const double cnt = (double)p.fin_count;
     const int G = p.groups > 1 ? p.groups : 1;
+    const int C2 = 2 * p.Cout;
+    const bool par = scratch != nullptr && scratch_n >= G * C2;
+    if (par) {                                        // one thread per (group, statistic, channel) sum
+        for (int o = threadIdx.x; o < G * C2; o += blockDim.x) scratch[o] = fin_slot_sum(p.stats + (size_t)(o / C2) * MRFA_STATS_SLOTS * C2 + o % C2, (size_t)C2);
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < p.Cout; c += blockDim.x) {
         float rm = p.fin_rmean ? p.fin_rmean[c] : 0.f, rv = p.fin_rmean ? p.fin_rvar[c] : 0.f;
         for (int g = 0; g < G; ++g) {                 // (statistic groups: one momentum update per group, in group order)
-            const double* sg = p.stats + (size_t)g * MRFA_STATS_SLOTS * 2 * p.Cout;
-            double t1 = 0.0, t2 = 0.0;
-            for (int s = 0; s < MRFA_STATS_SLOTS; ++s) {
-                t1 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t2 += __hip_atomic_load(sg + (size_t)s * 2 * p.Cout + p.Cout + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const double* sg = p.stats + (size_t)g * MRFA_STATS_SLOTS * C2;
+            const double t1 = par ? scratch[g * C2 + c] : fin_slot_sum(sg + c, (size_t)C2);
+            const double t2 = par ? scratch[g * C2 + p.Cout + c] : fin_slot_sum(sg + p.Cout + c, (size_t)C2);
             const double m = t1 / cnt;
             double var = t2 / cnt - m * m;
             if (var < 0.0) var = 0.0;

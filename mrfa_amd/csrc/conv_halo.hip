@@ -408,7 +408,7 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
-    if (p.fin_scale) fused_bn_finalize(p, (unsigned)total_tiles * gridDim.y);      // (every workgroup with a tile reaches this point with all of its threads)
+    if (p.fin_scale) fused_bn_finalize(p, (unsigned)total_tiles * gridDim.y, lin + total_tiles * (int)blockIdx.y, reinterpret_cast<double*>(smem), (int)(sizeof(smem) / 8));      // (every workgroup with a tile reaches this point with all of its threads)
 }
 
 int g_halo_on = -1;              // -1: not initialised (MRFA_CONV_HALO)
@@ -503,6 +503,9 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_fewout3")) return mrfa_tuning_fewout3(value != 0);
     if (!strcmp(key, "attention_mfma")) return mrfa_tuning_attention_mfma(value != 0);
     if (!strcmp(key, "conv_small")) { const int prev = g_conv_small; g_conv_small = value != 0; return prev; }
+    if (!strcmp(key, "conv_lean")) return mrfa_tuning_conv_lean(value != 0);
+    if (!strcmp(key, "conv_lean_min_wgs")) return mrfa_tuning_conv_lean_min(value);
+    if (!strcmp(key, "conv_lean_geo")) return mrfa_tuning_conv_lean_geo(value);
     return -1;
 }
 

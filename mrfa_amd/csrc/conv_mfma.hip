@@ -366,6 +366,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
 
 extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
     if (!p || !p->stats || p->fin_scale || p->stride < 0 || p->kflat > 0) return 0;
+    if (mrfa_conv_lean_eligible(*p)) return 1;
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     return small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
@@ -378,6 +379,7 @@ extern "C" int mrfa_conv2d_groups_supported(const mrfa_conv_params* p) {
     const long long M = (long long)p->N * p->Hout * p->Wout;
     const long long rows = group_rows(*p, M);
     if (rows <= 0) return 0;
+    if (p->kflat == 0 && mrfa_conv_lean_eligible(*p)) return 1;                                      // (a patch lies inside one image)
     if ((rows % 128) == 0) return 1;
     // shorter groups: the kernels whose tiles are smaller than 128 rows, where the dispatch would pick them
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
@@ -407,7 +409,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     if (pp->bst_x) {
         MRFA_CHECK_ARG(pp->stats && pp->bst_scale && pp->bst_shift && pp->bst_mean && pp->bst_invstd && !pp->fin_scale,
                        "conv2d: bst_x needs stats, bst_scale / _shift / _mean / _invstd and no fin_*");
-        MRFA_CHECK_ARG(mrfa_conv2d_bwdstats_supported(pp), "conv2d: bst_* is only implemented by the one-wave-per-tile kernel: ask mrfa_conv2d_bwdstats_supported() first");
+        MRFA_CHECK_ARG(mrfa_conv2d_bwdstats_supported(pp), "conv2d: bst_* is only implemented by the small-problem kernels: ask mrfa_conv2d_bwdstats_supported() first");
     }
     bool fin_done = false;
     const int rc = conv2d_dispatch(stream, pp, &fin_done);
@@ -437,6 +439,13 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     const int KT = (Ktot + BK - 1) / BK;
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
 
+    // ---- the keypoint encoder's <= 128-channel 3x3 layers in a split-operand mode: four-wave patches on the bf16 pipe (conv_lean.hip)
+    if (!flat && mrfa_conv_lean_eligible(p)) {
+        if (dry_split) { *dry_split = 1; return 0; }
+        g_last_tile = (32 << 16) | (32 << 4) | 4 | (1 << 27);    // bit 27: conv_lean
+        *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
+        return mrfa_conv_lean_launch(st, p);
+    }
     // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(p, M)) {

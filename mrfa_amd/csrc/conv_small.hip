@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const mrfa_conv_params 
                 atomicAdd(stat_slot(p, grp, blockIdx.x) + which * p.Cout + c, v);
             }
         }
-        if (p.fin_scale) fused_bn_finalize(p, gridDim.x);       // (common.h: the launch's last workgroup finishes the BatchNorm that follows)
+        if (p.fin_scale) fused_bn_finalize(p, gridDim.x, (int)blockIdx.x);       // (common.h: the launch's last workgroup finishes the BatchNorm that follows)
     }
 }
 

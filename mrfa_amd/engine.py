@@ -926,6 +926,14 @@ class Ctx:
         if rc:
             hip.check(rc, what)
 
+    def mark(self, name: str):
+        """measurement aid (engine.MARKS set): a device timestamp here in the forward pass and, on the tape, where the backward pass comes back to this point"""
+        if MARKS is None:
+            return
+        mark("fwd " + name)
+        if self.record:
+            self.tape.append(lambda: mark("bwd " + name))
+
     def rec(self, fn):
         if self.record:
             self.tape.append(fn)
@@ -1382,8 +1390,8 @@ class Ctx:
         self.nbt = {}
 
     def bn_stats_buf(self, bn):
-        """[groups][STATS_SLOTS][2C] zeroed doubles (+ one zeroed word behind them: the ticket counter of a finalize fused into the producing launch)"""
-        return self.f64z(self.groups * hip.STATS_SLOTS * 2 * bn.num_features + 1) if self.train else None
+        """[groups][STATS_SLOTS][2C] zeroed doubles (+ FIN_WORDS zeroed words behind them: the ticket counters of a finalize fused into the producing launch)"""
+        return self.f64z(self.groups * hip.STATS_SLOTS * 2 * bn.num_features + hip.FIN_WORDS // 2) if self.train else None
 
     def _bn_stats_into(self, x: View, stats: torch.Tensor):
         """per-channel sum / sum of squares of x into `stats` by a pass of its own (one per statistic group: a group is a run of consecutive rows)"""

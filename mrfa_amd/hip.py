@@ -215,7 +215,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 LN_SLOTS = 16          # MRFA_LN_SLOTS
 RESIZE_SUM_TERMS = 4   # MRFA_RESIZE_SUM_TERMS
-ABI_VERSION = 8        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
+ABI_VERSION = 9        # MRFA_ABI_VERSION of include/mrfa_hip.h: the struct layouts above mirror THAT header; lib() refuses any other library
 
 _lib = None
 
@@ -255,6 +255,7 @@ def lib():
 #   "bf16x3"  the same kernels with the three leading products only: ~1e-5 relative product error (opt-in)
 #   "bf16"    operands rounded to bf16, one product (a bf16 autocast's arithmetic; fp32 accumulate / storage): BASELINE config 4
 STATS_SLOTS = 32       # MRFA_STATS_SLOTS of include/mrfa_hip.h: BatchNorm statistics buffers are [STATS_SLOTS][2C] doubles
+FIN_WORDS = 16         # MRFA_FIN_WORDS: zeroed 32-bit ticket words behind a statistics buffer whose finalize rides in the producing launch
 MFMA_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}
 DEFAULT_MFMA = "bf16x6"
 

@@ -266,17 +266,21 @@ class HRNET_base(nn.Module):
         """x: (B,H,W,3) NHWC image view (no gradient is propagated into it)"""
         y = _conv_bn(e, x, self.conv1, self.bn1, relu=True, need_dx=False)
         y = _conv_bn(e, y, self.conv2, self.bn2, relu=True)
+        e.mark("enc stem")
         for blk in self.layer1:
             y = blk.run(e, y)
+        e.mark("enc layer1")
         xs = [y if t is None else self._transition(e, t, y) for t in self.transition1]
         for m in self.stage2:
             xs = m.run(e, xs)
+        e.mark("enc stage2")
         nxt = []
         for i, t in enumerate(self.transition2):
             nxt.append(xs[i] if t is None else self._transition(e, t, xs[-1]))
         xs = nxt
-        for m in self.stage3:
+        for k, m in enumerate(self.stage3):
             xs = m.run(e, xs)
+            e.mark(f"enc stage3.{k}")
         return xs[0]
 
     def forward(self, x):

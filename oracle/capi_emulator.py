@@ -351,7 +351,7 @@ class Emulator:
 
     # ---------------------------------------------------------------- misc
     def mrfa_version(self):
-        return 8              # MRFA_ABI_VERSION of include/mrfa_hip.h
+        return 9              # MRFA_ABI_VERSION of include/mrfa_hip.h
 
     def mrfa_last_error(self):
         return self._err

@@ -144,7 +144,7 @@ def conv_case(side, *, N=2, H=12, W=10, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
         keep.append(rt)
         p.res, p.ldr = rt.data_ptr(), Cout + 4
     G = groups                      # v7, statistic groups: [G][MRFA_STATS_SLOTS][2C] statistics, [G][C] per-channel vectors
-    stbuf = side.z((G * hip.STATS_SLOTS * 2 * Cout + 1,), torch.float64)  # [G][MRFA_STATS_SLOTS][2C], summed by the consumer (+ the finalize ticket word)
+    stbuf = side.z((G * hip.STATS_SLOTS * 2 * Cout + hip.FIN_WORDS // 2,), torch.float64)  # [G][MRFA_STATS_SLOTS][2C], summed by the consumer (+ the finalize ticket words)
     st = stbuf[:G * hip.STATS_SLOTS * 2 * Cout].view(G, hip.STATS_SLOTS, 2 * Cout)
     if stats:
         p.stats, p.groups = st.data_ptr(), G
@@ -379,14 +379,14 @@ def test_patch_tiled_kernel_is_run_to_run_identical(name):
     kw["stats"] = False
     assert L.mrfa_set_mfma_mode(1) == 0
     prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
-    L.mrfa_set_tuning(b"conv_small", 0)
+    L.mrfa_set_tuning(b"conv_small", 0); L.mrfa_set_tuning(b"conv_lean", 0)
     try:
         outs = [conv_case(Side(True), tag=f"halo/{name}", wsplit=True, **kw)[0] for _ in range(8)]
         assert L.mrfa_conv2d_last_config() & (1 << 28), "the patch-tiled kernel did not run"
     finally:
         L.mrfa_set_mfma_mode(0)
         L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
-        L.mrfa_set_tuning(b"conv_small", 1)
+        L.mrfa_set_tuning(b"conv_small", 1); L.mrfa_set_tuning(b"conv_lean", 1)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 
@@ -405,7 +405,7 @@ def test_conv2d_patch_tiled_kernel(name, mode):
     ref = conv_case(Side(False), tag=f"halo/{name}", **kw)
     assert L.mrfa_set_mfma_mode(mode) == 0
     prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", min_tiles)
-    L.mrfa_set_tuning(b"conv_small", 0)                     # (the small test shapes would otherwise go to conv_small.hip)
+    L.mrfa_set_tuning(b"conv_small", 0); L.mrfa_set_tuning(b"conv_lean", 0)                     # (the small test shapes would otherwise go to conv_small.hip)
     L.mrfa_set_tuning(b"conv_halo_bn192", bn192)
     try:
         got = conv_case(Side(True), tag=f"halo/{name}", wsplit=("rne" if mode == 3 else True), **kw)
@@ -413,10 +413,99 @@ def test_conv2d_patch_tiled_kernel(name, mode):
     finally:
         L.mrfa_set_mfma_mode(0)
         L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
-        L.mrfa_set_tuning(b"conv_small", 1)
+        L.mrfa_set_tuning(b"conv_small", 1); L.mrfa_set_tuning(b"conv_lean", 1)
         L.mrfa_set_tuning(b"conv_halo_bn192", 1)
     # mode 3: both operands rounded to 8 significand bits (2^-9 each), K = 288 .. 2304 products per output
     assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="halo " + name)
+
+
+LEAN_CASES = {          # conv_lean.hip: the keypoint encoder's <= 128-channel 3x3 layers; every geometry (geo = row of its table), every epilogue / prologue option, tails
+    # 32 channels: 8 x 32 patches with two pixel tiles per wave (geo 0), 4 x 32 patches (geo 3)
+    "g0_hr32_stats_fin": dict(geo=0, N=2, H=16, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, fin=True),
+    "g0_pro_res_relu_tail": dict(geo=0, N=1, H=12, W=32, Cin=32, Cout=32, pro=True, res=True, relu=True, stats=True),     # H % 8 != 0: the last patch is half empty
+    "g0_bst_groups2_c64": dict(geo=0, N=4, H=8, W=32, Cin=32, Cout=64, stats=True, relu=False, bias=False, bst=True, groups=2),
+    "g3_hr32_stats_fin": dict(geo=3, N=2, H=16, W=64, Cin=32, Cout=32, stats=True, relu=False, bias=False, fin=True),
+    "g3_hr32_pro_res_relu": dict(geo=3, N=1, H=8, W=32, Cin=32, Cout=32, pro=True, res=True, relu=True, stats=True),
+    "g3_tail_rows_c64": dict(geo=3, N=2, H=10, W=32, Cin=32, Cout=64, relu=True),                  # H % 4 != 0; two channel tiles
+    "g3_acc_alpha_affine": dict(geo=3, N=1, H=4, W=64, Cin=32, Cout=32, acc=True, alpha=0.37, relu=False, oaff=True),
+    "g3_bst_groups2": dict(geo=3, N=4, H=8, W=32, Cin=32, Cout=32, stats=True, relu=False, bias=False, bst=True, groups=2),
+    "g3_wide_ld": dict(geo=3, N=1, H=8, W=32, Cin=32, Cout=32, ldx_extra=8, ldy_extra=12, stats=True),
+    # 64 channels: 2 x 32 patches x 64 output channels in two input-channel slices, two tiles per wave (geo 1); one tile per wave, no slices (geo 4);
+    # 1 x 32 patches in two slices (geo 5)
+    "g1_hr64_stats_fin_groups2": dict(geo=1, N=4, H=8, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "g1_pro_res_tail": dict(geo=1, N=2, H=5, W=32, Cin=64, Cout=64, pro=True, res=True, relu=True),
+    "g1_bst_acc_c96": dict(geo=1, N=2, H=8, W=32, Cin=64, Cout=96, stats=True, relu=False, bias=False, acc=True, bst=True),
+    "g4_hr64_stats_fin_groups2": dict(geo=4, N=4, H=8, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "g4_hr64_pro_res": dict(geo=4, N=2, H=6, W=32, Cin=64, Cout=64, pro=True, res=True, relu=True),
+    "g4_bst_acc": dict(geo=4, N=2, H=8, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, acc=True, bst=True),
+    "g4_c96_out": dict(geo=4, N=1, H=8, W=32, Cin=64, Cout=96, stats=True),                          # three channel tiles over two 64-wide workgroup tiles
+    "g5_hr64_slices": dict(geo=5, N=1, H=8, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, fin=True),
+    "g5_bst_linear_tail": dict(geo=5, N=1, H=5, W=32, Cin=64, Cout=64, stats=True, relu=False, bias=False, bst="linear"),
+    # 128 channels on 16-wide patches: 4 x 16 x 32 output channels in four slices, two tiles per wave (geo 2); 2 x 16 x 64 in two slices (geo 6);
+    # 2 x 16 x 32 in four slices (geo 7)
+    "g2_hr128_stats_fin": dict(geo=2, N=2, H=16, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, fin=True),
+    "g2_pro_res_acc_tail": dict(geo=2, N=1, H=6, W=16, Cin=128, Cout=128, pro=True, res=True, acc=True, relu=False),
+    "g2_bst_groups3_w32": dict(geo=2, N=3, H=4, W=32, Cin=128, Cout=64, stats=True, relu=False, bias=False, bst=True, groups=3),
+    "g6_hr128_stats_fin": dict(geo=6, N=2, H=16, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, fin=True),
+    "g6_hr128_pro_res_acc": dict(geo=6, N=1, H=16, W=16, Cin=128, Cout=128, pro=True, res=True, acc=True, relu=False),
+    "g6_bst_groups3": dict(geo=6, N=3, H=8, W=16, Cin=128, Cout=128, stats=True, relu=False, bias=False, bst=True, groups=3),
+    "g6_tail_rows": dict(geo=6, N=2, H=7, W=16, Cin=128, Cout=128, stats=True, relu=True),           # H % 2 != 0
+    "g7_hr128_slices": dict(geo=7, N=1, H=16, W=16, Cin=128, Cout=128, stats=True, relu=True),
+    "g7_bst_c64": dict(geo=7, N=1, H=8, W=16, Cin=128, Cout=64, stats=True, relu=False, bias=False, bst=True),
+}
+
+
+def _lean_run(name, mode, **over):
+    """one conv_lean.hip launch of LEAN_CASES[name] in matrix mode `mode`, the geometry forced"""
+    L = hip.lib()
+    kw = dict(LEAN_CASES[name])
+    kw.update(over)
+    geo = kw.pop("geo")
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    L.mrfa_set_tuning(b"conv_lean_geo", geo)
+    try:
+        got = conv_case(Side(True), tag=f"lean/{name}", wsplit=("rne" if mode == 3 else True), **kw)
+        assert L.mrfa_conv2d_last_config() & (1 << 27), "the lean patch kernel did not run"
+    finally:
+        L.mrfa_set_mfma_mode(0)
+        L.mrfa_set_tuning(b"conv_lean_geo", -1)
+    return got
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("name", list(LEAN_CASES))
+def test_conv2d_lean_kernel(name, mode):
+    """conv_lean.hip (four-wave patches, the halo of all input channels split once into LDS, weight fragments straight from the pre-split planes) against the
+    CPU specification in the six-product (fp32-accurate), the three-product and the plain-bf16 mode"""
+    kw = dict(LEAN_CASES[name])
+    kw.pop("geo")
+    ref = conv_case(Side(False), tag=f"lean/{name}", **kw)
+    got = _lean_run(name, mode)
+    assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="lean " + name)
+
+
+def test_lean_kernel_is_run_to_run_identical_and_equals_the_one_wave_kernel():
+    """no atomics on the output path (the input-channel slices meet in LDS in a fixed order): eight launches agree bit for bit; and the result is the
+    fp32-pipe kernel's (conv_small.hip, exact fmaf chains) to fp32 rounding of the sums"""
+    L = hip.lib()
+    for name in ["g0_pro_res_relu_tail", "g1_pro_res_tail", "g2_pro_res_acc_tail", "g5_hr64_slices", "g6_hr128_pro_res_acc", "g7_hr128_slices"]:
+        outs = [_lean_run(name, 1, stats=False, fin=False)[0] for _ in range(8)]
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), name
+        if LEAN_CASES[name].get("pro"):
+            continue                                     # (conv_small.hip has no prologue)
+        kw = dict(LEAN_CASES[name])
+        kw.pop("geo")
+        kw.update(stats=False, fin=False)
+        L.mrfa_set_tuning(b"conv_lean", 0)
+        L.mrfa_set_tuning(b"conv_halo", 0)
+        try:
+            small = conv_case(Side(True), tag=f"lean/{name}", **kw)[0]
+            assert L.mrfa_conv2d_last_config() & 8, "not the one-wave-per-tile kernel"
+        finally:
+            L.mrfa_set_tuning(b"conv_lean", 1)
+            L.mrfa_set_tuning(b"conv_halo", 1)
+        assert_close([small], [outs[0]], tol=2e-5, what="lean vs fp32 pipe " + name)
 
 
 @pytest.mark.parametrize("cfg", [dict(N=2, H=8, W=32, Cin=64, Cout=128), dict(N=1, H=16, W=32, Cin=128, Cout=64, acc=True),
@@ -484,7 +573,7 @@ def test_patch_tiled_kernel_equals_the_row_tiled_kernel_and_fp64():
     errs = {}
     assert L.mrfa_set_mfma_mode(1) == 0
     prev = L.mrfa_set_tuning(b"conv_halo_min_tiles", 0)
-    L.mrfa_set_tuning(b"conv_small", 0)
+    L.mrfa_set_tuning(b"conv_small", 0); L.mrfa_set_tuning(b"conv_lean", 0)
     try:
         for halo in (0, 1):
             L.mrfa_set_tuning(b"conv_halo", halo)
@@ -504,7 +593,7 @@ def test_patch_tiled_kernel_equals_the_row_tiled_kernel_and_fp64():
         L.mrfa_set_mfma_mode(0)
         L.mrfa_set_tuning(b"conv_halo", 1)
         L.mrfa_set_tuning(b"conv_halo_min_tiles", prev)
-        L.mrfa_set_tuning(b"conv_small", 1)
+        L.mrfa_set_tuning(b"conv_small", 1); L.mrfa_set_tuning(b"conv_lean", 1)
     scale = float(exact.abs().max())
     assert errs[1][0] <= max(2.0 * errs[0][0], 1e-6 * scale) and errs[1][1] <= max(2.0 * errs[0][1], 1e-7 * scale), (errs, scale)
 
@@ -754,7 +843,7 @@ def test_wgrad_all_taps_kernel(cfg, mode):
     ref = wgrad_case(Side(False), tag=tag, **cfg)
     assert L.mrfa_set_mfma_mode(mode) == 0
     prev = L.mrfa_set_tuning(b"wgrad_halo_min_wgs", min_wgs)
-    L.mrfa_set_tuning(b"conv_small", 0)
+    L.mrfa_set_tuning(b"conv_small", 0); L.mrfa_set_tuning(b"conv_lean", 0)
     try:
         got = wgrad_case(Side(True), tag=tag, **cfg)
         plain = None
@@ -770,7 +859,7 @@ def test_wgrad_all_taps_kernel(cfg, mode):
         L.mrfa_set_tuning(b"wgrad_halo", 1)
         L.mrfa_set_tuning(b"wgrad_halo_phase", 1)
         L.mrfa_set_tuning(b"wgrad_halo_min_wgs", prev)
-        L.mrfa_set_tuning(b"conv_small", 1)
+        L.mrfa_set_tuning(b"conv_small", 1); L.mrfa_set_tuning(b"conv_lean", 1)
     tol = {1: 5e-4, 2: 5e-3, 3: 3e-2}[mode]
     assert_close(ref, got, tol=tol, what=tag)
     assert_close(other, got, tol=tol, what=tag + " vs per-tap kernel")
