@@ -634,14 +634,18 @@ def main(rank_body=None, script=None, argv=None, child_argv=None):
             for prm in model.parameters():
                 prm.grad = None
 
+    # statistics collectives of ONE step.  A captured step issued them while it was being captured (GraphedTrainStep counted them there); an eager step is
+    # counted over the first warm-up step -- the step that is timed, with its gradient exchange: no extra weight update on any rank
     syncbn_per_step = None
-    if a.sync_bn:
-        # statistics collectives of ONE step (a captured step issues them while it is being captured: counted over one eager step here)
-        from mrfa_amd import engine as _eng
-        c0 = _eng.SYNCBN_COLLECTIVES
-        train_step(model.module if hasattr(model, "module") else model, opt, src, drv, clip=clip, loss_fn=loss_fn) if launch == "hipGraph" else step()
-        syncbn_per_step = _eng.SYNCBN_COLLECTIVES - c0
-    for _ in range(a.warmup):
+    if a.sync_bn and launch == "hipGraph":
+        syncbn_per_step = gstep.syncbn_collectives
+    for i in range(a.warmup):
+        if a.sync_bn and launch != "hipGraph" and i == 0:
+            from mrfa_amd import engine as _eng
+            c0 = _eng.SYNCBN_COLLECTIVES
+            loss = step()
+            syncbn_per_step = _eng.SYNCBN_COLLECTIVES - c0
+            continue
         loss = step()
     barrier()
     if launch == "eager" and not a.no_roofline:

@@ -88,9 +88,7 @@ static inline int stream_grid(long long work_items, int block) {
 // BESIDE chip-filling matrix kernels (the deferred weight gradients, one 256-VGPR workgroup per CU for hundreds of microseconds), and a chain kernel's few
 // instructions otherwise take turns with that workgroup's on the same SIMD.  s_setprio only reorders instruction issue between co-resident waves.
 __device__ __forceinline__ void chain_prio() {
-#ifndef MRFA_AB_NO_CHAIN_PRIO
     __builtin_amdgcn_s_setprio(3);
-#endif
 }
 
 // Statistic groups (mrfa_hip.h, v7): the group of output row `row` of a launch with M = N Hout Wout rows, and the [MRFA_STATS_SLOTS][2 Cout] statistics

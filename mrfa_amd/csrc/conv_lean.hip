@@ -111,9 +111,6 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
     auto store_unit = [&](auto SC, int j) {
         constexpr int sc = decltype(SC)::value;
         f32x4 v = ra[sc][j];
-#ifdef LEAN_AB_NOSTORE
-        if (v.x != 12345.678f) return;
-#endif
         if constexpr (PRO) {                           // BatchNorm apply + ReLU of the producing layer (in_relu always comes with in_scale)
             const int c0 = sc * (16 * KS) + ((tid + j * 256) % (4 * KS)) * 4;
             const f32x4 psc = *reinterpret_cast<const f32x4*>(p.in_scale + c0), psh = *reinterpret_cast<const f32x4*>(p.in_shift + c0);
@@ -201,15 +198,6 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
     auto mfma_step = [&](int buf, int slot) {
-#ifdef LEAN_AB_NOMFMA
-        {
-#pragma unroll
-            for (int pc = 0; pc < NPC; ++pc)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i][0][pc] += __int_as_float(rb[slot][pc][0] ^ (unsigned)af[buf][i][pc][0]);
-            return;
-        }
-#endif
         bf16x8 b[NPC];
 #pragma unroll
         for (int pc = 0; pc < NPC; ++pc) b[pc] = __builtin_bit_cast(bf16x8, rb[slot][pc]);
@@ -261,24 +249,16 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
         for (int tap = 0; tap < 9; ++tap) {
             const int step = 9 * sc + tap;
             // the next step's activation fragments (inside a super-chunk: its LDS image is complete; across the barrier they are read behind it)
-#ifdef LEAN_AB_NOA
-            mfma_step(0, step % RING);
-#else
             if (tap < 8) read_a(step + 1, (step + 1) & 1);
             mfma_step(step & 1, step % RING);
-#endif
-#ifndef LEAN_AB_NOB
             load_b(step + RING, step % RING);
-#endif
             if constexpr (sc + 1 < NSC) {              // the next super-chunk's halo: split and stored in the shadow of this one's MFMAs
                 if (tap < NUS) store_unit(std::integral_constant<int, sc + 1>{}, tap);
             }
         }
         if constexpr (sc + 1 < NSC) {
             __syncthreads();
-#ifndef LEAN_AB_NOA
             read_a(9 * (sc + 1), (9 * (sc + 1)) & 1);
-#endif
         }
     };
     run_sc(std::integral_constant<int, 0>{});
@@ -317,11 +297,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
     float s1[16], s2[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
-#ifdef LEAN_AB_NOEPI
-    const bool wave_on = wg_on && wk == 0 && acc[0][0][0] == 12345.678f;
-#else
     const bool wave_on = wg_on && wk == 0;
-#endif
     if (wave_on) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -421,10 +397,8 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
             const int cch = n0 + col;
             if (wg_on && cch < p.Cout) atomicAdd(stat_slot(p, grp, blockIdx.x) + which * p.Cout + cch, (double)t);
         }
-#ifndef LEAN_AB_NOFIN
         // (every workgroup of the grid, with all of its threads; the halo images are dead: their LDS is the finalize's scratch)
         if (p.fin_scale) fused_bn_finalize(p, gridDim.x, (int)blockIdx.x, reinterpret_cast<double*>(smem), (int)(G::LDS_BYTES(NPC) / 8));
-#endif
     }
 }
 

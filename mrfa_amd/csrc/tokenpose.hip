@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 float t = 0.f;
                 for (int sl = 0; sl < LN_SLOTS; ++sl) t += __hip_atomic_load(scratch + (size_t)sl * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 float* dst = c < C ? dgamma : dbeta;
-                if (dst) dst[c < C ? c : c - C] += t;
+                if (dst) atomicAdd(dst + (c < C ? c : c - C), t);      // (2 C atomics per launch: two launches of one LayerNorm on different streams may overlap)
             }
         }
     }

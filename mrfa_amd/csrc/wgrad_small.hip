@@ -162,9 +162,6 @@ __device__ __forceinline__ void wgrad_small_body(const SmallProblem& p, const in
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) load(range + s * 16, ra[s], rb[s]);
-#ifdef MRFA_AB_NO_LOOP
-    nc = nc > 1 ? 1 : nc;
-#endif
     for (int c0 = 0; c0 < nc; c0 += 4) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -203,11 +200,7 @@ __device__ __forceinline__ void wgrad_small_body(const SmallProblem& p, const in
     float* dw = p.dw + ((size_t)tap * p.Cout + co0) * p.Cin + ci0;
     for (int i = threadIdx.x; i < B * B; i += 256) {
         const int r = i / B, c = i % B;
-#ifdef MRFA_AB_NO_ATOMICS
-        if (co0 + r < p.Cout && ci0 + c < p.Cin) dw[(size_t)r * p.Cin + c] = p.alpha * (sacc[0][r][c] + sacc[1][r][c]);
-#else
         if (co0 + r < p.Cout && ci0 + c < p.Cin) atomicAdd(dw + (size_t)r * p.Cin + c, p.alpha * (sacc[0][r][c] + sacc[1][r][c]));
-#endif
     }
     if (p.dbias && tap == 0 && ci0 == 0 && threadIdx.x < B && co0 + threadIdx.x < p.Cout) atomicAdd(p.dbias + co0 + threadIdx.x, sbias[threadIdx.x]);
 }

@@ -61,14 +61,6 @@ class Marks:
 MARKS: Optional[Marks] = None
 
 
-def mark(name: str):
-    m = MARKS
-    if m is None or len(m.names) >= m.buf.numel():
-        return
-    hip.check(hip.lib().mrfa_timestamp(hip.stream_ptr(), m.buf.data_ptr() + 8 * len(m.names)), "timestamp")
-    m.names.append(name)
-
-
 class DeferredWgrads:
     """The weight-gradient launches of the programs recorded under `defer_wgrads(d)` (dense motion + RaftFlow: ~100 launches, 22 ms of
     kernels that fill the chip) are not issued where the backward tape reaches them but collected, and issued on ONE side stream when
@@ -2159,7 +2151,7 @@ class Ctx:
             for fn in reversed(self.tape):
                 fn()
         else:
-            # determinism debugging (tools/graph_bisect.py): fingerprint of every activation gradient after each closure
+            # determinism debugging (Ctx.debug_backward = a list): fingerprint of every activation gradient after each closure
             rec = []
             for i, fn in enumerate(reversed(self.tape)):
                 fn()

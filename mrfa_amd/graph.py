@@ -28,7 +28,7 @@ ordered against the kernel nodes around it when the graph is replayed: the first
 source before its producer ran (observed: the 80-byte clone of d(loss)/d(keypoints) feeding the KPDetector backward, and
 the 4-byte semaphore memset of torch's multi-workgroup reductions -- the loss then reads 0.0).  Two defences:
   * mrfa_amd sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime initialises (mrfa_amd/__init__.py; same
-    replay speed on this GPU-bound path, replays then agree with eager launches -- tools/graph_bisect.py replays);
+    replay speed on this GPU-bound path, replays then agree with eager launches -- measured with a since-removed bisection script);
   * what the engine itself records is kernels only (no memcpy clones in IslandOut.add_grad, train.l1_loss reduces
     without a semaphore memset, zero fills are fill kernels); torch's autograd inside the glue islands still emits a
     few 8-byte memsets, which is why the first defence is needed;
@@ -38,7 +38,6 @@ from __future__ import annotations
 
 import math
 import os
-import time
 from typing import Optional
 
 import torch
@@ -248,24 +247,27 @@ class GraphedTrainStep:
         else:
             self.packs = engine.PackPlan(model)
             self.packs_rest = None
+        # All three graphs are captured in "thread_local" error mode: ProcessGroupNCCL's watchdog thread queries events of the eager warm pass's RCCL work
+        # while the capture runs, and in the default ("global") mode such a query from ANOTHER thread invalidated the capture (hipErrorCapturedEvent: 1 capture
+        # in 5 with the SyncBatchNorm collectives captured, round 5 -- then papered over with a 0.5 s pause that protected the first graph only).
+        # thread_local is the mode PyTorch itself uses around NCCL: only this thread's calls are checked against the capture.
         if syncbn_collectives or world > 1:
-            # RCCL work objects of the eager warm pass are still on ProcessGroupNCCL's watchdog list for up to one of its 100 ms polling periods; a capture that
-            # starts meanwhile was seen to die in that thread (hipErrorCapturedEvent from an event query: 1 capture in 5 with the SyncBatchNorm collectives
-            # captured, MRFA_SYNCBN_GRAPH=1; 0 in 16 with this pause): let the list drain first.  (The default exchange is issued BETWEEN the graphs, never captured.)
             torch.cuda.synchronize()
-            time.sleep(0.5)
         self.g_fb = torch.cuda.CUDAGraph()
+        syncbn0 = engine.SYNCBN_COLLECTIVES            # (the Python counter runs while the step is captured: the collectives of ONE step)
         GraphedTrainStep._captures += 1
         engine.CAPTURE_KEY = GraphedTrainStep._captures
         engine.WGRAD_STREAM = overlap_wgrad
         try:
-            with torch.cuda.graph(self.g_fb, stream=self.stream), engine.direct_param_grads():
+            with torch.cuda.graph(self.g_fb, stream=self.stream, capture_error_mode="thread_local"), engine.direct_param_grads():
                 if engine.MARKS is not None:
                     engine.MARKS.begin()
                 engine.mark("step: start")
                 self.flat.zero_()
                 self.packs.run()
                 if self.packs_rest is not None:
+                    # (round 6: forking this refresh BEHIND the encoder's stem and layer1 -- which stream 67 MB tensors and take 0.2 + 0.9 ms alone, 1.2 + 1.2 ms
+                    # beside it -- moved the same 1.3 ms of HBM contention onto stage 2: 83.6 / 82.2 ms against 83.2 / 81.4, profiles/r6_ab_late_pack.txt; removed)
                     self.pack_stream.wait_stream(self.stream)
                     with torch.cuda.stream(self.pack_stream):
                         self.packs_rest.run()
@@ -282,17 +284,18 @@ class GraphedTrainStep:
             self.g_tail = None
             if self.split is not None:                                # graph A2: the encoder's backward, from the keypoint gradients of A1
                 self.g_tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_tail, pool=self.g_fb.pool(), stream=self.stream), engine.direct_param_grads():
+                with torch.cuda.graph(self.g_tail, pool=self.g_fb.pool(), stream=self.stream, capture_error_mode="thread_local"), engine.direct_param_grads():
                     self._tail()
         finally:
             engine.CAPTURE_KEY = 0
             engine.WGRAD_STREAM = False
+        self.syncbn_collectives = engine.SYNCBN_COLLECTIVES - syncbn0
         assert self.grads.bound(), "a gradient left the flat buffer"
         self.g_opt = torch.cuda.CUDAGraph()
         if self.fused:
             optimizer.grad_scale = 1.0 / world
             optimizer.sync_lr()
-        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), stream=self.stream):
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), stream=self.stream, capture_error_mode="thread_local"):
             engine.mark("optimizer: start")
             if self.fused:
                 optimizer.step()                                      # 1/world, clipping and Adam: 6 launches

@@ -112,7 +112,7 @@ def test_graphed_train_step_equals_eager(fused):
     assert set(ga) <= set(gb)
     # The full randomly initialised train-mode model is ill-conditioned: two runs of the torch/MIOpen oracle on this GPU
     # at these weights differ by 4.6 % in the global L2 norm of the gradient, two eager runs of this engine by 3-6 %
-    # (tools/graph_bisect.py noise_oracle / noise).  The replay must sit inside that band; a missing or misrouted
+    # (measured in round 2 with a since-removed bisection script).  The replay must sit inside that band; a missing or misrouted
     # gradient is an O(1) error.  (Tight gradient parity lives in test_parity_gpu.py on well-conditioned cases.)
     num = sum(float(((ga[n] - gb[n]) ** 2).sum()) for n in ga)
     noise = sum(float(((ga[n] - ga2[n]) ** 2).sum()) for n in ga)

@@ -20,12 +20,18 @@ NONLY=16 ./tools/ubench/bin/lean_bench > $O/lean_bench.txt 2>&1; cat $O/lean_ben
 for g in 3 4 6; do NONLY=16 GEO=$g ONLY_LEAN=1 ./tools/ubench/bin/lean_bench 2>&1 | grep -v " -1.00" | grep -v "^shape" | cut -c1-52; done | tee $O/lean_bench_one_tile_per_wave.txt
 fi
 if has ab; then
-for r in 1 2; do for cfg in "MRFA_CONV_LEAN=1" "MRFA_CONV_LEAN=0"; do
+# ABCFGS="ENV=val ENV=val ..." (space-separated single settings; default: conv_lean on / off)
+for r in 1 2; do for cfg in ${ABCFGS:-MRFA_CONV_LEAN=1 MRFA_CONV_LEAN=0}; do
   env $cfg python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-forward --no-roofline 2>$O/err.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$cfg', d['ms_per_step'], d['value'])" || tail -3 $O/err.log
 done; done | tee $O/ab.txt
 fi
 if has phases; then
 python tools/step_phases.py 8 mtia 20 2>/dev/null | grep -v amdgpu > $O/step_phases.txt; cat $O/step_phases.txt
+fi
+if has probe; then
+python tools/headline_probe.py 2 _head 2>/dev/null | grep -v amdgpu > $O/headline_probe_bf16x6.txt
+MRFA_MFMA=f32 python tools/headline_probe.py 2 _head 2>/dev/null | grep -v amdgpu > $O/headline_probe_f32.txt
+grep -A1 "kp_head  \|kp_img_head  " $O/headline_probe_bf16x6.txt $O/headline_probe_f32.txt | cut -c1-200
 fi
 if has prof; then
 cd /tmp && export TMPDIR=/tmp
