@@ -41,7 +41,9 @@ const char* mrfa_last_error(void);
  *      mrfa_conv2d_split_k(); mrfa_layernorm_bwd += scratch; mrfa_resize_sum_multi() / _bwd(); MRFA_PACK_MAX_DESCS 48 -> 240.
  *   9  round 6: mrfa_conv_params.fin_counter points to MRFA_FIN_WORDS zeroed words (was: one); new kernel family behind mrfa_conv2d_nhwc for the keypoint
  *      encoder's <= 128-channel 3x3 layers (conv_lean.hip; mrfa_conv2d_last_config() bit 27; it honours in_scale / in_shift, stats / fin_* / bst_* / groups),
- *      tuning keys "conv_lean", "conv_lean_min_wgs", "conv_lean_geo".                                                                                      */
+ *      tuning keys "conv_lean", "conv_lean_min_wgs", "conv_lean_geo"; mrfa_wgrad_params += groups with mrfa_conv2d_wgrad_groups_supported(); with
+ *      groups > 1 the prologue vectors in_scale / in_shift of mrfa_conv_params are [groups][Cin] (only where mrfa_conv2d_groups_supported() says so:
+ *      conv_lean.hip); all-taps multi-problem weight gradient of the same layers (wgrad_lean.hip, tuning key "wgrad_lean").                               */
 #define MRFA_ABI_VERSION 9
 int mrfa_version(void);
 
@@ -69,7 +71,7 @@ typedef struct {
     int Hout, Wout;
     int R, S, pad;
     const float* in_scale; /* optional per-Cin affine + ReLU applied to in-bounds inputs (pre-activation BN:    */
-    const float* in_shift; /*   ResBlock2d / ChannelBlock2d, util.py:126-128,150-155)                           */
+    const float* in_shift; /*   ResBlock2d / ChannelBlock2d, util.py:126-128,150-155); v9: [groups][Cin] with groups > 1 */
     int in_relu;
     const float* bias;     /* optional per-Cout bias                                                            */
     const float* out_scale;/* optional per-Cout affine on the output (eval-mode BN folded into the epilogue)    */
@@ -204,6 +206,9 @@ typedef struct {
     long long ws_bytes;    /*   weights: 1x1 / few-channel layers); NULL => atomics only                          */
     int stride;            /* as mrfa_conv_params.stride: dY pixel (oy, ox) pairs with X pixel (stride * oy + r - pad, ...); only where   */
                            /*   mrfa_conv2d_wgrad_stride_supported() says so                                                                 */
+    int groups;            /* v9: statistic groups of the N samples for the PROLOGUE (0 / 1: one): in_scale / in_shift = [groups][Cin], sample n   */
+                           /*   uses row n / (N / groups) -- the BatchNorm-apply + ReLU of a batched keypoint-encoder pass folded into the weight  */
+                           /*   gradient of the convolution that consumes it.  Only where mrfa_conv2d_wgrad_groups_supported() says so             */
 } mrfa_wgrad_params;
 
 int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
@@ -212,6 +217,9 @@ int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* p);
  * ~415 small weight gradients per training step, issued together after its backward chains)                                                          */
 int mrfa_conv2d_wgrad_multi(void* stream, const mrfa_wgrad_params* ps, int n);
 int mrfa_conv2d_wgrad_stride_supported(const mrfa_wgrad_params* p);  /* 1: a call with these parameters honours stride = 2                       */
+int mrfa_conv2d_wgrad_groups_supported(const mrfa_wgrad_params* p);  /* 1: a call with these parameters honours groups > 1 (prologue rows per group) */
+int mrfa_conv2d_wgrad_lean_supported(const mrfa_wgrad_params* p);    /* 1: mrfa_conv2d_wgrad_multi runs this problem on the all-taps kernel of the keypoint
+                                                                        encoder's <= 128-channel 3x3 layers (wgrad_lean.hip) in the current matrix mode    */
 
 /* weight (un)packing between the reference's OIHW parameter layout and the kernel layouts.
  * mode 0: OIHW -> fwd  chunked [tap][CoutPad][CinPad]            (CoutPad % 128 == 0, CinPad % 32 == 0)

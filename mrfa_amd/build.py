@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libmrfa_hip.so")
-SOURCES = ["error.cpp", "conv_mfma.hip", "conv_split.hip", "conv_halo.hip", "conv_small.hip", "conv_lean.hip", "wgrad_mfma.hip", "wgrad_split.hip", "wgrad_halo.hip", "wgrad_small.hip", "conv_fewout.hip", "conv_fewout3.hip", "layout.hip", "pack_multi.hip", "norm.hip", "sample.hip", "elementwise.hip", "optim.hip", "tokenpose.hip", "attention_mfma.hip", "losses.hip", "prior.hip"]
+SOURCES = ["error.cpp", "conv_mfma.hip", "conv_split.hip", "conv_halo.hip", "conv_small.hip", "conv_lean.hip", "wgrad_mfma.hip", "wgrad_split.hip", "wgrad_halo.hip", "wgrad_small.hip", "wgrad_lean.hip", "conv_fewout.hip", "conv_fewout3.hip", "layout.hip", "pack_multi.hip", "norm.hip", "sample.hip", "elementwise.hip", "optim.hip", "tokenpose.hip", "attention_mfma.hip", "losses.hip", "prior.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"]
 

@@ -52,6 +52,11 @@ int mrfa_attention_bwd_mfma(hipStream_t st, const float* qkv, int ld, const floa
                             float* delta, int B, int n, int heads, int d, float scale, float* dqkv, int lddq);
 int mrfa_tuning_attention_mfma(int set);   // mrfa_set_tuning("attention_mfma", 0 / 1); set < 0: query
 
+// wgrad_lean.hip: all nine taps of the keypoint encoder's <= 128-channel 3x3 layers per staging, many problems per launch, prologue per statistic group
+bool mrfa_wgrad_lean_eligible(const mrfa_wgrad_params& p);
+int mrfa_wgrad_lean_multi(hipStream_t st, const mrfa_wgrad_params* ps, int n, unsigned char* taken);      // launches the eligible ones, taken[i] = 1 for each
+int mrfa_tuning_wgrad_lean(int set);       // mrfa_set_tuning("wgrad_lean", 0 / 1); set < 0: query
+
 // wgrad_small.hip: one wave per 32 x 32 weight block of one tap over a pixel range (small problems)
 bool mrfa_wgrad_small_eligible(const mrfa_wgrad_params& p, long long M);
 int mrfa_wgrad_small_launch(hipStream_t st, const mrfa_wgrad_params& p, long long M);

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
         constexpr int sc = decltype(SC)::value;
         f32x4 v = ra[sc][j];
         if constexpr (PRO) {                           // BatchNorm apply + ReLU of the producing layer (in_relu always comes with in_scale)
-            const int c0 = sc * (16 * KS) + ((tid + j * 256) % (4 * KS)) * 4;
+            // (statistic groups: the vectors are [groups][Cin], the patch lies in one image)
+            const int c0 = (p.groups > 1 ? n_img / (p.N / p.groups) * p.Cin : 0) + sc * (16 * KS) + ((tid + j * 256) % (4 * KS)) * 4;
             const f32x4 psc = *reinterpret_cast<const f32x4*>(p.in_scale + c0), psh = *reinterpret_cast<const f32x4*>(p.in_shift + c0);
             v = v * psc + psh;
 #pragma unroll

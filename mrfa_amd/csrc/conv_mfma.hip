@@ -375,11 +375,13 @@ extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
 // its partial tiles in a pass whose workgroups stride over ALL rows, so grouped launches never split K (the automatic choice is switched off for them)
 extern "C" int mrfa_conv2d_groups_supported(const mrfa_conv_params* p) {
     if (!p || p->groups <= 1) return p ? 1 : 0;
+    if (!p->stats && !p->fin_scale && !p->bst_x && !p->in_scale) return 1;       // (nothing per group in this call)
     if (p->nbatch > 1 || p->splitk > 1) return 0;
     const long long M = (long long)p->N * p->Hout * p->Wout;
     const long long rows = group_rows(*p, M);
     if (rows <= 0) return 0;
     if (p->kflat == 0 && mrfa_conv_lean_eligible(*p)) return 1;                                      // (a patch lies inside one image)
+    if (p->in_scale) return 0;                                                                       // (prologue vectors per group: conv_lean.hip only)
     if ((rows % 128) == 0) return 1;
     // shorter groups: the kernels whose tiles are smaller than 128 rows, where the dispatch would pick them
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
@@ -398,7 +400,7 @@ extern "C" int mrfa_conv2d_split_k(const mrfa_conv_params* p) {
 
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     MRFA_CHECK_ARG(pp, "conv2d: null parameter block");
-    if (pp->groups > 1 && (pp->stats || pp->fin_scale || pp->bst_x))
+    if (pp->groups > 1 && (pp->stats || pp->fin_scale || pp->bst_x || pp->in_scale))
         MRFA_CHECK_ARG(mrfa_conv2d_groups_supported(pp), "conv2d: groups = %d is not implemented for these parameters (N = %d, %d x %d outputs, splitk %d): ask "
                        "mrfa_conv2d_groups_supported() first", pp->groups, pp->N, pp->Hout, pp->Wout, pp->splitk);
     if (pp->fin_scale) {

@@ -363,6 +363,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 
 }  // namespace
 
+extern "C" int mrfa_conv2d_wgrad_lean_supported(const mrfa_wgrad_params* p) { return p && mrfa_wgrad_lean_eligible(*p) ? 1 : 0; }
+
+extern "C" int mrfa_conv2d_wgrad_groups_supported(const mrfa_wgrad_params* p) {
+    if (!p || p->groups <= 1 || !p->in_scale) return p ? 1 : 0;
+    return mrfa_wgrad_lean_eligible(*p) ? 1 : 0;
+}
+
 extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp) {
     const mrfa_wgrad_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
@@ -374,6 +381,13 @@ extern "C" int mrfa_conv2d_wgrad_nhwc(void* stream, const mrfa_wgrad_params* pp)
     const long long M = (long long)p.N * p.Hout * p.Wout;
     MRFA_CHECK_ARG(M < (1ll << 31) - 64, "wgrad: too many pixels");
     const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    // the keypoint encoder's <= 128-channel 3x3 layers WITH a prologue (a residual block's second convolution reading the raw output of its first): the
+    // all-taps kernel of wgrad_lean.hip as a one-problem launch (without a prologue a lone problem stays on wgrad_small.hip: its 2 000 waves fill the chip)
+    if (p.in_scale && mrfa_wgrad_lean_eligible(p)) {
+        unsigned char taken = 0;
+        return mrfa_wgrad_lean_multi(st, &p, 1, &taken);
+    }
+    MRFA_CHECK_ARG(p.groups <= 1 || !p.in_scale, "wgrad: groups = %d with a prologue is only implemented where mrfa_conv2d_wgrad_groups_supported() says so", p.groups);
     // small problems (the MTIA prior's layers): one wave per 32 x 32 weight block, no LDS staging, in-workgroup reduction (wgrad_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     if (small_on && mrfa_tuning_conv_small() && mrfa_wgrad_small_eligible(p, M)) return mrfa_wgrad_small_launch(st, p, M);

@@ -11,6 +11,7 @@
 // a strided channel set per tile, which costs nothing (only the final store knows).  No LDS staging, no barrier in the loop.
 // The four waves of a workgroup take four consecutive pixel ranges of the same block and add their 32 x 32 partials in LDS, so one
 // workgroup issues 1 024 global atomics; the number of pixel ranges is chosen for ~2 000 waves per launch.
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -351,7 +352,11 @@ extern "C" int mrfa_conv2d_wgrad_multi(void* stream, const mrfa_wgrad_params* ps
         b.n = 0;
         return 0;
     };
+    // the residual blocks' 3x3 layers (<= 128 channels): all nine taps per staging, up to 24 problems per launch (wgrad_lean.hip)
+    std::vector<unsigned char> taken((size_t)n, 0);
+    if (n > 0) { const int rc = mrfa_wgrad_lean_multi(st, ps, n, taken.data()); if (rc) return rc; }
     for (int i = 0; i < n; ++i) {
+        if (taken[i]) continue;
         const mrfa_wgrad_params& p = ps[i];
         MRFA_CHECK_ARG(p.x && p.dy && p.dw && p.N > 0 && p.Hout > 0 && p.Wout > 0, "wgrad_multi: problem %d: null pointer / bad sizes", i);
         const long long M = (long long)p.N * p.Hout * p.Wout;

@@ -61,6 +61,14 @@ class Marks:
 MARKS: Optional[Marks] = None
 
 
+def mark(name: str):
+    m = MARKS
+    if m is None or len(m.names) >= m.buf.numel():
+        return
+    hip.check(hip.lib().mrfa_timestamp(hip.stream_ptr(), m.buf.data_ptr() + 8 * len(m.names)), "timestamp")
+    m.names.append(name)
+
+
 class DeferredWgrads:
     """The weight-gradient launches of the programs recorded under `defer_wgrads(d)` (dense motion + RaftFlow: ~100 launches, 22 ms of
     kernels that fill the chip) are not issued where the backward tape reaches them but collected, and issued on ONE side stream when
@@ -247,6 +255,12 @@ BN_FIN_FUSED = os.environ.get("MRFA_BN_FIN_FUSED", "1") != "0"
 BN_BWD_IN_DGRAD = os.environ.get("MRFA_BN_BWD_IN_DGRAD", "1") != "0"
 FUSED_RESIZES = os.environ.get("MRFA_FUSED_RESIZES", "1") != "0"      # copies / resizes issued inside Ctx.fused_resizes() travel as ONE launch per direction (kept for same-box A/B runs)
 FUSED_SPLITK = os.environ.get("MRFA_FUSED_SPLITK", "1") != "0"        # K splits that finish inside their launch (Ctx._conv_out; kept for same-box A/B runs)
+# BatchNorm-apply + ReLU between the two convolutions of a residual block as the second one's prologue (Ctx.prologue_ok; hr_base.BasicBlock): 56 launches and
+# 56 x 8 MB tensors fewer per forward pass, exact (tests/test_graph_gpu.py::test_prologue_fusion_equals_the_bn_act_path) -- and measured SLOWER in the
+# training step: 81.61 ms (81.4-81.8) against 80.30 (79.5-80.9) without it over three alternating rounds of 40 steps on one box
+# (profiles/r6_ab_prologue_wgrad_lean.txt): the split + prologue arithmetic lands in the staging of conv_lean / wgrad_lean, whose one or two waves per SIMD
+# have no slack for it, while the bn_act launches it removes ran beside other lanes' kernels.  OFF by default (MRFA_PROLOGUE_FUSION=1 switches it on).
+PROLOGUE_FUSION = os.environ.get("MRFA_PROLOGUE_FUSION", "0") == "1"
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -1083,6 +1097,8 @@ class Ctx:
         p.R, p.S, p.pad = cw.R, cw.S, cw.pad
         if pre is not None:
             p.in_scale, p.in_shift, p.in_relu = pre[0].data_ptr(), pre[1].data_ptr(), 1
+            if self.train and self.groups > 1:        # (v9: the prologue vectors are [groups][Cin]; prologue_ok() asked the library)
+                p.groups = self.groups
         p.bias = bias.data_ptr() if bias is not None else None
         p.relu = int(relu)
         if res is not None:
@@ -1094,6 +1110,7 @@ class Ctx:
         out = self._conv_out(p, out, x.N, Ho, Wo, cw.Cout)
         if stats is not None:
             if self.groups > 1 and not self.L.mrfa_conv2d_groups_supported(C.byref(p)):
+                assert pre is None, "a prologue with statistic groups where the library has none: ask prologue_ok() first"
                 p.stats, p.groups, late_stats = None, 0, True       # (a tile would straddle two groups: one statistics pass per group behind the launch)
             elif fin is not None:
                 self._fin_params(p, fin, stats, out.rows)
@@ -1152,6 +1169,7 @@ class Ctx:
         q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
         if pre is not None:
             q.in_scale, q.in_shift, q.in_relu = pre[0].data_ptr(), pre[1].data_ptr(), 1
+            q.groups = pre[2].get("groups", 1)
         q.dy, q.ldy, q.Cout, q.Hout, q.Wout = out.gptr, out.ld, cw.Cout, out.H, out.W
         q.R, q.S, q.pad = cw.R, cw.S, cw.pad
         q.dw = dw.data_ptr()
@@ -1281,6 +1299,8 @@ class Ctx:
             if not fused:
                 p.mask, p.ldm = None, 0
         hint = getattr(x.st, "bn_hint", None) if (direct and BN_BWD_IN_DGRAD) else None
+        if pre is not None and not ups and BN_BWD_IN_DGRAD:
+            hint = pre[2].get("hint")                  # (prebn(): this launch is the only writer of d(relu(bn(x))), the fresh buffer `tgt`)
         if hint is not None and hint["red"] is None and not relu_in and x.coff == 0 and x.C == x.st.ld and not padded and not cw.dgrad_flat:
             # x is the output of a BatchNorm + activation whose ONLY consumer is this convolution (bn_act(out_sole=True)): this launch is the only writer
             # of its gradient, so the first phase of that BatchNorm's backward -- the per-channel sums of du and du * xhat -- rides in its epilogue
@@ -1504,23 +1524,53 @@ class Ctx:
     def prebn(self, x: View, bn, stats=None):
         """Pre-activation BN+ReLU folded into the next conv's prologue (ResBlock2d / ChannelBlock2d).  Returns the `pre`
         triple for conv(); must be called BEFORE that conv so the tape order is right (its closure runs AFTER the conv's)."""
-        assert self.groups == 1, "pre-activation BatchNorm (ResBlock2d / ChannelBlock2d) inside a program with statistic groups: not implemented"
+        assert self.groups == 1 or stats is not None, "pre-activation BatchNorm with statistic groups needs the producing convolution's grouped statistics"
         if self.train and stats is None:
             stats = self.f64z(hip.STATS_SLOTS * 2 * x.C)
             self._chk(self.L.mrfa_bn_stats(self.s, x.ptr, x.ld, x.rows, x.C, stats.data_ptr()), "bn_stats")
         scale, shift, mean, invstd = self._bn_finalize(bn, stats, x.rows)
-        stash = {}
+        groups = self.groups if (self.train and stats is not None) else 1
+        stash = {"groups": groups}
         if self.record:
             train = self.train
+            if train and not (isinstance(bn, torch.nn.SyncBatchNorm) and self._sync_collective(self._sync_world(bn))):
+                # the consuming convolution's data gradient writes d(relu(bn(x))) into a buffer of its own: the first phase of this BatchNorm's backward may
+                # ride in its epilogue (_conv_dgrad), as for bn_act(out_sole=True)
+                stash["hint"] = {"x": x, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd, "relu": True, "red": None, "groups": groups}
 
             def bwd():
                 dz = stash.get("dz")
                 if dz is None:
                     return
                 assert not stash.get("ups", False)
-                self._bn_bwd(x, bn, scale, shift, mean, invstd, True, False, dz.ptr, dz.ld, None, train, x)
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, True, False, dz.ptr, dz.ld, None, train, x, hint=stash.get("hint"), groups=groups)
             self.tape.append(bwd)
         return (scale, shift, stash)
+
+    def prologue_ok(self, x: View, conv) -> bool:
+        """may the BatchNorm-apply + ReLU between two convolutions of a residual block ride in the second one's prologue (forward, data gradient and weight
+        gradient read the first one's raw output; the bn_act launch and its tensor disappear)?  Training only; with statistic groups only where the library
+        keeps one prologue vector pair per group (conv_lean.hip / wgrad_lean.hip: the keypoint encoder's 3x3 layers)"""
+        if not (self.train and PROLOGUE_FUSION and (self.split or self.bf16)):
+            return False
+        cw = convw(conv)
+        if cw.stride != 1 or cw.fwd_flat or cw.dgrad_flat or cw.wgrad_flat or x.coff != 0 or x.C != x.st.ld:
+            return False
+        if self.groups <= 1:
+            return True
+        cop = (cw.Cout + 127) // 128 * 128
+        p = hip.ConvParams()
+        p.x, p.ldx, p.Hin, p.Win, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, x.N, cw.Cin
+        p.w = p.w_split = p.in_scale = p.in_shift = p.y = x.ptr           # (placeholders of the right alignment for the query)
+        p.w_ld, p.w_tap, p.w_rows, p.w_piece = cw.Cin, cop * cw.Cin, cop, (0 if self.bf16 else cw.T * cop * cw.Cin)
+        p.in_relu, p.ldy, p.Cout, p.Hout, p.Wout = 1, _r4(cw.Cout), cw.Cout, x.H + 2 * cw.pad - cw.R + 1, x.W + 2 * cw.pad - cw.S + 1
+        p.R, p.S, p.pad, p.alpha, p.nbatch, p.groups = cw.R, cw.S, cw.pad, 1.0, 1, self.groups
+        q = hip.WgradParams()
+        q.x, q.ldx, q.Hin, q.Win, q.N, q.Cin = x.ptr, x.ld, x.H, x.W, x.N, cw.Cin
+        q.in_scale = q.in_shift = q.dy = q.dw = x.ptr
+        q.in_relu, q.ldy, q.Cout, q.Hout, q.Wout, q.R, q.S, q.pad = 1, _r4(cw.Cout), cw.Cout, p.Hout, p.Wout, cw.R, cw.S, cw.pad
+        q.alpha, q.nbatch, q.groups = 1.0, 1, self.groups
+        return bool(self.L.mrfa_conv2d_groups_supported(C.byref(p)) and self.L.mrfa_conv2d_wgrad_groups_supported(C.byref(q)))
 
     # -- samplers ---------------------------------------------------------------------------------------------
     def grid_sample(self, inp: View, grid: View, mode: int, out: Optional[View] = None, in_rep: int = 1, need_din=True,
@@ -1873,13 +1923,14 @@ class Ctx:
             self.tape.append(bwd)
         return out
 
-    def conv_bn_raw(self, x: View, conv, bn, need_dx=True):
-        """raw = conv(x) for a conv of stride 1 or 2 that a BatchNorm follows -> (raw, batch statistics of raw)"""
+    def conv_bn_raw(self, x: View, conv, bn, need_dx=True, pre=None):
+        """raw = conv(pre(x)) for a conv of stride 1 or 2 that a BatchNorm follows -> (raw, batch statistics of raw); pre: see prebn() / prologue_ok()"""
         cw = convw(conv)
         fin = bn if BN_FIN_FUSED else None
         if cw.stride == 1:
             st = self.bn_stats_buf(bn)
-            return self.conv(x, conv, stats=st, need_dx=need_dx, fin=fin), st
+            return self.conv(x, conv, stats=st, need_dx=need_dx, fin=fin, pre=pre), st
+        assert pre is None
         if cw.stride == 2 and conv.bias is None:
             got = self._conv_strided(x, conv, cw, self.bn_stats_buf(bn), need_dx, fin=fin)
             if got is not None:

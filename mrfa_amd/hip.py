@@ -63,6 +63,7 @@ class WgradParams(C.Structure):
         ("ksplit", C.c_int), ("ktab", C.c_void_p), ("kflat", C.c_int), ("tile8_off", C.c_int),
         ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
         ("stride", C.c_int),
+        ("groups", C.c_int),
     ]
 
 
@@ -145,6 +146,8 @@ _SIGNATURES = {
     "mrfa_conv2d_mask_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_stride_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_wgrad_stride_supported": ([C.POINTER(WgradParams)], C.c_int),
+    "mrfa_conv2d_wgrad_groups_supported": ([C.POINTER(WgradParams)], C.c_int),
+    "mrfa_conv2d_wgrad_lean_supported": ([C.POINTER(WgradParams)], C.c_int),
     "mrfa_conv_fewout_dgrad_supported": ([_I, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weight": ([_V, _V, _V, _I, _I, _I, _I, _I], C.c_int),
     "mrfa_pack_conv_weights_multi": ([_V, C.POINTER(PackDesc), _I], C.c_int),

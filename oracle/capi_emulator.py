@@ -432,7 +432,10 @@ class Emulator:
     def _prep_input(p, x_ptr):
         x = nhwc(x_ptr, p.N, p.Hin, p.Win, p.ldx, p.Cin).permute(0, 3, 1, 2).clone()
         if p.in_scale:
-            x = x * vec(p.in_scale, p.Cin).view(1, -1, 1, 1) + vec(p.in_shift, p.Cin).view(1, -1, 1, 1)
+            G = max(int(getattr(p, "groups", 0)), 1)          # v9: prologue vectors [groups][Cin], sample n uses row n // (N / groups)
+            sc = vec(p.in_scale, G * p.Cin).view(G, 1, p.Cin, 1, 1)
+            sh = vec(p.in_shift, G * p.Cin).view(G, 1, p.Cin, 1, 1)
+            x = (x.view(G, p.N // G, p.Cin, p.Hin, p.Win) * sc + sh).view(p.N, p.Cin, p.Hin, p.Win)
             if p.in_relu:
                 x = F.relu(x)
         if p.ups == 1:
@@ -522,10 +525,36 @@ class Emulator:
         tiles = -(-M // 128) * -(-p.Cout // 128) * max(p.nbatch, 1)
         return 2 if (p.splitk == 0 and not small and tiles < 384 and K >= 128 and p.stride <= 1) else 1
 
+    @staticmethod
+    def _lean_shape(p, Cin, Cout, Hout, Wout, stride) -> bool:
+        """the shapes conv_lean.hip / wgrad_lean.hip take in the library's default (split-operand) matrix mode: the keypoint encoder's 3x3 stride-1 layers
+        with 32, 64 or 128 channels on maps that tile into their patches"""
+        if p.kflat > 0 or p.ups or p.R != 3 or p.S != 3 or p.pad != 1 or stride > 1 or p.nbatch > 1:
+            return False
+        if 2.0 * p.N * Hout * Wout * Cout * 9.0 * Cin > 2.6e9 or Cout % 32 or Cout > 128:
+            return False
+        return (Cin in (32, 64) and Wout % 32 == 0) or (Cin == 128 and Wout % 16 == 0)
+
+    def mrfa_conv2d_wgrad_lean_supported(self, pref):
+        p = _obj(pref)
+        return int(self._lean_shape(p, p.Cin, p.Cout, p.Hout, p.Wout, p.stride) and not p.dbias and ((p.Cin == 32 and p.Cout == 32) or (p.Cin % 64 == 0 and p.Cout % 64 == 0)))
+
+    def mrfa_conv2d_wgrad_groups_supported(self, pref):
+        """the library's rule: a prologue with one vector pair per statistic group exists in wgrad_lean.hip only"""
+        p = _obj(pref)
+        if p.groups <= 1 or not p.in_scale:
+            return 1
+        ok = self._lean_shape(p, p.Cin, p.Cout, p.Hout, p.Wout, p.stride) and not p.dbias and p.N % p.groups == 0
+        return int(ok and ((p.Cin == 32 and p.Cout == 32) or (p.Cin % 64 == 0 and p.Cout % 64 == 0)))
+
     def mrfa_conv2d_groups_supported(self, pref):
         """the library's rule (the emulator itself honours `groups` for every shape)"""
         p = _obj(pref)
         if p.groups <= 1:
+            return 1
+        if p.in_scale:                                   # prologue vectors per group: conv_lean.hip only
+            return int(bool(p.w_split) and p.splitk <= 1 and not p.mask and p.N % p.groups == 0 and self._lean_shape(p, p.Cin, p.Cout, p.Hout, p.Wout, p.stride))
+        if not (p.stats or p.fin_scale or p.bst_x):
             return 1
         rows = p.N // p.groups * p.Hout * p.Wout
         small = (p.kflat == 0 and not p.ups and not p.in_scale and p.Cin % 16 == 0 and p.N * p.Hout * p.Wout <= 65536 and p.Cout <= 640

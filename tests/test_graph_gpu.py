@@ -388,6 +388,55 @@ def test_pack_stream_replays_like_the_eager_step():
     step.verify(replays=3)
 
 
+@pytest.mark.parametrize("frames", [1, 2])
+def test_prologue_fusion_equals_the_bn_act_path(frames, monkeypatch):
+    """engine.PROLOGUE_FUSION (the BatchNorm-apply + ReLU between the two convolutions of a residual block as the second one's prologue: conv_lean.hip /
+    wgrad_lean.hip with one prologue vector pair per statistic group, the BatchNorm's first backward phase in the data gradient that writes d(relu(bn(x))))
+    against the default path (a bn_act launch and its tensor between the convolutions) on the HRNet trunk: same outputs, running statistics and parameter
+    gradients up to summation order, with one statistic group and with two"""
+    from mrfa_amd import engine
+    from mrfa_amd.utils.prng import det_uniform
+    from tests.test_wiring_cpu import small_hrnet
+    from mrfa_amd import hip
+    b, size = 1, 256                      # (the encoder's own maps: 64^2 x 32, 32^2 x 64, 16^2 x 128 -- the shapes conv_lean.hip / wgrad_lean.hip take)
+    x = torch.cat([(det_uniform(f"pf/x{i}", (b, 3, size, size)) * (1.0 + 0.5 * i)).to(DEV) for i in range(frames)], 0)
+    w = det_uniform("pf/w", (frames * b, 32, size // 4, size // 4)).to(DEV)
+    prev = hip.lib().mrfa_set_tuning(b"conv_lean_min_wgs", 1)           # (two frames do not make the workgroup count the bench batch does)
+    request_cleanup = lambda: hip.lib().mrfa_set_tuning(b"conv_lean_min_wgs", prev)
+
+    def run(fused):
+        monkeypatch.setattr(engine, "PROLOGUE_FUSION", fused)
+        used = []
+        real = engine.Ctx.prebn
+        monkeypatch.setattr(engine.Ctx, "prebn", lambda self, *a, **k: (used.append(1), real(self, *a, **k))[1])
+        m = small_hrnet().to(DEV)
+        m.train(True)
+        with engine.stat_groups(frames):
+            y = m(x)
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(engine.Ctx, "prebn", real)
+        return y.detach(), {n: p.grad.double().clone() for n, p in m.named_parameters()}, {n: v.clone() for n, v in m.named_buffers()}, len(used)
+    try:
+        y0, g0, b0, n0 = run(False)
+        y0b, g0b, _, _ = run(False)
+        y1, g1, b1, n1 = run(True)
+    finally:
+        request_cleanup()
+    assert n0 == 0 and n1 > 0, "the fused run must take the prologue path in its residual blocks"
+    assert (y0 - y1).abs().max().item() <= 1e-5 * max(1.0, y0.abs().max().item())
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert (b0[n] - b1[n]).abs().max().item() <= 1e-6 * max(1.0, b0[n].abs().max().item()), n
+    worst = noise = 0.0
+    for n in g0:
+        sc = max(g0[n].abs().max().item(), 1e-6)
+        worst = max(worst, (g0[n] - g1[n]).abs().max().item() / sc)
+        noise = max(noise, (g0[n] - g0b[n]).abs().max().item() / sc)
+    print(f"prologue fusion vs bn_act path: worst per-parameter gradient error {worst:.2e} of the parameter's scale (two default runs: {noise:.2e})")
+    assert worst <= 2e-4 + 4 * noise, (worst, noise)
+
+
 @pytest.mark.parametrize("frames,b", [(2, 2), (3, 2), (2, 8)])
 def test_statistic_groups_on_the_gpu_equal_separate_calls_sharply(frames, b):
     """The batched pass against the separate calls where summation-order noise is small enough to see a SYSTEMATIC error: the HRNet trunk with one

@@ -735,7 +735,7 @@ def test_dgrad_matches_autograd(cfg):
 
 
 def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=False, dbias=True, ksplit=0, dy_off=0, ws=False, stride=1,
-               launch=True, tag="w"):
+               launch=True, groups=1, tag="w"):
     x = side.t(f"{tag}/x", (N * H * W, (Cin + 3) // 4 * 4))
     Hv, Wv = H << ups, W << ups
     Ho, Wo = (Hv + 2 * pad - R) // stride + 1, (Wv + 2 * pad - R) // stride + 1
@@ -745,10 +745,10 @@ def wgrad_case(side, *, N=2, H=10, W=9, Cin=64, Cout=96, R=3, pad=1, ups=0, pro=
     q = hip.WgradParams()
     q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = x.data_ptr(), x.shape[1], H, W, ups, N, Cin
     keep = []
-    if pro:
-        sc, sh = side.t(f"{tag}/sc", (Cin,), 0.5, 1.5), side.t(f"{tag}/sh", (Cin,), -0.3, 0.3)
+    if pro:                         # v9: one prologue vector pair per statistic group
+        sc, sh = side.t(f"{tag}/sc", (groups * Cin,), 0.5, 1.5), side.t(f"{tag}/sh", (groups * Cin,), -0.3, 0.3)
         keep += [sc, sh]
-        q.in_scale, q.in_shift, q.in_relu = sc.data_ptr(), sh.data_ptr(), 1
+        q.in_scale, q.in_shift, q.in_relu, q.groups = sc.data_ptr(), sh.data_ptr(), 1, groups
     q.dy, q.ldy, q.Cout, q.Hout, q.Wout = dy.data_ptr() + 4 * dy_off, dy.shape[1], Cout, Ho, Wo
     q.R, q.S, q.pad = R, R, pad
     q.dw = dw.data_ptr()
@@ -820,6 +820,46 @@ def test_wgrad_multi():
         return side.done(*[t for p in probs for t in (p[1], p[2])])
     ref, got = both(run)
     assert_close(ref, got, tol=5e-4, what="wgrad_multi")
+
+
+WGRAD_LEAN_CASES = [       # wgrad_lean.hip: the residual blocks' 3x3 layers, all three geometries, prologue per statistic group, tails, shared outputs
+    dict(N=2, H=16, W=64, Cin=32, Cout=32), dict(N=4, H=10, W=32, Cin=32, Cout=32, pro=True, groups=2),          # (H % 4 != 0: half-empty last patch)
+    dict(N=2, H=8, W=32, Cin=64, Cout=64), dict(N=3, H=5, W=32, Cin=64, Cout=64, pro=True, groups=3),
+    dict(N=2, H=16, W=16, Cin=128, Cout=128), dict(N=2, H=7, W=16, Cin=128, Cout=128, pro=True, groups=2),        # (H % 2 != 0)
+    dict(N=1, H=8, W=32, Cin=64, Cout=128), dict(N=1, H=8, W=32, Cin=128, Cout=64, pro=True), dict(N=1, H=6, W=32, Cin=128, Cout=128),
+]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_wgrad_lean_multi(mode):
+    """mrfa_conv2d_wgrad_multi: the residual blocks' 3x3 weight gradients on the all-taps kernel (wgrad_lean.hip) -- more problems than one launch holds (24),
+    two that share their outputs, one the kernel does not take among them -- against the CPU specification; and a lone prologue problem through
+    mrfa_conv2d_wgrad_nhwc"""
+    L = hip.lib()
+    cfgs = [dict(c, dbias=False) for c in WGRAD_LEAN_CASES]
+    cfgs += [dict(N=1, H=8, W=32, Cin=32, Cout=32, dbias=False) for _ in range(26)] + [dict(N=2, H=16, W=16, Cin=32, Cout=32)]
+
+    def run(side):
+        probs = [wgrad_case(side, tag=f"wlean/{i}", launch=False, **c) for i, c in enumerate(cfgs)]
+        q2, dw2, db2, keep2 = wgrad_case(side, tag="wlean/0b", launch=False, **cfgs[0])
+        q2.dw = probs[0][0].dw                          # a second pass over other data into the output of problem 0
+        allq = [p[0] for p in probs] + [q2]
+        if side.gpu:
+            took = [L.mrfa_conv2d_wgrad_lean_supported(C.byref(q)) for q in allq]
+            assert all(took[:len(WGRAD_LEAN_CASES) + 26]) and not took[len(cfgs) - 1], took
+        arr = (hip.WgradParams * len(allq))()
+        for i, q in enumerate(allq):
+            C.memmove(C.byref(arr, i * C.sizeof(hip.WgradParams)), C.byref(q), C.sizeof(hip.WgradParams))
+        side.call("mrfa_conv2d_wgrad_multi", arr, len(allq))
+        lone = wgrad_case(side, tag="wlean/lone", N=2, H=8, W=32, Cin=64, Cout=64, pro=True, groups=2, dbias=False)
+        return side.done(*[p[1] for p in probs]) + lone[:1]
+    ref = run(Side(False))
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    try:
+        got = run(Side(True))
+    finally:
+        L.mrfa_set_mfma_mode(0)
+    assert_close(ref, got, tol={1: 5e-4, 2: 2e-3, 3: 2e-2}[mode], what="wgrad_lean_multi")
 
 
 WGRAD_HALO_CASES = [       # wgrad_halo.hip: 3x3 / pad 1, Wout % 32 == 0, Cin % 32 == 0; both block shapes, prologue, upsample, ragged Cout, tails

@@ -1,8 +1,9 @@
 """Conditioning band of the headline program (tests/test_headline.py: MTIA chain, B = 2, train-mode BatchNorm) by Monte-Carlo arithmetic:
 the fp64 oracle with every tensor-valued operation's result (convolutions, linears, BatchNorm / LayerNorm, samplers, resizes, pools, softmax,
-matrix products) multiplied by (1 + u * N(0, 1)), u = 2^-24 = fp32's unit roundoff, forward AND backward -- the smallest perturbation any fp32
-implementation makes (one rounding per operation result; real kernels round every partial sum).  K runs -> per sub-network the largest 1 - cos
-and relative norm deviation of the gradient from the unperturbed fp64 run: how far two correct fp32 implementations of THIS program may be
+matrix products) multiplied by (1 + e), e UNIFORM in [-u, u], u = 2^-24 = fp32's unit roundoff, forward AND backward: the error model of one
+round-to-nearest per operation result (bounded by u, rms u / sqrt(3)) -- a LOWER bound of what a real fp32 implementation does, which rounds every
+partial sum.  (Round 5 drew e from N(0, u): 1.7x the rms and unbounded tails; the bands here are correspondingly narrower.)  K runs -> per
+sub-network the largest 1 - cos and relative norm deviation of the gradient from the unperturbed fp64 run: how far two correct fp32 implementations of THIS program may be
 expected to disagree -- a property of the reference's arithmetic at these weights, measured without the implementation under test.
 Stored in tests/golden/chain_mtia_mca.npz (+ _groups.json); tests/headline_checks.reference_band() merges it with the reference's own
 fp32-vs-fp64 distances.        python tools/mca_band.py [runs=8]   |   python tools/mca_band.py fomm [runs=8]"""
@@ -25,11 +26,11 @@ U = 2.0 ** -24
 class Jitter(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        return x * (1.0 + U * torch.randn_like(x))
+        return x * (1.0 + U * (2.0 * torch.rand_like(x) - 1.0))
 
     @staticmethod
     def backward(ctx, g):
-        return g * (1.0 + U * torch.randn_like(g))
+        return g * (1.0 + U * (2.0 * torch.rand_like(g) - 1.0))
 
 
 def jittered(fn):
@@ -71,7 +72,7 @@ def main():
     saved = {k: getattr(F, k) for k in PATCH_F}
     saved_t = {k: getattr(torch, k) for k in PATCH_T}
     groups = sorted({H.subnet(n) for n in names})
-    worst = {grp: [0.0, 0.0] for grp in groups}
+    worst = {grp: [[], []] for grp in groups}          # per run: (1 - cos, relative norm deviation)
     try:
         for k in PATCH_F:
             setattr(F, k, jittered(saved[k]))
@@ -82,19 +83,24 @@ def main():
             s, n = run()
             tab = H.group_table(names, segs, s, n, base_s, base_n)
             for grp, (cd, nr, _) in tab.items():
-                worst[grp][0], worst[grp][1] = max(worst[grp][0], cd), max(worst[grp][1], nr)
+                worst[grp][0].append(cd)
+                worst[grp][1].append(nr)
             print(f"run {r}: " + "  ".join(f"{grp.split('.')[-1]} {tab[grp][1]:.1e}" for grp in groups), flush=True)
     finally:
         for k, v in saved.items():
             setattr(F, k, v)
         for k, v in saved_t.items():
             setattr(torch, k, v)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "chain_mtia_mca.npz"), train_cos=np.array([worst[grp][0] for grp in groups]),
-                        train_norm=np.array([worst[grp][1] for grp in groups]), runs=np.array([runs]), u=np.array([U]))
+    # the band = the 90th percentile over the runs (a quantile, not the largest of K draws); the maxima are kept beside it
+    q = lambda v: float(np.quantile(np.array(v), 0.9))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "chain_mtia_mca.npz"), train_cos=np.array([q(worst[grp][0]) for grp in groups]),
+                        train_norm=np.array([q(worst[grp][1]) for grp in groups]), train_cos_max=np.array([max(worst[grp][0]) for grp in groups]),
+                        train_norm_max=np.array([max(worst[grp][1]) for grp in groups]), runs=np.array([runs]), u=np.array([U]),
+                        model=np.array(["uniform[-u,u] per operation result, q90 over runs"]))
     with open(os.path.join(ROOT, "tests", "golden", "chain_mtia_mca_groups.json"), "w") as f:
         json.dump(groups, f)
     for grp in groups:
-        print(f"{grp:28s} 1-cos {worst[grp][0]:.2e}  |g| rel {worst[grp][1]:.2e}")
+        print(f"{grp:28s} 1-cos q90 {q(worst[grp][0]):.2e} max {max(worst[grp][0]):.2e}  |g| rel q90 {q(worst[grp][1]):.2e} max {max(worst[grp][1]):.2e}")
 
 
 def main_fomm_chain():
@@ -124,7 +130,7 @@ def main_fomm_chain():
     scale = np.maximum(base, 1e-3 * base.max())
     saved = {k: getattr(F, k) for k in PATCH_F}
     saved_t = {k: getattr(torch, k) for k in PATCH_T}
-    worst = np.zeros_like(base)
+    devs = []
     try:
         for k in PATCH_F:
             setattr(F, k, jittered(saved[k]))
@@ -133,14 +139,16 @@ def main_fomm_chain():
         for r in range(runs):
             torch.manual_seed(2000 + r)
             d = np.abs(run() - base) / scale
-            worst = np.maximum(worst, d)
+            devs.append(d)
             print(f"run {r}: median {np.median(d):.2e} max {d.max():.2e} ({names[int(np.argmax(d))]})", flush=True)
     finally:
         for k, v in saved.items():
             setattr(F, k, v)
         for k, v in saved_t.items():
             setattr(torch, k, v)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "prior_grads_mca.npz"), chain_train_norm=worst, runs=np.array([runs]), u=np.array([U]))
+    worst = np.quantile(np.stack(devs), 0.9, axis=0)          # (q90 over the runs; the maxima beside it)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "prior_grads_mca.npz"), chain_train_norm=worst, chain_train_norm_max=np.stack(devs).max(0),
+                        runs=np.array([runs]), u=np.array([U]), model=np.array(["uniform[-u,u] per operation result, q90 over runs"]))
     print(f"chain_train: per-parameter band median {np.median(worst):.2e} max {worst.max():.2e}")
 
 

@@ -9,7 +9,7 @@ PARTS=${*:-leantests lean ab phases}
 cd $R
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has leantests; then
-python -m pytest tests/test_kernels_gpu.py -x -q -k "lean or conv2d or fused_finalize or statistic or patch_tiled" 2>&1 | tail -15 > $O/pytest_conv.txt; tail -3 $O/pytest_conv.txt
+python -m pytest tests/test_kernels_gpu.py -x -q -k "lean or conv2d or fused_finalize or statistic or patch_tiled or wgrad" 2>&1 | tail -15 > $O/pytest_conv.txt; tail -3 $O/pytest_conv.txt
 fi
 if has tests; then
 python -m pytest tests -m gpu -q -x > $O/gputest.log 2>&1; grep -E "passed|failed" $O/gputest.log | tail -1
