@@ -228,9 +228,10 @@ def run_inference(a, emit=True):
         ach = tot_b / tot_ms / 1e6
         traffic = tsrc = None
         try:                                          # HBM bytes per six-level set from the committed PMC passes of this command
-            with open(os.path.join(ROOT, "profiles", "r2_config5_traffic.json")) as tf:
+            tname = next(n for n in ("r6_config5_traffic.json", "r2_config5_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", tname)) as tf:
                 traffic = round(json.load(tf)["hbm_bytes_per_six_level_set"] / 1e9, 3)
-            tsrc = "profiles/r2_config5_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (B=4, 512), not this run"
+            tsrc = f"profiles/{tname}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (B=4, 512), not this run"
         except Exception:
             pass
         if (B, size) != (4, 512):
@@ -293,7 +294,10 @@ def roofline_from_profile(prof, nprof, hip):
         traffic, tsrc = None, None
         try:                                  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
             if dom_name:                      # the patch-tiled kernel: the latest round's PMC passes (launch-weighted mean over its variants)
-                tsrc = next(f"profiles/r{r}_traffic.json" for r in (5, 4) if os.path.exists(os.path.join(ROOT, "profiles", f"r{r}_traffic.json")))
+                if hip.mfma_mode() == "bf16":       # config 4 has PMC passes of its own (one plane per operand moves other LDS / HBM traffic)
+                    tsrc = "profiles/r6_config4_traffic.json"
+                else:
+                    tsrc = next(f"profiles/r{r}_traffic.json" for r in (6, 5, 4) if os.path.exists(os.path.join(ROOT, "profiles", f"r{r}_traffic.json")))
                 with open(os.path.join(ROOT, tsrc)) as tf:
                     tj = json.load(tf)["kernels"]["conv_halo_kernel"]
             elif split:                       # measured in the default (bf16x6) mode; the other split modes run the same loads / stores
@@ -328,7 +332,7 @@ def roofline_from_profile(prof, nprof, hip):
                 "algorithmic_gflop_per_launch": round(fl / len(sel) / 1e9, 2),
                 "kernel_ms_per_step": round(ms / nprof, 2),
                 "timed_on": "HIP events around every launch of an EAGER re-issue of the same step right after the timed region (events cannot be recorded inside a "
-                            "replayed hipGraph); profiles/r5_final_bench_b8_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the replays",
+                            "replayed hipGraph); profiles/r6_final_bench_b8_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the replays",
                 "all_mfma_conv_ms_per_step": round(sum(t for _, t in allc) / nprof, 2),
                 "all_mfma_conv_tflops": round(sum(f for f, _ in allc) / (sum(t for _, t in allc) * 1e-3) / 1e12, 2)}
     return roof
@@ -822,6 +826,14 @@ def main(rank_body=None, script=None, argv=None, child_argv=None):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if hip.mfma_mode() == "bf16" else "f32"),
             "data": "synthetic",
+            # the headline figures of the sub-records at the END of this line, repeated here so that a truncated tail of the line still carries them
+            "summary": {"roofline_frac": (roof or {}).get("frac"),
+                        "densemotion_raftflow_forward": ((fwd or {}).get("densemotion_raftflow_forward") if isinstance(fwd, dict) else None),
+                        "config5_roofline_frac": ((c5 or {}).get("roofline") or {}).get("frac") if isinstance(c5, dict) else None,
+                        "config5_pairs_per_s": (c5 or {}).get("value") if isinstance(c5, dict) else None,
+                        "config4_roofline_frac": ((c4 or {}).get("roofline") or {}).get("frac") if isinstance(c4, dict) else None,
+                        "config4_pairs_per_s": (c4 or {}).get("value") if isinstance(c4, dict) else None,
+                        "cpu_baseline_pairs_per_s": (cpu or {}).get("value") if isinstance(cpu, dict) else None},
             "config": {"workload": ("celebvhq.yaml (bg_start 0: BGMotionPredictor -> bg_param), " if a.background else "vox1.yaml ") +
                                    ("MTIA (TokenPose_B)" if a.prior == "mtia" else "FOMM KPDetector") +
                                    " prior + DenseMotion + RaftFlow refinement, 256x256, "

@@ -134,6 +134,8 @@ typedef struct {
     int y_zero;
 } mrfa_conv_params;
 int mrfa_conv2d_split_k(const mrfa_conv_params* p);                  /* K slices a call with these parameters would use (1: no split; y / sk_ticket may be NULL) */
+int mrfa_conv2d_reads_fp32_weights(const mrfa_conv_params* p);       /* v9: 0 = the kernel this call would run reads w_split / w_phase only: `w` may be any non-NULL
+                                                                        pointer and the fp32 layout need not exist (y may be NULL for the query)            */
 
 /* Statistic groups (v7).  The reference runs its keypoint encoder as separate calls on the source frames, the driving frames (and the transformed driving frames
  * of the equivariance loss): modules/model.py:185-186,234 -- so in train mode every BatchNorm normalises each of those batches with ITS OWN batch statistics and

@@ -362,7 +362,7 @@ extern "C" int mrfa_conv2d_stride_supported(const mrfa_conv_params* p) {
     return small_on && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
 
-static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done, int* dry_split = nullptr);
+static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done, int* dry_split = nullptr, int* dry_reads_w = nullptr);
 
 extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
     if (!p || !p->stats || p->fin_scale || p->stride < 0 || p->kflat > 0) return 0;
@@ -398,6 +398,16 @@ extern "C" int mrfa_conv2d_split_k(const mrfa_conv_params* p) {
     return conv2d_dispatch(nullptr, p, &fin_done, &k) ? 1 : k;
 }
 
+// v9: does the kernel a call with these parameters would run read the fp32 weight layout `w` at all?  0: it reads the pre-split planes only (conv_halo.hip,
+// conv_lean.hip, the row-tiled split-operand tile with w_split in the split modes) -- the caller may pass any non-NULL `w` and need not keep (or refresh, once
+// per optimizer step) that layout: for the decoder's ~100 M parameters that is 8 of the 28 bytes per parameter the per-step re-packing moved.
+extern "C" int mrfa_conv2d_reads_fp32_weights(const mrfa_conv_params* p) {
+    if (!p || (!p->w_split && !p->w_phase)) return 1;
+    int k = 1, reads = 1;
+    bool fin_done = false;
+    return conv2d_dispatch(nullptr, p, &fin_done, &k, &reads) ? 1 : reads;
+}
+
 extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
     MRFA_CHECK_ARG(pp, "conv2d: null parameter block");
     if (pp->groups > 1 && (pp->stats || pp->fin_scale || pp->bst_x || pp->in_scale))
@@ -421,7 +431,7 @@ extern "C" int mrfa_conv2d_nhwc(void* stream, const mrfa_conv_params* pp) {
                                    pp->Cout, pp->groups > 1 ? pp->groups : 1, pp->fin_scale, pp->fin_shift, pp->fin_mean, pp->fin_invstd);
 }
 
-static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done, int* dry_split) {
+static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_done, int* dry_split, int* dry_reads_w) {
     const mrfa_conv_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     MRFA_CHECK_ARG(p.x && p.w && (p.y || dry_split), "conv2d: null pointer");
@@ -443,7 +453,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
 
     // ---- the keypoint encoder's <= 128-channel 3x3 layers in a split-operand mode: four-wave patches on the bf16 pipe (conv_lean.hip)
     if (!flat && mrfa_conv_lean_eligible(p)) {
-        if (dry_split) { *dry_split = 1; return 0; }
+        if (dry_split) { *dry_split = 1; if (dry_reads_w) *dry_reads_w = 0; return 0; }
         g_last_tile = (32 << 16) | (32 << 4) | 4 | (1 << 27);    // bit 27: conv_lean
         *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
         return mrfa_conv_lean_launch(st, p);
@@ -471,7 +481,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
     }
     // ---- 3x3 stride-1 layers with 32-aligned rows in split-operand mode: patch-tiled kernel, input halo split once per chunk (conv_halo.hip)
     if (!flat && mrfa_conv_halo_eligible(p)) {
-        if (dry_split) { *dry_split = 1; return 0; }
+        if (dry_split) { *dry_split = 1; if (dry_reads_w) *dry_reads_w = 0; return 0; }
         *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup, common.h: fused_bn_finalize)
         g_last_tile = (128 << 16) | ((p.Cout <= 64 ? 64 : 128) << 4) | 4 | (1 << 28);       // bit 28: conv_halo
         return mrfa_conv_halo_launch(st, p);
@@ -531,7 +541,12 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         BM = p.tile >> 16; BN = p.tile & 0x7fff; w8 = (p.tile & 0x8000) != 0;
         if (p.splitk >= 1) splitk = p.splitk;
     }
-    if (dry_split) { *dry_split = splitk; return 0; }
+    if (dry_split) {
+        *dry_split = splitk;
+        // (the row-tiled split-operand tile copies pre-split weight planes when it has them -- except in plain-bf16 mode, which rounds the fp32 layout itself)
+        if (dry_reads_w) *dry_reads_w = !(g_mfma_mode >= 1 && g_mfma_mode != 3 && BM == 128 && (BN == 128 || BN == 64) && !flat && p.w_split);
+        return 0;
+    }
     // v8: with sk_ticket the tile's last workgroup applies bias / affine / residual / ReLU / statistics (no epilogue pass); with y_zero the output already holds
     // zeros (no init pass: the bias then comes with the fused epilogue)
     const bool fused = splitk > 1 && p.sk_ticket && !p.accumulate;

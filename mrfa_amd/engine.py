@@ -261,6 +261,7 @@ FUSED_SPLITK = os.environ.get("MRFA_FUSED_SPLITK", "1") != "0"        # K splits
 # (profiles/r6_ab_prologue_wgrad_lean.txt): the split + prologue arithmetic lands in the staging of conv_lean / wgrad_lean, whose one or two waves per SIMD
 # have no slack for it, while the bn_act launches it removes ran beside other lanes' kernels.  OFF by default (MRFA_PROLOGUE_FUSION=1 switches it on).
 PROLOGUE_FUSION = os.environ.get("MRFA_PROLOGUE_FUSION", "0") == "1"
+LAZY_FP32_PACKS = os.environ.get("MRFA_LAZY_FP32_PACKS", "1") != "0"      # fp32 weight layouts only for the launches that read them (Ctx._fp32_weights)
 RELU_IN = os.environ.get("MRFA_RELU_IN", "1") != "0"                  # ReLU backward of single-consumer tensors inside the consumer's data gradient
 # gradient buffers of at least this many floats are not zero-filled before the backward pass (Storage.fresh); smaller ones share one
 # zero arena (one fill instead of hundreds of tiny ones).  9 MiB (round 2: 4): the TokenPose_B encoder's 4 and 8 MiB buffers (32 / 64
@@ -1069,9 +1070,7 @@ class Ctx:
         p = hip.ConvParams()
         p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.ptr, x.ld, x.H, x.W, int(ups), x.N, cw.Cin
         padded = cw.fwd_flat and x.zpad and x.coff % 4 == 0 and pre is None
-        wp = cw.fwd_pack(padded)
         cop = (cw.Cout + 127) // 128 * 128
-        p.w = wp.data_ptr()
         if padded:
             cip32 = (cw.Cin + 31) // 32 * 32
             p.Cin = cip32
@@ -1093,6 +1092,8 @@ class Ctx:
                     wph, p.w_phase_piece = cw.phase_pack()
                     p.w_phase = wph.data_ptr()
         p.w_rows = cop
+        # the fp32 weight layout only where the kernel this call runs reads it (_fp32_weights below): a placeholder until the block is complete
+        p.w = p.w_split if p.w_split else cw.fwd_pack(padded).data_ptr()
         p.Cout, p.Hout, p.Wout = cw.Cout, Ho, Wo
         p.R, p.S, p.pad = cw.R, cw.S, cw.pad
         if pre is not None:
@@ -1114,6 +1115,7 @@ class Ctx:
                 p.stats, p.groups, late_stats = None, 0, True       # (a tile would straddle two groups: one statistics pass per group behind the launch)
             elif fin is not None:
                 self._fin_params(p, fin, stats, out.rows)
+        self._fp32_weights(p, lambda: cw.fwd_pack(padded))
         self._launch_conv(p, "conv2d", cw.Cin)
         if late_stats:
             self._bn_stats_into(out, stats)
@@ -1135,6 +1137,17 @@ class Ctx:
             if cw not in self.touched_convs:
                 self.touched_convs.append(cw)
         return out
+
+    def _fp32_weights(self, p, pack):
+        """p.w of a complete parameter block whose `w` is still the placeholder (= w_split): the fp32 layout `pack()` only if the kernel this call runs reads
+        it (mrfa_conv2d_reads_fp32_weights, v9).  The patch-tiled, lean and row-tiled split-operand kernels read the pre-split planes only, so for most of
+        the decoder's ~100 M parameters the fp32 forward / data-gradient layouts are never built -- and never refreshed by the per-step PackPlan (8 of its
+        28 bytes per parameter; the refresh runs beside the keypoint encoder's forward and slowed it by what it moved)"""
+        ph = p.w_split or p.w_phase
+        if not ph or p.w != ph:
+            return                                    # (no pre-split planes: conv() / _conv_dgrad() put the fp32 layout there already)
+        if not (LAZY_FP32_PACKS and not self.L.mrfa_conv2d_reads_fp32_weights(C.byref(p))):
+            p.w = pack().data_ptr()
 
     def _conv_out(self, p, out: Optional[View], N, Ho, Wo, Cout) -> View:
         """the output of a forward convolution whose parameter block is complete but for y.  Launches that split K (the low-resolution levels: too few output
@@ -1247,11 +1260,11 @@ class Ctx:
             # straight into x.grad -- instead of the 3x3 data gradient on the 2H x 2W grid + the 2x2 sum-pooling pass
             q = hip.ConvParams()
             q.x, q.ldx, q.Hin, q.Win, q.ups, q.N, q.Cin = out.gptr, out.ld, out.H, out.W, 2, out.N, cw.Cout
-            wd = cw.dgrad_pack(False)                          # (fp32 pack: what the ABI's specification reads)
             cipd = (cw.Cin + 127) // 128 * 128
-            q.w, q.w_ld, q.w_tap, q.kflat, q.w_rows = wd.data_ptr(), cw.Cout, cipd * cw.Cout, 0, cipd
             wph, q.w_phase_piece = cw.phase_pack(dgrad=True)
             q.w_phase = wph.data_ptr()
+            q.w = q.w_phase                                    # (placeholder: the phase kernel reads w_phase only; the ABI's specification reads w: _fp32_weights)
+            q.w_ld, q.w_tap, q.kflat, q.w_rows = cw.Cout, cipd * cw.Cout, 0, cipd
             q.Cout, q.Hout, q.Wout = cw.Cin, x.H, x.W
             q.R, q.S, q.pad = cw.R, cw.S, cw.R - 1 - cw.pad
             q.alpha, q.nbatch = 1.0, 1
@@ -1259,6 +1272,7 @@ class Ctx:
                 first_ph = self._claim(x)
                 q.y, q.ldy = x.gptr, x.ld
                 q.accumulate = 0 if first_ph else 1
+                self._fp32_weights(q, lambda: cw.dgrad_pack(False))
                 self._launch_conv(q, "dgrad(phase)", cw.Cout)
                 return
         tgt = x if direct else self.new(x.N, Hv, Wv, cw.Cin)
@@ -1268,9 +1282,7 @@ class Ctx:
         # Cout % 32 != 0 but the dY view sits in a wider (zero-initialised, finite) gradient buffer: read it as co32
         # channels against zero-padded weights instead of taking the scalar-gather flat path
         padded = cw.dgrad_flat and out.coff % 4 == 0 and out.ld % 4 == 0 and out.coff + co32 <= out.ld
-        wp = cw.dgrad_pack(padded)
         cip = (cw.Cin + 127) // 128 * 128
-        p.w = wp.data_ptr()
         if padded:
             p.Cin = co32
             p.w_ld, p.w_tap, p.kflat = co32, cip * co32, 0
@@ -1287,6 +1299,7 @@ class Ctx:
                 ws, p.w_piece = cw.split_pack("d", False, rne=self.bf16)
                 p.w_split = ws.data_ptr()
         p.w_rows = cip
+        p.w = p.w_split if p.w_split else cw.dgrad_pack(padded).data_ptr()       # (placeholder: _fp32_weights below)
         p.y, p.ldy = (tgt.gptr if direct else tgt.ptr), tgt.ld
         p.Cout, p.Hout, p.Wout = cw.Cin, Hv, Wv
         p.R, p.S, p.pad = cw.R, cw.S, cw.R - 1 - cw.pad
@@ -1316,6 +1329,7 @@ class Ctx:
             else:
                 p.stats = p.bst_x = p.bst_scale = p.bst_shift = p.bst_mean = p.bst_invstd = None
                 p.groups = 0
+        self._fp32_weights(p, lambda: cw.dgrad_pack(padded))
         self._launch_conv(p, "dgrad", cw.Cout)
         if relu_in and not fused:
             self._relu_mask_pass(x)

@@ -177,6 +177,7 @@ _SIGNATURES = {
     "mrfa_timestamp": ([_V, _V], C.c_int),
     "mrfa_conv2d_bwdstats_supported": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_groups_supported": ([C.POINTER(ConvParams)], C.c_int),
+    "mrfa_conv2d_reads_fp32_weights": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_conv2d_split_k": ([C.POINTER(ConvParams)], C.c_int),
     "mrfa_bn_param_grad": ([_V, _V, _I, _V, _V], C.c_int),
     "mrfa_bn_param_grad_groups": ([_V, _V, _I, _I, _V, _V], C.c_int),

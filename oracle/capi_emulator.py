@@ -535,6 +535,10 @@ class Emulator:
             return False
         return (Cin in (32, 64) and Wout % 32 == 0) or (Cin == 128 and Wout % 16 == 0)
 
+    def mrfa_conv2d_reads_fp32_weights(self, pref):
+        """the specification always computes from the fp32 layout"""
+        return 1
+
     def mrfa_conv2d_wgrad_lean_supported(self, pref):
         p = _obj(pref)
         return int(self._lean_shape(p, p.Cin, p.Cout, p.Hout, p.Wout, p.stride) and not p.dbias and ((p.Cin == 32 and p.Cout == 32) or (p.Cin % 64 == 0 and p.Cout % 64 == 0)))
