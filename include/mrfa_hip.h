@@ -105,7 +105,7 @@ typedef struct {
     /* v6, optional, together with `stats` (fin_scale != NULL): FINISH the train-mode BatchNorm that follows this convolution as part of this call --   */
     /* exactly what mrfa_bn_finalize(stats, fin_count, fin_gamma, fin_beta, fin_rmean, fin_rvar, fin_momentum, fin_eps, Cout, 1, fin_scale, fin_shift,   */
     /* fin_mean, fin_invstd) would do after it (fin_rmean / fin_rvar / fin_mean / fin_invstd may be NULL).  The small-problem kernel does it in the     */
-    /* SAME launch: the last workgroup to finish (fin_counter: one zero-initialised 32-bit word per call, e.g. behind the statistics block) reduces the  */
+    /* SAME launch: the last workgroup to finish (fin_counter: MRFA_FIN_WORDS zero-initialised 32-bit words per call, e.g. behind the statistics block) reduces the */
     /* slots -- the keypoint encoder's ~180 BatchNorm layers per pass then cost two launches each instead of three; every other kernel is followed by   */
     /* the finalize launch inside the call                                                                                                               */
     const float* fin_gamma; const float* fin_beta; float* fin_rmean; float* fin_rvar;

@@ -39,6 +39,9 @@ bool mrfa_conv_lean_eligible(const mrfa_conv_params& p);
 int mrfa_conv_lean_launch(hipStream_t st, const mrfa_conv_params& p);
 int mrfa_tuning_conv_lean(int set);        // mrfa_set_tuning("conv_lean", 0 / 1); set < 0: query
 int mrfa_tuning_conv_lean_min(int set);    // mrfa_set_tuning("conv_lean_min_wgs", n)
+bool mrfa_gemm_lean_eligible(const mrfa_conv_params& p, long long M);      // 1x1 convolutions / linears: the K-pipelined kernel of conv_lean.hip
+int mrfa_gemm_lean_launch(hipStream_t st, const mrfa_conv_params& p, long long M);
+int mrfa_tuning_gemm_lean(int set);        // mrfa_set_tuning("gemm_lean", 0 / 1); set < 0: query
 int mrfa_tuning_conv_lean_geo(int set);    // mrfa_set_tuning("conv_lean_geo", i): only geometry i of conv_lean.hip's table (-1: by workgroup count)
 
 // conv_small.hip: one wave per 16..32-row output tile, operands straight from L1/L2 into v_mfma_f32_16x16x4_f32 (small problems)

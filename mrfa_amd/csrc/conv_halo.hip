@@ -507,6 +507,7 @@ extern "C" int mrfa_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_lean_min_wgs")) return mrfa_tuning_conv_lean_min(value);
     if (!strcmp(key, "conv_lean_geo")) return mrfa_tuning_conv_lean_geo(value);
     if (!strcmp(key, "wgrad_lean")) return mrfa_tuning_wgrad_lean(value != 0);
+    if (!strcmp(key, "gemm_lean")) return mrfa_tuning_gemm_lean(value);
     return -1;
 }
 

@@ -39,6 +39,148 @@ __device__ __forceinline__ unsigned lean_pack_hi16(float a, float b) {      // (
 }
 __device__ __forceinline__ float lean_chop_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
+// The part of the small-problem kernels behind their k-loops: the two accumulator chains of a tile are added, the input-channel slices of a tile meet in LDS
+// (fixed order: bit-identical run to run), then bias / affine / residual / ReLU / accumulate, 16-byte stores, the train-mode statistics (or the first phase of a
+// BatchNorm backward: bst_*) with ONE atomic per statistic, channel and workgroup, and the BatchNorm finalize by the launch's last workgroup.
+// Wave layout: wave = wk + KS * (wco + WCO * wpx); e_row[i] / e_ok[i]: output row of this lane in tile i (lane & 31) and whether it exists.
+template <int MT, int WPX, int WCO, int KS>
+__device__ __forceinline__ void lean_finish(const mrfa_conv_params& p, f32x16 (&acc)[MT][2], unsigned char* smem, int scratch_doubles, int wave, int lane, int tid, int wk,
+                                            bool wg_on, int n0, int cb, int fhalf, const long long (&e_row)[MT], const bool (&e_ok)[MT], int grp,
+                                            const f32x4 (&pre_res)[MT][4], const f32x4 (&pre_bx)[MT][4]) {
+    // ---- the two chains of a tile, then the input-channel slices of a tile (through LDS: the halo images are dead behind the barrier)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] += acc[i][1][r];
+    if constexpr (KS > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);    // [wave][tile][16][64]
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wave * MT + i) * 16 + r) * 64 + lane] = acc[i][0][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int k = 1; k < KS; ++k)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][0][r] += red[(((wave + k) * MT + i) * 16 + r) * 64 + lane];
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue (waves with wk == 0)
+    // lane = (output row e_row[i] of tile i, half); accumulator quad g = channels cb + 8 g .. + 3 of that row
+    float s1[16], s2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
+    const bool wave_on = wg_on && wk == 0;
+    if (wave_on) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (e_ok[i]) {
+                const long long m = e_row[i];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cb + 8 * g;
+                    if (c0 < p.Cout) {                      // (Cout % 4 == 0: whole quads)
+                        float* dst = p.y + (size_t)m * p.ldy + c0;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][0][4 * g + e] * p.alpha;
+                        if (p.bias) {
+                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + c0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                        }
+                        if (p.out_scale) {
+                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(p.out_scale + c0), h4 = *reinterpret_cast<const f32x4*>(p.out_shift + c0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] * o4[e] + h4[e];
+                        }
+                        if (p.res) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += pre_res[i][g][e];
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        if (p.accumulate) {
+                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += o4[e];
+                        }
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        if (p.bst_x) {
+                            // first phase of the BatchNorm backward (mrfa_conv_params.bst_*): v = d(act(bn(x))); through the activation, then the two sums
+                            const int gc = grp * p.Cout + c0;
+                            const f32x4 xr = pre_bx[i][g];
+                            const f32x4 bsc = *reinterpret_cast<const f32x4*>(p.bst_scale + gc), bsh = *reinterpret_cast<const f32x4*>(p.bst_shift + gc);
+                            const f32x4 bme = *reinterpret_cast<const f32x4*>(p.bst_mean + gc), biv = *reinterpret_cast<const f32x4*>(p.bst_invstd + gc);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float du = (p.bst_relu && xr[e] * bsc[e] + bsh[e] <= 0.f) ? 0.f : v[e];
+                                s1[4 * g + e] += du;
+                                s2[4 * g + e] += du * ((xr[e] - bme[e]) * biv[e]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { s1[4 * g + e] += v[e]; s2[4 * g + e] += v[e] * v[e]; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        if (wave_on) {
+            // per-channel sums over the 32 pixel lanes of a half: butterfly reduce-scatter; afterwards lane L holds channel index
+            // kk = 8 b4 + 4 b3 + 2 b2 + b1 (bN = bit N of L), lanes L and L ^ 1 the same total
+            auto stage = [&](float (&v)[16], auto W) {
+                constexpr int w = decltype(W)::value;
+                const bool hi = (lane & (2 * w)) != 0;
+#pragma unroll
+                for (int k = 0; k < w; ++k) {
+                    const float send = hi ? v[k] : v[k + w];
+                    const float keep = hi ? v[k + w] : v[k];
+                    v[k] = keep + __shfl_xor(send, 2 * w, 64);
+                }
+            };
+            auto reduce16 = [&](float (&v)[16]) {
+                stage(v, std::integral_constant<int, 8>{});
+                stage(v, std::integral_constant<int, 4>{});
+                stage(v, std::integral_constant<int, 2>{});
+                stage(v, std::integral_constant<int, 1>{});
+                v[0] += __shfl_xor(v[0], 1, 64);
+            };
+            reduce16(s1);
+            reduce16(s2);
+        }
+        // the pixel tiles of a workgroup that share their output channels (WPX waves) meet in LDS: ONE atomic per statistic, channel and workgroup
+        __shared__ float s_st[4][2][32];
+        if (wk == 0) {
+            const int kk = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const int ch = 4 * fhalf + 8 * (kk >> 2) + (kk & 3);
+            if ((lane & 1) == 0) { s_st[wave][0][ch] = wave_on ? s1[0] : 0.f; s_st[wave][1][ch] = wave_on ? s2[0] : 0.f; }
+        }
+        __syncthreads();
+        if (tid < 64 * WCO) {
+            const int which = tid / (32 * WCO), col = tid % (32 * WCO), wc = col >> 5, ch = col & 31;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < WPX; ++k) t += s_st[KS * (wc + WCO * k)][which][ch];
+            const int cch = n0 + col;
+            if (wg_on && cch < p.Cout) atomicAdd(stat_slot(p, grp, blockIdx.x) + which * p.Cout + cch, (double)t);
+        }
+        // (every workgroup of the grid, with all of its threads; the halo images are dead: their LDS is the finalize's scratch)
+        if (p.fin_scale) fused_bn_finalize(p, gridDim.x, (int)blockIdx.x, reinterpret_cast<double*>(smem), scratch_doubles);
+    }
+}
+
 // TW: patch width (32: a pixel tile is one row of 32; 16: two rows of 16).  The four waves: WPX (pixel tiles) x WCO (32-channel tiles) x KS (input-
 // channel slices); MT pixel tiles per wave.  NSC super-chunks of 16 KS input channels (Cin = 16 KS NSC), the whole k-loop unrolled.
 template <int TW, int WPX, int WCO, int KS, int MT, int NSC>
@@ -267,140 +409,186 @@ __global__ __launch_bounds__(256, MT == 2 ? 1 : 2) void conv_lean_kernel(const m
     if constexpr (NSC > 2) run_sc(std::integral_constant<int, 2>{});
     if constexpr (NSC > 3) run_sc(std::integral_constant<int, 3>{});
 
-    // ---- the two chains of a tile, then the input-channel slices of a tile (through LDS: the halo images are dead behind the barrier)
+    // ---- partial tiles -> output, statistics, finalize (lean_finish below: shared with the 1x1 / linear kernel)
+    long long e_row[MT];
+    bool e_ok[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pyl = y0 + (wpx * MT + i) * G::TR + j_row;
+        e_ok[i] = pyl < p.Hout;
+        e_row[i] = ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + j_col;
+    }
+    const int grp = stat_group(p, (long long)n_img * p.Hout * p.Wout, Mtot);      // (a patch lies in one image)
+    lean_finish<MT, WPX, WCO, KS>(p, acc, smem, (int)(G::LDS_BYTES(NPC) / 8), wave, lane, tid, wk, wg_on, n0, cb, fhalf, e_row, e_ok, grp, pre_res, pre_bx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same arithmetic for 1x1 convolutions / linears (the token transformer's 192 <-> 576 linears over 16 x 276 token rows, HRNet's 1x1 fuse and
+// bottleneck layers): K = Cin up to 640 does not fit the "whole halo in registers and LDS" scheme above, so the K axis is PIPELINED: a workgroup owns
+// 64 output rows x 32 WCO output channels; per stage the four waves stage 32 input channels per input-channel slice (KS slices: waves = WCO x KS) of
+// their 64 rows -- loads one stage ahead in registers, split, two LDS buffers, one barrier per stage -- and every wave multiplies TWO 32-row tiles by one
+// 32-channel weight fragment per k16 step (fragments straight from the pre-split planes, one stage ahead in a second register set).  conv_small.hip ran
+// these at 17-39 TF/s on the fp32 pipe (29 us for the 192 -> 576 linear); same epilogue as above (lean_finish).
+template <int WCO, int KS, int NP>
+__global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const mrfa_conv_params p, const long long M, const int tiles_n, const int total_tiles) {
+    static_assert(WCO * KS == 4, "four waves");
+    constexpr int MT = 2;
+    constexpr int NPC = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
+    constexpr int AHALF = 64 * 16 + 64;                        // half-plane (k 0..7 | k 8..15) of 64 rows; +64 B: the halves sit in different bank halves
+    constexpr int APLANE = 2 * AHALF, CHB = NPC * APLANE;      // one piece plane / one 16-channel chunk
+    constexpr int STAGE = KS * 2 * CHB;                        // one stage buffer: KS slices x two k16 chunks
+    constexpr int NU = KS * 2;                                 // float4 units per thread and stage (64 rows x 8 KS channel quads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 buffers][slice][k16 chunk][piece][half][row][16 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave % KS, wco = wave / KS;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const bool wg_on = lin < total_tiles;
+    const int lin_c = wg_on ? lin : 0;
+    const int tile_n = lin_c % tiles_n;
+    const long long m0 = (long long)(lin_c / tiles_n) * 64;
+    const int n0 = tile_n * (32 * WCO);
+    const int NS = p.Cin / (32 * KS);                          // stages: slice wk covers channels [wk * 32 NS, (wk + 1) * 32 NS)
+
+    // ---- staging units: unit u = tid + 256 j -> (row = u / (8 KS), slice, channel quad of its 32 channels)
+    size_t a_goff[NU];
+    int a_loff[NU];
+    bool a_ok[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int u = tid + j * 256;
+        const int row = u / (8 * KS), r = u - row * (8 * KS), sl = r >> 3, q = r & 7;
+        a_ok[j] = m0 + row < M;
+        a_goff[j] = (size_t)(a_ok[j] ? m0 + row : 0) * p.ldx + (size_t)sl * 32 * NS + q * 4;
+        a_loff[j] = sl * (2 * CHB) + (q >> 2) * CHB + ((q & 3) >> 1) * AHALF + row * 16 + (q & 1) * 8;
+    }
+    f32x4 ra[NU];
+    auto load_stage = [&](int st) {
+        const int s = st < NS ? st : NS - 1;                   // (past the end: a re-read nobody uses)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) ra[j] = *reinterpret_cast<const f32x4*>(p.x + a_goff[j] + (size_t)s * 32);
+    };
+    auto store_stage = [&](int buf) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const f32x4 v = a_ok[j] ? ra[j] : z;
+            u32x2 p1, p2, p3;
+            if constexpr (NP == 1) {
+                p1[0] = lean_rne16(v.x) | (lean_rne16(v.y) << 16);
+                p1[1] = lean_rne16(v.z) | (lean_rne16(v.w) << 16);
+            } else {
+                const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float a = xs[2 * h], b = xs[2 * h + 1];
+                    p1[h] = lean_pack_hi16(a, b);
+                    const float ar = lean_chop_rest(a), br = lean_chop_rest(b);
+                    p2[h] = lean_pack_hi16(ar, br);
+                    p3[h] = lean_pack_hi16(lean_chop_rest(ar), lean_chop_rest(br));
+                }
+            }
+            unsigned char* dst = smem + buf * STAGE + a_loff[j];
+            *reinterpret_cast<u32x2*>(dst) = p1;
+            if constexpr (NPC >= 2) *reinterpret_cast<u32x2*>(dst + APLANE) = p2;
+            if constexpr (NPC == 3) *reinterpret_cast<u32x2*>(dst + 2 * APLANE) = p3;
+        }
+    };
+
+    // ---- weight fragments of this wave: rows n0 + 32 wco .., chunks of slice wk; two k16 steps per stage, one stage ahead (two register sets)
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const unsigned short* __restrict__ ws = reinterpret_cast<const unsigned short*>(p.w_split) + (size_t)(n0 + wco * 32 + frow) * 16 + fhalf * 8 +
+                                            (size_t)(wk * 2 * NS) * ((size_t)p.w_rows * 16);
+    const size_t chunk_stride = (size_t)p.w_rows * 16;
+    const long long w_piece = p.w_piece;
+    u32x4 rb[2][2][NPC];
+    auto load_b = [&](int st, auto SET) {
+        constexpr int set = decltype(SET)::value;
+        const int s = st < NS ? st : NS - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) rb[set][h][pc] = *reinterpret_cast<const u32x4*>(ws + (size_t)(2 * s + h) * chunk_stride + (size_t)pc * w_piece);
+    };
+
+    f32x16 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] += acc[i][1][r];
-    if constexpr (KS > 1) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);    // [wave][tile][16][64]
-        if (wk > 0) {
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    const int a_frag = wk * (2 * CHB) + fhalf * AHALF + frow * 16;        // + i * 32 * 16 per row tile, + h * CHB per k16 step
+    auto compute = [&](int buf, auto SET) {
+        constexpr int set = decltype(SET)::value;
+        const unsigned char* A = smem + buf * STAGE + a_frag;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 af[MT][NPC], b[NPC];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((wave * MT + i) * 16 + r) * 64 + lane] = acc[i][0][r];
-        }
-        __syncthreads();
-        if (wk == 0) {
+                for (int pc = 0; pc < NPC; ++pc) af[i][pc] = *reinterpret_cast<const bf16x8*>(A + h * CHB + pc * APLANE + i * (32 * 16));
 #pragma unroll
-            for (int k = 1; k < KS; ++k)
+            for (int pc = 0; pc < NPC; ++pc) b[pc] = __builtin_bit_cast(bf16x8, rb[set][h][pc]);
+#pragma unroll
+            for (int t = 6 - NP; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][0][r] += red[(((wave + k) * MT + i) * 16 + r) * 64 + lane];
+                    acc[i][t < 3 ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB[t]], af[i][PA[t]], acc[i][t < 3 ? 1 : 0], 0, 0, 0);
         }
-    }
+    };
 
-    // ------------------------------------------------------------------ epilogue (waves with wk == 0)
-    // lane = (pixel j = lane & 31 of the tile, half); accumulator quad g = channels cb + 8 g .. + 3 of that pixel
-    const int grp = stat_group(p, (long long)n_img * p.Hout * p.Wout, Mtot);      // (a patch lies in one image)
-    float s1[16], s2[16];
+    // epilogue operands with a row per output row: fetched before the last stage
+    const int cb = n0 + wco * 32 + 4 * fhalf;
+    long long e_row[MT];
+    bool e_ok[MT];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
-    const bool wave_on = wg_on && wk == 0;
-    if (wave_on) {
+    for (int i = 0; i < MT; ++i) {
+        e_row[i] = m0 + 32 * i + frow;
+        e_ok[i] = e_row[i] < M;
+    }
+    f32x4 pre_res[MT][4], pre_bx[MT][4];
+    auto prefetch_epilogue = [&]() {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int pyl = y0 + (wpx * MT + i) * G::TR + j_row;
-            if (pyl < p.Hout) {
-                const long long m = ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + j_col;
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = cb + 8 * g;
-                    if (c0 < p.Cout) {                      // (Cout % 4 == 0: whole quads)
-                        float* dst = p.y + (size_t)m * p.ldy + c0;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][0][4 * g + e] * p.alpha;
-                        if (p.bias) {
-                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + c0);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                        }
-                        if (p.out_scale) {
-                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(p.out_scale + c0), h4 = *reinterpret_cast<const f32x4*>(p.out_shift + c0);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] * o4[e] + h4[e];
-                        }
-                        if (p.res) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += pre_res[i][g][e];
-                        }
-                        if (p.relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        if (p.accumulate) {
-                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += o4[e];
-                        }
-                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                        if (p.bst_x) {
-                            // first phase of the BatchNorm backward (mrfa_conv_params.bst_*): v = d(act(bn(x))); through the activation, then the two sums
-                            const int gc = grp * p.Cout + c0;
-                            const f32x4 xr = pre_bx[i][g];
-                            const f32x4 bsc = *reinterpret_cast<const f32x4*>(p.bst_scale + gc), bsh = *reinterpret_cast<const f32x4*>(p.bst_shift + gc);
-                            const f32x4 bme = *reinterpret_cast<const f32x4*>(p.bst_mean + gc), biv = *reinterpret_cast<const f32x4*>(p.bst_invstd + gc);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float du = (p.bst_relu && xr[e] * bsc[e] + bsh[e] <= 0.f) ? 0.f : v[e];
-                                s1[4 * g + e] += du;
-                                s2[4 * g + e] += du * ((xr[e] - bme[e]) * biv[e]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { s1[4 * g + e] += v[e]; s2[4 * g + e] += v[e] * v[e]; }
-                        }
-                    }
-                }
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = cb + 8 * g < p.Cout ? cb + 8 * g : p.Cout - 4;
+                const long long mr = e_ok[i] ? e_row[i] : 0;
+                if (p.res) pre_res[i][g] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mr * p.ldr + c0);
+                if (p.bst_x) pre_bx[i][g] = *reinterpret_cast<const f32x4*>(p.bst_x + (size_t)mr * p.bst_ldx + c0);
             }
-        }
-    }
-    if (p.stats) {
-        if (wave_on) {
-            // per-channel sums over the 32 pixel lanes of a half: butterfly reduce-scatter; afterwards lane L holds channel index
-            // kk = 8 b4 + 4 b3 + 2 b2 + b1 (bN = bit N of L), lanes L and L ^ 1 the same total
-            auto stage = [&](float (&v)[16], auto W) {
-                constexpr int w = decltype(W)::value;
-                const bool hi = (lane & (2 * w)) != 0;
-#pragma unroll
-                for (int k = 0; k < w; ++k) {
-                    const float send = hi ? v[k] : v[k + w];
-                    const float keep = hi ? v[k + w] : v[k];
-                    v[k] = keep + __shfl_xor(send, 2 * w, 64);
-                }
-            };
-            auto reduce16 = [&](float (&v)[16]) {
-                stage(v, std::integral_constant<int, 8>{});
-                stage(v, std::integral_constant<int, 4>{});
-                stage(v, std::integral_constant<int, 2>{});
-                stage(v, std::integral_constant<int, 1>{});
-                v[0] += __shfl_xor(v[0], 1, 64);
-            };
-            reduce16(s1);
-            reduce16(s2);
-        }
-        // the pixel tiles of a workgroup that share their output channels (WPX waves) meet in LDS: ONE atomic per statistic, channel and workgroup
-        __shared__ float s_st[4][2][32];
-        if (wk == 0) {
-            const int kk = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-            const int ch = 4 * fhalf + 8 * (kk >> 2) + (kk & 3);
-            if ((lane & 1) == 0) { s_st[wave][0][ch] = wave_on ? s1[0] : 0.f; s_st[wave][1][ch] = wave_on ? s2[0] : 0.f; }
-        }
+    };
+
+    // ---- pipeline: stage s in buffer s & 1; registers hold stage s + 1 (activations) and the weight set (s + 1) & 1
+    load_stage(0);
+    load_b(0, std::integral_constant<int, 0>{});
+    store_stage(0);
+    load_stage(1);
+    __syncthreads();
+    for (int s = 0; s < NS; s += 2) {
+        // even stage s: weight set 0, buffer 0
+        load_b(s + 1, std::integral_constant<int, 1>{});
+        if (s + 1 < NS) store_stage(1);                        // (buffer 1 was last read as stage s - 1: barrier behind it)
+        load_stage(s + 2);
+        if (s + 1 >= NS) prefetch_epilogue();
+        compute(0, std::integral_constant<int, 0>{});
         __syncthreads();
-        if (tid < 64 * WCO) {
-            const int which = tid / (32 * WCO), col = tid % (32 * WCO), wc = col >> 5, ch = col & 31;
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < WPX; ++k) t += s_st[KS * (wc + WCO * k)][which][ch];
-            const int cch = n0 + col;
-            if (wg_on && cch < p.Cout) atomicAdd(stat_slot(p, grp, blockIdx.x) + which * p.Cout + cch, (double)t);
+        if (s + 1 < NS) {
+            load_b(s + 2, std::integral_constant<int, 0>{});
+            if (s + 2 < NS) store_stage(0);
+            load_stage(s + 3);
+            if (s + 2 >= NS) prefetch_epilogue();
+            compute(1, std::integral_constant<int, 1>{});
+            __syncthreads();
         }
-        // (every workgroup of the grid, with all of its threads; the halo images are dead: their LDS is the finalize's scratch)
-        if (p.fin_scale) fused_bn_finalize(p, gridDim.x, (int)blockIdx.x, reinterpret_cast<double*>(smem), (int)(G::LDS_BYTES(NPC) / 8));
     }
+    const int grp = stat_group(p, m0, M);                      // (the launcher keeps a workgroup's 64 rows inside one statistic group)
+    lean_finish<MT, 1, WCO, KS>(p, acc, smem, (int)((size_t)2 * STAGE / 8), wave, lane, tid, wk, wg_on, n0, cb, fhalf, e_row, e_ok, grp, pre_res, pre_bx);
 }
 
 int g_lean_on = -1;              // -1: not initialised (MRFA_CONV_LEAN)
@@ -514,6 +702,79 @@ bool mrfa_conv_lean_eligible(const mrfa_conv_params& p) {
     // ~2.5 GFLOP at most: beyond that the 8-row patches of conv_halo.hip (weights shared through LDS by 8 waves) are the faster kernel
     if (2.0 * (double)p.N * p.Hout * p.Wout * p.Cout * 9.0 * p.Cin > 2.6e9) return false;
     return lean_pick(p) >= 0;
+}
+
+// ---- 1x1 convolutions / linears on gemm_lean_kernel
+namespace {
+int g_gemm_lean_on = -1;
+bool gemm_lean_on() {
+    if (g_gemm_lean_on < 0) { const char* e = getenv("MRFA_GEMM_LEAN"); g_gemm_lean_on = e ? atoi(e) : 1; }      // 0 off, 1 where measured faster, 2 wherever it can run
+    return g_gemm_lean_on != 0;
+}
+// 0: 64 rows x 128 channels per workgroup; 1: 64 x 64 with the input channels in two slices (short N or long K: more workgroups, half the k-loop)
+int gemm_lean_cfg(const mrfa_conv_params& p, long long M) {
+    const long long rows = (M + 63) / 64;
+    const bool can_b = (p.Cin % 64) == 0;
+    if (!can_b) return 0;
+    const long long wa = rows * cdiv(p.Cout, 128);
+    return (p.Cout >= 128 && wa >= 256) ? 0 : 1;
+}
+template <int WCO, int KS>
+int gemm_lean_launch_cfg(hipStream_t st, const mrfa_conv_params& p, long long M, int mode) {
+    const int tiles_n = cdiv(p.Cout, 32 * WCO);
+    const long long total = ((M + 63) / 64) * tiles_n;
+    dim3 grid((unsigned)(cdiv(total, 8) * 8));
+#define GL(NP_)                                                                                                                        \
+    do {                                                                                                                               \
+        constexpr int npc = NP_ == 6 ? 3 : (NP_ == 3 ? 2 : 1);                                                                          \
+        constexpr size_t st_bytes = (size_t)2 * KS * 2 * npc * 2 * (64 * 16 + 64), red = KS > 1 ? (size_t)4 * 2 * 16 * 64 * 4 : 0;       \
+        constexpr size_t lds = st_bytes > red ? st_bytes : red;                                                                        \
+        hipLaunchKernelGGL((gemm_lean_kernel<WCO, KS, NP_>), grid, dim3(256), lds, st, p, M, tiles_n, (int)total);                     \
+    } while (0)
+    if (mode == 3) GL(1); else if (mode == 2) GL(3); else GL(6);
+#undef GL
+    return 0;
+}
+}  // namespace
+
+int mrfa_tuning_gemm_lean(int set) {
+    gemm_lean_on();
+    const int prev = g_gemm_lean_on;
+    if (set >= 0) g_gemm_lean_on = set > 2 ? 2 : set;
+    return prev;
+}
+
+// 1: the 1x1 convolution / linear runs on gemm_lean_kernel: a split-operand (or plain bf16) mode with pre-split weights, 32-aligned channel counts, 16-byte
+// addressable tensors, no prologue, and a problem small enough that the 128-row tiles of conv_split.hip cannot fill the chip with long k-loops
+bool mrfa_gemm_lean_eligible(const mrfa_conv_params& p, long long M) {
+    const int mode = mrfa_get_mfma_mode();
+    if (!gemm_lean_on() || (mode != 1 && mode != 2 && mode != 3)) return false;
+    if (p.kflat > 0 || p.R != 1 || p.S != 1 || p.pad != 0 || !p.w_split || p.nbatch > 1 || p.splitk > 1 || p.tile || p.stride > 1 || p.stride < 0 || p.ups || p.mask || p.in_scale) return false;
+    if (mode != 3 && p.w_piece <= 0) return false;
+    if (p.Hout != p.Hin || p.Wout != p.Win) return false;
+    if ((p.Cout % 32) != 0 || (p.Cin % 32) != 0 || p.Cin > 1024 || M < 256) return false;
+    if ((p.ldy % 4) != 0 || !aligned16(p.y) || (p.ldx % 4) != 0 || !aligned16(p.x)) return false;
+    if (p.res && ((p.ldr % 4) != 0 || !aligned16(p.res))) return false;
+    if (p.bias && !aligned16(p.bias)) return false;
+    if (p.out_scale && (!aligned16(p.out_scale) || !aligned16(p.out_shift))) return false;
+    if (p.bst_x && ((p.bst_ldx % 4) != 0 || !aligned16(p.bst_x) || !aligned16(p.bst_scale) || !aligned16(p.bst_shift) || !aligned16(p.bst_mean) || !aligned16(p.bst_invstd)))
+        return false;
+    if (p.groups > 1 && ((p.N % p.groups) != 0 || ((M / p.groups) % 64) != 0)) return false;      // a workgroup's 64 rows inside one statistic group
+    if (3 * p.w_piece >= (1ll << 31) || M * p.ldx >= (1ll << 31) * 2) return false;
+    if (2.0 * (double)M * p.Cout * (double)p.Cin > 2.6e9) return false;
+    if (g_gemm_lean_on >= 2) return true;
+    // measured (profiles/r6_gemm_lean_bench.txt): ahead on the transformer's token linears (4 416 rows, 192 / 576 channels: 17 against 25-27 us); behind the
+    // 128-row tiles on the 65 536-row layer1 bottlenecks and behind conv_small's 32-row tiles where 64-row tiles leave most of the chip idle (the fuse layers)
+    const long long wgs = ((M + 63) / 64) * cdiv(p.Cout, gemm_lean_cfg(p, M) == 0 ? 128 : 64);
+    return wgs >= 192 && M <= 32768 && p.Cout >= 64;
+}
+
+int mrfa_gemm_lean_launch(hipStream_t st, const mrfa_conv_params& p, long long M) {
+    const int mode = mrfa_get_mfma_mode();
+    const int rc = gemm_lean_cfg(p, M) == 0 ? gemm_lean_launch_cfg<4, 1>(st, p, M, mode) : gemm_lean_launch_cfg<2, 2>(st, p, M, mode);
+    if (rc) return rc;
+    MRFA_CHECK_LAUNCH("mrfa_conv2d_nhwc(gemm_lean)");
+    return 0;
 }
 
 int mrfa_conv_lean_launch(hipStream_t st, const mrfa_conv_params& p) {

@@ -366,7 +366,7 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
 
 extern "C" int mrfa_conv2d_bwdstats_supported(const mrfa_conv_params* p) {
     if (!p || !p->stats || p->fin_scale || p->stride < 0 || p->kflat > 0) return 0;
-    if (mrfa_conv_lean_eligible(*p)) return 1;
+    if (mrfa_conv_lean_eligible(*p) || mrfa_gemm_lean_eligible(*p, (long long)p->N * p->Hout * p->Wout)) return 1;
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();
     return small_on && mrfa_tuning_conv_small() && mrfa_conv_small_eligible(*p, (long long)p->N * p->Hout * p->Wout) ? 1 : 0;
 }
@@ -381,6 +381,7 @@ extern "C" int mrfa_conv2d_groups_supported(const mrfa_conv_params* p) {
     const long long rows = group_rows(*p, M);
     if (rows <= 0) return 0;
     if (p->kflat == 0 && mrfa_conv_lean_eligible(*p)) return 1;                                      // (a patch lies inside one image)
+    if (p->kflat == 0 && mrfa_gemm_lean_eligible(*p, M)) return 1;                                   // (its own rule: rows of a group % 64 == 0)
     if (p->in_scale) return 0;                                                                       // (prologue vectors per group: conv_lean.hip only)
     if ((rows % 128) == 0) return 1;
     // shorter groups: the kernels whose tiles are smaller than 128 rows, where the dispatch would pick them
@@ -457,6 +458,13 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         g_last_tile = (32 << 16) | (32 << 4) | 4 | (1 << 27);    // bit 27: conv_lean
         *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
         return mrfa_conv_lean_launch(st, p);
+    }
+    // ---- 1x1 convolutions / linears of the keypoint encoder in a split-operand mode: K-pipelined four-wave tiles on the bf16 pipe (conv_lean.hip)
+    if (!flat && mrfa_gemm_lean_eligible(p, M)) {
+        if (dry_split) { *dry_split = 1; if (dry_reads_w) *dry_reads_w = 0; return 0; }
+        g_last_tile = (64 << 16) | (64 << 4) | 4 | (1 << 26);    // bit 26: gemm_lean
+        *fin_done = p.fin_scale != nullptr;                      // (finished by the launch's last workgroup)
+        return mrfa_gemm_lean_launch(st, p, M);
     }
     // ---- small problems (the MTIA prior's 0.1-0.6 GFLOP layers): one wave per output tile, no LDS / barrier / split-K (conv_small.hip)
     static const bool small_on = [] { const char* e = getenv("MRFA_CONV_SMALL"); return !(e && e[0] == '0'); }();

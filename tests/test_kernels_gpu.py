@@ -484,6 +484,37 @@ def test_conv2d_lean_kernel(name, mode):
     assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="lean " + name)
 
 
+GEMM_LEAN_CASES = {     # gemm_lean_kernel (conv_lean.hip): 1x1 convolutions / linears, K pipelined; both workgroup shapes, every epilogue option, ragged rows
+    "linear_192_576_res": dict(N=16, H=1, W=276, Cin=192, Cout=576, R=1, pad=0, res=True, relu=False),                 # 64 x 128 tiles, 4.5 column tiles
+    "linear_576_192_affine": dict(N=16, H=1, W=276, Cin=576, Cout=192, R=1, pad=0, oaff=True),                        # 64 x 64 tiles, two input-channel slices
+    "linear_192_192_tail": dict(N=1, H=1, W=276, Cin=192, Cout=192, R=1, pad=0, relu=False),                          # M = 276: the last 64-row tile holds 20 rows
+    "fuse_64_32_stats_fin_groups2": dict(N=4, H=32, W=32, Cin=64, Cout=32, R=1, pad=0, stats=True, relu=False, bias=False, fin=True, groups=2),
+    "fuse_128_64_bst": dict(N=4, H=16, W=16, Cin=128, Cout=64, R=1, pad=0, stats=True, relu=False, bias=False, bst=True),
+    "bottleneck_64_256_stats": dict(N=2, H=64, W=64, Cin=64, Cout=256, R=1, pad=0, stats=True, relu=False, bias=False, fin=True),
+    "bottleneck_256_64_acc": dict(N=1, H=64, W=64, Cin=256, Cout=64, R=1, pad=0, acc=True, alpha=0.5, relu=False, bias=False),
+    "k32_c96": dict(N=2, H=16, W=16, Cin=32, Cout=96, R=1, pad=0, stats=True),                                           # one stage only
+}
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("name", list(GEMM_LEAN_CASES))
+def test_conv2d_gemm_lean_kernel(name, mode):
+    """gemm_lean_kernel (1x1 convolutions / linears of the keypoint encoder: 64-row workgroup tiles, the K axis pipelined through two LDS stage buffers,
+    weight fragments straight from the pre-split planes) against the CPU specification in the three split / bf16 matrix modes"""
+    L = hip.lib()
+    kw = dict(GEMM_LEAN_CASES[name])
+    ref = conv_case(Side(False), tag=f"glean/{name}", **kw)
+    assert L.mrfa_set_mfma_mode(mode) == 0
+    prev = L.mrfa_set_tuning(b"gemm_lean", 2)          # 2: wherever it can run (1, the default, keeps it to the sizes it is faster at)
+    try:
+        got = conv_case(Side(True), tag=f"glean/{name}", wsplit=("rne" if mode == 3 else True), **kw)
+        assert L.mrfa_conv2d_last_config() & (1 << 26), "the lean 1x1 kernel did not run"
+    finally:
+        L.mrfa_set_tuning(b"gemm_lean", prev)
+        L.mrfa_set_mfma_mode(0)
+    assert_close(ref, got, tol={1: 2e-4, 2: 2e-3, 3: 2e-2}[mode], what="gemm lean " + name)
+
+
 def test_lean_kernel_is_run_to_run_identical_and_equals_the_one_wave_kernel():
     """no atomics on the output path (the input-channel slices meet in LDS in a fixed order): eight launches agree bit for bit; and the result is the
     fp32-pipe kernel's (conv_small.hip, exact fmaf chains) to fp32 rounding of the sums"""

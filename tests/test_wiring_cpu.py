@@ -873,7 +873,7 @@ def test_statistic_groups_equal_separate_calls(frames):
 
 
 @pytest.mark.parametrize("src,kernel,least", [("conv_small", "conv_small_kernel", 6), ("conv_mfma", "conv_mfma_kernel", 8), ("conv_split", "conv_bf16x6_kernel", 8),
-                                              ("conv_halo", "conv_halo_kernel", 20), ("conv_lean", "conv_lean_kernel", 48)])
+                                              ("conv_halo", "conv_halo_kernel", 20), ("conv_lean", "conv_lean_kernel", 48), ("conv_lean", "gemm_lean_kernel", 6)])
 def test_fused_finalize_waits_for_its_statistics_atomics_before_the_ticket(tmp_path, src, kernel, least):
     """the fence-free hand-offs to a launch's LAST workgroup (common.h: fused_bn_finalize -- the BatchNorm statistics, device-scope fp64
     atomics into the slots -- and splitk_last_arriver -- the partial tiles of a K split, device-scope fp32 atomics into y): a barrier, then a device-scope

@@ -19,6 +19,9 @@ if has lean; then
 NONLY=16 ./tools/ubench/bin/lean_bench > $O/lean_bench.txt 2>&1; cat $O/lean_bench.txt
 for g in 3 4 6; do NONLY=16 GEO=$g ONLY_LEAN=1 ./tools/ubench/bin/lean_bench 2>&1 | grep -v " -1.00" | grep -v "^shape" | cut -c1-52; done | tee $O/lean_bench_one_tile_per_wave.txt
 fi
+if has gemm; then
+GEMM=1 ./tools/ubench/bin/lean_bench > $O/gemm_lean_bench.txt 2>&1; cat $O/gemm_lean_bench.txt
+fi
 if has ab; then
 # ABCFGS="ENV=val ENV=val ..." (space-separated single settings; default: conv_lean on / off)
 for r in 1 2; do for cfg in ${ABCFGS:-MRFA_CONV_LEAN=1 MRFA_CONV_LEAN=0}; do

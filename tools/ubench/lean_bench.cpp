@@ -19,7 +19,78 @@ static float* dalloc(size_t n, float v, unsigned seed) {
     return p;
 }
 
+// GEMM=1: gemm_lean_kernel against whatever the dispatcher picks without it (conv_small / row-tiled) on the encoder's 1x1 shapes
+static int gemm_main() {
+    struct G { const char* name; long long M; int W, Cin, Cout; };
+    const G gs[] = {{"tokens 192->576", 4416, 276, 192, 576}, {"tokens 576->192", 4416, 276, 576, 192}, {"tokens 192->192", 4416, 276, 192, 192},
+                    {"layer1 64->256 @64^2", 65536, 64, 64, 256}, {"layer1 256->64 @64^2", 65536, 64, 256, 64}, {"layer1 64->64 @64^2", 65536, 64, 64, 64},
+                    {"fuse 64->32 @32^2", 16384, 32, 64, 32}, {"fuse 128->32 @16^2", 4096, 16, 128, 32}, {"fuse 128->64 @16^2", 4096, 16, 128, 64}};
+    const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 200;
+    mrfa_set_mfma_mode(1);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-22s %-9s | %9s %7s | %9s %7s %10s | max |lean - other| (scale)\n", "shape", "variant", "lean us", "TF/s", "other us", "TF/s", "config");
+    for (const G& g : gs) {
+        const int Ci = g.Cin, Co = g.Cout, cop = (Co + 127) / 128 * 128;
+        const int N = (int)(g.M / g.W / (g.W == 276 ? 1 : g.W)), H = g.W == 276 ? 1 : g.W;
+        float* x = dalloc(g.M * Ci, 2.f, 1);
+        float* wo = dalloc((size_t)Co * Ci, 0.2f, 2);
+        float *w, *y[2];
+        hipMalloc(&w, (size_t)cop * Ci * 4); hipMemset(w, 0, (size_t)cop * Ci * 4);
+        mrfa_pack_conv_weight(nullptr, wo, w, Co, Ci, 1, 1, 0);
+        short* wsb; const long long piece = (long long)cop * Ci;
+        hipMalloc(&wsb, 3 * piece * 2); hipMemset(wsb, 0, 3 * piece * 2);
+        mrfa_pack_desc d; memset(&d, 0, sizeof(d));
+        d.src = wo; d.dst[0] = (float*)wsb; d.mode[0] = 8; d.ndst = 1; d.Cout = Co; d.Cin = Ci; d.R = 1; d.S = 1;
+        if (mrfa_pack_conv_weights_multi(nullptr, &d, 1)) { printf("pack: %s\n", mrfa_last_error()); return 1; }
+        for (int k = 0; k < 2; ++k) { hipMalloc(&y[k], g.M * Co * 4); hipMemset(y[k], 0, g.M * Co * 4); }
+        float* res = dalloc(g.M * Co, 1.f, 3); float* bias = dalloc(Co, 1.f, 6);
+        double* stats; const size_t sbytes = (size_t)3 * MRFA_STATS_SLOTS * 2 * Co * 8;
+        hipMalloc(&stats, sbytes); hipMemset(stats, 0, sbytes);
+        unsigned* tickets; hipMalloc(&tickets, (size_t)(iters + 8) * MRFA_FIN_WORDS * 4);
+        float* fin[6]; for (int k = 0; k < 6; ++k) fin[k] = dalloc(3 * Co, 1.f, 10 + k);
+        for (int variant = 0; variant < 2; ++variant) {        // 0: bias + residual (the token linears); 1: statistics + finalize (the 1x1 conv + BN layers)
+            mrfa_conv_params p; memset(&p, 0, sizeof(p));
+            p.x = x; p.ldx = Ci; p.Hin = H; p.Win = g.W; p.N = N; p.Cin = Ci;
+            p.w = w; p.w_ld = Ci; p.w_tap = (long long)cop * Ci; p.w_rows = cop; p.w_split = wsb; p.w_piece = piece;
+            p.ldy = Co; p.Cout = Co; p.Hout = H; p.Wout = g.W; p.R = 1; p.S = 1; p.pad = 0; p.alpha = 1.f; p.nbatch = 1;
+            if (variant == 0) { p.bias = bias; p.res = res; p.ldr = Co; }
+            else {
+                p.stats = stats; p.groups = 1;
+                p.fin_gamma = fin[0]; p.fin_beta = fin[1]; p.fin_momentum = 0.1f; p.fin_eps = 1e-5f; p.fin_count = g.M;
+                p.fin_scale = fin[2]; p.fin_shift = fin[3]; p.fin_mean = fin[4]; p.fin_invstd = fin[5]; p.fin_counter = tickets;
+            }
+            float us[2] = {0, 0}; int cfg[2] = {0, 0};
+            for (int k = 0; k < 2; ++k) {
+                mrfa_set_tuning("gemm_lean", k == 0);
+                p.y = y[k];
+                hipMemset(tickets, 0, (size_t)(iters + 8) * MRFA_FIN_WORDS * 4);
+                for (int i = 0; i < iters + 5; ++i) {
+                    if (i == 5) { hipDeviceSynchronize(); hipEventRecord(e0); }
+                    if (p.fin_scale) p.fin_counter = tickets + (size_t)i * MRFA_FIN_WORDS;
+                    if (mrfa_conv2d_nhwc(nullptr, &p)) { printf("error: %s\n", mrfa_last_error()); return 1; }
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                us[k] = 1e3f * ms / iters; cfg[k] = mrfa_conv2d_last_config();
+                if (k == 0 && !(cfg[0] & (1 << 26))) us[0] = -1.f;
+            }
+            mrfa_set_tuning("gemm_lean", 1);
+            double md = 0, sc = 0;
+            std::vector<float> a(g.M * Co), b(g.M * Co);
+            hipMemcpy(a.data(), y[0], g.M * Co * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), y[1], g.M * Co * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < a.size(); ++i) { md = fmax(md, fabs((double)a[i] - b[i])); sc = fmax(sc, fabs((double)b[i])); }
+            const double fl = 2.0 * g.M * Ci * (double)Co;
+            printf("%-22s %-9s | %9.2f %7.1f | %9.2f %7.1f 0x%08x | %.3e (%.2f)\n", g.name, variant ? "stats+fin" : "bias+res", us[0], us[0] > 0 ? fl / us[0] / 1e6 : 0, us[1], fl / us[1] / 1e6,
+                   cfg[1], md, sc);
+        }
+        hipFree(x); hipFree(wo); hipFree(w); hipFree(wsb); hipFree(y[0]); hipFree(y[1]); hipFree(res); hipFree(bias); hipFree(stats); hipFree(tickets);
+        for (int k = 0; k < 6; ++k) hipFree(fin[k]);
+    }
+    return 0;
+}
+
 int main() {
+    if (getenv("GEMM")) return gemm_main();
     struct Shape { const char* name; int H, W, C; };
     const Shape shapes[] = {{"32->32 @64^2", 64, 64, 32}, {"64->64 @32^2", 32, 32, 64}, {"128->128 @16^2", 16, 16, 128}};
     const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 200;
@@ -48,7 +119,7 @@ int main() {
             res = dalloc(M * Cc, 1.f, 3); bx = dalloc(M * Cc, 1.f, 4); vecs = dalloc(16 * Cc * 3, 1.f, 5);
             double* stats; const size_t sbytes = (size_t)3 * MRFA_STATS_SLOTS * 2 * Cc * 8;
             hipMalloc(&stats, sbytes); hipMemset(stats, 0, sbytes);
-            unsigned* tickets; hipMalloc(&tickets, (iters + 8) * 4);        // one finalize ticket word per launch, zeroed outside the timed loop
+            unsigned* tickets; hipMalloc(&tickets, (size_t)(iters + 8) * MRFA_FIN_WORDS * 4);        // one finalize ticket block per launch, zeroed outside the timed loop
             float *fin[6]; for (int k = 0; k < 6; ++k) fin[k] = dalloc(3 * Cc, 1.f, 10 + k);
             for (int variant = 0; variant < 3; ++variant) {       // 0: forward conv + statistics + finalize; 1: + prologue + residual + ReLU; 2: data gradient with bst_*
                 mrfa_conv_params p; memset(&p, 0, sizeof(p));
@@ -73,10 +144,10 @@ int main() {
                     mrfa_set_tuning("conv_small", k <= 1);
                     p.y = y[k];
                     if (variant == 2 && !mrfa_conv2d_bwdstats_supported(&p)) { if (k == 1) small_ok = false; continue; }   // (past conv_small's limits)
-                    hipMemset(tickets, 0, (iters + 8) * 4);
+                    hipMemset(tickets, 0, (size_t)(iters + 8) * MRFA_FIN_WORDS * 4);
                     for (int i = 0; i < iters + 5; ++i) {
                         if (i == 5) { hipDeviceSynchronize(); hipEventRecord(e0); }
-                        if (p.fin_scale) p.fin_counter = tickets + i;
+                        if (p.fin_scale) p.fin_counter = tickets + (size_t)i * MRFA_FIN_WORDS;
                         if (mrfa_conv2d_nhwc(nullptr, &p)) { printf("error: %s\n", mrfa_last_error()); return 1; }
                     }
                     hipEventRecord(e1); hipEventSynchronize(e1);
