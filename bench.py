@@ -640,15 +640,16 @@ def main(rank_body=None, script=None, argv=None, child_argv=None):
 
     # statistics collectives of ONE step.  A captured step issued them while it was being captured (GraphedTrainStep counted them there); an eager step is
     # counted over the first warm-up step -- the step that is timed, with its gradient exchange: no extra weight update on any rank
-    syncbn_per_step = None
+    # (per_layer_form: what the same step issues with one collective per layer and direction, MRFA_SYNCBN_LOCKSTEP=0 -- independent layers share one here)
+    syncbn_per_step = syncbn_per_layer_form = None
     if a.sync_bn and launch == "hipGraph":
-        syncbn_per_step = gstep.syncbn_collectives
+        syncbn_per_step, syncbn_per_layer_form = gstep.syncbn_collectives, gstep.syncbn_exchanges
     for i in range(a.warmup):
         if a.sync_bn and launch != "hipGraph" and i == 0:
             from mrfa_amd import engine as _eng
-            c0 = _eng.SYNCBN_COLLECTIVES
+            c0, e0 = _eng.SYNCBN_COLLECTIVES, _eng.SYNCBN_EXCHANGES
             loss = step()
-            syncbn_per_step = _eng.SYNCBN_COLLECTIVES - c0
+            syncbn_per_step, syncbn_per_layer_form = _eng.SYNCBN_COLLECTIVES - c0, _eng.SYNCBN_EXCHANGES - e0
             continue
         loss = step()
     barrier()
@@ -840,7 +841,7 @@ def main(rank_body=None, script=None, argv=None, child_argv=None):
                                    f"bs={B}/GPU, fwd+bwd+clip+Adam, train-mode BN, " +
                                    ("surrogate L1 loss" if a.loss == "surrogate" else
                                     "the reference's generator losses (VGG19 perceptual pyramid on random-init weights + equivariance, 3 encoder passes)"),
-                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "background_predictor": bool(a.background), "sync_bn": bool(a.sync_bn), "sync_bn_collectives_per_step": syncbn_per_step, "launch": launch,
+                       "global_batch": world * B, "parallelism": f"dp{world}", "prior": a.prior, "background_predictor": bool(a.background), "sync_bn": bool(a.sync_bn), "sync_bn_collectives_per_step": syncbn_per_step, "sync_bn_collectives_per_step_one_per_layer_form": syncbn_per_layer_form, "launch": launch,
                        "optimizer": "FlatAdam (K20)" if fused else "torch.optim.Adam", "mfma": hip.mfma_mode(), "loss": float(f"{loss_val:.6f}"),
                        "tuning": a.tune or None, "graph_verify": gstep_info,
                        "bn_statistics": ("SyncBatchNorm" if a.sync_bn else "per-rank batch statistics; train.sync_bn_buffers (explicit collective) averages the running "

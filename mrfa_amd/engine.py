@@ -241,12 +241,38 @@ class defer_wgrads:
 
 SYNCBN_FORCE = os.environ.get("MRFA_SYNCBN_FORCE_COLLECTIVE", "0") == "1"
 SYNCBN_COLLECTIVES = 0          # statistics all-reduces issued by this process so far (bench.py --sync-bn reports the number per step)
+SYNCBN_EXCHANGES = 0            # ... and the layer passes (forward / backward) they served: the collective count of the one-collective-per-layer form
 
 
-def _syncbn_all_reduce(t: torch.Tensor):
-    global SYNCBN_COLLECTIVES
+def _syncbn_all_reduce(t: torch.Tensor, layers: int = 1):
+    global SYNCBN_COLLECTIVES, SYNCBN_EXCHANGES
     SYNCBN_COLLECTIVES += 1
+    SYNCBN_EXCHANGES += layers
     torch.distributed.all_reduce(t)
+
+
+# SyncBatchNorm layers whose inputs do not depend on each other's outputs -- the same block position of HRNet's parallel resolution branches, the terms of a
+# fuse layer (transformer/hr_base.py) -- exchange their statistics in ONE collective (Ctx.sync_stats; the backward sums likewise): 422 -> 245 collectives
+# per training step with the MTIA prior.  A collective of a few KB costs its latency, and that latency sits on the step's critical chain once per layer and
+# direction, so at N = 8 the count is what matters; at one rank (a forced collective) it measures nothing.  MRFA_SYNCBN_LOCKSTEP=0: one collective per layer.
+SYNCBN_LOCKSTEP = os.environ.get("MRFA_SYNCBN_LOCKSTEP", "1") != "0"
+
+
+def _syncbn_all_reduce_many(ts):
+    """all-reduce the 1-D fp64 blocks `ts` (slices of the zero-filled pool chunks of Pool.take) with ONE collective per run of blocks that lie back to back in a
+    chunk.  The words between two blocks of a run (alignment padding, the unused ticket / barrier words behind a block) travel along: they are the same on
+    every rank and nothing reads them in a SyncBatchNorm step."""
+    runs = []
+    for t in sorted(ts, key=lambda t: t.data_ptr()):
+        base = t._base if t._base is not None else t
+        lo, hi = t.storage_offset(), t.storage_offset() + (t.numel() + 3) // 4 * 4
+        if runs and runs[-1][0] is base and runs[-1][2] == lo:
+            runs[-1][2] = hi
+            runs[-1][3] += 1
+        else:
+            runs.append([base, lo, hi, 1])
+    for base, lo, hi, n in runs:
+        _syncbn_all_reduce(base.view(-1)[lo:min(hi, base.numel())], n)
 SYNCBN_DIRECT_BYTES = int(os.environ.get("MRFA_SYNCBN_DIRECT_KIB", "128")) << 10      # statistics blocks up to this size are all-reduced whole (all slots)
 PHASE_UPCONV = os.environ.get("MRFA_PHASE_UPCONV", "1") != "0"        # forward / data gradient of fused-upsample 3x3 layers in phase form
 # BatchNorm finalize of the conv -> BatchNorm pairs of the keypoint encoder inside the convolution's launch (last workgroup; mrfa_conv_params.fin_*)
@@ -843,6 +869,7 @@ class Ctx:
         self._pools = {}                 # (stream, dtype) -> ZeroPool: a chunk is zero-filled on the stream that carves it up
         self._home = hip.stream_ptr() if device.type == "cuda" else 0
         self._fin_done = {}              # statistics buffer -> result of a BatchNorm finalize done inside the producing convolution's call
+        self._synced = {}                # statistics buffer -> backward group of a SyncBatchNorm layer whose statistics sync_stats() exchanged already
         # set of forward-activation indices whose (large, lazily initialised) gradient buffer needed a zero fill on first touch the last time this program
         # ran (run_program keeps one per module and input shapes: the programs are static): run_backward() zero-fills them in one multi-tensor launch
         # instead of ~100 fill launches scattered over the backward chains (tools/trace_fills.py: 121 fills per step, ~10 us each on the critical path)
@@ -1372,7 +1399,9 @@ class Ctx:
         scale, shift, mean, invstd = self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn), self.f32(G * Cn)
         if train and stats is not None:
             world = self._sync_world(bn)
-            if self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
+            if stats.data_ptr() in self._synced:          # exchanged by sync_stats() together with the layers beside it
+                count = count * world
+            elif self._sync_collective(world) and isinstance(bn, torch.nn.SyncBatchNorm):
                 # sum / sum-of-squares over every rank's pixels.  Small layers: ALL slots (of all statistic groups: one collective for the source and the
                 # driving pass) are all-reduced in place (<= 128 KB: the collective is latency-bound
                 # there, and nothing but the collective is launched -- round 3 summed, zeroed and copied: three glue launches per layer and direction,
@@ -1395,6 +1424,40 @@ class Ctx:
         if train:
             self.nbt[bn] = self.nbt.get(bn, 0) + G     # num_batches_tracked += 1 per statistic group, batched in flush_forward()
         return scale, shift, mean, invstd
+
+    def syncbn_lockstep(self, bn) -> bool:
+        """should the caller walk independent SyncBatchNorm layers side by side (all convolutions, sync_stats(), all BatchNorm applications)?"""
+        return bool(SYNCBN_LOCKSTEP and self.train and isinstance(bn, torch.nn.SyncBatchNorm) and self._sync_collective(self._sync_world(bn)))
+
+    def sync_stats(self, items):
+        """items = [(bn, stats)] of SyncBatchNorm layers that do not depend on each other, statistics accumulated (conv_bn_raw), not yet applied: ONE
+        statistics collective for all of them now, and ONE for the sums of their backward passes -- the bn_act() backward closures of the group run their
+        first phase as they come and the last one exchanges all the sums and runs every second phase (the residual gradient is a first-phase output, the
+        data gradient of a member is only read by its convolution's closure, which the caller recorded before any bn_act of the group)."""
+        if not items or not self.syncbn_lockstep(items[0][0]):
+            return
+        grp = {"left": 0, "pending": [], "red": {}} if self.record else None
+        blocks = []
+        for bn, st in items:
+            nsl = self.groups * hip.STATS_SLOTS * 2 * bn.num_features
+            if st is None or nsl * 8 > SYNCBN_DIRECT_BYTES:
+                continue                                   # (wide layers sum their slots first: on their own, _bn_finalize)
+            blocks.append(st)
+            self._synced[st.data_ptr()] = grp
+            if grp is not None:
+                grp["left"] += 1
+                grp["red"][st.data_ptr()] = self.f64z(nsl + 2)      # the members' backward sums: carved now, back to back (their closures do not run in a row)
+        _syncbn_all_reduce_many(blocks)
+
+    def _bn_group_done(self, grp):
+        """one member of a sync_stats() group has run (or skipped) the first phase of its backward; the last one finishes all of them"""
+        grp["left"] -= 1
+        if grp["left"] > 0 or not grp["pending"]:
+            return
+        _syncbn_all_reduce_many([red for _, red in grp["pending"]])
+        for q, _ in grp["pending"]:
+            self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(2)")
+        grp["pending"] = []
 
     def _allreduce_slot_sums(self, slots: torch.Tensor, G: int, Cn: int) -> torch.Tensor:
         """wide layers under SyncBatchNorm: the [G][STATS_SLOTS][2C] blocks are summed over the slots locally, the [G][2C] sums are all-reduced (a message of
@@ -1481,22 +1544,31 @@ class Ctx:
                                          "groups": p.groups}
 
             groups = p.groups
+            grp = self._synced.pop(stats.data_ptr(), None) if stats is not None else None       # sync_stats(): the backward sums travel together too
+            if grp is not None:
+                grp = (grp, grp["red"].pop(stats.data_ptr()))
 
             def bwd():
                 if not out.has_grad:
+                    if grp is not None:
+                        self._bn_group_done(grp[0])
                     return
-                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res, hint=hint, groups=groups)
+                self._bn_bwd(x, bn, scale, shift, mean, invstd, relu, pool, out.gptr, out.ld, blend, train, x, res, hint=hint, groups=groups, group=grp)
             self.tape.append(bwd)
+        elif stats is not None:
+            self._synced.pop(stats.data_ptr(), None)
         return out
 
-    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None, hint=None, groups=1):
+    def _bn_bwd(self, x, bn, scale, shift, mean, invstd, relu, pool, dy_ptr, dy_ld, blend, train, dx_view, res=None, hint=None, groups=1, group=None):
         bg = bngrad(bn)
         if bg not in self.touched_bns:
             self.touched_bns.append(bg)
         dg, db = bg.acc(self.pool32)
         nred = groups * hip.STATS_SLOTS * 2 * x.C          # (statistic groups: [groups][STATS_SLOTS][2C])
         pre_red = hint["red"] if hint is not None else None          # the sums of phase 1, already accumulated by the data gradient that wrote dy
-        red = pre_red if pre_red is not None else self.f64z(nred + 2)    # slotted like the statistics buffers (MRFA_STATS_SLOTS) + the fused launch's barrier word
+        group, group_red = group if group is not None else (None, None)
+        # slotted like the statistics buffers (MRFA_STATS_SLOTS) + the fused launch's barrier word
+        red = pre_red if pre_red is not None else (group_red if group_red is not None else self.f64z(nred + 2))
         q = hip.BnBwdParams()
         q.x, q.ldx, q.N, q.H, q.W, q.C = x.ptr, x.ld, x.N, x.H, x.W, x.C
         q.scale, q.shift, q.relu, q.pool = scale.data_ptr(), shift.data_ptr(), int(relu), int(pool)
@@ -1526,12 +1598,19 @@ class Ctx:
             # (Round 3: sum, two adds, the collective and a division = five launches per layer.)
             Cn = x.C
             self._chk(self.L.mrfa_bn_param_grad_groups(self.s, red.data_ptr(), Cn, groups, dg.data_ptr(), db.data_ptr()), "bn_param_grad")
+            q.red_world = world
+            q.dgamma = q.dbeta = None
+            q.phase = 2
+            if group is not None:                           # sync_stats(): the sums of the group's members are exchanged together (_bn_group_done)
+                group["pending"].append((q, red))
+                self._bn_group_done(group)
+                return
             if nred * 8 <= SYNCBN_DIRECT_BYTES:
                 _syncbn_all_reduce(red[:nred])
             else:
                 q.red = self._allreduce_slot_sums(red, groups, Cn).data_ptr()
-            q.red_world = world
-            q.dgamma = q.dbeta = None
+        elif group is not None:
+            self._bn_group_done(group)
         q.phase = 2
         self._chk(self.L.mrfa_bn_act_bwd(self.s, C.byref(q)), "bn_act_bwd(2)")
 

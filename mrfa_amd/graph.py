@@ -169,6 +169,14 @@ class GraphedForward:
         return self.out
 
 
+def _drain_watchdog(seconds: float = 0.3):
+    """before a capture that will hold RCCL collectives: wait until the device is idle and ProcessGroupNCCL's watchdog thread (one pass per 100 ms) has
+    retired every eager collective issued so far -- see GraphedTrainStep.__init__"""
+    import time
+    torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
 class GraphedTrainStep:
     """fwd + bwd + (all-reduce) + clip + Adam of mrfa_amd.train.train_step as two hipGraphs (see module docstring).
 
@@ -251,10 +259,14 @@ class GraphedTrainStep:
         # while the capture runs, and in the default ("global") mode such a query from ANOTHER thread invalidated the capture (hipErrorCapturedEvent: 1 capture
         # in 5 with the SyncBatchNorm collectives captured, round 5 -- then papered over with a 0.5 s pause that protected the first graph only).
         # thread_local is the mode PyTorch itself uses around NCCL: only this thread's calls are checked against the capture.
-        if syncbn_collectives or world > 1:
-            torch.cuda.synchronize()
+        # That alone left 1 capture in 3 failing at the end of round 6 (hipErrorStreamCaptureInvalidated in BOTH collective forms): RCCL's stream joins the
+        # capture at the first captured collective, and HIP then refuses the watchdog's query of an EAGER work's end event on that stream
+        # (hipErrorCapturedEvent) although the event was recorded before the capture began.  So the watchdog is also given the time to retire the eager work
+        # first: device idle, then three of its 100 ms polling periods, before each capture (_drain_watchdog).
+        drain = (lambda: _drain_watchdog()) if (syncbn_collectives or world > 1) else (lambda: None)
+        drain()
         self.g_fb = torch.cuda.CUDAGraph()
-        syncbn0 = engine.SYNCBN_COLLECTIVES            # (the Python counter runs while the step is captured: the collectives of ONE step)
+        syncbn0, syncex0 = engine.SYNCBN_COLLECTIVES, engine.SYNCBN_EXCHANGES       # (the Python counters run while the step is captured: the collectives of ONE step)
         GraphedTrainStep._captures += 1
         engine.CAPTURE_KEY = GraphedTrainStep._captures
         engine.WGRAD_STREAM = overlap_wgrad
@@ -284,17 +296,20 @@ class GraphedTrainStep:
             self.g_tail = None
             if self.split is not None:                                # graph A2: the encoder's backward, from the keypoint gradients of A1
                 self.g_tail = torch.cuda.CUDAGraph()
+                drain()
                 with torch.cuda.graph(self.g_tail, pool=self.g_fb.pool(), stream=self.stream, capture_error_mode="thread_local"), engine.direct_param_grads():
                     self._tail()
         finally:
             engine.CAPTURE_KEY = 0
             engine.WGRAD_STREAM = False
         self.syncbn_collectives = engine.SYNCBN_COLLECTIVES - syncbn0
+        self.syncbn_exchanges = engine.SYNCBN_EXCHANGES - syncex0       # = the collectives of the one-per-layer form (engine.SYNCBN_LOCKSTEP off)
         assert self.grads.bound(), "a gradient left the flat buffer"
         self.g_opt = torch.cuda.CUDAGraph()
         if self.fused:
             optimizer.grad_scale = 1.0 / world
             optimizer.sync_lr()
+        drain()
         with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), stream=self.stream, capture_error_mode="thread_local"):
             engine.mark("optimizer: start")
             if self.fused:

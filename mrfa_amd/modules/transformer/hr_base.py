@@ -61,6 +61,18 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         return run_block(self, x)
 
+    @staticmethod
+    def run_lockstep(e: Ctx, blocks: List["BasicBlock"], xs: List[View]) -> List[View]:
+        """the same block position of independent branches under SyncBatchNorm (reference train.py:43): all first convolutions, ONE statistics
+        collective, all BatchNorm applications; likewise the second half -- two collectives per depth and direction instead of two per block
+        (engine.Ctx.sync_stats).  The arithmetic of every layer is that of run()."""
+        raws = [e.conv_bn_raw(x, b.conv1, b.bn1) for b, x in zip(blocks, xs)]
+        e.sync_stats([(b.bn1, st) for b, (_, st) in zip(blocks, raws)])
+        ys = [e.bn_act(raw, b.bn1, st, relu=True, sole_consumer=True, out_sole=True) for b, (raw, st) in zip(blocks, raws)]
+        raws = [e.conv_bn_raw(y, b.conv2, b.bn2) for b, y in zip(blocks, ys)]
+        e.sync_stats([(b.bn2, st) for b, (_, st) in zip(blocks, raws)])
+        return [e.bn_act(raw, b.bn2, st, relu=True, res=x, sole_consumer=True) for b, x, (raw, st) in zip(blocks, xs, raws)]
+
 
 class Bottleneck(nn.Module):
     """1x1 -> 3x3 -> 1x1 (x4 channels) conv+BN, residual, ReLU.  reference: hr_base.py:57-95"""
@@ -167,6 +179,52 @@ class HighResolutionModule(nn.Module):
             y = _conv_bn(e, y, step[0], step[1], relu=not last, res=res if last else None)
         return y
 
+    def _lockstep(self, e: Ctx) -> bool:
+        """SyncBatchNorm with a statistics collective per layer: walk the branches side by side (BasicBlock.run_lockstep, _fuse_lockstep)"""
+        blocks = [b for br in self.branches for b in br]
+        return (e.syncbn_lockstep(blocks[0].bn1) and all(isinstance(b, BasicBlock) and b.downsample is None for b in blocks)
+                and len({len(br) for br in self.branches}) == 1)
+
+    def _fuse_lockstep(self, e: Ctx, x: List[View]) -> List[View]:
+        """run()'s fuse sums with the FIRST convolution of every term issued up front and one statistics collective for all of them (the terms
+        of a fuse layer read the branch outputs only): 2 collectives per module and direction instead of 7 (three branches)"""
+        nb = self.num_branches
+        first = {}
+        for i in range(len(self.fuse_layers)):
+            for j in range(nb):
+                if j != i:
+                    f = self.fuse_layers[i][j]
+                    conv, bn = (f[0], f[1]) if j > i else (f[0][0], f[0][1])
+                    first[(i, j)] = (bn,) + tuple(e.conv_bn_raw(x[j], conv, bn))
+        e.sync_stats([(bn, st) for bn, _, st in first.values()])
+
+        def term(i, j, res=None):
+            bn, raw, st = first[(i, j)]
+            if j > i:
+                return e.bn_act(raw, bn, st, relu=False, sole_consumer=True)
+            f = self.fuse_layers[i][j]
+            y = None
+            for k, step in enumerate(f):
+                last = k == len(f) - 1
+                if k == 0:
+                    y = e.bn_act(raw, bn, st, relu=not last, res=res if last else None, sole_consumer=True)
+                else:
+                    y = _conv_bn(e, y, step[0], step[1], relu=not last, res=res if last else None)
+            return y
+        out = []
+        for i in range(len(self.fuse_layers)):
+            y = x[0] if i == 0 else term(i, 0)
+            for j in range(1, nb):
+                last = j == nb - 1
+                if j == i:
+                    y = e.ups_add(x[j], y, 1, relu=last)
+                elif j > i:
+                    y = e.ups_add(term(i, j), y, 2 ** (j - i), relu=last)
+                else:
+                    y = term(i, j, res=y)
+            out.append(y)
+        return out
+
     def run(self, e: Ctx, x: List[View]) -> List[View]:
         if self.num_branches == 1:
             y = x[0]
@@ -174,6 +232,10 @@ class HighResolutionModule(nn.Module):
                 y = blk.run(e, y)
             return [y]
         x = list(x)
+        if self._lockstep(e):
+            for d in range(len(self.branches[0])):
+                x = BasicBlock.run_lockstep(e, [br[d] for br in self.branches], x)
+            return self._fuse_lockstep(e, x)
 
         def chain(i):
             y = x[i]

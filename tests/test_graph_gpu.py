@@ -324,6 +324,64 @@ def test_sync_batchnorm_collectives_are_captured_into_the_graph(monkeypatch):
             dist.destroy_process_group()
 
 
+def test_depth_batched_sync_batchnorm_collectives_equal_one_per_layer(monkeypatch):
+    """engine.Ctx.sync_stats: under SyncBatchNorm the same block position of HRNet's resolution branches and the terms of a fuse
+    layer exchange their statistics -- and their backward sums -- in ONE collective (transformer/hr_base.py: BasicBlock.run_lockstep, _fuse_lockstep).
+    One-rank RCCL group with the collectives forced, the trunk of tests/test_wiring_cpu.small_hrnet(deep=1) with two statistic groups (the batched source +
+    driving pass): the depth-batched walk against one collective per layer and direction -- same kernels on the same data in another issue order, so the
+    outputs and running statistics agree to rounding of the statistics atomics and every parameter gradient to what two runs of one form differ by; the
+    collective count drops as the world-2 gloo test (test_sync_batchnorm_hrnet_world2_matches_big_batch) states, and the layer passes served stay the same."""
+    import os
+    import torch.distributed as dist
+    from mrfa_amd import engine
+    from mrfa_amd.utils.prng import det_uniform
+    from tests.test_wiring_cpu import small_hrnet
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(36300 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    monkeypatch.setattr(engine, "SYNCBN_FORCE", True)
+    frames, b, size = 2, 2, 64
+    x = torch.cat([(det_uniform(f"lk/x{i}", (b, 3, size, size)) * (1.0 + 0.5 * i)).to(DEV) for i in range(frames)], 0)
+    w = det_uniform("lk/w", (frames * b, 32, size // 4, size // 4)).to(DEV)
+
+    def run(lockstep):
+        monkeypatch.setattr(engine, "SYNCBN_LOCKSTEP", lockstep)
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(small_hrnet(1)).to(DEV)
+        m.train(True)
+        c0, e0 = engine.SYNCBN_COLLECTIVES, engine.SYNCBN_EXCHANGES
+        with engine.stat_groups(frames):
+            y = m(x)
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+        return (y.detach(), {n: p.grad.double().clone() for n, p in m.named_parameters()}, {n: v.clone() for n, v in m.named_buffers()},
+                engine.SYNCBN_COLLECTIVES - c0, engine.SYNCBN_EXCHANGES - e0)
+    try:
+        y0, g0, b0, c0, e0 = run(False)
+        y0b, g0b, _, _, _ = run(False)
+        y1, g1, b1, c1, e1 = run(True)
+    finally:
+        torch.cuda.synchronize()
+        if own_group:
+            dist.destroy_process_group()
+    n_bn = len([1 for n in b0 if n.endswith("running_mean")])
+    assert c0 == e0 == e1 == 2 * n_bn, (c0, e0, e1, n_bn)
+    assert c1 == 2 * (n_bn - 25), (c1, n_bn)               # (the count of the world-2 gloo test's deep case)
+    assert (y0 - y1).abs().max().item() <= 1e-5 * max(1.0, y0.abs().max().item())
+    for n in b0:
+        if b0[n].dtype.is_floating_point:
+            assert (b0[n] - b1[n]).abs().max().item() <= 1e-6 * max(1.0, b0[n].abs().max().item()), n
+    worst = noise = 0.0
+    for n in g0:
+        sc = max(g0[n].abs().max().item(), 1e-6)
+        worst = max(worst, (g0[n] - g1[n]).abs().max().item() / sc)
+        noise = max(noise, (g0[n] - g0b[n]).abs().max().item() / sc)
+    print(f"depth-batched SyncBatchNorm collectives: {c1} instead of {c0} per pass pair; worst per-parameter gradient difference {worst:.2e} of the parameter's scale "
+          f"(two runs of the per-layer form: {noise:.2e})")
+    assert worst <= 2e-4 + 4 * noise, (worst, noise)
+
+
 def test_encoder_weight_gradients_dealt_onto_side_streams_match_the_inline_order():
     """HotPath._wdefer_enc (the keypoint encoder's ~200 weight-gradient launches collected during its backward chain and dealt onto
     four side streams afterwards, their un-packing last): one eager forward + backward with the fan-out on and off; a randomly initialised

@@ -246,7 +246,8 @@ rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.ar
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 with emulated_hip():
-    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(small_hrnet())       # reference train.py:43
+    deep = int(os.environ.get("SBH_DEEP", "0"))
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(small_hrnet(deep))       # reference train.py:43
     m.train(True)
     y = m(det_uniform("sbh/x", (4, 3, 32, 32))[rank * 2:(rank + 1) * 2])
     (y * det_uniform("sbh/w", (4, 32, 8, 8))[rank * 2:(rank + 1) * 2]).sum().div(4.0).mul(world).backward()
@@ -254,39 +255,55 @@ with emulated_hip():
         dist.all_reduce(p.grad)
         p.grad.div_(world)
     if rank == 0:
-        torch.save({"grads": {n: p.grad for n, p in m.named_parameters()}, "y": y.detach(), "bufs": {n: b.clone() for n, b in m.named_buffers()}}, out)
+        from mrfa_amd import engine
+        torch.save({"grads": {n: p.grad for n, p in m.named_parameters()}, "y": y.detach(), "bufs": {n: b.clone() for n, b in m.named_buffers()},
+                    "collectives": engine.SYNCBN_COLLECTIVES}, out)
 dist.destroy_process_group()
 """
 
 
-def small_hrnet():
+def small_hrnet(deep=0):
     """the MTIA prior's HRNet trunk with one module and one block per branch (every BatchNorm call pattern of the encoder: conv-epilogue
-    statistics, the separate statistics pass behind stride-2 convolutions, residual-closing BatchNorm, 1x1 fuse layers)"""
+    statistics, the separate statistics pass behind stride-2 convolutions, residual-closing BatchNorm, 1x1 fuse layers); deep: two stage-3 modules
+    (the first with all three fuse outputs: the two-step 1/4 -> 1/16 term, running sums through BatchNorm passes) and two blocks per branch"""
     from mrfa_amd.modules.transformer.hr_base import HRNET_base
     from mrfa_amd.utils.prng import fill_state_dict
     cfg = {"MODEL": {"EXTRA": {"PRETRAINED_LAYERS": [],
                                "STAGE2": dict(NUM_MODULES=1, NUM_BRANCHES=2, BLOCK="BASIC", NUM_BLOCKS=[1, 1], NUM_CHANNELS=[32, 64], FUSE_METHOD="SUM"),
-                               "STAGE3": dict(NUM_MODULES=1, NUM_BRANCHES=3, BLOCK="BASIC", NUM_BLOCKS=[1, 1, 1], NUM_CHANNELS=[32, 64, 128],
-                                              FUSE_METHOD="SUM")}}}
+                               "STAGE3": dict(NUM_MODULES=2 if deep else 1, NUM_BRANCHES=3, BLOCK="BASIC", NUM_BLOCKS=[2 if deep else 1] * 3,
+                                              NUM_CHANNELS=[32, 64, 128], FUSE_METHOD="SUM")}}}
     m = HRNET_base(cfg)
     m.load_state_dict(fill_state_dict(m.state_dict(), "sbh"))
     return m
 
 
-def test_sync_batchnorm_hrnet_world2_matches_big_batch(tmp_path):
+@pytest.mark.parametrize("lockstep,deep", [(1, 0), (0, 0), (1, 1)], ids=["depth_batched_collectives", "one_collective_per_layer", "depth_batched_two_modules"])
+def test_sync_batchnorm_hrnet_world2_matches_big_batch(tmp_path, lockstep, deep):
     """SyncBatchNorm through the MTIA encoder's BatchNorm call patterns (transformer/hr_base.py): 2 gloo ranks x 2 samples == 1 process
-    x 4 samples for the output, every running statistic / batch counter and every gradient."""
+    x 4 samples for the output, every running statistic / batch counter and every gradient -- with the statistics of independent layers (the
+    resolution branches' blocks, the terms of a fuse layer) travelling in one collective per depth (engine.Ctx.sync_stats, the default) and with
+    one collective per layer and direction (MRFA_SYNCBN_LOCKSTEP=0): 32 layers x 2 directions = 64 collectives against 48."""
     from mrfa_amd.utils.prng import det_uniform
     script = tmp_path / "worker.py"
     script.write_text(SYNCBN_HRNET_WORKER)
     out = tmp_path / "res.pt"
-    port = str(37500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)]) for r in range(2)]
+    port = str(37500 + os.getpid() % 2000 + 2000 * lockstep)
+    env = dict(os.environ, MRFA_SYNCBN_LOCKSTEP=str(lockstep), SBH_DEEP=str(deep))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(out)], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     got = torch.load(out)
+    n_sync = sum(isinstance(mod, torch.nn.BatchNorm2d) for mod in small_hrnet(deep).modules())
+    if lockstep and deep:
+        # stage 2 as below; stage 3: two modules x (two block depths x three branches: 12 -> 4), fuse layers 7 -> 2 (three outputs) and 2 -> 1
+        assert got["collectives"] == 2 * (n_sync - 3 - 16 - 5 - 1), (got["collectives"], n_sync)
+    elif lockstep:
+        # stage 2: two branch blocks 4 -> 2 collectives, its fuse layer 2 -> 1; stage 3: three branch blocks 6 -> 2, its (single-output) fuse layer 2 -> 1
+        assert got["collectives"] == 2 * (n_sync - 8), (got["collectives"], n_sync)
+    else:
+        assert got["collectives"] == 2 * n_sync, (got["collectives"], n_sync)
     with emulated_hip():
-        m = small_hrnet()
+        m = small_hrnet(deep)
         m.train(True)
         y = m(det_uniform("sbh/x", (4, 3, 32, 32)))
         (y * det_uniform("sbh/w", (4, 32, 8, 8))).sum().div(4.0).backward()
