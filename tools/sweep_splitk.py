@@ -13,7 +13,9 @@ from mrfa_amd import hip  # noqa: E402
 dev = torch.device("cuda:0")
 L = hip.lib()
 hip.set_mfma_mode("bf16x6")
-SHAPES = [("256->512 3x3 @8", 8, 8, 8, 256, 512, 0), ("1024->256 3x3 @8 ups", 8, 4, 4, 1024, 256, 1), ("512->128 3x3 @16 ups", 8, 8, 8, 512, 128, 1),
+SHAPES = [("512->512 3x3 @4", 8, 4, 4, 512, 512, 0), ("1024->1024 3x3 @4", 8, 4, 4, 1024, 1024, 0), ("512->512 3x3 @8", 8, 8, 8, 512, 512, 0),
+          ("1024->512 3x3 @8", 8, 8, 8, 1024, 512, 0), ("512->1024 3x3 @8", 8, 8, 8, 512, 1024, 0), ("2048->512 3x3 @8 ups", 8, 4, 4, 2048, 512, 1),
+          ("1024->512 3x3 @16", 8, 16, 16, 1024, 512, 0), ("256->512 3x3 @8", 8, 8, 8, 256, 512, 0), ("1024->256 3x3 @8 ups", 8, 4, 4, 1024, 256, 1), ("512->128 3x3 @16 ups", 8, 8, 8, 512, 128, 1),
           ("512->512 3x3 @16", 8, 16, 16, 512, 512, 0), ("256->64 3x3 @32 ups", 8, 16, 16, 256, 64, 1), ("128->256 3x3 @16", 8, 16, 16, 128, 256, 0),
           ("128->32 3x3 @64 ups", 8, 32, 32, 128, 32, 1), ("64->128 3x3 @32", 8, 32, 32, 64, 128, 0)]
 for name, N, H, W, Cin, Cout, ups in SHAPES:
@@ -40,14 +42,35 @@ for name, N, H, W, Cin, Cout, ups in SHAPES:
     p.stats = stats.data_ptr()
     fl = 2.0 * N * Ho * Wo * Cout * Cin * 9
     res = []
-    for sk in (0, 1, 2, 4, 8, 16, 32, 64):
+    # COLD=1: every call reads another copy of the weight planes (600 MB of copies: more than the 256 MB Infinity Cache) -- the training step reads each
+    # layer's planes once per pass, straight from HBM; without it the 30 timed calls re-read one copy from the caches
+    cold = os.environ.get("COLD", "0") == "1"
+    copies = [wsb] + ([wsb.clone() for _ in range(min(63, (600 << 20) // (wsb.numel() * 2)))] if cold else [])
+    # FUSED=1: the form the training step launches (engine.Ctx._conv_out): the K split finishes inside the launch (sk_ticket), the output is a fresh
+    # zero-filled buffer (y_zero) -- 33 outputs + ticket blocks zeroed outside the timed loop
+    fused = os.environ.get("FUSED", "0") == "1"
+    if fused:
+        nt = ((N * Ho * Wo + 31) // 32) * ((Cout + 31) // 32)
+        ys = [torch.zeros(N * Ho * Wo, Cout, device=dev) for _ in range(33)]
+        tks = [torch.zeros(nt * 64, dtype=torch.int32, device=dev) for _ in range(33)]
+        bias = torch.randn(Cout, device=dev)
+        p.bias, p.relu, p.y_zero = bias.data_ptr(), 1, 1
+    for sk in ((0, 1, 8, 16, 32) if cold else (0, 1, 2, 4, 8, 16, 32, 64)):
         p.splitk = sk
-        for _ in range(3):
+        if fused:
+            for t in ys + tks:
+                t.zero_()
+        for i in range(3):
+            if fused:
+                p.y, p.sk_ticket = ys[30 + i].data_ptr(), tks[30 + i].data_ptr()
             hip.check(L.mrfa_conv2d_nhwc(hip.stream_ptr(), C.byref(p)), "conv")
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(30):
+        for i in range(30):
+            p.w_split = copies[i % len(copies)].data_ptr()
+            if fused:
+                p.y, p.sk_ticket = ys[i].data_ptr(), tks[i].data_ptr()
             hip.check(L.mrfa_conv2d_nhwc(hip.stream_ptr(), C.byref(p)), "conv")
         e1.record()
         torch.cuda.synchronize()
