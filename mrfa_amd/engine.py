@@ -1183,9 +1183,9 @@ class Ctx:
         exists (107 launches per training step on the serial low-resolution chains of the hourglasses and the generator's bottleneck)."""
         rows = N * Ho * Wo
         if FUSED_SPLITK and rows <= 32768:
-            nt = ((rows + 31) // 32) * ((Cout + 31) // 32)
-            p.sk_ticket = self.pool32.take(nt).data_ptr()
-            if self.L.mrfa_conv2d_split_k(C.byref(p)) > 1:
+            p.sk_ticket = p.x                         # (placeholder for the query, which only asks whether tickets will be there: ADVICE r5 -- the ticket
+            if self.L.mrfa_conv2d_split_k(C.byref(p)) > 1:      # block is carved from the zero arena only for launches that do split)
+                p.sk_ticket = self.pool32.take(((rows + 31) // 32) * ((Cout + 31) // 32)).data_ptr()
                 if out is None:
                     ld = _r4(Cout)
                     out = View(Storage(self.pool32.take(rows * ld).view(rows, ld)), N, Ho, Wo, Cout)
