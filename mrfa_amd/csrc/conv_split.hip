@@ -331,19 +331,46 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
             if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
         }
         float s1 = 0.f, s2 = 0.f;
+        // Everything a 32-row block of this column tile READS first, all of it in flight together, from clamped (always valid) addresses.  With the loads inside the
+        // per-element branch the compiler waited for each one before the next was issued: the last arriver of a K split read its 64 values per lane
+        // back one memory-side round trip at a time -- ~30 us of a 65 us launch on the low-resolution levels (round 6, the ISA of this loop:
+        // global_load_dword ... sc1 ; s_waitcnt vmcnt(0), 64 times; tools/sweep_splitk.py FUSED=1 before / after in profiles/r6_sweep_splitk_*)
+        const int cq = c_ok ? c : 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float yv[16], rv[16];
+            auto row_of = [&](int r) {                     // (rows past M read the last row: a valid address, never stored)
+                const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                return m < M ? m : M - 1;
+            };
+            if (splitk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = __hip_atomic_load(y + (size_t)row_of(r) * p.ldy + cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = y[(size_t)row_of(r) * p.ldy + cq];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+            }
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = p.res[(size_t)row_of(r) * p.ldr + cq];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (c_ok && m < M) {
                     float* dst = y + (size_t)m * p.ldy + c;
-                    float v = splitk ? __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[i][j][r] * p.alpha;
+                    float v = splitk ? yv[r] : acc[i][j][r] * p.alpha;
                     v += bias;
                     v = v * osc + osh;
-                    if (p.res) v += p.res[(size_t)m * p.ldr + c];
+                    v += rv[r];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.accumulate && !splitk) v += *dst;
+                    if (!splitk) v += yv[r];                // (accumulate; zeros otherwise)
                     *dst = v;
                     s1 += v;
                     s2 += v * v;
