@@ -317,61 +317,96 @@ __global__ __launch_bounds__(PR * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         float s1[16], s2[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
+        // Round 6: everything a channel quad READS -- its per-channel constants, and for BOTH patch rows the ReLU mask, the residual and the old output of an
+        // accumulating launch -- is issued first, from clamped (always valid) addresses, and waited for once.  Before, every load sat inside the per-row /
+        // per-quad branches and the compiler waited for each before the next (218 s_waitcnt vmcnt(0) behind the last MFMA of this kernel): up to four
+        // dependent round trips per quad, 8-16 quads per lane, with ONE workgroup per CU and nothing else to run meanwhile.
+        long long m_row[2];
+        bool row_ok[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // patch row; phase form: output pixel (2 pyl + ph_y, 2 (x0 + px) + ph_x)
             const int pyl = y0 + 2 * wm + i;
-            const long long m = PH ? ((long long)n_img * p.Hout + 2 * pyl + ph_y) * p.Wout + 2 * (x0 + px) + ph_x
-                                   : ((long long)n_img * p.Hout + pyl) * p.Wout + x0 + px;
-            if (pyl < (PH ? p.Hin : p.Hout)) {
+            row_ok[i] = pyl < (PH ? p.Hin : p.Hout);
+            const int pyc = row_ok[i] ? pyl : y0;               // (a patch's first row always exists)
+            m_row[i] = PH ? ((long long)n_img * p.Hout + 2 * pyc + ph_y) * p.Wout + 2 * (x0 + px) + ph_x
+                          : ((long long)n_img * p.Hout + pyc) * p.Wout + x0 + px;
+        }
+        const bool mask_vec = p.mask && (p.ldm % 4) == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 15) == 0;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = cb + 8 * g;
-                    float* dst = y + (size_t)m * p.ldy + c0;
-                    float v[4];
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = cb + 8 * g;
+            const bool full = c0 + 3 < p.Cout;                  // whole quad inside Cout: 16-byte accesses (ldy, ldr % 4 == 0, 16-B aligned bases)
+            const int cq = full ? c0 : 0;
+            float bias[4], osc[4], osh[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {                  // (per-channel constants re-read per quad: L1 / scalar-cache hits, 48 fewer live registers)
-                        const bool c_ok = c0 + e < p.Cout;
-                        const float bias = (p.bias && c_ok) ? p.bias[c0 + e] : 0.f;
-                        const float osc = (p.out_scale && c_ok) ? p.out_scale[c0 + e] : 1.f;
-                        const float osh = (p.out_scale && c_ok) ? p.out_shift[c0 + e] : 0.f;
-                        v[e] = (acc[i][j][4 * g + e] * p.alpha + bias) * osc + osh;
+            for (int e = 0; e < 4; ++e) { bias[e] = 0.f; osc[e] = 1.f; osh[e] = 0.f; }
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias[e] = p.bias[c0 + e < p.Cout ? c0 + e : 0];
+            }
+            if (p.out_scale) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { osc[e] = p.out_scale[c0 + e < p.Cout ? c0 + e : 0]; osh[e] = p.out_shift[c0 + e < p.Cout ? c0 + e : 0]; }
+            }
+            f32x4 mk[2], r4[2], o4[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                mk[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+                r4[i] = o4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.mask) {                                       // fused ReLU backward of the producer of this gradient (data-gradient launches)
+                if (mask_vec) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) mk[i] = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m_row[i] * p.ldm + cq);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mk[i][e] = p.mask[(size_t)m_row[i] * p.ldm + (c0 + e < p.Cout ? c0 + e : 0)];
+                }
+            }
+            if (p.res) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) r4[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m_row[i] * p.ldr + cq);
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) o4[i] = *reinterpret_cast<const f32x4*>(y + (size_t)m_row[i] * p.ldy + cq);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!row_ok[i]) continue;
+                float* dst = y + (size_t)m_row[i] * p.ldy + c0;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (acc[i][j][4 * g + e] * p.alpha + bias[e]) * osc[e] + osh[e];
+                    v[e] = mk[i][e] > 0.f ? v[e] : 0.f;
+                }
+                if (full) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r4[i][e];
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
-                    if (p.mask) {                              // fused ReLU backward of the producer of this gradient (data-gradient launches)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c0 + e < p.Cout) v[e] = p.mask[(size_t)m * p.ldm + c0 + e] > 0.f ? v[e] : 0.f;
-                    }
-                    if (c0 + 3 < p.Cout) {                      // whole quad inside Cout: 16-byte accesses (ldy, ldr % 4 == 0, 16-B aligned bases)
-                        if (p.res) {
-                            const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + c0);
+                    for (int e = 0; e < 4; ++e) v[e] += o4[i][e];
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += r4[e];
-                        }
-                        if (p.relu) {
+                    for (int e = 0; e < 4; ++e) { s1[4 * g + e] += v[e]; s2[4 * g + e] += v[e] * v[e]; }
+                } else {                                       // ragged Cout (e.g. 126 channels next to 2 foreign ones in a wider buffer)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        if (p.accumulate) {
-                            const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += o4[e];
-                        }
-                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1[4 * g + e] += v[e]; s2[4 * g + e] += v[e] * v[e]; }
-                    } else {                                   // ragged Cout (e.g. 126 channels next to 2 foreign ones in a wider buffer)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (c0 + e < p.Cout) {
-                                float u = v[e];
-                                if (p.res) u += p.res[(size_t)m * p.ldr + c0 + e];
-                                if (p.relu) u = fmaxf(u, 0.f);
-                                if (p.accumulate) u += dst[e];
-                                dst[e] = u;
-                                s1[4 * g + e] += u;
-                                s2[4 * g + e] += u * u;
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        if (c0 + e < p.Cout) {
+                            float u = v[e];
+                            if (p.res) u += p.res[(size_t)m_row[i] * p.ldr + c0 + e];
+                            if (p.relu) u = fmaxf(u, 0.f);
+                            if (p.accumulate) u += dst[e];
+                            dst[e] = u;
+                            s1[4 * g + e] += u;
+                            s2[4 * g + e] += u * u;
                         }
                     }
                 }

@@ -405,6 +405,19 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long long m = m0 + (wm * TM + i) * 32 + px;
+            // (as in the epilogue above: the residual / old-output quads of this pixel are read first, together, from clamped addresses)
+            const long long mc = m < M ? m : M - 1;
+            f32x4 r4q[4], o4q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) r4q[g] = o4q[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.res && vec_ok && !splitk) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r4q[g] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.ldr + (cb + 8 * g + 3 < p.Cout ? cb + 8 * g : 0));
+            }
+            if (p.accumulate && vec_ok && !splitk) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) o4q[g] = *reinterpret_cast<const f32x4*>(y + (size_t)mc * p.ldy + (cb + 8 * g + 3 < p.Cout ? cb + 8 * g : 0));
+            }
             if (m < M) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -427,20 +440,14 @@ __global__ __launch_bounds__(NT, 3) void conv_bf16x6_kernel(const mrfa_conv_para
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias[e]) * osc[e] + osh[e];
                         if (vec_ok && c0 + 3 < p.Cout) {
-                            if (p.res) {
-                                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + c0);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += r4[e];
-                            }
+                            for (int e = 0; e < 4; ++e) v[e] += r4q[g][e];
                             if (p.relu) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                             }
-                            if (p.accumulate) {
-                                const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += o4[e];
-                            }
+                            for (int e = 0; e < 4; ++e) v[e] += o4q[g][e];
                             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { s1[4 * g + e] += v[e]; s2[4 * g + e] += v[e] * v[e]; }
