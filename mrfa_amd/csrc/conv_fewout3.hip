@@ -39,7 +39,8 @@ __device__ __forceinline__ void load_col(const float* __restrict__ base, int ld,
     }
 }
 
-template <int COUT, int LPP>
+// RD: the launch reads a ReLU mask and / or the old gradient (their batched read-ahead costs 32 registers: kept out of the launches that read neither)
+template <int COUT, int LPP, bool RD>
 __global__ __launch_bounds__(256) void fewout3_dgrad_kernel(const float* __restrict__ dy, int lddy, int N, int H, int W, int Cin,
                                                            const float* __restrict__ w, float* __restrict__ dx, int lddx, int accumulate,
                                                            long long units, int runs_x, const float* __restrict__ mask, int ldm) {
@@ -72,29 +73,51 @@ __global__ __launch_bounds__(256) void fewout3_dgrad_kernel(const float* __restr
         };
         load_dcol(ut.x0 - 1, win[0]);
         load_dcol(ut.x0, win[1]);
+        // what four pixels' stores need (ReLU mask, old gradient of an accumulating launch) is read together, ahead of them, from clamped addresses --
+        // inside the `xo < W` branch each read was a round trip of its own per pixel (round 6)
+        const size_t pix0 = (size_t)(ut.n * H + ut.y) * W;
 #pragma unroll
-        for (int i = 0; i < RUN; ++i) {
-            const int xo = ut.x0 + i;
-            float(&c0)[3][COUT] = win[i % 3];
-            float(&c1)[3][COUT] = win[(i + 1) % 3];
-            float(&c2)[3][COUT] = win[(i + 2) % 3];
-            load_dcol(xo + 1, c2);
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < RUN; i0 += 4) {
+            f32x4 mk[RD ? 4 : 1], old[RD ? 4 : 1];
+            if constexpr (RD) {
+            if (mask) {
 #pragma unroll
-            for (int co = 0; co < COUT; ++co)
+                for (int q = 0; q < 4; ++q) mk[q] = *reinterpret_cast<const f32x4*>(mask + (pix0 + min(ut.x0 + i0 + q, W - 1)) * ldm + c);
+            } else {
 #pragma unroll
-                for (int r = 0; r < 3; ++r)          // window row r' = y - 1 + r' is the source of tap row r = 2 - r'; column slot likewise
-                    a += wr[co][(2 - r) * 3 + 2] * c0[r][co] + wr[co][(2 - r) * 3 + 1] * c1[r][co] + wr[co][(2 - r) * 3 + 0] * c2[r][co];
-            if (xo < W) {
-                const size_t pixo = (size_t)(ut.n * H + ut.y) * W + xo;
-                float* d = dx + pixo * lddx + c;
-                if (mask) {                          // fused ReLU backward of the producer of x (mrfa_conv_params.mask semantics)
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + pixo * ldm + c);
+                for (int q = 0; q < 4; ++q) mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+            if (accumulate) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = mk[e] > 0.f ? a[e] : 0.f;
+                for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const f32x4*>(dx + (pix0 + min(ut.x0 + i0 + q, W - 1)) * lddx + c);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) old[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q;
+                const int xo = ut.x0 + i;
+                float(&c0)[3][COUT] = win[i % 3];
+                float(&c1)[3][COUT] = win[(i + 1) % 3];
+                float(&c2)[3][COUT] = win[(i + 2) % 3];
+                load_dcol(xo + 1, c2);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)          // window row r' = y - 1 + r' is the source of tap row r = 2 - r'; column slot likewise
+                        a += wr[co][(2 - r) * 3 + 2] * c0[r][co] + wr[co][(2 - r) * 3 + 1] * c1[r][co] + wr[co][(2 - r) * 3 + 0] * c2[r][co];
+                if (xo < W) {
+                    float* d = dx + (pix0 + xo) * lddx + c;
+                    if constexpr (RD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = mk[q][e] > 0.f ? a[e] : 0.f;     // fused ReLU backward of the producer of x (mrfa_conv_params.mask semantics)
+                        a += old[q];
+                    }
+                    *reinterpret_cast<f32x4*>(d) = a;
                 }
-                if (accumulate) a += *reinterpret_cast<const f32x4*>(d);
-                *reinterpret_cast<f32x4*>(d) = a;
             }
         }
     }
@@ -187,6 +210,20 @@ int mrfa_tuning_fewout3(int set) {
     return prev;
 }
 
+#define FEW3R(KERNEL, RD, ...)                                                                                          \
+    do {                                                                                                                \
+        const int lpp = Cin / 4;                                                                                        \
+        const dim3 grid((unsigned)grid_for(units, lpp));                                                                \
+        if (Cout == 1) {                                                                                                \
+            if (lpp == 16) hipLaunchKernelGGL((KERNEL<1, 16, RD>), grid, dim3(256), 0, st, __VA_ARGS__);                 \
+            else if (lpp == 32) hipLaunchKernelGGL((KERNEL<1, 32, RD>), grid, dim3(256), 0, st, __VA_ARGS__);            \
+            else hipLaunchKernelGGL((KERNEL<1, 64, RD>), grid, dim3(256), 0, st, __VA_ARGS__);                           \
+        } else {                                                                                                        \
+            if (lpp == 16) hipLaunchKernelGGL((KERNEL<2, 16, RD>), grid, dim3(256), 0, st, __VA_ARGS__);                 \
+            else if (lpp == 32) hipLaunchKernelGGL((KERNEL<2, 32, RD>), grid, dim3(256), 0, st, __VA_ARGS__);            \
+            else hipLaunchKernelGGL((KERNEL<2, 64, RD>), grid, dim3(256), 0, st, __VA_ARGS__);                           \
+        }                                                                                                               \
+    } while (0)
 #define FEW3(KERNEL, ...)                                                                                               \
     do {                                                                                                                \
         const int lpp = Cin / 4;                                                                                        \
@@ -225,7 +262,8 @@ extern "C" int mrfa_conv_fewout_dgrad(void* stream, const float* dy, int lddy, i
     const int runs_x = cdiv(W, RUN);
     const long long units = (long long)N * H * runs_x;
     MRFA_CHECK_ARG(!mask || ((ldm % 4) == 0 && aligned16(mask)), "conv_fewout_dgrad: mask must be a 16-B aligned view with ldm %% 4 == 0");
-    FEW3(fewout3_dgrad_kernel, dy, lddy, N, H, W, Cin, w, dx, lddx, accumulate, units, runs_x, mask, ldm);
+    if (mask || accumulate) FEW3R(fewout3_dgrad_kernel, true, dy, lddy, N, H, W, Cin, w, dx, lddx, accumulate, units, runs_x, mask, ldm);
+    else FEW3R(fewout3_dgrad_kernel, false, dy, lddy, N, H, W, Cin, w, dx, lddx, accumulate, units, runs_x, mask, ldm);
     MRFA_CHECK_LAUNCH("conv_fewout_dgrad");
     return 0;
 }
