@@ -37,6 +37,8 @@ for name, N, H, W, Cin, Cout, ups in SHAPES:
     p.x, p.ldx, p.Hin, p.Win, p.ups, p.N, p.Cin = x.data_ptr(), Cin, H, W, ups, N, Cin
     p.w, p.w_ld, p.w_tap, p.kflat, p.w_rows = wp.data_ptr(), Cin, cop * Cin, 0, cop
     p.w_split, p.w_piece = wsb.data_ptr(), piece
+    if os.environ.get("NOWS", "0") == "1":           # the fp32 weight layout, split inside the kernel (4 instead of 6 bytes per weight from HBM)
+        p.w_split, p.w_piece = None, 0
     p.y, p.ldy, p.Cout, p.Hout, p.Wout = y.data_ptr(), Cout, Cout, Ho, Wo
     p.R, p.S, p.pad, p.alpha, p.nbatch = 3, 3, 1, 1.0, 1
     p.stats = stats.data_ptr()
