@@ -57,8 +57,10 @@ for name, N, H, W, Cin, Cout, ups in SHAPES:
         tks = [torch.zeros(nt * 64, dtype=torch.int32, device=dev) for _ in range(33)]
         bias = torch.randn(Cout, device=dev)
         p.bias, p.relu, p.y_zero = bias.data_ptr(), 1, 1
-    for sk in ((0, 1, 8, 16, 32) if cold else (0, 1, 2, 4, 8, 16, 32, 64)):
+    tile128 = os.environ.get("TILE128", "0") == "1"      # forced splits keep the 128 x 128 (or 128 x 64) split-operand tile instead of shrinking the tile
+    for sk in ((0, 1, 8, 16, 32, 64) if cold else (0, 1, 2, 4, 8, 16, 32, 64)):
         p.splitk = sk
+        p.tile = ((128 << 16) | (64 if Cout <= 64 else 128)) if (tile128 and sk > 0) else 0
         if fused:
             for t in ys + tks:
                 t.zero_()
