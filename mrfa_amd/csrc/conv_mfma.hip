@@ -369,6 +369,7 @@ int launch_cfg(hipStream_t st, const mrfa_conv_params& p, int KT, long long M, i
 // 2: the same kernels keeping the three leading products only (bf16x3: 2^-16-class product error instead of 2^-24);
 // 3: plain bf16 operands (round-to-nearest-even), one product: the arithmetic of a bf16 autocast (BASELINE config 4)
 static int g_mfma_mode = 0;
+static int g_split_target_256 = getenv("MRFA_SPLIT_TARGET_256") ? atoi(getenv("MRFA_SPLIT_TARGET_256")) : 1;
 extern "C" int mrfa_set_mfma_mode(int mode) {
     if (mode < 0 || mode > 3) { mrfa_set_error("set_mfma_mode: unknown mode %d", mode); return 1; }
     g_mfma_mode = mode;
@@ -557,10 +558,15 @@ static int conv2d_dispatch(void* stream, const mrfa_conv_params* pp, bool* fin_d
         // shapes -- 128 -> 32 @64^2 fused upsample would prefer no split (74 -> 54 us), 256 -> 512 @8^2 a quarter of the slices (40 -> 30 us).  Lowering the
         // target here to catch those two moved OTHER layers onto the 64-row fp32 tiles through the BM loop below: +0.8 ms per step.  Left as it was.)
         if (t < 384 && !(short_k_big_m && t >= 128)) {
-            int want = (int)((512 + t - 1) / t);
+            // 512 workgroups -- or 256 for the deep-K launches that finish their split themselves (sk_ticket): their partial sums pass the memory-side atomic
+            // units in one burst behind the k-loop (12 + 6 us of a 51 us launch, profiles/r6_splitk_launch_timeline.txt), and with the 128-row tile kept half the
+            // slices are 5-6 us faster on 8 <= t <= 16 tiles (tools/sweep_splitk.py TILE128=1 COLD=1 FUSED=1: 1024 -> 1024 @4^2 52.3 -> 47.1, 512 -> 512 @8^2
+            // 51.4 -> 46.7, 1024 -> 256 @8^2 up 53.0 -> 46.5, 256 -> 512 @8^2 42.8 -> 36.0)
+            const bool half_target = g_split_target_256 && auto_split && p.sk_ticket && !p.accumulate && KT >= 72 && KT <= 320 && BM == 128 && t >= 8 && t <= 16;      // (deeper K: 2048 -> 512 @8^2 up wants its 32 slices, 86 against 101 us)
+            int want = (int)(((half_target ? 256 : 512) + t - 1) / t);
             if (auto_split) splitk = want <= max_split ? want : max_split;
             const int min_bm = (BN == 128) ? 32 : (BN == 64 ? 64 : 128);
-            while (ntiles(BM, BN) * splitk < 384 && BM > min_bm) {
+            while (!half_target && ntiles(BM, BN) * splitk < 384 && BM > min_bm) {
                 BM >>= 1;
                 if (auto_split) {
                     t = ntiles(BM, BN);
